@@ -1,0 +1,74 @@
+"""Helpers to read tests/golden/*.npz (written by tools/make_golden.py from the reference)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def unpack(bits, shape):
+    n = int(np.prod(shape))
+    return np.unpackbits(bits, count=n, bitorder="little").reshape(shape).astype(np.float32)
+
+
+class CACase:
+    def __init__(self, z, name):
+        self.name = name
+        self.meta = json.loads(bytes(z[f"{name}/meta"]).decode())
+        m = self.meta
+        n, s = m["n"], m["size"]
+        self.n, self.size, self.asize = n, s, m["action_size"]
+        self.birth, self.survive = m["birth"], m["survive"]
+        self.steps = m["steps"]
+        self.record = m["record"]
+        self.init = unpack(z[f"{name}/init"], (n, 1, s, s))
+        ashape = (m["steps"],) + tuple(m["action_shape"])
+        if m["actions_binary"]:
+            self.actions = unpack(z[f"{name}/actions"], ashape)
+        else:
+            self.actions = z[f"{name}/actions"].astype(np.float32)
+        self.obs = unpack(z[f"{name}/obs"], (len(self.record), n, 1, s, s))
+        self.step_number = z[f"{name}/step_number"]
+        self.steps_since_action = z[f"{name}/steps_since_action"]
+
+
+_CACHE = {}
+
+
+def ca_cases():
+    if "ca" not in _CACHE:
+        z = np.load(os.path.join(GOLDEN, "ca_cases.npz"))
+        names = sorted(k[:-5] for k in z.files if k.endswith("/meta"))
+        _CACHE["ca"] = [CACase(z, nm) for nm in names]
+    return _CACHE["ca"]
+
+
+def ca_case_names():
+    z = np.load(os.path.join(GOLDEN, "ca_cases.npz"))
+    return sorted(k[:-5] for k in z.files if k.endswith("/meta"))
+
+
+def ca_case(name):
+    for c in ca_cases():
+        if c.name == name:
+            return c
+    raise KeyError(name)
+
+
+def known():
+    with open(os.path.join(GOLDEN, "ca_known.json")) as f:
+        return json.load(f)
+
+
+def load_sd(z, prefix):
+    """-> ordered dict name -> numpy array (state_dict stored by tools/make_golden.py)."""
+    keys = json.loads(bytes(z[f"{prefix}/keys"]).decode())
+    return {k: z[f"{prefix}/t{i}"] for i, k in enumerate(keys)}
+
+
+def nets(size):
+    key = f"nets{size}"
+    if key not in _CACHE:
+        _CACHE[key] = np.load(os.path.join(GOLDEN, f"nets_{size}.npz"))
+    return _CACHE[key]

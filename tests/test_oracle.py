@@ -1,0 +1,114 @@
+"""The oracle (oracle/ca_oracle.c + oracle/ca.py) against the reference's golden vectors.
+
+CPU only.  This is what PINS the oracle: every fixture was produced by the genuine reference
+(tools/make_golden.py); both restatements must reproduce every recorded grid bit for bit.
+"""
+import numpy as np
+import pytest
+
+import golden_util as G
+from oracle import ca as O
+
+
+@pytest.mark.parametrize("name", G.ca_case_names())
+def test_oracle_replays_golden_case(name):
+    c = G.ca_case(name)
+    rule = O.rule_mask(c.birth, c.survive)
+    u_c = c.init.copy()
+    u_np = c.init.copy()
+    rec = 0
+    step_number = 0
+    ssa = 0
+    for t in range(c.steps):
+        a_full = c.actions[t]
+        a = O.crop_oversize(a_full, c.size, c.size, c.asize, c.asize)
+        # flags are evaluated on the action AS PASSED (before the crop), env.py:191,208
+        flags = np.zeros(2, np.int32)
+        s = a_full.astype(np.float64).sum()
+        any_nz, all_one = (s != 0), (s == a_full.size)
+        if not any_nz:
+            ssa += 1
+        if all_one:
+            # master reset: the action as passed has mean 1.0
+            u_c = np.zeros_like(u_c)
+            u_np = np.zeros_like(u_np)
+            step_number = 0
+            ssa = 0
+        else:
+            u_c2, reset, flags = O.c_env_step(u_c, a, rule)
+            assert not reset
+            u_np2, reset_np = O.np_env_step(u_np, a, rule)
+            assert not reset_np
+            u_c, u_np = u_c2, u_np2
+            step_number += 1
+        assert step_number == c.step_number[t]
+        assert ssa == c.steps_since_action[t]
+        if (t + 1) in c.record:
+            exp = c.obs[rec]
+            rec += 1
+            assert np.array_equal(u_c, exp), f"C oracle differs at step {t + 1}"
+            assert np.array_equal(u_np, exp), f"numpy oracle differs at step {t + 1}"
+    assert rec == len(c.record)
+
+
+def test_oracle_reset_inside_c():
+    """all-ones action through the C entry point: zeros out, reset reported (env.py:208-216)."""
+    rng = np.random.default_rng(0)
+    u = (rng.random((3, 1, 64, 64)) < 0.5).astype(np.float32)
+    out, reset, flags = O.c_env_step(u, np.ones((3, 1, 64, 64), np.float32), O.rule_mask([3], [2, 3]))
+    assert reset and flags.tolist() == [1, 1] and not out.any()
+    out, reset, flags = O.c_env_step(u, np.zeros((3, 1, 64, 64), np.float32), O.rule_mask([3], [2, 3]))
+    assert not reset and flags.tolist() == [0, 0]
+
+
+def _pops(cells, rule, at, size=64):
+    u = np.zeros((1, 1, size, size), np.float32)
+    a = np.zeros((1, 1, size, size), np.float32)
+    for r, c in cells:
+        a[0, 0, r, c] = 1.0
+    res = {}
+    for t in range(1, max(at) + 1):
+        u, _, _ = O.c_env_step(u, a if t == 1 else np.zeros_like(a), rule)
+        if t in at:
+            res[str(t)] = int(u.sum())
+    return res
+
+
+def test_oracle_known_answers():
+    k = G.known()
+    at = [1, 2, 3, 4, 11, 51, 101, 256]
+    life = O.rule_mask([3], [2, 3])
+    assert _pops(k["glider_cells"], life, at) == k["glider_life_pop"]
+    assert _pops(k["rpent_cells"], life, at) == k["rpent_life_pop"]
+    assert _pops(k["rpent_cells"], O.rule_mask([3, 6], [2, 3]), at) == k["rpent_highlife_pop"]
+    assert _pops(k["puffer_cells"], O.rule_mask([3, 6, 8], [2, 4, 5]), at) == k["puffer_morley_pop"]
+    for key_in, key_out in (("seam_in", "seam_out"), ("seam2_in", "seam2_out")):
+        a = np.zeros((1, 1, 64, 64), np.float32)
+        for r, c in k[key_in]:
+            a[0, 0, r, c] = 1.0
+        u, _, _ = O.c_env_step(np.zeros_like(a), a, life)
+        assert np.argwhere(u[0, 0] != 0).tolist() == k[key_out]
+
+
+def test_rule_mask():
+    assert O.rule_mask([3], [2, 3]) == (1 << 12) | 0b1100
+    assert O.rule_mask([], []) == 0
+    assert O.rule_mask([9, -1, 3], [2.0]) == (1 << 12) | 0b100
+
+
+@pytest.mark.parametrize("name", ["tog64a64_life", "tog256a64_daynight", "reset64_life",
+                                  "soup64_b2s0", "values64_life"])
+def test_torch_port_matches_golden(name):
+    """oracle/torch_port.py (the cpu_baseline port) is bit-identical to the reference."""
+    import torch
+    from oracle.torch_port import TorchPortEnv
+    c = G.ca_case(name)
+    env = TorchPortEnv(c.n, c.size, c.asize, c.birth, c.survive)
+    env.universe = torch.from_numpy(c.init.copy())
+    rec = 0
+    for t in range(c.steps):
+        obs = env.step(torch.from_numpy(c.actions[t].copy()))[0]
+        assert env.step_number == c.step_number[t]
+        if (t + 1) in c.record:
+            assert np.array_equal(obs.numpy(), c.obs[rec])
+            rec += 1

@@ -1,0 +1,46 @@
+"""oracle/nets.py (fp32 CPU restatement of RND2D/AE2D forward) against the golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from oracle import nets as ON
+
+
+@pytest.mark.parametrize("size,n", [(64, 16), (256, 4)])
+def test_nets_oracle_matches_reference(size, n):
+    z = G.nets(size)
+    grids = G.unpack(z["grids"], (n, 1, size, size))
+    rnd_sd = G.load_sd(z, "rnd_sd")
+    ae_sd = G.load_sd(z, "ae_sd")
+    with torch.no_grad():
+        rb = ON.rnd_bonus(grids, rnd_sd).numpy()
+        ab = ON.ae_bonus(grids, ae_sd).numpy()
+    np.testing.assert_allclose(rb, z["rnd_bonus"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ab, z["ae_bonus"], rtol=0, atol=1e-6)
+
+
+def test_nets_oracle_intermediates_64():
+    z = G.nets(64)
+    grids = G.unpack(z["grids"], (16, 1, 64, 64))
+    rnd_sd = G.load_sd(z, "rnd_sd")
+    ae_sd = G.load_sd(z, "ae_sd")
+    with torch.no_grad():
+        np.testing.assert_allclose(ON.rnd_random(grids, rnd_sd).numpy(), z["rnd_target"], atol=1e-6)
+        np.testing.assert_allclose(ON.rnd_predictor(grids, rnd_sd).numpy(), z["rnd_pred"], atol=1e-6)
+        np.testing.assert_allclose(ON.ae_predictor(grids, ae_sd).numpy(), z["ae_pred"], atol=1e-6)
+
+
+def test_state_dict_key_layout():
+    """The key layout the build's modules must load strictly."""
+    z = G.nets(256)
+    rk = list(G.load_sd(z, "rnd_sd").keys())
+    assert rk[:2] == ["inner_env.neighborhood.weight", "env.neighborhood.weight"]
+    assert [k for k in rk if k.startswith("predictor.")] == [
+        "predictor.0.weight", "predictor.0.bias", "predictor.5.weight", "predictor.5.bias",
+        "predictor.11.weight", "predictor.11.bias"]
+    assert [k for k in rk if k.startswith("random_network.")] == [
+        "random_network.0.weight", "random_network.0.bias", "random_network.4.weight",
+        "random_network.4.bias", "random_network.8.weight", "random_network.8.bias"]
+    ak = list(G.load_sd(z, "ae_sd").keys())
+    assert len(ak) == 23 and "env.random_network.8.bias" in ak and "predictor.11.bias" in ak

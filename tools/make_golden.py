@@ -1,0 +1,421 @@
+#!/usr/bin/env python3
+"""Generate the golden parity fixtures under tests/golden/ from the GENUINE reference.
+
+TEST INFRASTRUCTURE -- runs only in the build container, where the reference checkout is
+mounted read-only at /root/reference.  The reference never travels to the GPU box; only the
+small .npz files this script writes do (inputs + expected outputs, no reference source).
+
+How the reference is imported (no file of the reference is modified):
+  * scikit-image is not installed -> empty in-memory ``skimage``/``skimage.io`` modules are put
+    into ``sys.modules`` (only ``CARLE.save_frame`` uses them, carle/env.py:511).
+  * torch >= 1.7 rejects the in-place kernel write at carle/env.py:113 outside ``no_grad`` ->
+    ``CARLE.set_neighborhood`` is wrapped with ``torch.no_grad()`` after import.
+
+Run (from any cwd that is NOT /root/repo, so ``import carle`` resolves to the reference):
+
+    cd /tmp && MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference \
+        python /root/repo/tools/make_golden.py --out /root/repo/tests/golden
+
+Fixture files
+  ca_cases.npz     CA-step cases: initial grids, per-step actions, expected grids (bit-packed)
+  ca_known.json    RNG-free known answers (populations of glider / R-pentomino / puffer ...)
+  nets_64.npz      RND2D + AE2D(RND2D) freshly constructed under torch.manual_seed(0) at 64x64:
+                   state_dicts, 16 input grids, get_bonus_only outputs (eval mode), stacked
+                   wrapper rewards over a few steps, and a predictor-update trajectory
+  nets_256.npz     the shipped evaluation/*.pt weights (256x256): state_dicts (as arrays),
+                   4 input grids, get_bonus_only outputs (eval mode)
+"""
+import argparse
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+
+
+def import_reference():
+    if os.path.realpath(os.getcwd()).startswith("/root/repo"):
+        raise SystemExit("run from a cwd outside /root/repo (see module docstring)")
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    sk = types.ModuleType("skimage")
+    skio = types.ModuleType("skimage.io")
+    sk.io = skio
+    sys.modules.setdefault("skimage", sk)
+    sys.modules.setdefault("skimage.io", skio)
+    import torch
+    import carle.env as ref_env
+    assert ref_env.__file__.startswith(REF), ref_env.__file__
+    ref_env.CARLE.set_neighborhood = torch.no_grad()(ref_env.CARLE.set_neighborhood)
+    import carle.mcl as ref_mcl
+    return torch, ref_env, ref_mcl
+
+
+def pack(a):
+    """float/bool array of 0/1 -> (uint8 packed bits along the flattened array, shape)"""
+    a = np.asarray(a)
+    return np.packbits((a != 0).reshape(-1), bitorder="little"), np.array(a.shape, dtype=np.int64)
+
+
+RULES = {
+    "life": ([3], [2, 3]),
+    "highlife": ([3, 6], [2, 3]),
+    "morley": ([3, 6, 8], [2, 4, 5]),
+    "daynight": ([3, 6, 7, 8], [3, 4, 6, 7, 8]),
+    "lfod": ([3], [0, 2, 3]),           # "live free or die" as written in train_mcl.py:98
+    "b2s0": ([2], [0]),                 # single-element lists: bool grids, eval.py:94
+    "b0357s2468": ([0, 3, 5, 7], [2, 4, 6, 8]),   # B0 rule (tests/test_env.py:24-25)
+    "b012345678s012345678": (list(range(9)), list(range(9))),
+}
+
+
+def run_case(torch, ref_env, name, rule, n, size, asize, steps, init_p, action_kind, record,
+             seed, extra=None):
+    """Drive the genuine reference and record everything needed to replay the case."""
+    rng = np.random.default_rng(seed)
+    env = ref_env.CARLE(width=size, height=size, action_width=asize, action_height=asize,
+                        instances=n, device="cpu")
+    env.birth, env.survive = list(RULES[rule][0]), list(RULES[rule][1])
+    env.reset()
+    init = (rng.random((n, 1, size, size)) < init_p).astype(np.float32)
+    env.universe = torch.from_numpy(init.copy())     # what load_universe does, carle/env.py:406
+    acts, snaps, stepno, ssa = [], [], [], []
+    aw = env.action_width
+    for t in range(steps):
+        if action_kind == "zero":
+            a = np.zeros((n, 1, aw, aw), np.float32)
+        elif action_kind == "p10":
+            a = (rng.random((n, 1, aw, aw)) <= 0.1).astype(np.float32)
+        elif action_kind == "p50_first":
+            a = (rng.random((n, 1, aw, aw)) < 0.5).astype(np.float32) if t == 0 else \
+                np.zeros((n, 1, aw, aw), np.float32)
+        elif action_kind == "oversize":      # full-grid action -> centre crop, env.py:164-167
+            a = (rng.random((n, 1, size, size)) <= 0.1).astype(np.float32)
+        elif action_kind == "values":        # any non-zero value toggles, env.py:182
+            vals = np.array([0.0, 0.0, 0.0, 0.5, -1.0, 2.0, 1.0, -0.0, 1e-30, np.inf],
+                            np.float32)
+            a = vals[rng.integers(0, len(vals), (n, 1, aw, aw))]
+        elif action_kind == "reset_mid":     # all-ones action at t==3: master reset, env.py:208
+            if t == 3:
+                a = np.ones((n, 1, aw, aw), np.float32)
+            elif t == 5:                      # all ones for one instance only: no reset
+                a = (rng.random((n, 1, aw, aw)) <= 0.1).astype(np.float32)
+                a[0] = 1.0
+            else:
+                a = (rng.random((n, 1, aw, aw)) <= 0.1).astype(np.float32)
+        else:
+            raise ValueError(action_kind)
+        acts.append(a)
+        obs, reward, done, info = env.step(torch.from_numpy(a.copy()))
+        assert obs is env.universe
+        assert tuple(reward.shape) == (n, 1) and tuple(done.shape) == (n, 1)
+        assert float(reward.abs().sum()) == 0.0 and float(done.abs().sum()) == 0.0
+        assert len(info) == n
+        o = obs.detach().numpy()
+        assert set(np.unique(o)).issubset({0.0, 1.0})
+        stepno.append(env.step_number)
+        ssa.append(env.steps_since_action)
+        if (t + 1) in record:
+            snaps.append(o.copy())
+    acts = np.stack(acts)
+    binary = bool(np.all((acts == 0) | (acts == 1)))
+    out = {}
+    meta = dict(name=name, rule=rule, birth=RULES[rule][0], survive=RULES[rule][1], n=n,
+                size=size, action_size=int(aw), steps=steps, record=sorted(record),
+                action_kind=action_kind, actions_binary=binary, seed=seed,
+                action_shape=list(acts.shape[1:]))
+    if extra:
+        meta.update(extra)
+    out[f"{name}/meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    out[f"{name}/init"], _ = pack(init)
+    if binary:
+        out[f"{name}/actions"], _ = pack(acts)
+    else:
+        out[f"{name}/actions"] = acts
+    out[f"{name}/obs"], _ = pack(np.stack(snaps))
+    out[f"{name}/step_number"] = np.array(stepno, np.int64)
+    out[f"{name}/steps_since_action"] = np.array(ssa, np.int64)
+    return out
+
+
+def make_ca(torch, ref_env, outdir):
+    cases = {}
+    seed = 1000
+    # (1) every rule on 64x64, random soup then zero actions; long horizon for Life
+    for rule in RULES:
+        seed += 1
+        steps = 256 if rule == "life" else 32
+        rec = {1, 2, 3, 16, 32} | ({64, 256} if rule == "life" else set())
+        cases.update(run_case(torch, ref_env, f"soup64_{rule}", rule, 4, 64, 64, steps, 0.5,
+                              "zero", rec, seed))
+    # (2) random toggles every step (RandomAgent-like, agents.py:38-40)
+    for rule, n, size, asize, steps in [("life", 8, 64, 64, 32), ("highlife", 3, 64, 64, 16),
+                                        ("morley", 2, 128, 64, 16), ("life", 2, 256, 64, 16),
+                                        ("daynight", 2, 256, 64, 8), ("highlife", 1, 512, 64, 8),
+                                        ("life", 1, 512, 256, 6), ("life", 2, 64, 32, 16),
+                                        ("lfod", 2, 128, 128, 8)]:
+        seed += 1
+        cases.update(run_case(torch, ref_env, f"tog{size}a{asize}_{rule}", rule, n, size, asize,
+                              steps, 0.3, "p10", {1, 2, 3, steps // 2, steps}, seed))
+    # (3) sizes that are not multiples of 64 (legal in the reference: square, even)
+    for rule, n, size, asize in [("life", 3, 32, 32), ("highlife", 2, 96, 64),
+                                 ("life", 2, 100, 64), ("morley", 2, 48, 16), ("life", 1, 8, 8),
+                                 ("life", 2, 192, 64), ("b0357s2468", 1, 40, 40)]:
+        seed += 1
+        cases.update(run_case(torch, ref_env, f"odd{size}a{asize}_{rule}", rule, n, size, asize,
+                              12, 0.4, "p10", {1, 2, 5, 12}, seed))
+    # (4) oversize action (crop path), arbitrary values, master reset
+    seed += 1
+    cases.update(run_case(torch, ref_env, "crop256_life", "life", 2, 256, 64, 6, 0.3, "oversize",
+                          {1, 3, 6}, seed))
+    seed += 1
+    cases.update(run_case(torch, ref_env, "crop128_highlife", "highlife", 2, 128, 64, 6, 0.3,
+                          "oversize", {1, 3, 6}, seed))
+    seed += 1
+    cases.update(run_case(torch, ref_env, "values64_life", "life", 3, 64, 64, 6, 0.3, "values",
+                          {1, 2, 6}, seed))
+    seed += 1
+    cases.update(run_case(torch, ref_env, "values256_morley", "morley", 2, 256, 64, 4, 0.3,
+                          "values", {1, 2, 4}, seed))
+    seed += 1
+    cases.update(run_case(torch, ref_env, "reset64_life", "life", 3, 64, 64, 8, 0.5, "reset_mid",
+                          set(range(1, 9)), seed))
+    seed += 1
+    cases.update(run_case(torch, ref_env, "reset256_life", "life", 2, 256, 64, 8, 0.5,
+                          "reset_mid", set(range(1, 9)), seed))
+    # (5) the reference's own CPU-runnable config (BASELINE.json configs[0]): N=1, 64x64, 256 steps
+    seed += 1
+    cases.update(run_case(torch, ref_env, "cfg1_life", "life", 1, 64, 64, 256, 0.5, "zero",
+                          {1, 64, 128, 256}, seed))
+    np.savez_compressed(os.path.join(outdir, "ca_cases.npz"), **cases)
+    print("ca_cases.npz:", len([k for k in cases if k.endswith("/meta")]), "cases")
+
+
+def make_known(torch, ref_env, ref_mcl, outdir):
+    """RNG-free known answers + behavioural quirks of the reference, as plain JSON."""
+    known = {}
+
+    def pops(action, rule, at, size=64):
+        env = ref_env.CARLE(width=size, height=size, instances=1, device="cpu")
+        env.birth, env.survive = list(RULES[rule][0]), list(RULES[rule][1])
+        env.reset()
+        res = {}
+        for t in range(1, max(at) + 1):
+            a = action if t == 1 else torch.zeros_like(action)
+            obs = env.step(a)[0]
+            if t in at:
+                res[t] = int(obs.sum().item())
+        return res, env
+
+    at = [1, 2, 3, 4, 11, 51, 101, 256]
+    g, env = pops(ref_mcl.get_glider(), "life", at)
+    known["glider_life_pop"] = g
+    known["glider_life_step_number"] = env.step_number
+    rp = torch.zeros(1, 1, 64, 64)
+    rp[0, 0, 31, 32:34] = 1.0
+    rp[0, 0, 32, 31:33] = 1.0
+    rp[0, 0, 33, 32] = 1.0
+    known["rpent_cells"] = [[31, 32], [31, 33], [32, 31], [32, 32], [33, 32]]
+    known["rpent_life_pop"], _ = pops(rp, "life", at)
+    known["rpent_highlife_pop"], _ = pops(rp, "highlife", at)
+    known["puffer_morley_pop"], _ = pops(ref_mcl.get_morley_puffer(), "morley", at)
+    known["glider_cells"] = np.argwhere(ref_mcl.get_glider()[0, 0].numpy() != 0).tolist()
+    known["puffer_cells"] = np.argwhere(ref_mcl.get_morley_puffer()[0, 0].numpy() != 0).tolist()
+    # torus seam
+    env = ref_env.CARLE(width=64, height=64, instances=1, device="cpu")
+    env.reset()
+    a = torch.zeros(1, 1, 64, 64)
+    for (r, c) in [(0, 63), (0, 0), (0, 1)]:
+        a[0, 0, r, c] = 1.0
+    obs = env.step(a)[0]
+    known["seam_in"] = [[0, 63], [0, 0], [0, 1]]
+    known["seam_out"] = np.argwhere(obs[0, 0].numpy() != 0).tolist()
+    # corner blinker across both seams
+    env.reset()
+    a = torch.zeros(1, 1, 64, 64)
+    for (r, c) in [(63, 63), (0, 63), (1, 63)]:
+        a[0, 0, r, c] = 1.0
+    obs = env.step(a)[0]
+    known["seam2_in"] = [[63, 63], [0, 63], [1, 63]]
+    known["seam2_out"] = np.argwhere(obs[0, 0].numpy() != 0).tolist()
+    # master reset
+    env = ref_env.CARLE(width=64, height=64, instances=2, device="cpu")
+    env.reset()
+    env.step((torch.rand(2, 1, 64, 64) < 0.3).float())
+    env.step(torch.zeros(2, 1, 64, 64))
+    sn_before = env.step_number
+    obs = env.step(torch.ones(2, 1, 64, 64))[0]
+    known["master_reset"] = dict(step_number_before=sn_before, step_number_after=env.step_number,
+                                 obs_sum=float(obs.sum()),
+                                 steps_since_action_after=env.steps_since_action)
+    # rule parsing (tests/test_env.py:17-39)
+    env = ref_env.CARLE()
+    env.birth_rule_from_string("asdfasdfB0357*!@#!@$%")
+    env.survive_rule_from_string("S2468")
+    known["parse_b"] = env.birth
+    known["parse_s"] = env.survive
+    env.rules_from_string("B368/S245")
+    known["parse_rules_b368s245"] = [env.birth, env.survive]
+    env.rules_from_string("b3/s23")
+    known["parse_rules_lower"] = [env.birth, env.survive]
+    env.rules_from_string("B9a33/S")
+    known["parse_rules_dup_empty"] = [env.birth, env.survive]
+    # attribute surface
+    env = ref_env.CARLE()
+    known["defaults"] = dict(width=env.width, height=env.height, action_width=env.action_width,
+                             action_height=env.action_height, instances=env.instances,
+                             device=str(env.my_device), birth=env.birth, survive=env.survive,
+                             state_dict_keys=list(env.state_dict().keys()),
+                             weight=env.state_dict()["neighborhood.weight"].reshape(-1).tolist(),
+                             weight_requires_grad=bool(env.neighborhood.weight.requires_grad))
+    env.reset()
+    pad = env.action_padding(torch.ones(1, 1, 64, 64))
+    known["default_action_window"] = [int(np.argwhere(pad[0, 0].numpy())[:, 0].min()),
+                                      int(np.argwhere(pad[0, 0].numpy())[:, 0].max()),
+                                      int(np.argwhere(pad[0, 0].numpy())[:, 1].min()),
+                                      int(np.argwhere(pad[0, 0].numpy())[:, 1].max())]
+    # empty rule list raises TypeError (reduce of empty sequence, env.py:221-224)
+    env = ref_env.CARLE(width=64, height=64)
+    env.reset()
+    env.birth = []
+    try:
+        env.step(torch.zeros(1, 1, 64, 64))
+        known["empty_birth_raises"] = None
+    except Exception as e:   # noqa: BLE001
+        known["empty_birth_raises"] = type(e).__name__
+    # action given as 2-D / 3-D / list (env.py:152-156) -- N=1
+    env = ref_env.CARLE(width=64, height=64)
+    env.reset()
+    a2 = np.zeros((64, 64), np.float32)
+    a2[10, 10:13] = 1
+    # NB: step() calls torch.sum(action) first, so a raw ndarray/list works only via Tensor
+    o2 = env.step(torch.from_numpy(a2))[0]
+    known["action_2d_out"] = np.argwhere(o2[0, 0].numpy() != 0).tolist()
+    with open(os.path.join(outdir, "ca_known.json"), "w") as f:
+        json.dump(known, f, indent=1, sort_keys=True)
+    print("ca_known.json written")
+
+
+def sd_to_npz(prefix, sd, out):
+    keys = list(sd.keys())
+    out[f"{prefix}/keys"] = np.frombuffer(json.dumps(keys).encode(), dtype=np.uint8)
+    for i, k in enumerate(keys):
+        out[f"{prefix}/t{i}"] = sd[k].detach().cpu().numpy()
+
+
+def make_nets(torch, ref_env, ref_mcl, outdir):
+    import contextlib
+    sink = io.StringIO()
+    # ---- 64x64, fresh seeded construction (predictor before random net, mcl.py:248-249)
+    out = {}
+    n = 16
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sink):
+        env = ref_env.CARLE(width=64, height=64, instances=n, device="cpu")
+        rnd = ref_mcl.RND2D(env)
+        ae = ref_mcl.AE2D(rnd)
+    rnd.eval()
+    ae.eval()
+    rng = np.random.default_rng(77)
+    dens = np.linspace(0.02, 0.6, n).reshape(n, 1, 1, 1)
+    grids = (rng.random((n, 1, 64, 64)) < dens).astype(np.float32)
+    grids[0] = 0.0                      # all-dead grid
+    grids[1] = 1.0                      # all-alive grid
+    g = torch.from_numpy(grids)
+    ae.reset()
+    sd_to_npz("rnd_sd", rnd.state_dict(), out)
+    sd_to_npz("ae_sd", ae.state_dict(), out)
+    out["grids"], _ = pack(grids)
+    out["rnd_bonus"] = rnd.get_bonus_only(g).numpy()
+    out["ae_bonus"] = ae.get_bonus_only(g).numpy()
+    out["rnd_target"] = rnd.random_forward(g).detach().numpy()
+    out["rnd_pred"] = rnd.forward(g).detach().numpy()
+    out["ae_pred"] = ae.forward(g).detach().numpy().astype(np.float32)
+    # stacked wrappers, eval mode, rewards over 4 steps, no predictor update (batch_size large)
+    rnd.batch_size = 10 ** 6
+    ae.batch_size = 10 ** 6
+    ae.reset()
+    env.universe = g.clone()
+    acts, rews = [], []
+    for t in range(4):
+        a = (rng.random((n, 1, 64, 64)) <= 0.1).astype(np.float32)
+        obs, reward, done, info = ae.step(torch.from_numpy(a.copy()))
+        acts.append(a)
+        rews.append(reward.detach().numpy().copy())
+    out["stack_actions"], _ = pack(np.stack(acts))
+    out["stack_rewards"] = np.stack(rews)
+    out["stack_final_obs"], _ = pack(obs.detach().numpy())
+    # predictor-update trajectory ("next" row): eval mode (no dropout),
+    # batch_size=2, 6 steps -> 3 Adam updates for each wrapper
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sink):
+        env = ref_env.CARLE(width=64, height=64, instances=4, device="cpu")
+        rnd = ref_mcl.RND2D(env)
+        ae = ref_mcl.AE2D(rnd)
+    rnd.eval()
+    ae.eval()
+    rnd.batch_size = 2
+    ae.batch_size = 2
+    ae.reset()
+    env.universe = g[4:8].clone()
+    acts, rews = [], []
+    for t in range(6):
+        a = (rng.random((4, 1, 64, 64)) <= 0.1).astype(np.float32)
+        obs, reward, done, info = ae.step(torch.from_numpy(a.copy()))
+        acts.append(a)
+        rews.append(reward.detach().numpy().copy())
+    out["upd_init"], _ = pack(grids[4:8])
+    out["upd_actions"], _ = pack(np.stack(acts))
+    out["upd_rewards"] = np.stack(rews)
+    out["upd_updates"] = np.array([rnd.updates, ae.updates], np.int64)
+    sd_to_npz("upd_rnd_sd", rnd.state_dict(), out)
+    sd_to_npz("upd_ae_sd", ae.state_dict(), out)
+    np.savez_compressed(os.path.join(outdir, "nets_64.npz"), **out)
+    print("nets_64.npz written")
+
+    # ---- 256x256, the shipped evaluation weights
+    out = {}
+    with contextlib.redirect_stdout(sink):
+        env = ref_env.CARLE(instances=4, device="cpu")
+        rnd = ref_mcl.RND2D(env)
+        rnd.load_state_dict(torch.load(os.path.join(REF, "evaluation/RND2D_mcl.pt"), map_location="cpu"))
+        ae = ref_mcl.AE2D(rnd)
+        ae.load_state_dict(torch.load(os.path.join(REF, "evaluation/AE2D_mcl.pt"), map_location="cpu"))
+    rnd.eval()
+    ae.eval()
+    ae.reset()
+    dens = np.array([0.0, 0.05, 0.2, 0.5]).reshape(4, 1, 1, 1)
+    grids = (rng.random((4, 1, 256, 256)) < dens).astype(np.float32)
+    g = torch.from_numpy(grids)
+    sd_to_npz("rnd_sd", rnd.state_dict(), out)
+    sd_to_npz("ae_sd", ae.state_dict(), out)
+    out["grids"], _ = pack(grids)
+    out["rnd_bonus"] = rnd.get_bonus_only(g).numpy()
+    out["ae_bonus"] = ae.get_bonus_only(g).numpy()
+    np.savez_compressed(os.path.join(outdir, "nets_256.npz"), **out)
+    print("nets_256.npz written")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="/root/repo/tests/golden")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch, ref_env, ref_mcl = import_reference()
+    torch.set_num_threads(8)
+    todo = args.only.split(",") if args.only else ["ca", "known", "nets"]
+    if "ca" in todo:
+        make_ca(torch, ref_env, args.out)
+    if "known" in todo:
+        make_known(torch, ref_env, ref_mcl, args.out)
+    if "nets" in todo:
+        make_nets(torch, ref_env, ref_mcl, args.out)
+
+
+if __name__ == "__main__":
+    main()
