@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the CARLE hot path on MI355X (BASELINE.json metric).
+
+A "step" is one CARLE.step(action) over the whole batch: the fused HIP CA kernel
+(toggle + 3x3 torus count + B/S rule) plus the epilogue kernel, driven through the drop-in
+Python surface (carle_amd.env.CARLE).  Workload at N=1: BASELINE.json configs[1] -- B3/S23,
+N=4096, 64x64 grids, fp32 drop-in format, a fresh device-resident Bernoulli(0.1) 64x64 action
+every step (ring of action buffers larger than the 256 MiB Infinity Cache, so state and action
+really stream from HBM).  For --gpus N > 1 the batch is sharded: every rank owns 4096 instances
+(weak scaling, no data-path collective: universes are independent).
+
+Prints ONE JSON line on rank 0 (contract in the task description), with two extra objects:
+  roofline      algorithmic bytes of the dominant kernel (ca_step_f32_64) / its average launch
+                duration measured here with HIP events on the launch stream, against 8 TB/s
+  cpu_baseline  oracle/torch_port.py (a port of the reference's per-step ATen op sequence; the
+                reference itself cannot travel) timed on this host's cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--instances", type=int, default=4096, help="instances PER GPU")
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--rule", default="B3/S23")
+    ap.add_argument("--action-ring", type=int, default=6,
+                    help="number of distinct device action buffers cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(size, rule, seconds):
+    """Port of the reference step (oracle/torch_port.py) on the host cores, bounded sample."""
+    from oracle.torch_port import TorchPortEnv
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = 256
+    b, s = rule
+    env = TorchPortEnv(n, size, min(64, size), b, s)
+    g = torch.Generator().manual_seed(1234)
+    env.universe = (torch.rand(n, 1, size, size, generator=g) < 0.5).float()
+    acts = [(torch.rand(n, 1, min(64, size), min(64, size), generator=g) <= 0.1).float()
+            for _ in range(4)]
+    for i in range(2):
+        env.step(acts[i % 4])
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        env.step(acts[k % 4])
+        k += 1
+        if time.perf_counter() - t0 >= seconds and k >= 3:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/torch_port.py (reference ATen op sequence), N={n} {size}x{size} "
+                      f"{k} steps in {dt:.1f} s, torch {torch.__version__} {cores} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from carle_amd import hip
+    from carle_amd.env import CARLE
+
+    n, size = args.instances, args.size
+    asize = min(64, size)
+    env = CARLE(width=size, height=size, action_width=asize, action_height=asize, instances=n,
+                device=str(dev))
+    env.rules_from_string(args.rule)
+    env.reset()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    env.universe = (torch.rand(n, 1, size, size, device=dev, generator=g) < 0.5).float()
+    ga = torch.Generator(device=dev).manual_seed(4321 + rank)
+    ring = [(torch.rand(n, 1, asize, asize, device=dev, generator=ga) <= 0.1).float()
+            for _ in range(args.action_ring)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        env.step(ring[i % len(ring)])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        env.step(ring[i % len(ring)])
+    torch.cuda.synchronize(dev)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    pop = float(env.universe.sum().item())      # keeps the result live / sanity
+
+    # ---- roofline of the dominant kernel: back-to-back launches of the step kernel alone,
+    # HIP events on the launch stream (torch's current stream is the stream the ABI is given)
+    rule = env.rule_mask()
+    a_buf, b_buf = env.universe, torch.empty_like(env.universe)
+    reps = max(32, min(args.steps, 256))
+    for i in range(4):
+        hip.ca_step_f32(a_buf, ring[i % len(ring)], b_buf, rule, env._status, 0)
+        a_buf, b_buf = b_buf, a_buf
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for i in range(reps):
+        hip.ca_step_f32(a_buf, ring[i % len(ring)], b_buf, rule, env._status, 0)
+        a_buf, b_buf = b_buf, a_buf
+    e1.record()
+    torch.cuda.synchronize(dev)
+    k_ms = e0.elapsed_time(e1) / reps
+    alg_bytes = n * (size * size * 8 + asize * asize * 4)
+    achieved = alg_bytes / (k_ms * 1e-3)
+
+    if rank == 0:
+        out = {
+            "metric": "env-steps/sec at N=4096x64x64 (B3/S23, fp32 drop-in grids, action every step)",
+            "value": world * n * args.steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {args.rule} N={n}/GPU {size}x{size} "
+                                   f"fp32 grids, Bernoulli(0.1) {asize}x{asize} fp32 action per step "
+                                   f"(ring of {len(ring)} device buffers), CARLE.step drop-in surface",
+                       "instances_per_gpu": n, "height": size, "width": size,
+                       "action": asize, "rule": args.rule, "sharding": f"batch x{world}"},
+            "cell_updates_per_s": world * n * args.steps * size * size / dt,
+            "final_population_rank0": pop,
+            "roofline": {"bound": "hbm", "kernel": "ca_step_f32_64_kernel<true>" if size == 64
+                         else "ca_step_f32 (see DESIGN.md)",
+                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_us": k_ms * 1e3, "launches_timed": reps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            b, s = env.birth, env.survive
+            out["cpu_baseline"] = cpu_baseline(size, (b, s), args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

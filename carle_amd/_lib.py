@@ -1,0 +1,60 @@
+"""ctypes loader for libcarle_hip.so (the C ABI declared in include/carle_hip.h).
+
+Fails loudly: a missing / stale library is an error, never a reason to fall back to PyTorch ops.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcarle_hip.so")
+ABI_VERSION = 1
+
+_c_i64, _c_int, _c_u32, _c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/carle_hip.h one to one
+SIGNATURES = {
+    "carle_abi_version": (_c_int, []),
+    "carle_last_error": (ctypes.c_char_p, []),
+    "carle_build_arch": (ctypes.c_char_p, []),
+    "carle_ca_step_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int,
+                                   _c_u32, _c_vp, _c_int, _c_vp]),
+    "carle_ca_toggle_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int,
+                                     _c_vp]),
+    "carle_ca_finish": (_c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_int, _c_int, _c_vp]),
+}
+
+_lib = None
+
+
+class CarleHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CarleHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C carle_amd/csrc`).  carle_amd has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CarleHipError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.carle_abi_version()
+    if got != ABI_VERSION:
+        raise CarleHipError(f"libcarle_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().carle_last_error().decode(errors="replace")
+        raise CarleHipError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,49 @@
+// common.hpp -- host-side helpers shared by the C-ABI entry points of libcarle_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/carle_hip.h"
+
+namespace carle {
+
+// thread-local error text behind carle_last_error()
+std::string &last_error();
+
+inline int fail_arg(int code, const char *msg) {
+    last_error() = msg;
+    return code;
+}
+
+inline int fail_hip(hipError_t e, const char *where) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", where, hipGetErrorString(e));
+    last_error() = buf;
+    return -(int)e;
+}
+
+// call after every kernel launch (launch-configuration errors only; no sync)
+inline int check_launch(const char *where) {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail_hip(e, where);
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline bool overlap(const void *a, size_t na, const void *b, size_t nb) {
+    auto pa = reinterpret_cast<uintptr_t>(a), pb = reinterpret_cast<uintptr_t>(b);
+    return pa < pb + nb && pb < pa + na;
+}
+
+// The reference's consistent domain (carle/env.py:119-132): square, even, centred window.
+inline int check_dims(int64_t n, int h, int w, bool has_action, int ah, int aw) {
+    if (n < 0 || h < 2 || w < 2 || h != w || (h & 1))
+        return fail_arg(CARLE_E_DIMS, "grid must be square with even H == W >= 2 and N >= 0");
+    if (has_action && (ah != aw || ah < 1 || ah > h || ((h - ah) & 1)))
+        return fail_arg(CARLE_E_DIMS, "action window must be square, AH == AW <= H, (H-AH) even");
+    return 0;
+}
+
+}  // namespace carle

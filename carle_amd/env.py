@@ -1,0 +1,290 @@
+"""carle_amd.env -- the CARLE environment surface on top of the HIP hot path.
+
+Mirrors the public surface of the reference's ``carle.env.CARLE`` (riveSunder/carle,
+carle/env.py:15-242) so that train/eval loops written against it run unchanged:
+``CARLE(**kwargs)``, ``reset() -> obs``, ``step(action) -> (obs, reward, done, info)``, the
+``universe`` / ``birth`` / ``survive`` attributes, the rule-string setters and the
+``neighborhood.weight`` parameter that appears in every wrapper ``state_dict``.
+
+What is different underneath:
+  * the ~19 ATen ops / 15 memory passes of one reference step are ONE HIP kernel
+    (``carle_ca_step_f32``) plus a tiny epilogue kernel (``carle_ca_finish``);
+  * the reference's two host synchronisations per step (``if torch.sum(action)``, env.py:191,
+    and ``torch.mean(action) == 1.0``, env.py:208) are evaluated on the device: the step kernel
+    publishes two flags, the epilogue applies the master reset and keeps ``step_number`` /
+    ``steps_since_action`` in device memory; reading those attributes synchronises lazily;
+  * this build is GPU-only: without a HIP device ``reset``/``step`` raise (no CPU fallback).
+"""
+import time
+
+import torch
+import torch.nn as nn
+
+from . import hip
+
+_MOORE = ((1.0, 1.0, 1.0), (1.0, 0.0, 1.0), (1.0, 1.0, 1.0))
+
+
+def _resolve_device(kwargs):
+    """Device choice of carle/env.py:25-37, widened to cuda:0..7 and defaulting to the GPU.
+
+    The reference defaults to the CPU; this implementation has no CPU compute path, so with no
+    device argument (or use_cuda=True) the first HIP device is used.  An explicit "cpu" is kept
+    as-is: construction, rule parsing and state_dict handling work, compute calls raise.
+    """
+    dev = kwargs.get("device", None)
+    if dev is not None:
+        return torch.device(dev)
+    if kwargs.get("use_cuda", False) or torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return torch.device("cpu")
+
+
+class CARLE(nn.Module):
+    """Batched toroidal Life-like cellular automaton with a gym-style interface."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.inner_env = None                                   # carle/env.py:20
+        self.width = kwargs.get("width", 256)
+        self.height = kwargs.get("height", 256)
+        self.action_width = kwargs.get("action_width", 64)
+        self.action_height = kwargs.get("action_height", 64)
+        self.use_cuda = kwargs.get("use_cuda", False)
+        self.my_device = _resolve_device(kwargs)
+        self.use_grad = kwargs.get("use_grad", False)
+        self.alive_rate = kwargs.get("alive_rate", 0.0)         # stored, never used (env.py:43)
+        self.instances = kwargs.get("instances", 1)
+        self.logging = kwargs.get("logging", False)
+        # reference behaviour for an empty birth/survive list is a TypeError (env.py:221-224);
+        # by default this build treats an empty list as "never" (a superset); strict mirrors it
+        self.strict_reference_errors = kwargs.get("strict_reference_errors", False)
+
+        self.set_neighborhood()
+        self.set_action_padding()
+
+        self.allowed_rules = [str(num) for num in range(9)]
+        self.birth = [3]                                         # Conway's Life, env.py:58-59
+        self.survive = [2, 3]
+
+        self._status = None          # device int32[16]: flags + counters (include/carle_hip.h)
+        self._slot = 0
+        self.universe = None
+        self.action = None
+        self.log = []
+        self.instance_id = str(int(time.time()))
+
+    # ------------------------------------------------------------------ rules (env.py:62-85)
+    def birth_rule_from_string(self, my_string="B3"):
+        self.birth = sorted({int(ch) for ch in my_string if ch in self.allowed_rules})
+
+    def survive_rule_from_string(self, my_string="S23"):
+        self.survive = sorted({int(ch) for ch in my_string if ch in self.allowed_rules})
+
+    def rules_from_string(self, my_string="B3/S23"):
+        parts = my_string.split("/")
+        self.birth_rule_from_string(parts[0])
+        self.survive_rule_from_string(parts[1])
+
+    def rule_mask(self):
+        """18-bit rule mask from the CURRENT ``birth``/``survive`` lists (re-read every step:
+        callers assign them directly, train_mcl.py:56-57, eval.py:58-59)."""
+        if self.strict_reference_errors and (len(self.birth) == 0 or len(self.survive) == 0):
+            raise TypeError("reduce() of empty sequence with no initial value")
+        return hip.rule_mask(self.birth, self.survive)
+
+    # ------------------------------------------------------------------ construction helpers
+    def set_neighborhood(self):
+        """Registers the Moore-neighbourhood conv so that ``neighborhood.weight`` (1,1,3,3)
+        exists in state_dicts exactly as in the reference (env.py:87-116).  The HIP kernel has
+        the Moore kernel built in; a loaded state_dict with different weights is rejected."""
+        self.neighborhood = nn.Conv2d(1, 1, 3, padding=1, padding_mode="circular", bias=False)
+        with torch.no_grad():
+            self.neighborhood.weight.copy_(torch.tensor(_MOORE).reshape(1, 1, 3, 3))
+        self.neighborhood.to(self.my_device if self.my_device.type == "cpu" or
+                             torch.cuda.is_available() else "cpu")
+        self.register_load_state_dict_post_hook(_check_moore)
+
+    def set_action_padding(self):
+        """Centre placement of the action window, env.py:119-132 (same arithmetic, so the odd /
+        non-square inconsistencies of the reference are NOT extended: see ``_check_domain``)."""
+        asym_w = (self.width - self.action_width) % 2
+        asym_h = (self.height - self.action_height) % 2
+        self.action_width -= (self.width % 2)
+        self.action_height -= (self.height % 2)
+        wp = (self.width - self.action_width) // 2
+        hp = (self.height - self.action_height) // 2
+        self.action_padding = nn.ZeroPad2d(padding=(hp, hp + asym_h, wp, wp + asym_w))
+
+    def _check_domain(self):
+        h, w, ah, aw = self.height, self.width, self.action_height, self.action_width
+        if h != w or h % 2 or ah != aw or ah > h or (h - ah) % 2 or ah < 1:
+            raise ValueError(
+                f"unsupported geometry {h}x{w} / action {ah}x{aw}: the reference is only "
+                "consistent for square even grids with a centred square window, (H-AH) even "
+                "(carle/env.py:119-132)")
+
+    # ------------------------------------------------------------------ counters (device side)
+    def _ensure_status(self):
+        if self._status is None or self._status.device != self.my_device:
+            self._status = hip.new_status(self.my_device)
+            self._slot = 0
+
+    def _read_counter(self, idx):
+        if self._status is None:
+            return 0
+        host = self._status.cpu()                 # lazy synchronisation point
+        return int(host[idx:idx + 2].view(torch.int64).item())
+
+    def _write_counter(self, idx, value):
+        if self._status is None:
+            return
+        v = torch.tensor([int(value)], dtype=torch.int64).view(torch.int32)
+        self._status[idx:idx + 2] = v.to(self._status.device, non_blocking=True)
+
+    @property
+    def step_number(self):
+        return self._read_counter(hip.ST_STEP_NUMBER)
+
+    @step_number.setter
+    def step_number(self, value):
+        self._write_counter(hip.ST_STEP_NUMBER, value)
+
+    @property
+    def steps_since_action(self):
+        return self._read_counter(hip.ST_STEPS_SINCE_ACTION)
+
+    @steps_since_action.setter
+    def steps_since_action(self, value):
+        self._write_counter(hip.ST_STEPS_SINCE_ACTION, value)
+
+    @property
+    def master_resets(self):
+        """Number of whole-batch master resets so far (build-side diagnostic)."""
+        return self._read_counter(hip.ST_RESETS)
+
+    # ------------------------------------------------------------------ gym surface
+    def reset(self):
+        """All-dead universe, counters zeroed; returns the universe tensor itself (env.py:134-148)."""
+        hip.require_gpu()
+        self._check_domain()
+        self.universe = torch.zeros(self.instances, 1, self.height, self.width,
+                                    dtype=torch.float32, device=self.my_device)
+        self._ensure_status()
+        self._status.zero_()
+        self._slot = 0
+        self.instance_id = str(int(time.time()))
+        self.log = []
+        return self.universe
+
+    def get_observation(self):
+        return self.universe
+
+    def _device_action(self, action):
+        """Tensor conversion / rank padding / device move of env.py:152-159, then the centre crop
+        of an oversize action (env.py:164-169).  Returns (cropped fp32 action, was_cropped,
+        uncropped device action)."""
+        if not isinstance(action, torch.Tensor):
+            action = torch.as_tensor(action, dtype=torch.float32)
+        while action.dim() < 4:
+            action = action.unsqueeze(0)
+        if action.device != self.my_device:
+            action = action.to(self.my_device, non_blocking=True)
+        if action.dtype != torch.float32:
+            action = action.float()
+        full = action
+        cropped = False
+        if action.shape[3] > self.action_width and action.shape[1] < self.width:
+            off_y = (self.width - self.action_width) // 2
+            off_x = (self.height - self.action_height) // 2
+            action = action[:, :, off_y:action.shape[2] - off_y, off_x:action.shape[3] - off_x]
+            cropped = True
+        assert action.shape[2] == self.action_width, \
+            f"action width is wrong {action.shape[2]} not {self.action_width}, {tuple(action.shape)}"
+        assert action.shape[3] == self.action_height, \
+            f"action height is wrong {action.shape[3]} not {self.action_height}, {tuple(action.shape)}"
+        if action.shape[0] != self.instances:
+            if action.shape[0] != 1:
+                raise ValueError(f"action batch {action.shape[0]} != instances {self.instances}")
+            action = action.expand(self.instances, -1, -1, -1)   # broadcast like logical_xor
+        return action.contiguous(), cropped, full
+
+    def _device_universe(self):
+        u = self.universe
+        if u is None:
+            raise RuntimeError("call reset() before step()/apply_action()")
+        if not isinstance(u, torch.Tensor):
+            u = torch.as_tensor(u, dtype=torch.float32)
+        if u.dim() != 4 or tuple(u.shape) != (self.instances, 1, self.height, self.width):
+            raise ValueError(f"universe has shape {tuple(u.shape)}, expected "
+                             f"{(self.instances, 1, self.height, self.width)}")
+        if u.device != self.my_device or u.dtype != torch.float32 or not u.is_contiguous():
+            u = u.to(self.my_device, torch.float32).contiguous()
+        return u
+
+    def apply_action(self, action):
+        """Toggle only (env.py:150-182): universe <- 1.0 * xor(universe, pad(action)).
+
+        Stand-alone use of the reference method (``step`` fuses the toggle into the CA kernel);
+        runs the elementwise HIP kernel ``carle_ca_toggle_f32``.
+        """
+        hip.require_gpu()
+        self._check_domain()
+        a, _, _ = self._device_action(action)
+        u = self._device_universe()
+        out = torch.empty_like(u)
+        hip.ca_toggle_f32(u, a, out)
+        self.universe = out
+
+    def step(self, action):
+        """One environment step (env.py:188-242): toggle, master-reset check, one CA generation.
+
+        Returns ``(obs, reward, done, info)`` with ``obs is self.universe`` (N,1,H,W) fp32 on the
+        device, ``reward`` zeros (N,1) on the device, ``done`` zeros (N,1) on the CPU and
+        ``info`` a list of N dicts -- the reference's exact return structure (env.py:236-242).
+        """
+        hip.require_gpu()
+        self._check_domain()
+        self._ensure_status()
+        self.action = action
+        if self.logging:
+            self.log_universe()
+        u_in = self._device_universe()
+        act, cropped, full = self._device_action(action)
+        rule = self.rule_mask()
+        slot = self._slot
+        out = torch.empty_like(u_in)
+        reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
+        if cropped:
+            # the two whole-batch predicates are defined on the action AS PASSED (env.py:191,208);
+            # for an oversize action evaluate them on the uncropped tensor (cold path, no sync)
+            self._status[slot] = (full != 0).any().to(torch.int32)
+            self._status[2 + slot] = (full != 1).any().to(torch.int32)
+            hip.ca_step_f32(u_in, act, out, rule, None, slot)
+        else:
+            hip.ca_step_f32(u_in, act, out, rule, self._status, slot)
+        hip.ca_finish(out, reward, self._status, slot, True)
+        self._slot = slot ^ 1
+        self.universe = out
+        done = torch.zeros(self.instances, 1)
+        info = [{}] * self.instances
+        return self.universe, reward, done, info
+
+    # ------------------------------------------------------------------ cold helpers
+    def render(self):
+        rows = self.universe[0, 0].cpu()
+        print("\n CA Universe")
+        for r in rows:
+            print("".join("o" if v else " " for v in r.tolist()))
+
+    def log_universe(self):
+        raise NotImplementedError(
+            "universe logging (RLE, carle/env.py:466-491) is outside the hot path of this build")
+
+
+def _check_moore(module, incompatible_keys):
+    w = module.neighborhood.weight.detach().cpu().reshape(3, 3)
+    if not torch.equal(w, torch.tensor(_MOORE)):
+        raise NotImplementedError(
+            "loaded neighborhood.weight is not the Moore kernel; the HIP CA kernel implements "
+            "the Moore neighbourhood only (carle/env.py:95-96)")

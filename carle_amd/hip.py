@@ -1,0 +1,92 @@
+"""Thin tensor-level wrappers over the C ABI: pointer / stream plumbing only, no arithmetic.
+
+PyTorch is used for device memory and streams; every function here enqueues hand-written HIP
+kernels on torch's current stream of the tensors' device and returns without synchronising.
+"""
+import torch
+
+from . import _lib
+
+STATUS_WORDS = 16
+ST_LAST_RESET, ST_STEP_NUMBER, ST_STEPS_SINCE_ACTION, ST_RESETS = 4, 6, 8, 10
+
+
+def require_gpu(device=None):
+    if not torch.cuda.is_available():
+        raise _lib.CarleHipError(
+            "carle_amd needs a HIP device (MI355X): torch.cuda.is_available() is False and "
+            "there is no CPU fallback")
+    _lib.load()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk_grid(t, name, dtype):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous {dtype} tensor on a HIP device, got "
+                         f"{t.dtype} on {t.device}, contiguous={t.is_contiguous()}")
+
+
+def rule_mask(birth, survive):
+    """Lists of neighbour counts -> 18-bit mask (bit k survive, bit 9+k birth); the `elem ==
+    count` membership of carle/env.py:221-224 (values outside 0..8 can never match)."""
+    m = 0
+    for k in survive:
+        if k == int(k) and 0 <= int(k) <= 8:
+            m |= 1 << int(k)
+    for k in birth:
+        if k == int(k) and 0 <= int(k) <= 8:
+            m |= 1 << (9 + int(k))
+    return m
+
+
+def new_status(device):
+    """Zeroed per-environment status block (layout: include/carle_hip.h CARLE_ST_*)."""
+    return torch.zeros(STATUS_WORDS, dtype=torch.int32, device=device)
+
+
+def ca_step_f32(u_in, action, u_out, rule, status=None, slot=0):
+    """u_out <- one generation of (u_in XOR centred action); all (N,1,H,W)/(N,1,AH,AW) fp32."""
+    lib = _lib.load()
+    _chk_grid(u_in, "u_in", torch.float32)
+    _chk_grid(u_out, "u_out", torch.float32)
+    n, _, h, w = u_in.shape
+    if u_out.shape != u_in.shape:
+        raise ValueError("u_out shape differs from u_in")
+    ap, ah, aw = None, 0, 0
+    if action is not None:
+        _chk_grid(action, "action", torch.float32)
+        if action.shape[0] != n:
+            raise ValueError("action batch differs from universe batch")
+        ah, aw = action.shape[2], action.shape[3]
+        ap = action.data_ptr()
+    sp = status.data_ptr() if status is not None else None
+    with torch.cuda.device(u_in.device):
+        rc = lib.carle_ca_step_f32(u_in.data_ptr(), ap, u_out.data_ptr(), n, h, w, ah, aw, rule,
+                                   sp, slot, _stream(u_in))
+    _lib.check(rc, "carle_ca_step_f32")
+
+
+def ca_finish(u_out, reward, status, slot, has_action):
+    lib = _lib.load()
+    n = u_out.shape[0]
+    rp = reward.data_ptr() if reward is not None else None
+    with torch.cuda.device(u_out.device):
+        rc = lib.carle_ca_finish(u_out.data_ptr(), u_out.numel() * u_out.element_size(), rp, n,
+                                 status.data_ptr(), slot, 1 if has_action else 0, _stream(u_out))
+    _lib.check(rc, "carle_ca_finish")
+
+
+def ca_toggle_f32(u_in, action, u_out):
+    """u_out <- (u_in != 0) XOR centred (action != 0); stand-alone CARLE.apply_action."""
+    lib = _lib.load()
+    _chk_grid(u_in, "u_in", torch.float32)
+    _chk_grid(u_out, "u_out", torch.float32)
+    _chk_grid(action, "action", torch.float32)
+    n, _, h, w = u_in.shape
+    with torch.cuda.device(u_in.device):
+        rc = lib.carle_ca_toggle_f32(u_in.data_ptr(), action.data_ptr(), u_out.data_ptr(), n, h, w,
+                                     action.shape[2], action.shape[3], _stream(u_in))
+    _lib.check(rc, "carle_ca_toggle_f32")

@@ -1,0 +1,105 @@
+/*
+ * carle_hip.h -- C ABI of libcarle_hip.so, the MI355X (gfx950) hot path of CARLE.
+ *
+ * The reference (riveSunder/carle) is pure Python/PyTorch and has no FFI of its own; the
+ * interface each entry point replaces is therefore a Python method of the reference, cited as
+ * file:line next to every declaration.  INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions (all entry points)
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer on the current HIP
+ *     device, owned by the caller, contiguous, 16-byte aligned.  The library allocates no
+ *     persistent device memory and keeps no global mutable state (thread-local error text only).
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); no host
+ *     synchronisation inside; safe from several host threads on different streams.
+ *   - return 0 on success; a POSITIVE value is an argument error (CARLE_E_*); a NEGATIVE value
+ *     is -(hipError_t).  carle_last_error() returns the message of the calling thread.
+ *   - grids are (N,1,H,W) row-major; the action window (N,1,AH,AW) is centred at row offset
+ *     (H-AH)/2 and column offset (W-AW)/2 (carle/env.py:119-132).
+ *   - `rule` = 18-bit mask: bit k (k=0..8) = a live cell with k live neighbours survives,
+ *     bit 9+k = a dead cell with k live neighbours is born (carle/env.py:221-227).
+ */
+#ifndef CARLE_HIP_H
+#define CARLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CARLE_ABI_VERSION 1
+
+/* argument error codes (positive return values) */
+#define CARLE_E_NULL      1   /* required pointer is NULL */
+#define CARLE_E_DIMS      2   /* unsupported / inconsistent N,H,W,AH,AW */
+#define CARLE_E_RULE      3   /* rule mask has bits above bit 17 */
+#define CARLE_E_ALIGN     4   /* pointer not 16-byte aligned */
+#define CARLE_E_ALIAS     5   /* u_in and u_out overlap */
+#define CARLE_E_FORMAT    6   /* unknown grid format */
+
+/* grid storage formats */
+#define CARLE_FMT_F32 0   /* float32 per cell, any non-zero = alive (the reference's format)  */
+#define CARLE_FMT_U8  1   /* uint8 per cell, any non-zero = alive                              */
+#define CARLE_FMT_B1  2   /* 1 bit per cell: W/64 little-endian uint64 words per row, bit j of
+                             word i = column 64*i+j; requires W % 64 == 0                     */
+
+/* Layout of the per-environment device status block (int32[16], zero-initialised by the
+ * caller once).  Two flag slots alternate between consecutive steps (slot = step parity). */
+#define CARLE_ST_ANY_NONZERO(slot)   (0 + (slot))   /* some action element != 0   (env.py:191) */
+#define CARLE_ST_NOT_ALL_ONES(slot)  (2 + (slot))   /* some action element != 1.0 (env.py:208) */
+#define CARLE_ST_LAST_RESET          4              /* 1 if the last finished step was a master reset */
+#define CARLE_ST_STEP_NUMBER         6              /* int64 at int32 index 6..7  (env.py:142,230) */
+#define CARLE_ST_STEPS_SINCE_ACTION  8              /* int64 at int32 index 8..9  (env.py:145,200) */
+#define CARLE_ST_RESETS              10             /* int64 at int32 index 10..11: number of master resets */
+#define CARLE_ST_WORDS               16
+
+int         carle_abi_version(void);
+const char *carle_last_error(void);
+/* "gfx950" etc.: the offload architectures compiled into the library */
+const char *carle_build_arch(void);
+
+/*
+ * One CA generation, fp32 drop-in format.  Replaces CARLE.apply_action + the update branch of
+ * CARLE.step (carle/env.py:150-182, 219-229): u_out = rule(count3x3_torus(u_in XOR pad(action))).
+ *   u_in, u_out  N*H*W floats; must not alias.  Any non-zero u_in value counts as alive; u_out
+ *                holds exactly 0.0f / 1.0f.
+ *   action       N*AH*AW floats or NULL (= no toggles; AH/AW ignored).  Any non-zero toggles.
+ *   status       NULL, or the status block: the kernel sets ANY_NONZERO(slot) if some action
+ *                element is non-zero and NOT_ALL_ONES(slot) if some element differs from 1.0f.
+ *                The generation is ALWAYS computed; the master reset (env.py:208-216) is applied
+ *                afterwards by carle_ca_finish().
+ * Supported: square even grids H == W >= 2, AH == AW <= H with (H-AH) even (the reference's
+ * consistent domain, env.py:119-132).  64x64 grids with AW % 8 == 0 (and 256/512 grids, see
+ * DESIGN.md) take the wavefront-per-strip fast path; everything else a generic kernel.
+ */
+int carle_ca_step_f32(const float *u_in, const float *action, float *u_out,
+                      int64_t n, int h, int w, int ah, int aw, uint32_t rule,
+                      int32_t *status, int slot, void *stream);
+
+/*
+ * Toggle only: u_out = (u_in != 0) XOR pad(action != 0), as 0.0f/1.0f.  Replaces a stand-alone
+ * call of CARLE.apply_action (carle/env.py:150-182); CARLE.step uses the fused kernel above.
+ * u_out may alias u_in (elementwise).
+ */
+int carle_ca_toggle_f32(const float *u_in, const float *action, float *u_out,
+                        int64_t n, int h, int w, int ah, int aw, void *stream);
+
+/*
+ * Completes a step started by carle_ca_step_*: applies the whole-batch master reset of
+ * CARLE.step (carle/env.py:208-216) and maintains the counters (env.py:142-145,200,230).
+ *   if has_action and NOT_ALL_ONES(slot) == 0  ->  u_out := 0 (all instances), step_number := 0,
+ *                                                   steps_since_action := 0, resets += 1
+ *   else                                        ->  step_number += 1
+ *   if ANY_NONZERO(slot) == 0 (or no action)    ->  steps_since_action += 1   (before the reset)
+ *   reward[0..n) := 0.0f  (the fresh zero reward of env.py:238; may be NULL)
+ *   flag slot (slot ^ 1) is cleared for the next step.
+ * `u_out_bytes` is the size of the output grid buffer in bytes (any format).
+ */
+int carle_ca_finish(void *u_out, int64_t u_out_bytes, float *reward, int64_t n,
+                    int32_t *status, int slot, int has_action, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARLE_HIP_H */

@@ -1,0 +1,201 @@
+"""GPU parity tests for the CA step: the HIP path (through the C ABI) against
+  (1) every golden case recorded from the genuine reference (tests/golden/ca_cases.npz),
+  (2) the RNG-free known answers (ca_known.json),
+  (3) the CPU oracle (oracle/ca_oracle.c) on seeded random inputs at awkward batch sizes,
+  (4) size-independent properties at BASELINE.json's full size (N=4096, 64x64).
+Bit-exact everywhere (integer/boolean work carried in fp32)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from oracle import ca as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(**kw):
+    from carle_amd.env import CARLE
+    return CARLE(device="cuda:0", **kw)
+
+
+@pytest.mark.parametrize("name", G.ca_case_names())
+def test_env_replays_golden_case(name):
+    c = G.ca_case(name)
+    env = _env(width=c.size, height=c.size, action_width=c.asize, action_height=c.asize,
+               instances=c.n)
+    env.birth, env.survive = list(c.birth), list(c.survive)
+    env.reset()
+    env.universe = torch.from_numpy(c.init.copy()).cuda()
+    rec = 0
+    for t in range(c.steps):
+        a = torch.from_numpy(c.actions[t].copy())
+        if t % 2:
+            a = a.cuda()                      # actions arrive from the CPU or the device
+        obs, reward, done, info = env.step(a)
+        assert obs is env.universe and obs.is_cuda and obs.dtype == torch.float32
+        assert tuple(reward.shape) == (c.n, 1) and reward.is_cuda
+        assert tuple(done.shape) == (c.n, 1) and not done.is_cuda and len(info) == c.n
+        if (t + 1) in c.record:
+            got = obs.cpu().numpy()
+            assert np.array_equal(got, c.obs[rec]), f"grid mismatch at step {t + 1}"
+            assert float(reward.abs().sum()) == 0.0
+            assert env.step_number == c.step_number[t]
+            assert env.steps_since_action == c.steps_since_action[t]
+            rec += 1
+    assert rec == len(c.record)
+
+
+def _pops(cells, birth, survive, at):
+    env = _env(width=64, height=64)
+    env.birth, env.survive = birth, survive
+    env.reset()
+    a = torch.zeros(1, 1, 64, 64)
+    for r, c in cells:
+        a[0, 0, r, c] = 1.0
+    z = torch.zeros(1, 1, 64, 64, device="cuda")
+    res = {}
+    for t in range(1, max(at) + 1):
+        obs = env.step(a if t == 1 else z)[0]
+        if t in at:
+            res[str(t)] = int(obs.sum().item())
+    return res, env
+
+
+def test_known_answers():
+    k = G.known()
+    at = [1, 2, 3, 4, 11, 51, 101, 256]
+    res, env = _pops(k["glider_cells"], [3], [2, 3], at)
+    assert res == k["glider_life_pop"] and env.step_number == k["glider_life_step_number"]
+    assert _pops(k["rpent_cells"], [3], [2, 3], at)[0] == k["rpent_life_pop"]
+    assert _pops(k["rpent_cells"], [3, 6], [2, 3], at)[0] == k["rpent_highlife_pop"]
+    assert _pops(k["puffer_cells"], [3, 6, 8], [2, 4, 5], at)[0] == k["puffer_morley_pop"]
+    for key_in, key_out in (("seam_in", "seam_out"), ("seam2_in", "seam2_out")):
+        env = _env(width=64, height=64)
+        env.reset()
+        a = torch.zeros(1, 1, 64, 64)
+        for r, c in k[key_in]:
+            a[0, 0, r, c] = 1.0
+        obs = env.step(a)[0]
+        assert obs[0, 0].nonzero().cpu().tolist() == k[key_out]
+
+
+def test_master_reset_and_counters():
+    k = G.known()["master_reset"]
+    env = _env(width=64, height=64, instances=2)
+    env.reset()
+    env.step((torch.rand(2, 1, 64, 64) < 0.3).float())
+    env.step(torch.zeros(2, 1, 64, 64))
+    assert env.step_number == k["step_number_before"] and env.steps_since_action == 1
+    obs = env.step(torch.ones(2, 1, 64, 64))[0]
+    assert float(obs.sum()) == k["obs_sum"]
+    assert env.step_number == k["step_number_after"]
+    assert env.steps_since_action == k["steps_since_action_after"]
+    assert env.master_resets == 1
+    # the reference's own test (tests/test_env.py:42-67)
+    env = _env()
+    reset_obs = env.reset()
+    action = torch.ones(env.instances, 1, env.action_height, env.action_width)
+    toggle_obs = env.step(action)[0]
+    action[:, :, 0:10, 0:10] = 0.0
+    normal_obs = env.step(action)[0]
+    assert toggle_obs.mean().item() == 0.0 and reset_obs.mean().item() == 0.0
+    assert (1.0 * (reset_obs == toggle_obs)).mean().item() == 1.0
+    assert (1.0 * (toggle_obs == normal_obs)).mean().item() != 1.0
+
+
+@pytest.mark.parametrize("n,size,asize,rule", [
+    (1, 64, 64, ([3], [2, 3])), (5, 64, 64, ([3, 6], [2, 3])), (37, 64, 64, ([3, 6, 8], [2, 4, 5])),
+    (7, 64, 32, ([3], [2, 3])), (3, 64, 48, ([1, 3, 5, 7], [0, 2, 4, 6, 8])), (2, 64, 62, ([3], [2, 3])),
+    (3, 128, 64, ([3], [2, 3])), (2, 256, 64, ([3, 6], [2, 3])), (1, 512, 64, ([3], [2, 3])),
+    (2, 20, 10, ([3], [2, 3])), (1, 2, 2, ([1], [1])), (3, 66, 64, ([2], [])),
+])
+def test_abi_against_oracle_random(n, size, asize, rule):
+    """carle_ca_step_f32 called directly (no env) vs the C oracle, with and without action."""
+    from carle_amd import hip
+    rng = np.random.default_rng(n * 1000 + size)
+    mask = O.rule_mask(*rule)
+    u = (rng.random((n, 1, size, size)) < 0.4).astype(np.float32)
+    u[u != 0] = rng.choice(np.array([1.0, 2.0, -3.5, np.nan, 1e-40], np.float32), int((u != 0).sum()))
+    a = (rng.random((n, 1, asize, asize)) < 0.2).astype(np.float32)
+    a[a != 0] = rng.choice(np.array([1.0, 0.5, -1.0, np.inf], np.float32), int((a != 0).sum()))
+    a[0, 0, 0, 0] = -0.0
+    d_u, d_a = torch.from_numpy(u).cuda(), torch.from_numpy(a).cuda()
+    out = torch.empty_like(d_u)
+    st = hip.new_status("cuda:0")
+    for act_np, act_d in ((a, d_a), (None, None)):
+        exp, _, flags = O.c_env_step(u, act_np, mask)
+        out.fill_(7.0)
+        st.zero_()
+        hip.ca_step_f32(d_u, act_d, out, mask, st, 1)
+        assert np.array_equal(out.cpu().numpy(), exp)
+        if act_np is not None:
+            s = st.cpu().tolist()
+            assert s[1] == 1 and s[3] == 1 and s[0] == 0 and s[2] == 0   # slot 1 only
+
+
+def test_full_size_properties():
+    """BASELINE configs[1]: N=4096, 64x64, B3/S23.  Size-independent checks + sampled oracle."""
+    from carle_amd import hip
+    n = 4096
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    u = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.5).float()
+    a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) <= 0.1).float()
+    life = O.rule_mask([3], [2, 3])
+    out = torch.empty_like(u)
+    hip.ca_step_f32(u, a, out, life, None, 0)
+    # (1) sampled instances against the oracle
+    idx = [0, 1, 2047, 2048, 4094, 4095, 777]
+    exp, _, _ = O.c_env_step(u[idx].cpu().numpy(), a[idx].cpu().numpy(), life)
+    assert np.array_equal(out[idx].cpu().numpy(), exp)
+    # (2) batch-permutation equivariance: instances are independent
+    perm = torch.randperm(n, device="cuda", generator=g)
+    out_p = torch.empty_like(u)
+    hip.ca_step_f32(u[perm].contiguous(), a[perm].contiguous(), out_p, life, None, 0)
+    assert torch.equal(out_p, out[perm])
+    # (3) translation equivariance on the torus (rolls commute with the step)
+    out_r = torch.empty_like(u)
+    hip.ca_step_f32(torch.roll(u, (5, -9), (2, 3)).contiguous(),
+                    torch.roll(a, (5, -9), (2, 3)).contiguous(), out_r, life, None, 0)
+    assert torch.equal(out_r, torch.roll(out, (5, -9), (2, 3)))
+    # (4) toggling twice is the identity: step(u ^ a, a) == step(u, 0)
+    ua = torch.logical_xor(u, a).float()
+    o1, o2 = torch.empty_like(u), torch.empty_like(u)
+    hip.ca_step_f32(ua, a, o1, life, None, 0)
+    hip.ca_step_f32(u, None, o2, life, None, 0)
+    assert torch.equal(o1, o2)
+    # (5) output alphabet
+    assert set(torch.unique(out).cpu().tolist()) <= {0.0, 1.0}
+    # (6) rule B012345678/S012345678 -> all alive; empty rule -> all dead
+    hip.ca_step_f32(u, a, out, (1 << 18) - 1, None, 0)
+    assert float(out.min()) == 1.0
+    hip.ca_step_f32(u, a, out, 0, None, 0)
+    assert float(out.max()) == 0.0
+
+
+def test_apply_action_standalone():
+    env = _env(width=256, height=256, instances=2)
+    env.reset()
+    u = (torch.rand(2, 1, 256, 256) < 0.5).float()
+    a = (torch.rand(2, 1, 64, 64) < 0.5).float()
+    env.universe = u.clone()
+    env.apply_action(a)
+    exp = O.np_apply_action(u.numpy(), a.numpy()).astype(np.float32)
+    assert np.array_equal(env.universe.cpu().numpy(), exp)
+
+
+def test_action_forms():
+    """2-D / 3-D / broadcast actions (env.py:152-156) and the 2-D known answer."""
+    k = G.known()
+    env = _env(width=64, height=64)
+    env.reset()
+    a2 = torch.zeros(64, 64)
+    a2[10, 10:13] = 1
+    assert env.step(a2)[0][0, 0].nonzero().cpu().tolist() == k["action_2d_out"]
+    env = _env(width=64, height=64, instances=3)
+    env.reset()
+    obs = env.step(a2.unsqueeze(0))[0]          # (1,64,64) broadcast over 3 instances
+    for i in range(3):
+        assert obs[i, 0].nonzero().cpu().tolist() == k["action_2d_out"]
+    with pytest.raises(AssertionError):
+        env.step(torch.zeros(3, 1, 32, 32))
