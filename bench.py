@@ -48,7 +48,15 @@ def parse():
 def cpu_baseline(size, rule, seconds):
     """Port of the reference step (oracle/torch_port.py) on the host cores, bounded sample."""
     from oracle.torch_port import TorchPortEnv
-    cores = os.cpu_count() or 1
+    # the threads this process may actually run on (a 1-GPU box exposes a CPU share, not all cores)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:        # cgroup v2 CPU quota ("1600000 100000" = 16 CPUs): more threads only thrash
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(cores, int(os.environ.get("CARLE_CPU_THREADS", cores))))
     torch.set_num_threads(cores)
     n = 256
     b, s = rule

@@ -72,7 +72,7 @@ extern "C" int carle_ca_finish(void *u_out, int64_t u_out_bytes, float *reward, 
     const int64_t n16 = u_out_bytes / 16;
     const int tail = (int)(u_out_bytes % 16);
     // small fixed grid: in the common (no reset) case every block exits after one flag load
-    hipLaunchKernelGGL(ca_finish_kernel, dim3(128), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(ca_finish_kernel, dim3(32), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<uint4 *>(u_out), n16,
                        reinterpret_cast<unsigned char *>(u_out) + n16 * 16, tail, reward, n, status,
                        slot, (n > 0 && has_action) ? 1 : 0);
