@@ -1,0 +1,376 @@
+// nets_staged.hip -- RND2D / AE2D forward passes (eval mode) as staged HIP kernels, any
+// H == W that is a multiple of 8.  fp32 direct convolution; intermediates live in a
+// caller-provided workspace.  This is the size-general path; 64x64 grids take the fused
+// LDS kernels of nets_fused.hip.
+//
+// Networks (riveSunder/carle, carle/mcl.py; Dropout = identity in eval mode):
+//   RND2D predictor  mcl.py:262-276  conv(1->4,3x3,p1) relu pool2 pool2 conv(4->1,3x3,p1) relu pool2
+//                                    flatten linear(D->16) tanh,   D = (H/8)(W/8)
+//   RND2D random     mcl.py:285-296  conv(1->2) relu pool2 pool2 conv(2->1) relu pool2 flatten linear tanh
+//   RND2D bonus      mcl.py:343-352  mean_k (target_k - prediction_k)^2
+//   AE2D predictor   mcl.py:452-467  conv(1->4) relu pool2 conv(4->2) relu pool2
+//                                    convT(2->1,k4,s2,p1) relu convT(1->1,k4,s2,p1) sigmoid
+//   AE2D bonus       mcl.py:504-512  mean_{h,w} (obs - prediction)^2
+// relu and max-pool commute, and two stacked 2x2 pools are one 4x4 pool.
+//
+// Parameter blobs (flat fp32, state_dict order of each nn.Sequential):
+//   RND predictor: conv1.w[4][1][3][3] conv1.b[4] conv2.w[1][4][3][3] conv2.b[1] lin.w[16][D] lin.b[16]
+//   RND random   : conv1.w[2][1][3][3] conv1.b[2] conv2.w[1][2][3][3] conv2.b[1] lin.w[16][D] lin.b[16]
+//   AE predictor : conv1.w[4][1][3][3] b[4] conv2.w[2][4][3][3] b[2] convT1.w[2][1][4][4] b[1]
+//                  convT2.w[1][1][4][4] b[1]                                          (164 floats)
+#include "common.hpp"
+
+namespace carle {
+
+static constexpr int kRndDim = 16;
+
+// ---------------------------------------------------------------------------------------------
+// RND2D stage 1: conv1 (6 channels: 4 predictor + 2 random) + relu + 4x4 max-pool
+// one thread per (grid, pooled pixel)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rnd_conv1_pool4_kernel(
+    const float *__restrict__ obs, const float *__restrict__ pp, const float *__restrict__ rp,
+    float *__restrict__ ws1, int64_t n, int h, int w) {
+    const int h4 = h >> 2, w4 = w >> 2;
+    const int64_t total = n * (int64_t)h4 * w4;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int px = (int)(idx % w4), py = (int)((idx / w4) % h4);
+    const int64_t g = idx / ((int64_t)h4 * w4);
+    const float *go = obs + g * (int64_t)h * w;
+    float patch[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int y = 4 * py - 1 + r;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int x = 4 * px - 1 + c;
+            patch[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? go[y * w + x] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 6; ++ch) {
+        const float *wt = ch < 4 ? pp + ch * 9 : rp + (ch - 4) * 9;
+        const float bias = ch < 4 ? pp[36 + ch] : rp[18 + (ch - 4)];
+        float k[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) k[t] = wt[t];
+        float m = 0.0f;                                   // relu floor
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        acc = fmaf(k[ky * 3 + kx], patch[dy + ky][dx + kx], acc);
+                m = fmaxf(m, acc + bias);
+            }
+        ws1[((g * 6 + ch) * h4 + py) * (int64_t)w4 + px] = m;
+    }
+}
+
+// RND2D stage 2: conv2 (C->1, 3x3, zero pad) + relu + 2x2 max-pool; thread per (grid, net, F pixel)
+__global__ __launch_bounds__(256) void rnd_conv2_pool2_kernel(
+    const float *__restrict__ ws1, const float *__restrict__ pp, const float *__restrict__ rp,
+    float *__restrict__ ws2, int64_t n, int h, int w) {
+    const int h4 = h >> 2, w4 = w >> 2, h8 = h >> 3, w8 = w >> 3;
+    const int d = h8 * w8;
+    const int64_t total = n * 2 * (int64_t)d;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int fx = (int)(idx % w8), fy = (int)((idx / w8) % h8);
+    const int net = (int)((idx / d) % 2);                 // 0 = predictor, 1 = random
+    const int64_t g = idx / (2 * (int64_t)d);
+    const int nch = net == 0 ? 4 : 2, chbase = net == 0 ? 0 : 4;
+    const float *wt = net == 0 ? pp + 40 : rp + 20;       // conv2.w
+    const float bias = net == 0 ? pp[76] : rp[38];        // conv2.b
+    float o[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int c = 0; c < nch; ++c) {
+        const float *pl = ws1 + (g * 6 + chbase + c) * (int64_t)h4 * w4;
+        float patch[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = 2 * fy - 1 + r;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int x = 2 * fx - 1 + cc;
+                patch[r][cc] = (y >= 0 && y < h4 && x >= 0 && x < w4) ? pl[y * w4 + x] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+            for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        o[oy][ox] = fmaf(wt[c * 9 + ky * 3 + kx], patch[oy + ky][ox + kx], o[oy][ox]);
+    }
+    const float m = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1])) + bias;
+    ws2[(g * 2 + net) * (int64_t)d + fy * w8 + fx] = fmaxf(m, 0.0f);
+}
+
+// RND2D stage 3: linear(D->16) + tanh for both nets, bonus = mean_k (t_k - p_k)^2
+// one wavefront per grid: lane = (net, k, quarter of D); quarters reduced by shuffles
+__global__ __launch_bounds__(64) void rnd_linear_bonus_kernel(
+    const float *__restrict__ ws2, const float *__restrict__ pp, const float *__restrict__ rp,
+    float *__restrict__ bonus, float *__restrict__ pred_out, float *__restrict__ target_out,
+    int64_t n, int d) {
+    const int64_t g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int quarter = lane & 1, k = (lane >> 1) & 15, net = lane >> 5;   // 2 partials per output
+    const float *f = ws2 + (g * 2 + net) * (int64_t)d;
+    const float *lw = (net == 0 ? pp + 77 : rp + 39) + (int64_t)k * d;
+    const float *lb = (net == 0 ? pp + 77 : rp + 39) + (int64_t)kRndDim * d;
+    float acc = 0.0f;
+    for (int i = quarter; i < d; i += 2) acc = fmaf(lw[i], f[i], acc);
+    acc += __shfl_xor(acc, 1, 64);
+    const float out = tanhf(acc + lb[k]);
+    if (quarter == 0) {
+        if (net == 0 && pred_out) pred_out[g * kRndDim + k] = out;
+        if (net == 1 && target_out) target_out[g * kRndDim + k] = out;
+    }
+    const float other = __shfl_xor(out, 32, 64);          // same k, other net
+    float sq = (out - other) * (out - other);             // identical on both nets' lanes
+    // sum over k within lanes 0..31 (each k appears on two lanes: quarter 0/1 -> halve)
+#pragma unroll
+    for (int s = 2; s < 32; s <<= 1) sq += __shfl_xor(sq, s, 64);
+    if (lane == 0) bonus[g] = sq * (1.0f / kRndDim);
+}
+
+// ---------------------------------------------------------------------------------------------
+// AE2D stage 1: conv1 (1->4) + relu + 2x2 pool; thread per (grid, A1 pixel)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ae_conv1_pool2_kernel(
+    const float *__restrict__ obs, const float *__restrict__ ap, float *__restrict__ a1,
+    int64_t n, int h, int w) {
+    const int h2 = h >> 1, w2 = w >> 1;
+    const int64_t total = n * (int64_t)h2 * w2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int px = (int)(idx % w2), py = (int)((idx / w2) % h2);
+    const int64_t g = idx / ((int64_t)h2 * w2);
+    const float *go = obs + g * (int64_t)h * w;
+    float patch[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = 2 * py - 1 + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int x = 2 * px - 1 + c;
+            patch[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? go[y * w + x] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        float m = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        acc = fmaf(ap[ch * 9 + ky * 3 + kx], patch[dy + ky][dx + kx], acc);
+                m = fmaxf(m, acc + ap[36 + ch]);
+            }
+        a1[((g * 4 + ch) * h2 + py) * (int64_t)w2 + px] = m;
+    }
+}
+
+// AE2D stage 2: conv2 (4->2) + relu + 2x2 pool; thread per (grid, A2 pixel), both channels
+__global__ __launch_bounds__(256) void ae_conv2_pool2_kernel(
+    const float *__restrict__ a1, const float *__restrict__ ap, float *__restrict__ a2,
+    int64_t n, int h, int w) {
+    const int h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
+    const int64_t total = n * (int64_t)h4 * w4;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int px = (int)(idx % w4), py = (int)((idx / w4) % h4);
+    const int64_t g = idx / ((int64_t)h4 * w4);
+    const float *wt = ap + 40;                            // conv2.w[2][4][3][3]
+    float o[2][2][2] = {};
+    for (int c = 0; c < 4; ++c) {
+        const float *pl = a1 + (g * 4 + c) * (int64_t)h2 * w2;
+        float patch[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = 2 * py - 1 + r;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int x = 2 * px - 1 + cc;
+                patch[r][cc] = (y >= 0 && y < h2 && x >= 0 && x < w2) ? pl[y * w2 + x] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            o[oc][oy][ox] = fmaf(wt[(oc * 4 + c) * 9 + ky * 3 + kx],
+                                                 patch[oy + ky][ox + kx], o[oc][oy][ox]);
+    }
+#pragma unroll
+    for (int oc = 0; oc < 2; ++oc) {
+        const float m = fmaxf(fmaxf(o[oc][0][0], o[oc][0][1]), fmaxf(o[oc][1][0], o[oc][1][1])) +
+                        ap[112 + oc];
+        a2[((g * 2 + oc) * h4 + py) * (int64_t)w4 + px] = fmaxf(m, 0.0f);
+    }
+}
+
+// transposed conv k4 s2 p1: output row y takes input rows iy with ky = y + 1 - 2*iy in [0,3]:
+//   y even (2m):   (iy=m, ky=1), (iy=m-1, ky=3);   y odd (2m+1): (iy=m, ky=2), (iy=m+1, ky=0)
+__device__ __forceinline__ void convt_taps(int y, int &i0, int &k0, int &i1, int &k1) {
+    const int m = y >> 1;
+    if (y & 1) { i0 = m; k0 = 2; i1 = m + 1; k1 = 0; }
+    else       { i0 = m; k0 = 1; i1 = m - 1; k1 = 3; }
+}
+
+// AE2D stage 3: convT1 (2->1) + relu; thread per (grid, A3 pixel), A3 is (H/2 x W/2)
+__global__ __launch_bounds__(256) void ae_convt1_kernel(
+    const float *__restrict__ a2, const float *__restrict__ ap, float *__restrict__ a3,
+    int64_t n, int h, int w) {
+    const int h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
+    const int64_t total = n * (int64_t)h2 * w2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % w2), y = (int)((idx / w2) % h2);
+    const int64_t g = idx / ((int64_t)h2 * w2);
+    const float *wt = ap + 114;                           // convT1.w[2][1][4][4]
+    int iy[2], ky[2], ix[2], kx[2];
+    convt_taps(y, iy[0], ky[0], iy[1], ky[1]);
+    convt_taps(x, ix[0], kx[0], ix[1], kx[1]);
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float *pl = a2 + (g * 2 + c) * (int64_t)h4 * w4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                if (iy[a] >= 0 && iy[a] < h4 && ix[b] >= 0 && ix[b] < w4)
+                    acc = fmaf(pl[iy[a] * w4 + ix[b]], wt[c * 16 + ky[a] * 4 + kx[b]], acc);
+    }
+    a3[idx] = fmaxf(acc + ap[146], 0.0f);
+}
+
+// AE2D stage 4: convT2 (1->1) + sigmoid, squared error against obs, mean over the grid.
+// one 256-thread block per grid, deterministic tree reduction.
+__global__ __launch_bounds__(256) void ae_convt2_mse_kernel(
+    const float *__restrict__ obs, const float *__restrict__ a3, const float *__restrict__ ap,
+    float *__restrict__ bonus, float *__restrict__ recon, int64_t n, int h, int w) {
+    __shared__ float red[256];
+    const int h2 = h >> 1, w2 = w >> 1;
+    const int64_t g = blockIdx.x;
+    const float *wt = ap + 147;                           // convT2.w[1][1][4][4]
+    const float bias = ap[163];
+    const float *pl = a3 + g * (int64_t)h2 * w2;
+    const float *go = obs + g * (int64_t)h * w;
+    float sum = 0.0f;
+    for (int p = threadIdx.x; p < h * w; p += 256) {
+        const int x = p % w, y = p / w;
+        int iy[2], ky[2], ix[2], kx[2];
+        convt_taps(y, iy[0], ky[0], iy[1], ky[1]);
+        convt_taps(x, ix[0], kx[0], ix[1], kx[1]);
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                if (iy[a] >= 0 && iy[a] < h2 && ix[b] >= 0 && ix[b] < w2)
+                    acc = fmaf(pl[iy[a] * w2 + ix[b]], wt[ky[a] * 4 + kx[b]], acc);
+        const float pr = 1.0f / (1.0f + expf(-(acc + bias)));
+        if (recon) recon[g * (int64_t)h * w + p] = pr;
+        const float df = go[p] - pr;
+        sum = fmaf(df, df, sum);
+    }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bonus[g] = red[0] / (float)(h * w);
+}
+
+static inline int check_net_dims(int64_t n, int h, int w, const char *who) {
+    if (n < 0 || h != w || h < 8 || (h % 8) != 0) {
+        static thread_local char buf[160];
+        snprintf(buf, sizeof buf, "%s: grids must be square with H == W a multiple of 8", who);
+        return fail_arg(CARLE_E_DIMS, buf);
+    }
+    return 0;
+}
+
+static inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace carle
+
+using namespace carle;
+
+extern "C" int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w) {
+    if (n < 0 || h < 8 || w < 8) return 0;
+    return n * (6 * (int64_t)(h / 4) * (w / 4) + 2 * (int64_t)(h / 8) * (w / 8));
+}
+
+extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
+                                     const float *pred_params, const float *rand_params,
+                                     float *workspace, float *bonus, float *pred_out,
+                                     float *target_out, void *stream) {
+    if (!obs || !pred_params || !rand_params || !workspace || !bonus)
+        return fail_arg(CARLE_E_NULL, "carle_rnd2d_bonus_f32: NULL pointer");
+    if (int e = check_net_dims(n, h, w, "carle_rnd2d_bonus_f32")) return e;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t p1 = n * (int64_t)(h / 4) * (w / 4);
+    const int d = (h / 8) * (w / 8);
+    if (p1 * 6 / 256 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_rnd2d_bonus_f32: batch too large");
+    float *ws1 = workspace, *ws2 = workspace + 6 * p1;
+    hipLaunchKernelGGL(rnd_conv1_pool4_kernel, dim3(blocks_for(p1)), dim3(256), 0, s, obs,
+                       pred_params, rand_params, ws1, n, h, w);
+    hipLaunchKernelGGL(rnd_conv2_pool2_kernel, dim3(blocks_for(n * 2 * (int64_t)d)), dim3(256), 0, s,
+                       ws1, pred_params, rand_params, ws2, n, h, w);
+    hipLaunchKernelGGL(rnd_linear_bonus_kernel, dim3((unsigned)n), dim3(64), 0, s, ws2, pred_params,
+                       rand_params, bonus, pred_out, target_out, n, d);
+    return check_launch("carle_rnd2d_bonus_f32");
+}
+
+extern "C" int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w) {
+    if (n < 0 || h < 8 || w < 8) return 0;
+    const int64_t q = (int64_t)(h / 2) * (w / 2);
+    return n * (4 * q + 2 * (q / 4) + q);                 // A1 (4ch) + A2 (2ch) + A3
+}
+
+extern "C" int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float *params,
+                                    float *workspace, float *bonus, float *recon_out,
+                                    void *stream) {
+    if (!obs || !params || !workspace || !bonus)
+        return fail_arg(CARLE_E_NULL, "carle_ae2d_bonus_f32: NULL pointer");
+    if (int e = check_net_dims(n, h, w, "carle_ae2d_bonus_f32")) return e;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t q = (int64_t)(h / 2) * (w / 2);
+    if (n * q / 256 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ae2d_bonus_f32: batch too large");
+    float *a1 = workspace, *a2 = a1 + n * 4 * q, *a3 = a2 + n * 2 * (q / 4);
+    hipLaunchKernelGGL(ae_conv1_pool2_kernel, dim3(blocks_for(n * q)), dim3(256), 0, s, obs, params,
+                       a1, n, h, w);
+    hipLaunchKernelGGL(ae_conv2_pool2_kernel, dim3(blocks_for(n * (q / 4))), dim3(256), 0, s, a1,
+                       params, a2, n, h, w);
+    hipLaunchKernelGGL(ae_convt1_kernel, dim3(blocks_for(n * q)), dim3(256), 0, s, a2, params, a3, n,
+                       h, w);
+    hipLaunchKernelGGL(ae_convt2_mse_kernel, dim3((unsigned)n), dim3(256), 0, s, obs, a3, params,
+                       bonus, recon_out, n, h, w);
+    return check_launch("carle_ae2d_bonus_f32");
+}

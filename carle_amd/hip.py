@@ -90,3 +90,44 @@ def ca_toggle_f32(u_in, action, u_out):
         rc = lib.carle_ca_toggle_f32(u_in.data_ptr(), action.data_ptr(), u_out.data_ptr(), n, h, w,
                                      action.shape[2], action.shape[3], _stream(u_in))
     _lib.check(rc, "carle_ca_toggle_f32")
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=False):
+    """RND2D bonus (N,) for fp32 obs (N,1,H,W); params = flat fp32 blobs (see carle_hip.h)."""
+    lib = _lib.load()
+    _chk_grid(obs, "obs", torch.float32)
+    n, _, h, w = obs.shape
+    need = lib.carle_rnd2d_workspace_floats(n, h, w)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 1), dtype=torch.float32, device=obs.device)
+    bonus = torch.empty(n, dtype=torch.float32, device=obs.device)
+    pred = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
+    targ = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
+    with torch.cuda.device(obs.device):
+        rc = lib.carle_rnd2d_bonus_f32(obs.data_ptr(), n, h, w, pred_params.data_ptr(),
+                                       rand_params.data_ptr(), workspace.data_ptr(),
+                                       bonus.data_ptr(), _ptr(pred), _ptr(targ), _stream(obs))
+    _lib.check(rc, "carle_rnd2d_bonus_f32")
+    return (bonus, pred, targ, workspace) if want_outputs else (bonus, workspace)
+
+
+def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False):
+    """AE2D bonus (N,) for fp32 obs (N,1,H,W); params = flat 164-float blob."""
+    lib = _lib.load()
+    _chk_grid(obs, "obs", torch.float32)
+    n, _, h, w = obs.shape
+    need = lib.carle_ae2d_workspace_floats(n, h, w)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 1), dtype=torch.float32, device=obs.device)
+    bonus = torch.empty(n, dtype=torch.float32, device=obs.device)
+    recon = torch.empty_like(obs) if want_recon else None
+    with torch.cuda.device(obs.device):
+        rc = lib.carle_ae2d_bonus_f32(obs.data_ptr(), n, h, w, params.data_ptr(),
+                                      workspace.data_ptr(), bonus.data_ptr(), _ptr(recon),
+                                      _stream(obs))
+    _lib.check(rc, "carle_ae2d_bonus_f32")
+    return (bonus, recon, workspace) if want_recon else (bonus, workspace)

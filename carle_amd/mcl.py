@@ -1,0 +1,320 @@
+"""carle_amd.mcl -- reward wrappers ("mesocorticolimbic" system) on top of the HIP hot path.
+
+Mirrors ``carle.mcl.{Motivator, RND2D, AE2D}`` of the reference (riveSunder/carle,
+carle/mcl.py:29-84, 233-421, 424-556): same constructor, attribute names, module / parameter
+names (so ``evaluation/RND2D_mcl.pt`` / ``AE2D_mcl.pt`` style state_dicts load strictly), same
+``reset`` / ``step`` / ``get_bonus*`` methods.
+
+Underneath, every forward pass that produces a reward (``get_bonus``, ``get_bonus_only``,
+``get_bonus_accumulate``, ``forward``, ``random_forward``) runs the hand-written HIP kernels
+``carle_rnd2d_bonus_f32`` / ``carle_ae2d_bonus_f32`` (eval-mode semantics: Dropout = identity).
+The predictor UPDATE (backward + Adam, mcl.py:333-341, 368-386) is a "next" row of the scope
+table: observations of the current window are retained and, when ``batch_size`` steps have
+accumulated, forward+backward is recomputed with PyTorch-ROCm autograd on the ``nn.Sequential``
+below (mathematically identical in eval mode: parameters are constant inside a window).
+"""
+import torch
+import torch.nn as nn
+
+from . import hip
+
+
+class Motivator(nn.Module):
+    """Wrapper base (mcl.py:29-84): holds ``env``, resolves ``inner_env``, forwards rules."""
+
+    def __init__(self, env, **kwargs):
+        super().__init__()
+        # registration order fixes the state_dict key order: inner_env.* before env.*
+        if env.inner_env is None:
+            self.inner_env = env
+        else:
+            self.inner_env = env.inner_env
+        self.env = env
+        self.height = self.inner_env.height
+        self.width = self.inner_env.width
+        self.action_height = self.inner_env.action_height
+        self.action_width = self.inner_env.action_width
+        self.birth = self.inner_env.birth
+        self.survive = self.inner_env.survive
+        self.my_device = self.inner_env.my_device
+
+    def rules_from_string(self, my_string="B3/S23"):
+        self.inner_env.rules_from_string(my_string)
+        self.birth = self.inner_env.birth
+        self.survive = self.inner_env.survive
+
+    def birth_rule_from_string(self, my_string="b3"):
+        self.inner_env.birth_rule_from_string(my_string)
+        self.birth = self.inner_env.birth
+
+    def survive_rule_from_string(self, my_string="s23"):
+        self.inner_env.survive_rule_from_string(my_string)
+        self.survive = self.inner_env.survive
+
+    def reset(self):
+        return self.env.reset()
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def set_no_grad(self):
+        pass
+
+    def set_grad(self):
+        pass
+
+
+class _ParamBlob:
+    """Flat fp32 copy of a module's parameters in state_dict order, rebuilt only when a
+    parameter changed (in-place version counter) or moved (data_ptr / device)."""
+
+    def __init__(self, module):
+        self.module = module
+        self.key = None
+        self.blob = None
+
+    def get(self, device):
+        ps = list(self.module.parameters())
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self.key:
+            with torch.no_grad():
+                self.blob = torch.cat([p.detach().reshape(-1).to(device, torch.float32) for p in ps])
+            self.key = key
+        return self.blob
+
+
+class RND2D(Motivator):
+    """Random network distillation bonus on (N,1,H,W) grids (mcl.py:233-421)."""
+
+    def __init__(self, env, **kwargs):
+        super().__init__(env, **kwargs)
+        self.my_name = "RND2D"
+        self.learning_rate = 6e-2
+        self.reward_scale = 1.0
+        self.rnd_dim = 16
+        self.initialize_predictor()          # predictor BEFORE the random net: same RNG order
+        self.initialize_random_network()     # as the reference (mcl.py:248-249)
+        self.buffer_length = 0
+        self.batch_size = 64
+        self.updates = 0
+        self._window = []                    # observations of the current update window
+        self._ws = None                      # kernel workspace, reused across steps
+        self.accumulate_loss = 0.0
+
+    # ------------------------------------------------------------------ networks
+    def initialize_predictor(self):
+        dense_nodes = (self.inner_env.width // 8) * (self.inner_env.height // 8)
+        self.predictor = nn.Sequential(
+            nn.Conv2d(1, 4, 3, padding=1, stride=1),
+            nn.Dropout(p=0.1),
+            nn.ReLU(),
+            nn.MaxPool2d(2, 2, padding=0),
+            nn.MaxPool2d(2, 2, padding=0),
+            nn.Conv2d(4, 1, 3, padding=1, stride=1),
+            nn.Dropout(p=0.1),
+            nn.ReLU(),
+            nn.MaxPool2d(2, 2, padding=0),
+            nn.Dropout(p=0.1),
+            nn.Flatten(),
+            nn.Linear(dense_nodes, self.rnd_dim),
+            nn.Tanh())
+        self.optimizer = torch.optim.Adam(self.predictor.parameters(), lr=self.learning_rate)
+        self._pred_blob = _ParamBlob(self.predictor)
+
+    def initialize_random_network(self):
+        dense_nodes = (self.inner_env.width // 8) * (self.inner_env.height // 8)
+        self.random_network = nn.Sequential(
+            nn.Conv2d(1, 2, 3, padding=1, stride=1),
+            nn.ReLU(),
+            nn.MaxPool2d(2, 2, padding=0),
+            nn.MaxPool2d(2, 2, padding=0),
+            nn.Conv2d(2, 1, 3, padding=1, stride=1),
+            nn.ReLU(),
+            nn.MaxPool2d(2, 2, padding=0),
+            nn.Flatten(),
+            nn.Linear(dense_nodes, self.rnd_dim),
+            nn.Tanh())
+        self._rand_blob = _ParamBlob(self.random_network)
+        self.set_grad()
+
+    def set_grad(self):
+        for p in self.predictor.parameters():
+            p.requires_grad = True
+        for p in self.random_network.parameters():
+            p.requires_grad = False
+
+    def set_no_grad(self):
+        for p in self.predictor.parameters():
+            p.requires_grad = False
+        for p in self.random_network.parameters():
+            p.requires_grad = False
+
+    # ------------------------------------------------------------------ HIP forward passes
+    def _obs(self, obs):
+        hip.require_gpu()
+        dev = self.inner_env.my_device
+        if obs.device != dev or obs.dtype != torch.float32 or not obs.is_contiguous():
+            obs = obs.to(dev, torch.float32).contiguous()
+        if obs.dim() == 3:
+            obs = obs.unsqueeze(1)
+        return obs
+
+    def _hip_forward(self, obs, want_outputs=False):
+        obs = self._obs(obs)
+        dev = obs.device
+        res = hip.rnd2d_bonus_f32(obs, self._pred_blob.get(dev), self._rand_blob.get(dev),
+                                  self._ws, want_outputs)
+        self._ws = res[-1]
+        return res
+
+    def random_forward(self, obs):
+        """Target embedding (N,16) of the frozen random network (mcl.py:319-321)."""
+        return self._hip_forward(obs, True)[2]
+
+    def forward(self, obs):
+        """Predictor embedding (N,16) (mcl.py:323-330); HIP kernel, no autograd graph."""
+        return self._hip_forward(obs, True)[1]
+
+    def get_bonus(self, obs):
+        """Per-instance bonus (N,) = mean_k |(target - prediction)^2| (mcl.py:343-352)."""
+        return self._hip_forward(obs)[0]
+
+    def get_bonus_only(self, obs):
+        return self.get_bonus(obs)
+
+    # ------------------------------------------------------------------ predictor update
+    def _torch_loss(self, obs):
+        """The same loss through the nn.Sequential modules, WITH autograd (update path only)."""
+        with torch.no_grad():
+            target = self.random_network(obs)
+        prediction = self.predictor(obs)
+        return torch.mean(torch.abs((target - prediction) ** 2), dim=[1])
+
+    def update_predictor(self, loss):
+        loss.backward()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        self.updates += 1
+
+    def _replay_window(self, scale):
+        """backward of sum_t mean(loss_t) * scale over the retained window, one step at a time
+        (gradients accumulate in .grad exactly as one backward through the summed graph)."""
+        total = 0.0
+        for o in self._window:
+            loss = torch.mean(self._torch_loss(o)) * scale
+            loss.backward()
+            total = total + loss.detach()
+        self._window = []
+        return total
+
+    def get_bonus_update(self, obs):
+        """Bonus + immediate predictor update on this observation (mcl.py:354-366)."""
+        self.predictor.zero_grad()
+        bonus = self.get_bonus(obs)
+        self._window = [self._obs(obs)]
+        self._replay_window(1.0)
+        self.optimizer.step()
+        self._after_update()
+        return bonus
+
+    def get_bonus_accumulate(self, obs):
+        """Bonus now, predictor update every ``batch_size`` calls (mcl.py:368-386)."""
+        if self.buffer_length == 0:
+            self.predictor.zero_grad()
+            self.accumulate_loss = 0.0
+            self._window = []
+        bonus = self.get_bonus(obs)
+        self._window.append(self._obs(obs))
+        self.buffer_length += 1
+        if self.buffer_length >= self.batch_size:
+            self.accumulate_loss = self._replay_window(1.0 / self.batch_size)
+            self.optimizer.step()
+            self._after_update()
+            self.buffer_length = 0
+        return bonus
+
+    def _after_update(self):
+        self.optimizer.zero_grad()           # RND2D.update_predictor, mcl.py:339
+        self.updates += 1
+
+    # ------------------------------------------------------------------ gym surface
+    def step(self, action):
+        if isinstance(action, torch.Tensor):
+            action = action.to(self.inner_env.my_device)
+        obs, reward, done, info = self.env.step(action)
+        bonus = self.get_bonus_accumulate(obs).unsqueeze(1)
+        reward += self.reward_scale * bonus
+        return obs, reward, done, info
+
+    def reset(self):
+        obs = self.env.reset()
+        self.to(self.inner_env.my_device)
+        self.updates = 0
+        return obs
+
+
+class AE2D(RND2D):
+    """Convolutional auto-encoder reconstruction-error bonus (mcl.py:424-556)."""
+
+    def __init__(self, env, **kwargs):
+        super().__init__(env, **kwargs)
+        # assigned after the optimiser exists, as in the reference: Adam really runs at 6e-2
+        self.learning_rate = 9e-2
+        self.my_name = "AE2D"
+
+    def initialize_random_network(self):
+        pass
+
+    def initialize_predictor(self):
+        self.predictor = nn.Sequential(
+            nn.Conv2d(1, 4, 3, padding=1, stride=1),
+            nn.Dropout(p=0.1),
+            nn.ReLU(),
+            nn.MaxPool2d(2, 2, padding=0),
+            nn.Conv2d(4, 2, 3, padding=1, stride=1),
+            nn.Dropout(p=0.1),
+            nn.ReLU(),
+            nn.MaxPool2d(2, 2, padding=0),
+            nn.ConvTranspose2d(2, 1, 4, padding=1, stride=2),
+            nn.Dropout(p=0.1),
+            nn.ReLU(),
+            nn.ConvTranspose2d(1, 1, 4, padding=1, stride=2),
+            nn.Dropout(p=0.1),
+            nn.Sigmoid())
+        self.optimizer = torch.optim.Adam(self.predictor.parameters(), lr=self.learning_rate)
+        self._pred_blob = _ParamBlob(self.predictor)
+
+    def set_grad(self):
+        for p in self.predictor.parameters():
+            p.requires_grad = True
+
+    def set_no_grad(self):
+        for p in self.predictor.parameters():
+            p.requires_grad = False
+
+    def _hip_forward(self, obs, want_outputs=False):
+        obs = self._obs(obs)
+        res = hip.ae2d_bonus_f32(obs, self._pred_blob.get(obs.device), self._ws, want_outputs)
+        self._ws = res[-1]
+        return res
+
+    def random_forward(self, obs):
+        raise AttributeError("AE2D has no random network (mcl.py:433-434)")
+
+    def forward(self, obs):
+        """Reconstruction (instances,1,H,W) (mcl.py:436-443); HIP kernel, no autograd graph."""
+        recon = self._hip_forward(obs, True)[1]
+        return recon.reshape(self.inner_env.instances, 1, self.inner_env.height,
+                             self.inner_env.width)
+
+    def _torch_loss(self, obs):
+        prediction = self.predictor(obs).reshape(obs.shape)
+        return torch.mean(torch.abs((obs - prediction) ** 2), dim=[1, 2, 3])
+
+    def update_predictor(self, loss):
+        loss.backward()
+        self.optimizer.step()
+
+    def _after_update(self):
+        self.updates += 0                    # AE2D.update_predictor neither zeroes grads nor
+        # counts updates (mcl.py:498-502); grads are zeroed at the start of the next window

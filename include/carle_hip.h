@@ -99,6 +99,32 @@ int carle_ca_toggle_f32(const float *u_in, const float *action, float *u_out,
 int carle_ca_finish(void *u_out, int64_t u_out_bytes, float *reward, int64_t n,
                     int32_t *status, int slot, int has_action, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Intrinsic-reward forward passes (eval mode: Dropout = identity), fp32, tolerance 1e-5 abs.
+ * Parameter blobs are flat fp32 arrays in the state_dict order of the reference's
+ * nn.Sequential modules (carle/mcl.py:262-276, 285-296, 452-467):
+ *   RND predictor: conv1.w[4,1,3,3] conv1.b[4] conv2.w[1,4,3,3] conv2.b[1] lin.w[16,D] lin.b[16]
+ *   RND random   : conv1.w[2,1,3,3] conv1.b[2] conv2.w[1,2,3,3] conv2.b[1] lin.w[16,D] lin.b[16]
+ *   AE predictor : conv1.w[4,1,3,3] b[4] conv2.w[2,4,3,3] b[2] convT1.w[2,1,4,4] b[1]
+ *                  convT2.w[1,1,4,4] b[1]                                    (164 floats)
+ * with D = (H/8)*(W/8).  `workspace` is caller-owned scratch of at least
+ * carle_*_workspace_floats(n,h,w) floats.  H == W, multiple of 8.
+ * ------------------------------------------------------------------------------------------- */
+
+/* RND2D.get_bonus (carle/mcl.py:319-330,343-352): bonus[i] = mean_k (random(obs_i)_k -
+ * predictor(obs_i)_k)^2.  pred_out / target_out: optional (N,16) network outputs, may be NULL. */
+int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w);
+int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
+                          const float *pred_params, const float *rand_params,
+                          float *workspace, float *bonus, float *pred_out, float *target_out,
+                          void *stream);
+
+/* AE2D.get_bonus (carle/mcl.py:436-443,504-512): bonus[i] = mean_{h,w} (obs_i - decoder(obs_i))^2.
+ * recon_out: optional (N,1,H,W) reconstruction, may be NULL. */
+int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w);
+int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float *params,
+                         float *workspace, float *bonus, float *recon_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
