@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--rule", default="B3/S23")
     ap.add_argument("--action-ring", type=int, default=6,
                     help="number of distinct device action buffers cycled through")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1")
+    ap.add_argument("--stats-every", type=int, default=16,
+                    help="steps between reward-statistics all-gathers (reporting interval)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -80,21 +83,29 @@ def cpu_baseline(size, rule, seconds):
                       f"{k} steps in {dt:.1f} s, torch {torch.__version__} {cores} threads"}
 
 
+def pmc_traffic(size):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py).  The
+    counters cannot be collected from inside this process, so the value is read from
+    profiles/pmc_latest.json when it describes the same workload, else null."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        rec = json.load(open(path))
+        if rec.get("size") == size and rec.get("instances") == 4096:
+            return {"traffic": rec["traffic_bytes_per_launch"],
+                    "traffic_source": rec.get("source", "profiles/pmc_latest.json")}
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"traffic": None}
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from carle_amd import dist as cdist
+    rank, world, dev = cdist.init_from_env(args.backend)
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist = None
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-
     from carle_amd import hip
     from carle_amd.env import CARLE
 
@@ -110,22 +121,33 @@ def main():
     ring = [(torch.rand(n, 1, asize, asize, device=dev, generator=ga) <= 0.1).float()
             for _ in range(args.action_ring)]
 
+    # reward statistics shared by all shards: local moments every step (HIP kernel), one 24-B
+    # all-gather per rank every --stats-every steps (the only collective of the path)
+    stats = cdist.RunningRewardStats(dev, sync_every=args.stats_every)
+
     def barrier():
+        torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def one_step(i):
+        obs, reward, done, info = env.step(ring[i % len(ring)])
+        stats.update(reward)
+
     for i in range(args.warmup):
-        env.step(ring[i % len(ring)])
+        one_step(i)
+    stats.flush()                       # first collective (RCCL setup) stays out of the timing
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        env.step(ring[i % len(ring)])
+        one_step(i)
+    stats.flush()
     torch.cuda.synchronize(dev)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     pop = float(env.universe.sum().item())      # keeps the result live / sanity
@@ -168,13 +190,14 @@ def main():
                                    f"fp32 grids, Bernoulli(0.1) {asize}x{asize} fp32 action per step "
                                    f"(ring of {len(ring)} device buffers), CARLE.step drop-in surface",
                        "instances_per_gpu": n, "height": size, "width": size,
-                       "action": asize, "rule": args.rule, "sharding": f"batch x{world}"},
+                       "action": asize, "rule": args.rule, "sharding": f"batch x{world}",
+                       "collective": f"all-gather of 24 B/rank reward moments every {args.stats_every} steps"},
             "cell_updates_per_s": world * n * args.steps * size * size / dt,
             "final_population_rank0": pop,
             "roofline": {"bound": "hbm", "kernel": "ca_step_f32_64_kernel<true>" if size == 64
                          else "ca_step_f32 (see DESIGN.md)",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, **pmc_traffic(size),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": k_ms * 1e3, "launches_timed": reps},
         }
@@ -183,6 +206,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(size, (b, s), args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

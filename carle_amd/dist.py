@@ -1,0 +1,165 @@
+"""carle_amd.dist -- batch sharding of CARLE over the GPUs of one node.
+
+One process per GPU (``torch.distributed``, backend ``"nccl"`` = RCCL over xGMI on ROCm).
+Universes are independent along the batch axis (carle/env.py:136: one conv channel per
+instance), so rank r simply owns instances [r*N/W, (r+1)*N/W): the CA step, the action toggle
+and the per-instance RND2D / AE2D bonuses need NO data-path collective.
+
+The only exchange is the reward-normalisation running statistics (north star; absent from the
+reference): each rank reduces its (N/W,1) rewards to a moment triple (count, mean, M2) on the
+device (HIP kernel ``carle_batch_moments_f32``), the triples are all-gathered -- 24 bytes per
+rank, latency-bound, one hop on the fully connected xGMI mesh -- and Chan-merged in rank order
+on every rank, so all ranks hold bit-identical statistics.  The merged triple also yields the
+batch-global scalars of the reference's harness (total reward, train_mcl.py:68-69).
+
+The master reset of CARLE.step fires on "every element of the whole action batch == 1"
+(env.py:208); under sharding it is evaluated per rank (documented deviation):
+``global_all_ones`` offers the exact global predicate as a 1-int all-reduce for callers that
+need it.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def init_from_env(backend="nccl"):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)
+    and bind this process to its GPU.  Returns (rank, world, device)."""
+    w = int(os.environ.get("WORLD_SIZE", "1"))
+    r = int(os.environ.get("RANK", "0"))
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    dev = torch.device("cuda", lr % max(torch.cuda.device_count(), 1)) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(dev)
+    if w > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = dev
+        dist.init_process_group(backend, rank=r, world_size=w, **kw)
+    return r, w, dev
+
+
+def shard(total, r=None, w=None):
+    """Contiguous block of instances owned by rank r: (start, count).  Sizes differ by at most
+    one; the first ``total % w`` ranks take the extra instance."""
+    r = rank() if r is None else r
+    w = world() if w is None else w
+    base, extra = divmod(int(total), w)
+    count = base + (1 if r < extra else 0)
+    start = r * base + min(r, extra)
+    return start, count
+
+
+def chan_merge(triples):
+    """Merge (count, mean, M2) rows [W,3] in row order (Chan et al. pairwise update).  Pure
+    tensor arithmetic on a handful of scalars: runs wherever the gathered tensor lives."""
+    t = triples.to(torch.float64)
+    n, mean, m2 = t[0, 0], t[0, 1], t[0, 2]
+    for i in range(1, t.shape[0]):
+        nb, mb, qb = t[i, 0], t[i, 1], t[i, 2]
+        tot = n + nb
+        safe = torch.where(tot > 0, tot, torch.ones_like(tot))
+        delta = mb - mean
+        mean = mean + delta * nb / safe
+        m2 = m2 + qb + delta * delta * n * nb / safe
+        n = tot
+    return torch.stack([n, mean, m2])
+
+
+class RunningRewardStats:
+    """Running (count, mean, M2) of all rewards seen by ALL ranks.
+
+    ``update(reward)`` costs: one single-block HIP kernel, one all-gather of 24 B/rank, a few
+    scalar tensor ops.  No host synchronisation; ``mean``/``var``/``total`` read back lazily.
+    """
+
+    def __init__(self, device, sync_every=1):
+        self.device = torch.device(device)
+        self.state = torch.zeros(3, dtype=torch.float64, device=self.device)
+        self.last_batch = torch.zeros(3, dtype=torch.float64, device=self.device)
+        # sync_every > 1: fold the local triples of that many steps together before the
+        # all-gather (a reporting interval): the exchange is latency-bound, so amortise it
+        self.sync_every = max(1, int(sync_every))
+        self._pending = None
+        self._pending_steps = 0
+
+    def local_moments(self, reward):
+        from . import hip
+        return hip.batch_moments_f32(reward.reshape(-1).contiguous())
+
+    def update_from_local(self, local_triple):
+        """All-gather the per-rank triples, merge them, fold into the running state."""
+        local_triple = local_triple.to(self.device, torch.float64).reshape(1, 3)
+        w = world()
+        if w > 1:
+            gathered = torch.empty(w, 3, dtype=torch.float64, device=self.device)
+            dist.all_gather_into_tensor(gathered, local_triple)
+        else:
+            gathered = local_triple
+        self.last_batch = chan_merge(gathered)
+        self.state = chan_merge(torch.stack([self.state, self.last_batch]))
+        return self.last_batch
+
+    def update(self, reward):
+        local = self.local_moments(reward)
+        if self.sync_every == 1:
+            return self.update_from_local(local)
+        self._pending = local if self._pending is None else \
+            chan_merge(torch.stack([self._pending, local]))
+        self._pending_steps += 1
+        if self._pending_steps >= self.sync_every:
+            return self.flush()
+        return None
+
+    def flush(self):
+        """Exchange whatever has accumulated since the last all-gather."""
+        if self._pending is None:
+            return None
+        local, self._pending, self._pending_steps = self._pending, None, 0
+        return self.update_from_local(local)
+
+    def normalize(self, reward, eps=1e-8):
+        from . import hip
+        flat = reward.reshape(-1).contiguous()
+        return hip.normalize_f32(flat, self.state, eps).reshape(reward.shape)
+
+    # lazy host views
+    @property
+    def count(self):
+        return float(self.state[0].item())
+
+    @property
+    def mean(self):
+        return float(self.state[1].item())
+
+    @property
+    def var(self):
+        c = self.count
+        return float(self.state[2].item()) / c if c > 0 else 0.0
+
+    @property
+    def last_total(self):
+        """Global sum of the rewards of the last update (= reward.sum() of the unsharded run)."""
+        return float((self.last_batch[0] * self.last_batch[1]).item())
+
+
+def global_all_ones(local_not_all_ones_flag):
+    """Exact whole-batch master-reset predicate under sharding: 1-int all-reduce (MAX) of the
+    per-rank "some element != 1" flag; returns a tensor that is 0 iff EVERY rank's action is all
+    ones."""
+    t = local_not_all_ones_flag.clone()
+    if world() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t

@@ -131,3 +131,27 @@ def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False):
                                       _stream(obs))
     _lib.check(rc, "carle_ae2d_bonus_f32")
     return (bonus, recon, workspace) if want_recon else (bonus, workspace)
+
+
+def batch_moments_f32(x, out=None):
+    """(count, mean, M2) of a fp32 device vector as a fp64[3] device tensor (no host sync)."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise ValueError("batch_moments_f32 needs a contiguous fp32 tensor on a HIP device")
+    if out is None:
+        out = torch.empty(3, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.carle_batch_moments_f32(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x))
+    _lib.check(rc, "carle_batch_moments_f32")
+    return out
+
+
+def normalize_f32(x, moments, eps=1e-8):
+    """(x - mean) / sqrt(M2/count + eps) with fp64[3] device moments."""
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.carle_normalize_f32(x.data_ptr(), y.data_ptr(), x.numel(), moments.data_ptr(),
+                                     float(eps), _stream(x))
+    _lib.check(rc, "carle_normalize_f32")
+    return y

@@ -125,6 +125,16 @@ int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w);
 int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float *params,
                          float *workspace, float *bonus, float *recon_out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Reward statistics for batch-sharded runs (build-side feature required by the north star; the
+ * reference has none).  out3 / moments3 = fp64 (count, mean, M2) on the device.  The triples of
+ * all ranks are all-gathered over RCCL and Chan-merged by carle_amd/dist.py; the merged triple
+ * also gives the global reward sum of train_mcl.py:68-69 / eval.py:69-70.
+ * ------------------------------------------------------------------------------------------- */
+int carle_batch_moments_f32(const float *x, int64_t n, double *out3, void *stream);
+int carle_normalize_f32(const float *x, float *y, int64_t n, const double *moments3, double eps,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,93 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU host logic: sharding, the running-stat
+all-gather + Chan merge, and the global master-reset predicate."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _moments(x):
+    x = np.asarray(x, np.float64)
+    return torch.tensor([x.size, x.mean() if x.size else 0.0, ((x - x.mean()) ** 2).sum() if x.size else 0.0],
+                        dtype=torch.float64)
+
+
+def _worker(rank, world, port, total, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from carle_amd import dist as cd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        rewards = rng.normal(size=(3, total)).astype(np.float32)      # 3 steps, whole batch
+        start, count = cd.shard(total)
+        stats = cd.RunningRewardStats("cpu")
+        totals = []
+        for t in range(3):
+            local = rewards[t, start:start + count]
+            stats.update_from_local(_moments(local))
+            totals.append(stats.last_total)
+        flag = torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)
+        g1 = int(cd.global_all_ones(flag).item())
+        g0 = int(cd.global_all_ones(torch.zeros(1, dtype=torch.int32)).item())
+        q.put((rank, start, count, stats.state.tolist(), totals, g1, g0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [4096, 7])
+def test_running_stats_two_ranks_gloo(total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(5)
+    rewards = rng.normal(size=(3, total)).astype(np.float32).astype(np.float64)
+    flat = rewards.reshape(-1)
+    exp = [flat.size, flat.mean(), ((flat - flat.mean()) ** 2).sum()]
+    # shards tile the batch exactly
+    assert res[0][1] == 0 and res[0][1] + res[0][2] == res[1][1] and res[1][1] + res[1][2] == total
+    for r in res:
+        np.testing.assert_allclose(r[3], exp, rtol=1e-12)
+        np.testing.assert_allclose(r[4], rewards.sum(axis=1), rtol=1e-10, atol=1e-9)
+        assert r[5] == 1 and r[6] == 0
+    assert res[0][3] == res[1][3]              # bit-identical statistics on every rank
+
+
+def test_shard_partition():
+    from carle_amd import dist as cd
+    for total in (0, 1, 7, 8, 4096, 32768):
+        for w in (1, 2, 3, 8):
+            got = [cd.shard(total, r, w) for r in range(w)]
+            assert got[0][0] == 0 and sum(c for _, c in got) == total
+            for (s0, c0), (s1, c1) in zip(got, got[1:]):
+                assert s0 + c0 == s1 and 0 <= c0 - c1 <= 1
+
+
+def test_chan_merge_matches_numpy():
+    from carle_amd import dist as cd
+    rng = np.random.default_rng(0)
+    parts = [rng.normal(3, 2, size=k) for k in (5, 0, 17, 1)]
+    merged = cd.chan_merge(torch.stack([_moments(p) for p in parts]))
+    allx = np.concatenate(parts)
+    np.testing.assert_allclose(merged.numpy(), [allx.size, allx.mean(), ((allx - allx.mean()) ** 2).sum()],
+                               rtol=1e-12)
