@@ -83,7 +83,7 @@ def cpu_baseline(size, rule, seconds):
                       f"{k} steps in {dt:.1f} s, torch {torch.__version__} {cores} threads"}
 
 
-def pmc_traffic(size):
+def pmc_traffic(size, n):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py).  The
     counters cannot be collected from inside this process, so the value is read from
@@ -91,7 +91,7 @@ def pmc_traffic(size):
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         rec = json.load(open(path))
-        if rec.get("size") == size and rec.get("instances") == 4096:
+        if rec.get("size") == size and rec.get("instances") == n:
             return {"traffic": rec["traffic_bytes_per_launch"],
                     "traffic_source": rec.get("source", "profiles/pmc_latest.json")}
     except (OSError, ValueError, KeyError):
@@ -197,7 +197,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "ca_step_f32_64_kernel<true>" if size == 64
                          else "ca_step_f32 (see DESIGN.md)",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, **pmc_traffic(size),
+                         "frac": achieved / HBM_PEAK, **pmc_traffic(size, n),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": k_ms * 1e3, "launches_timed": reps},
         }

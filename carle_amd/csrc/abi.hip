@@ -16,8 +16,13 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
                                                         int tail_bytes, float *__restrict__ reward,
                                                         int64_t n, int32_t *__restrict__ st,
                                                         int slot, int has_action) {
-    const bool reset = has_action && st[CARLE_ST_NOT_ALL_ONES(slot)] == 0;
-    const bool any = has_action && st[CARLE_ST_ANY_NONZERO(slot)] != 0;
+    // the whole status block in one round trip (it is one 64-byte line)
+    const uint4 *st4 = reinterpret_cast<const uint4 *>(st);
+    const uint4 w0 = st4[0], w1 = st4[1], w2 = st4[2];
+    const int32_t any_flag = slot ? (int32_t)w0.y : (int32_t)w0.x;
+    const int32_t notone_flag = slot ? (int32_t)w0.w : (int32_t)w0.z;
+    const bool reset = has_action && notone_flag == 0;
+    const bool any = has_action && any_flag != 0;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
     if (reset) {
@@ -28,20 +33,25 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
     if (reward)
         for (int64_t i = tid; i < n; i += nthreads) reward[i] = 0.0f;
     if (tid == 0) {
-        int64_t *step_number = reinterpret_cast<int64_t *>(st + CARLE_ST_STEP_NUMBER);
-        int64_t *since = reinterpret_cast<int64_t *>(st + CARLE_ST_STEPS_SINCE_ACTION);
-        int64_t *resets = reinterpret_cast<int64_t *>(st + CARLE_ST_RESETS);
-        if (!any) *since += 1;                      // env.py:199-200
+        int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z);       // int32 index 6..7
+        int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x);             // index 8..9
+        int64_t resets = (int64_t)(((uint64_t)w2.w << 32) | w2.z);            // index 10..11
+        if (!any) since += 1;                       // env.py:199-200
         if (reset) {                                // env.py:216 -> reset(): env.py:142-145
-            *step_number = 0;
-            *since = 0;
-            *resets += 1;
+            step_number = 0;
+            since = 0;
+            resets += 1;
         } else {
-            *step_number += 1;                      // env.py:230
+            step_number += 1;                       // env.py:230
         }
-        st[CARLE_ST_LAST_RESET] = reset ? 1 : 0;
-        st[CARLE_ST_ANY_NONZERO(slot ^ 1)] = 0;     // the next step publishes into the other slot
-        st[CARLE_ST_NOT_ALL_ONES(slot ^ 1)] = 0;
+        uint4 o0 = w0, o1 = w1, o2;
+        if (slot) { o0.x = 0u; o0.z = 0u; } else { o0.y = 0u; o0.w = 0u; }   // recycle slot^1
+        o1.x = reset ? 1u : 0u;                     // CARLE_ST_LAST_RESET (index 4)
+        o1.z = (uint32_t)step_number; o1.w = (uint32_t)((uint64_t)step_number >> 32);
+        o2.x = (uint32_t)since; o2.y = (uint32_t)((uint64_t)since >> 32);
+        o2.z = (uint32_t)resets; o2.w = (uint32_t)((uint64_t)resets >> 32);
+        uint4 *so = reinterpret_cast<uint4 *>(st);
+        so[0] = o0; so[1] = o1; so[2] = o2;
     }
 }
 
@@ -72,9 +82,23 @@ extern "C" int carle_ca_finish(void *u_out, int64_t u_out_bytes, float *reward, 
     const int64_t n16 = u_out_bytes / 16;
     const int tail = (int)(u_out_bytes % 16);
     // small fixed grid: in the common (no reset) case every block exits after one flag load
-    hipLaunchKernelGGL(ca_finish_kernel, dim3(32), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(ca_finish_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<uint4 *>(u_out), n16,
                        reinterpret_cast<unsigned char *>(u_out) + n16 * 16, tail, reward, n, status,
                        slot, (n > 0 && has_action) ? 1 : 0);
     return check_launch("carle_ca_finish");
+}
+
+// step + epilogue in one call: the per-step host cost of the drop-in surface is dominated by
+// Python/ctypes overhead, so CARLE.step makes ONE library call per step.
+extern "C" int carle_env_step_f32(const float *u_in, const float *action, float *u_out,
+                                  float *reward, int64_t n, int h, int w, int ah, int aw,
+                                  uint32_t rule, int32_t *status, int slot, int publish_flags,
+                                  void *stream) {
+    if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32: status is NULL");
+    if (int e = carle_ca_step_f32(u_in, action, u_out, n, h, w, ah, aw, rule,
+                                  publish_flags ? status : nullptr, slot, stream))
+        return e;
+    return carle_ca_finish(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status,
+                           slot, action != nullptr, stream);
 }

@@ -92,8 +92,10 @@ class RunningRewardStats:
         # sync_every > 1: fold the local triples of that many steps together before the
         # all-gather (a reporting interval): the exchange is latency-bound, so amortise it
         self.sync_every = max(1, int(sync_every))
-        self._pending = None
+        self._pending = torch.zeros(3, dtype=torch.float64, device=self.device)
+        self._batch = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._pending_steps = 0
+        self._gathered = None
 
     def local_moments(self, reward):
         from . import hip
@@ -113,11 +115,10 @@ class RunningRewardStats:
         return self.last_batch
 
     def update(self, reward):
-        local = self.local_moments(reward)
-        if self.sync_every == 1:
-            return self.update_from_local(local)
-        self._pending = local if self._pending is None else \
-            chan_merge(torch.stack([self._pending, local]))
+        """One HIP kernel per call: batch moments, merged on the device into the pending triple;
+        every ``sync_every`` calls the pending triple is exchanged (``flush``)."""
+        from . import hip
+        hip.batch_moments_f32(reward.reshape(-1), self._batch, self._pending)
         self._pending_steps += 1
         if self._pending_steps >= self.sync_every:
             return self.flush()
@@ -125,10 +126,24 @@ class RunningRewardStats:
 
     def flush(self):
         """Exchange whatever has accumulated since the last all-gather."""
-        if self._pending is None:
+        if self._pending_steps == 0:
             return None
-        local, self._pending, self._pending_steps = self._pending, None, 0
-        return self.update_from_local(local)
+        self._pending_steps = 0
+        if self.device.type != "cuda":           # CPU process groups (gloo tests): tensor ops
+            local = self._pending.clone()
+            self._pending.zero_()
+            return self.update_from_local(local)
+        from . import hip
+        w = world()
+        if w > 1:
+            if self._gathered is None or self._gathered.shape[0] != w:
+                self._gathered = torch.empty(w, 3, dtype=torch.float64, device=self.device)
+            dist.all_gather_into_tensor(self._gathered, self._pending.reshape(1, 3))
+            src = self._gathered
+        else:
+            src = self._pending
+        hip.merge_moments(src, w, self.state, self.last_batch, self._pending)
+        return self.last_batch
 
     def normalize(self, reward, eps=1e-8):
         from . import hip

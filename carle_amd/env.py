@@ -40,8 +40,19 @@ def _resolve_device(kwargs):
     return torch.device("cpu")
 
 
+# attributes rewritten every step: bypass nn.Module.__setattr__ (parameter/buffer/module
+# bookkeeping, ~3 us each) -- they are plain Python / tensor attributes
+_PLAIN_ATTRS = frozenset(("universe", "action", "_slot", "log"))
+
+
 class CARLE(nn.Module):
     """Batched toroidal Life-like cellular automaton with a gym-style interface."""
+
+    def __setattr__(self, name, value):
+        if name in _PLAIN_ATTRS:
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
 
     def __init__(self, **kwargs):
         super().__init__()
@@ -260,10 +271,7 @@ class CARLE(nn.Module):
             # for an oversize action evaluate them on the uncropped tensor (cold path, no sync)
             self._status[slot] = (full != 0).any().to(torch.int32)
             self._status[2 + slot] = (full != 1).any().to(torch.int32)
-            hip.ca_step_f32(u_in, act, out, rule, None, slot)
-        else:
-            hip.ca_step_f32(u_in, act, out, rule, self._status, slot)
-        hip.ca_finish(out, reward, self._status, slot, True)
+        hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, not cropped)
         self._slot = slot ^ 1
         self.universe = out
         done = torch.zeros(self.instances, 1)

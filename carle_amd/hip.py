@@ -11,16 +11,51 @@ STATUS_WORDS = 16
 ST_LAST_RESET, ST_STEP_NUMBER, ST_STEPS_SINCE_ACTION, ST_RESETS = 4, 6, 8, 10
 
 
+_gpu_ok = False
+
+
 def require_gpu(device=None):
+    global _gpu_ok
+    if _gpu_ok:
+        return
     if not torch.cuda.is_available():
         raise _lib.CarleHipError(
             "carle_amd needs a HIP device (MI355X): torch.cuda.is_available() is False and "
             "there is no CPU fallback")
     _lib.load()
+    _gpu_ok = True
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def _stream(t):
+    """Raw hipStream_t of torch's CURRENT stream on the tensor's device (the stream the caller's
+    other work is ordered on)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _on_device:
+    """Make the tensor's device current for the duration of a launch; free when it already is."""
+    __slots__ = ("idx", "ctx")
+
+    def __init__(self, device):
+        self.idx = device.index
+        self.ctx = None
+
+    def __enter__(self):
+        cur = _get_device() if _get_device is not None else torch.cuda.current_device()
+        if cur != self.idx:
+            self.ctx = torch.cuda.device(self.idx)
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 def _chk_grid(t, name, dtype):
@@ -63,7 +98,7 @@ def ca_step_f32(u_in, action, u_out, rule, status=None, slot=0):
         ah, aw = action.shape[2], action.shape[3]
         ap = action.data_ptr()
     sp = status.data_ptr() if status is not None else None
-    with torch.cuda.device(u_in.device):
+    with _on_device(u_in.device):
         rc = lib.carle_ca_step_f32(u_in.data_ptr(), ap, u_out.data_ptr(), n, h, w, ah, aw, rule,
                                    sp, slot, _stream(u_in))
     _lib.check(rc, "carle_ca_step_f32")
@@ -73,7 +108,7 @@ def ca_finish(u_out, reward, status, slot, has_action):
     lib = _lib.load()
     n = u_out.shape[0]
     rp = reward.data_ptr() if reward is not None else None
-    with torch.cuda.device(u_out.device):
+    with _on_device(u_out.device):
         rc = lib.carle_ca_finish(u_out.data_ptr(), u_out.numel() * u_out.element_size(), rp, n,
                                  status.data_ptr(), slot, 1 if has_action else 0, _stream(u_out))
     _lib.check(rc, "carle_ca_finish")
@@ -86,7 +121,7 @@ def ca_toggle_f32(u_in, action, u_out):
     _chk_grid(u_out, "u_out", torch.float32)
     _chk_grid(action, "action", torch.float32)
     n, _, h, w = u_in.shape
-    with torch.cuda.device(u_in.device):
+    with _on_device(u_in.device):
         rc = lib.carle_ca_toggle_f32(u_in.data_ptr(), action.data_ptr(), u_out.data_ptr(), n, h, w,
                                      action.shape[2], action.shape[3], _stream(u_in))
     _lib.check(rc, "carle_ca_toggle_f32")
@@ -107,7 +142,7 @@ def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=
     bonus = torch.empty(n, dtype=torch.float32, device=obs.device)
     pred = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
     targ = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
-    with torch.cuda.device(obs.device):
+    with _on_device(obs.device):
         rc = lib.carle_rnd2d_bonus_f32(obs.data_ptr(), n, h, w, pred_params.data_ptr(),
                                        rand_params.data_ptr(), workspace.data_ptr(),
                                        bonus.data_ptr(), _ptr(pred), _ptr(targ), _stream(obs))
@@ -125,7 +160,7 @@ def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False):
         workspace = torch.empty(max(need, 1), dtype=torch.float32, device=obs.device)
     bonus = torch.empty(n, dtype=torch.float32, device=obs.device)
     recon = torch.empty_like(obs) if want_recon else None
-    with torch.cuda.device(obs.device):
+    with _on_device(obs.device):
         rc = lib.carle_ae2d_bonus_f32(obs.data_ptr(), n, h, w, params.data_ptr(),
                                       workspace.data_ptr(), bonus.data_ptr(), _ptr(recon),
                                       _stream(obs))
@@ -133,15 +168,17 @@ def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False):
     return (bonus, recon, workspace) if want_recon else (bonus, workspace)
 
 
-def batch_moments_f32(x, out=None):
-    """(count, mean, M2) of a fp32 device vector as a fp64[3] device tensor (no host sync)."""
+def batch_moments_f32(x, out=None, acc=None):
+    """(count, mean, M2) of a fp32 device vector as a fp64[3] device tensor (no host sync);
+    ``acc`` (fp64[3] device) is additionally Chan-merged with the batch inside the kernel."""
     lib = _lib.load()
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
         raise ValueError("batch_moments_f32 needs a contiguous fp32 tensor on a HIP device")
     if out is None:
         out = torch.empty(3, dtype=torch.float64, device=x.device)
-    with torch.cuda.device(x.device):
-        rc = lib.carle_batch_moments_f32(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x))
+    with _on_device(x.device):
+        rc = lib.carle_batch_moments_f32(x.data_ptr(), x.numel(), out.data_ptr(), _ptr(acc),
+                                         _stream(x))
     _lib.check(rc, "carle_batch_moments_f32")
     return out
 
@@ -150,8 +187,34 @@ def normalize_f32(x, moments, eps=1e-8):
     """(x - mean) / sqrt(M2/count + eps) with fp64[3] device moments."""
     lib = _lib.load()
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         rc = lib.carle_normalize_f32(x.data_ptr(), y.data_ptr(), x.numel(), moments.data_ptr(),
                                      float(eps), _stream(x))
     _lib.check(rc, "carle_normalize_f32")
     return y
+
+
+def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=True):
+    """CARLE.step hot path: fused CA kernel + epilogue, one library call (shapes are validated by
+    the caller; pointers by the library)."""
+    lib = _lib.load()
+    n, _, h, w = u_in.shape
+    if action is None:
+        ap, ah, aw = None, 0, 0
+    else:
+        ap, ah, aw = action.data_ptr(), action.shape[2], action.shape[3]
+    with _on_device(u_in.device):
+        rc = lib.carle_env_step_f32(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h,
+                                    w, ah, aw, rule, status.data_ptr(), slot,
+                                    1 if publish_flags else 0, _stream(u_in))
+    if rc != 0:
+        _lib.check(rc, "carle_env_step_f32")
+
+
+def merge_moments(gathered, world, state, last, pending):
+    """Device-side Chan merge of all-gathered (count, mean, M2) rows into last / running state."""
+    lib = _lib.load()
+    with _on_device(state.device):
+        rc = lib.carle_merge_moments(gathered.data_ptr(), world, state.data_ptr(), last.data_ptr(),
+                                     _ptr(pending), _stream(state))
+    _lib.check(rc, "carle_merge_moments")

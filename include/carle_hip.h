@@ -99,6 +99,16 @@ int carle_ca_toggle_f32(const float *u_in, const float *action, float *u_out,
 int carle_ca_finish(void *u_out, int64_t u_out_bytes, float *reward, int64_t n,
                     int32_t *status, int slot, int has_action, void *stream);
 
+/*
+ * Whole CARLE.step (carle/env.py:188-242) in one call: carle_ca_step_f32 followed by
+ * carle_ca_finish on the same stream.  publish_flags = 0 keeps the step kernel from writing the
+ * action flags (the caller has already stored them in the status block, e.g. for an oversize
+ * action whose predicates are defined on the uncropped tensor, env.py:164-169,191,208).
+ */
+int carle_env_step_f32(const float *u_in, const float *action, float *u_out, float *reward,
+                       int64_t n, int h, int w, int ah, int aw, uint32_t rule,
+                       int32_t *status, int slot, int publish_flags, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Intrinsic-reward forward passes (eval mode: Dropout = identity), fp32, tolerance 1e-5 abs.
  * Parameter blobs are flat fp32 arrays in the state_dict order of the reference's
@@ -131,7 +141,12 @@ int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float 
  * all ranks are all-gathered over RCCL and Chan-merged by carle_amd/dist.py; the merged triple
  * also gives the global reward sum of train_mcl.py:68-69 / eval.py:69-70.
  * ------------------------------------------------------------------------------------------- */
-int carle_batch_moments_f32(const float *x, int64_t n, double *out3, void *stream);
+/* out3 := moments of x[0..n); if acc3 != NULL additionally acc3 := merge(acc3, out3) (Chan). */
+int carle_batch_moments_f32(const float *x, int64_t n, double *out3, double *acc3, void *stream);
+/* last3 := Chan-merge of gathered[world][3] in rank order; state3 := merge(state3, last3);
+ * pending3 (nullable, may alias gathered when world == 1) := 0. */
+int carle_merge_moments(const double *gathered, int world, double *state3, double *last3,
+                        double *pending3, void *stream);
 int carle_normalize_f32(const float *x, float *y, int64_t n, const double *moments3, double eps,
                         void *stream);
 

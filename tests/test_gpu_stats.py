@@ -12,7 +12,14 @@ def test_batch_moments(n):
     x = torch.randn(n, device="cuda") * 3 + 1.5
     got = hip.batch_moments_f32(x).cpu().numpy()
     xd = x.cpu().numpy().astype(np.float64)
-    np.testing.assert_allclose(got, [n, xd.mean(), ((xd - xd.mean()) ** 2).sum()], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got, [n, xd.mean(), ((xd - xd.mean()) ** 2).sum()], rtol=1e-9, atol=1e-9)
+    acc = torch.zeros(3, dtype=torch.float64, device="cuda")
+    x2 = torch.randn(n + 3, device="cuda") - 4.0
+    hip.batch_moments_f32(x, acc=acc)
+    hip.batch_moments_f32(x2, acc=acc)
+    both = np.concatenate([xd, x2.cpu().numpy().astype(np.float64)])
+    np.testing.assert_allclose(acc.cpu().numpy(), [both.size, both.mean(), ((both - both.mean()) ** 2).sum()],
+                               rtol=1e-9)
 
 
 def test_running_stats_and_normalize():
