@@ -69,19 +69,43 @@ __device__ __forceinline__ void publish_flags(const ActionSeen &s, int32_t *stat
 // ---------------------------------------------------------------------------------------------
 // 64x64 fast path: one wavefront per grid
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_ACT>
-__global__ __launch_bounds__(256) void ca_step_f32_64_kernel(
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const uint4 *p) {
+    if (NT) {
+        uint4 v;
+        v.x = __builtin_nontemporal_load(&p->x);
+        v.y = __builtin_nontemporal_load(&p->y);
+        v.z = __builtin_nontemporal_load(&p->z);
+        v.w = __builtin_nontemporal_load(&p->w);
+        return v;
+    }
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(uint4 *p, const uint4 &v) {
+    if (NT) {
+        __builtin_nontemporal_store(v.x, &p->x);
+        __builtin_nontemporal_store(v.y, &p->y);
+        __builtin_nontemporal_store(v.z, &p->z);
+        __builtin_nontemporal_store(v.w, &p->w);
+    } else {
+        *p = v;
+    }
+}
+
+template <bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK) void ca_step_f32_64_kernel(
     const uint4 *__restrict__ u_in, const float *__restrict__ act, uint4 *__restrict__ u_out,
     int64_t n, int aw, uint32_t rule, int32_t *__restrict__ status, int slot) {
     const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t g = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (g >= n) return;                              // wave-uniform
     const int q = lane >> 4, k = lane & 15;
     const uint4 *gin = u_in + g * 1024 + lane;       // 4096 floats = 1024 x 16 B per grid
 
     uint4 v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = gin[i * 64];
+    for (int i = 0; i < 16; ++i) v[i] = ld16<NT_LD>(gin + i * 64);
     uint64_t c = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) c |= (uint64_t)nibble_of(v[i]) << (4 * i);
@@ -99,7 +123,7 @@ __global__ __launch_bounds__(256) void ca_step_f32_64_kernel(
         for (int i = 0; i < 16; ++i) {
             const int ay = 4 * i + q - o;
             if (col_in && ay >= 0 && ay < aw) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(abase + (int64_t)ay * aw);
+                const uint4 a = ld16<NT_LD>(reinterpret_cast<const uint4 *>(abase + (int64_t)ay * aw));
                 seen.add(a);
                 tog |= (uint64_t)nibble_of(a) << (4 * i);
             }
@@ -135,7 +159,7 @@ __global__ __launch_bounds__(256) void ca_step_f32_64_kernel(
         o4.y = (nib & 2u) ? kOneBits : 0u;
         o4.z = (nib & 4u) ? kOneBits : 0u;
         o4.w = (nib & 8u) ? kOneBits : 0u;
-        gout[i * 64] = o4;
+        st16<NT_ST>(gout + i * 64, o4);
     }
 }
 
@@ -216,14 +240,17 @@ extern "C" int carle_ca_step_f32(const float *u_in, const float *action, float *
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     if (h == 64 && w == 64 && (!action || (aw % 8) == 0)) {
-        const unsigned blocks = (unsigned)((n + 3) / 4);
+        // one wavefront per workgroup, non-temporal loads and stores: measured best of the
+        // {plain, nt} x {64,128,256,512}-thread variants (tools/kbench, profiles/r01_kbench.txt)
+        if (n > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32: batch too large");
+        const unsigned blocks = (unsigned)n;
         if (action)
-            hipLaunchKernelGGL(ca_step_f32_64_kernel<true>, dim3(blocks), dim3(256), 0, s,
-                               reinterpret_cast<const uint4 *>(u_in), action,
+            hipLaunchKernelGGL((ca_step_f32_64_kernel<true, true, true, 64>), dim3(blocks), dim3(64),
+                               0, s, reinterpret_cast<const uint4 *>(u_in), action,
                                reinterpret_cast<uint4 *>(u_out), n, aw, rule, status, slot);
         else
-            hipLaunchKernelGGL(ca_step_f32_64_kernel<false>, dim3(blocks), dim3(256), 0, s,
-                               reinterpret_cast<const uint4 *>(u_in), action,
+            hipLaunchKernelGGL((ca_step_f32_64_kernel<false, true, true, 64>), dim3(blocks), dim3(64),
+                               0, s, reinterpret_cast<const uint4 *>(u_in), action,
                                reinterpret_cast<uint4 *>(u_out), n, 0, rule, status, slot);
         return check_launch("carle_ca_step_f32(64x64)");
     }
