@@ -164,6 +164,184 @@ __global__ __launch_bounds__(BLOCK) void ca_step_f32_64_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// wide fast path: W = 256 * NS (NS = 1, 2), one wavefront per strip of R = 16 * RW rows
+// ---------------------------------------------------------------------------------------------
+// One load instruction covers 256 consecutive floats = (a 256-column block of) one row, so lane k
+// owns the column quad 4k..4k+3 of every row of the strip (for NS = 2 also quad 256+4k..).  Row
+// 16m+i of the strip is nibble i of word m: north/south neighbours are 4-bit shifts INSIDE the
+// lane (carried across words), west/east neighbours are the edge columns of lanes k-1 / k+1
+// (rotation over the whole wave, and over the column blocks, = the x torus seam).  The rows just
+// above and below the strip (y torus seam included) are loaded as two extra "halo" rows.
+// Workgroup ids are remapped so that vertically adjacent strips run on the same XCD (blocks b and
+// b+8 share an L2): the halo rows are then L2 hits instead of second HBM reads.
+static constexpr int kWideRW = 1;     // words (x16 rows) per strip; tuned in tools/kbench
+
+template <int NS, int RW>
+struct WideGeom {
+    static constexpr int kW = 256 * NS;
+    static constexpr int kR = 16 * RW;
+};
+
+__device__ __forceinline__ void horiz_neighbours(uint64_t c, uint64_t cw, uint64_t ce,
+                                                 uint64_t &wst, uint64_t &est) {
+    wst = ((c << 1) & 0xEEEEEEEEEEEEEEEEull) | ((cw >> 3) & 0x1111111111111111ull);
+    est = ((c >> 1) & 0x7777777777777777ull) | ((ce << 3) & 0x8888888888888888ull);
+}
+
+template <bool HAS_ACT, int NS, int RW>
+__global__ __launch_bounds__(64) void ca_step_f32_wide_kernel(
+    const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out,
+    int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot) {
+    constexpr int W = WideGeom<NS, RW>::kW, H = W, R = WideGeom<NS, RW>::kR;
+    constexpr int kStrips = H / R;
+    const int k = threadIdx.x;                       // lane = column quad
+    // XCD-aware, bijective remap of the workgroup id (cdna_hip_programming.md T1)
+    const int64_t nwg = gridDim.x, b = blockIdx.x;
+    const int64_t qd = nwg / 8, rm = nwg % 8, xcd = b % 8;
+    const int64_t wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + b / 8;
+    const int64_t g = wid / kStrips;
+    const int r0 = (int)(wid % kStrips) * R;
+    if (g >= n) return;
+    const float *gin = u_in + g * (int64_t)H * W;
+    const int rt = (r0 + H - 1) % H, rb = (r0 + R) % H;      // halo rows (torus in y)
+
+    uint64_t c[NS][RW];
+    uint32_t halo[NS];                               // bits 0-3: row above, bits 4-7: row below
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int m = 0; m < RW; ++m) {
+            uint4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                v[i] = ld16<true>(reinterpret_cast<const uint4 *>(gin + (int64_t)(r0 + 16 * m + i) * W + 256 * s) + k);
+            uint64_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc |= (uint64_t)nibble_of(v[i]) << (4 * i);
+            c[s][m] = acc;
+        }
+        // halo rows are re-read by the neighbouring strip: default cache policy keeps them in L2
+        const uint4 vt = *(reinterpret_cast<const uint4 *>(gin + (int64_t)rt * W + 256 * s) + k);
+        const uint4 vb = *(reinterpret_cast<const uint4 *>(gin + (int64_t)rb * W + 256 * s) + k);
+        halo[s] = nibble_of(vt) | (nibble_of(vb) << 4);
+    }
+
+    if (HAS_ACT) {
+        const int oy = (H - ah) >> 1, ox = (W - aw) >> 1;   // ox % 4 == 0 (host guarantees)
+        // does this strip (with its halo rows) touch the window rows at all?  (wave-uniform)
+        const bool touches = (r0 + R > oy && r0 < oy + ah) || (rt >= oy && rt < oy + ah) ||
+                             (rb >= oy && rb < oy + ah);
+        if (touches) {
+            const float *ga = act + g * (int64_t)ah * aw;
+            ActionSeen seen;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int ax = 256 * s + 4 * k - ox;
+                const bool col_in = ax >= 0 && ax < aw;
+#pragma unroll
+                for (int m = 0; m < RW; ++m) {
+                    uint64_t tog = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ay = r0 + 16 * m + i - oy;
+                        if (col_in && ay >= 0 && ay < ah) {
+                            const uint4 a = ld16<true>(reinterpret_cast<const uint4 *>(ga + (int64_t)ay * aw + ax));
+                            seen.add(a);
+                            tog |= (uint64_t)nibble_of(a) << (4 * i);
+                        }
+                    }
+                    c[s][m] ^= tog;
+                }
+                const int ayt = rt - oy, ayb = rb - oy;
+                if (col_in && ayt >= 0 && ayt < ah)
+                    halo[s] ^= nibble_of(*reinterpret_cast<const uint4 *>(ga + (int64_t)ayt * aw + ax));
+                if (col_in && ayb >= 0 && ayb < ah)
+                    halo[s] ^= nibble_of(*reinterpret_cast<const uint4 *>(ga + (int64_t)ayb * aw + ax)) << 4;
+            }
+            publish_flags(seen, status, slot);
+        } else if (status != nullptr && k == 0) {
+            // a strip outside the window sees no action element; the flags describe the whole
+            // action, which the in-window strips publish.  Nothing to do.
+        }
+    }
+
+    // horizontal sums of every row (strip words and the two halo rows)
+    uint64_t h0[NS][RW], h1[NS][RW], p0[NS][RW], p1[NS][RW];
+    uint32_t hh0[NS], hh1[NS];
+    const int lw = (k + 63) & 63, le = (k + 1) & 63;
+#pragma unroll
+    for (int m = 0; m < RW; ++m) {
+        uint64_t prv[NS], nxt[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { prv[s] = shfl64(c[s][m], lw); nxt[s] = shfl64(c[s][m], le); }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint64_t cw = (NS == 1 || k > 0) ? prv[s] : prv[(s + NS - 1) % NS];
+            const uint64_t ce = (NS == 1 || k < 63) ? nxt[s] : nxt[(s + 1) % NS];
+            uint64_t wst, est;
+            horiz_neighbours(c[s][m], cw, ce, wst, est);
+            row_sums(wst, c[s][m], est, h0[s][m], h1[s][m], p0[s][m], p1[s][m]);
+        }
+    }
+    {
+        uint32_t prv[NS], nxt[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { prv[s] = __shfl(halo[s], lw, 64); nxt[s] = __shfl(halo[s], le, 64); }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint32_t cw = (NS == 1 || k > 0) ? prv[s] : prv[(s + NS - 1) % NS];
+            const uint32_t ce = (NS == 1 || k < 63) ? nxt[s] : nxt[(s + 1) % NS];
+            uint64_t wst, est, a, bq, pa, pb;
+            horiz_neighbours((uint64_t)halo[s], (uint64_t)cw, (uint64_t)ce, wst, est);
+            row_sums(wst, (uint64_t)halo[s], est, a, bq, pa, pb);
+            hh0[s] = (uint32_t)a & 0xFFu;
+            hh1[s] = (uint32_t)bq & 0xFFu;
+        }
+    }
+
+    float *gout = u_out + g * (int64_t)H * W;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int m = 0; m < RW; ++m) {
+            // triple sums of the row above / below every row of word m
+            const uint64_t up0 = (h0[s][m] << 4) | (m == 0 ? (uint64_t)(hh0[s] & 0xFu) : (h0[s][m > 0 ? m - 1 : 0] >> 60));
+            const uint64_t up1 = (h1[s][m] << 4) | (m == 0 ? (uint64_t)(hh1[s] & 0xFu) : (h1[s][m > 0 ? m - 1 : 0] >> 60));
+            const uint64_t dn0 = (h0[s][m] >> 4) |
+                ((m == RW - 1 ? (uint64_t)(hh0[s] >> 4) : (h0[s][m < RW - 1 ? m + 1 : 0] & 0xFull)) << 60);
+            const uint64_t dn1 = (h1[s][m] >> 4) |
+                ((m == RW - 1 ? (uint64_t)(hh1[s] >> 4) : (h1[s][m < RW - 1 ? m + 1 : 0] & 0xFull)) << 60);
+            const uint64_t nx = apply_rule(neighbour_count(up0, up1, dn0, dn1, p0[s][m], p1[s][m]),
+                                           c[s][m], rule);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t nib = (uint32_t)(nx >> (4 * i));
+                uint4 o4;
+                o4.x = (nib & 1u) ? kOneBits : 0u;
+                o4.y = (nib & 2u) ? kOneBits : 0u;
+                o4.z = (nib & 4u) ? kOneBits : 0u;
+                o4.w = (nib & 8u) ? kOneBits : 0u;
+                st16<true>(reinterpret_cast<uint4 *>(gout + (int64_t)(r0 + 16 * m + i) * W + 256 * s) + k, o4);
+            }
+        }
+    }
+}
+
+template <int NS, int RW>
+static int launch_wide(const float *u_in, const float *action, float *u_out, int64_t n, int ah,
+                       int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
+    const int64_t wgs = n * (WideGeom<NS, RW>::kW / WideGeom<NS, RW>::kR);
+    if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32: batch too large");
+    if (action)
+        hipLaunchKernelGGL((ca_step_f32_wide_kernel<true, NS, RW>), dim3((unsigned)wgs), dim3(64), 0,
+                           s, u_in, action, u_out, n, ah, aw, rule, status, slot);
+    else
+        hipLaunchKernelGGL((ca_step_f32_wide_kernel<false, NS, RW>), dim3((unsigned)wgs), dim3(64), 0,
+                           s, u_in, action, u_out, n, 0, 0, rule, status, slot);
+    return check_launch("carle_ca_step_f32(wide)");
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic path: any even square grid, one thread per cell
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ca_step_f32_generic_kernel(
@@ -253,6 +431,11 @@ extern "C" int carle_ca_step_f32(const float *u_in, const float *action, float *
                                0, s, reinterpret_cast<const uint4 *>(u_in), action,
                                reinterpret_cast<uint4 *>(u_out), n, 0, rule, status, slot);
         return check_launch("carle_ca_step_f32(64x64)");
+    }
+    // 256x256 / 512x512: wavefront-per-strip path; needs a 16-byte aligned action window
+    if ((w == 256 || w == 512) && (!action || ((aw % 4) == 0 && ((w - aw) % 8) == 0))) {
+        if (w == 256) return launch_wide<1, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
+        return launch_wide<2, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
     }
     const int64_t cells = n * (int64_t)h * w;
     const int64_t blocks = (cells + 255) / 256;
