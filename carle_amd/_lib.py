@@ -18,6 +18,10 @@ SIGNATURES = {
     "carle_build_arch": (ctypes.c_char_p, []),
     "carle_ca_step_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int,
                                    _c_u32, _c_vp, _c_int, _c_vp]),
+    "carle_ca_step_b1": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int,
+                                  _c_u32, _c_vp, _c_int, _c_vp]),
+    "carle_pack_f32_b1": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_int, _c_vp]),
+    "carle_unpack_b1_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp]),
     "carle_ca_toggle_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int,
                                      _c_vp]),
     "carle_rnd2d_workspace_floats": (_c_i64, [_c_i64, _c_int, _c_int]),

@@ -42,6 +42,33 @@ __device__ __forceinline__ Count4<T> neighbour_count(T a0, T a1, T b0, T b1, T p
     return r;
 }
 
+// Rule lookup, sparse form: one equality mask per neighbour count that the rule actually uses
+// (wave-uniform branches on the SGPR rule bits), 3 three-input boolean ops per used count and
+// 32-bit half.  Life-like rules use 2-5 counts, so this beats the dense mux tree below.
+template <typename T>
+__device__ __forceinline__ T apply_rule_sparse(const Count4<T> &n, T c, uint32_t rule) {
+    T nxt = T(0);
+#pragma unroll
+    for (int k = 0; k <= 8; ++k) {
+        const uint32_t sk = (rule >> k) & 1u, bk = (rule >> (9 + k)) & 1u;
+        if (sk | bk) {                                     // uniform: rule bits live in SGPRs
+            T eq;
+            if (k == 8) {
+                eq = n.s3;                                 // count 8 <=> s3
+            } else {
+                const T b0 = (k & 1) ? n.s0 : ~n.s0;
+                const T b1 = (k & 2) ? n.s1 : ~n.s1;
+                const T b2 = (k & 4) ? n.s2 : ~n.s2;
+                eq = (b0 & b1) & (b2 & ~n.s3);
+            }
+            if (sk & bk) nxt |= eq;
+            else if (sk) nxt |= eq & c;
+            else nxt |= eq & ~c;
+        }
+    }
+    return nxt;
+}
+
 // Rule lookup as a multiplexer tree over the count bits; the 18 rule bits are wave-uniform
 // (SGPRs), so every select mask below is a scalar constant and each line is one 3-input
 // boolean op per 32-bit half.
@@ -61,6 +88,14 @@ __device__ __forceinline__ T apply_rule(const Count4<T> &n, T c, uint32_t rule) 
     T m47 = mux(n.s1, m67, m45);
     T m07 = mux(n.s2, m47, m03);
     return mux(n.s3, leaf(8), m07);     // s3 set implies count == 8 exactly
+}
+
+// dense rules (many used counts) -> mux tree (17 ops/half); sparse rules -> equality masks
+template <typename T>
+__device__ __forceinline__ T apply_rule_auto(const Count4<T> &n, T c, uint32_t rule) {
+    const int used = __builtin_popcount((rule | (rule >> 9)) & 0x1FFu);
+    if (used <= 5) return apply_rule_sparse(n, c, rule);   // uniform branch
+    return apply_rule(n, c, rule);
 }
 
 }  // namespace carle

@@ -218,3 +218,51 @@ def merge_moments(gathered, world, state, last, pending):
         rc = lib.carle_merge_moments(gathered.data_ptr(), world, state.data_ptr(), last.data_ptr(),
                                      _ptr(pending), _stream(state))
     _lib.check(rc, "carle_merge_moments")
+
+
+# ---------------------------------------------------------------------------------------------
+# bit-packed format (CARLE_FMT_B1): tensors are int64 (N,1,H,W/64), bit j of word i = col 64i+j
+# ---------------------------------------------------------------------------------------------
+
+def pack_f32_b1(src, status=None, slot=0, out=None):
+    """fp32 (N,1,H,W) -> int64 (N,1,H,W/64); optionally publishes the fp32 action predicates."""
+    lib = _lib.load()
+    _chk_grid(src, "src", torch.float32)
+    n, _, h, w = src.shape
+    if out is None:
+        out = torch.empty(n, 1, h, w // 64, dtype=torch.int64, device=src.device)
+    with _on_device(src.device):
+        rc = lib.carle_pack_f32_b1(src.data_ptr(), out.data_ptr(), n, h, w, _ptr(status), slot,
+                                   _stream(src))
+    _lib.check(rc, "carle_pack_f32_b1")
+    return out
+
+
+def unpack_b1_f32(src, out=None):
+    """int64 (N,1,H,W/64) -> fp32 (N,1,H,W) of 0.0 / 1.0."""
+    lib = _lib.load()
+    _chk_grid(src, "src", torch.int64)
+    n, _, h, ww = src.shape
+    if out is None:
+        out = torch.empty(n, 1, h, ww * 64, dtype=torch.float32, device=src.device)
+    with _on_device(src.device):
+        rc = lib.carle_unpack_b1_f32(src.data_ptr(), out.data_ptr(), n, h, ww * 64, _stream(src))
+    _lib.check(rc, "carle_unpack_b1_f32")
+    return out
+
+
+def ca_step_b1(u_in, action, u_out, rule, status=None, slot=0):
+    """One generation on packed grids; action = packed (N,1,AH,AW/64) int64 or None."""
+    lib = _lib.load()
+    _chk_grid(u_in, "u_in", torch.int64)
+    _chk_grid(u_out, "u_out", torch.int64)
+    n, _, h, ww = u_in.shape
+    ap, ah, aw = None, 0, 0
+    if action is not None:
+        _chk_grid(action, "action", torch.int64)
+        ah, aw = action.shape[2], action.shape[3] * 64
+        ap = action.data_ptr()
+    with _on_device(u_in.device):
+        rc = lib.carle_ca_step_b1(u_in.data_ptr(), ap, u_out.data_ptr(), n, h, ww * 64, ah, aw, rule,
+                                  _ptr(status), slot, _stream(u_in))
+    _lib.check(rc, "carle_ca_step_b1")

@@ -78,6 +78,26 @@ int carle_ca_step_f32(const float *u_in, const float *action, float *u_out,
                       int32_t *status, int slot, void *stream);
 
 /*
+ * One CA generation on bit-packed grids (CARLE_FMT_B1): 0.25 B of traffic per cell update.
+ * Same semantics as carle_ca_step_f32 (carle/env.py:150-182, 219-229) on 1-bit cells.
+ *   u_in, u_out  N*H*(W/64) uint64 words; must not alias.  H == W in {64, 128, 256, 512}.
+ *   action       N*AH*(AW/64) words or NULL; AW % 64 == 0; a set bit toggles.  The status flags
+ *                are derived from the bits (any bit set / every bit set): exact for {0,1}-valued
+ *                actions.  A caller holding an fp32 action packs it with carle_pack_f32_b1, which
+ *                publishes the exact fp32 predicates; then pass status = NULL here.
+ */
+int carle_ca_step_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out,
+                     int64_t n, int h, int w, int ah, int aw, uint32_t rule,
+                     int32_t *status, int slot, void *stream);
+
+/* fp32 (N,1,H,W) -> bit-packed, bit = (value != 0) (the truthiness of env.py:182); W % 64 == 0.
+ * status (nullable): publishes ANY_NONZERO / NOT_ALL_ONES of the fp32 source into `slot`. */
+int carle_pack_f32_b1(const float *src, uint64_t *dst, int64_t n, int h, int w,
+                      int32_t *status, int slot, void *stream);
+/* bit-packed -> fp32 0.0f / 1.0f (materialises the reference-format observation). */
+int carle_unpack_b1_f32(const uint64_t *src, float *dst, int64_t n, int h, int w, void *stream);
+
+/*
  * Toggle only: u_out = (u_in != 0) XOR pad(action != 0), as 0.0f/1.0f.  Replaces a stand-alone
  * call of CARLE.apply_action (carle/env.py:150-182); CARLE.step uses the fused kernel above.
  * u_out may alias u_in (elementwise).

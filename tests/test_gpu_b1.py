@@ -1,0 +1,121 @@
+"""GPU parity tests of the bit-packed (CARLE_FMT_B1) path: pack / unpack / step, bit-exact
+against numpy packing, the CPU oracle and the golden cases of the genuine reference."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from oracle import ca as O
+
+pytestmark = pytest.mark.gpu
+
+
+def np_pack(a):
+    """(N,1,H,W) 0/1 -> (N,1,H,W/64) int64, bit j of word i = column 64*i+j."""
+    n, _, h, w = a.shape
+    bits = np.packbits((a != 0).reshape(n, 1, h, w // 64, 64), axis=-1, bitorder="little")
+    return bits.reshape(n, 1, h, w // 64, 8).copy().view("<u8").reshape(n, 1, h, w // 64).astype(np.int64)
+
+
+@pytest.mark.parametrize("n,size", [(1, 64), (3, 64), (130, 64), (2, 128), (2, 256), (1, 512)])
+def test_pack_unpack(n, size):
+    from carle_amd import hip
+    rng = np.random.default_rng(size + n)
+    a = (rng.random((n, 1, size, size)) < 0.5).astype(np.float32)
+    a[a != 0] = rng.choice(np.array([1.0, -2.0, np.nan, 1e-40, 0.5], np.float32), int((a != 0).sum()))
+    a[0, 0, 0, 0] = -0.0
+    st = hip.new_status("cuda:0")
+    packed = hip.pack_f32_b1(torch.from_numpy(a).cuda(), st, 1)
+    assert np.array_equal(packed.cpu().numpy(), np_pack(a))
+    assert st.cpu().tolist()[:4] == [0, 1, 0, 1]
+    back = hip.unpack_b1_f32(packed).cpu().numpy()
+    assert np.array_equal(back, (a != 0).astype(np.float32))
+    st.zero_()
+    hip.pack_f32_b1(torch.ones(n, 1, size, size, device="cuda"), st, 0)
+    assert st.cpu().tolist()[:4] == [1, 0, 0, 0]
+    st.zero_()
+    hip.pack_f32_b1(torch.zeros(n, 1, size, size, device="cuda"), st, 0)
+    assert st.cpu().tolist()[:4] == [0, 0, 1, 0]
+
+
+@pytest.mark.parametrize("n,size,asize,rule", [
+    (1, 64, 64, ([3], [2, 3])), (5, 64, 64, ([3, 6], [2, 3])), (3, 128, 64, ([3, 6, 8], [2, 4, 5])),
+    (3, 128, 128, ([3], [2, 3])), (2, 256, 64, ([3], [2, 3])), (2, 256, 128, ([3, 6, 7, 8], [3, 4, 6, 7, 8])),
+    (2, 256, 256, ([2], [0])), (1, 512, 64, ([3, 6], [2, 3])), (2, 512, 256, ([3], [2, 3])),
+    (1, 512, 512, (list(range(9)), [])), (2, 512, 448, ([0, 3, 5, 7], [2, 4, 6, 8])),
+])
+def test_step_b1_against_oracle(n, size, asize, rule):
+    from carle_amd import hip
+    rng = np.random.default_rng(n * 7 + size + asize)
+    mask = O.rule_mask(*rule)
+    u = (rng.random((n, 1, size, size)) < 0.4).astype(np.float32)
+    a = (rng.random((n, 1, asize, asize)) < 0.2).astype(np.float32)
+    d_u = torch.from_numpy(np_pack(u)).cuda()
+    d_a = torch.from_numpy(np_pack(a)).cuda()
+    out = torch.empty_like(d_u)
+    st = hip.new_status("cuda:0")
+    for act_np, act_d in ((a, d_a), (None, None)):
+        exp, _, _ = O.c_env_step(u, act_np, mask)
+        out.fill_(-1)
+        st.zero_()
+        hip.ca_step_b1(d_u, act_d, out, mask, st, 0)
+        assert np.array_equal(out.cpu().numpy(), np_pack(exp))
+        if act_np is not None:
+            assert st.cpu().tolist()[:4] == [1, 0, 1, 0]
+    # several generations: packed evolution stays identical to the oracle
+    cur_np, cur = u, d_u
+    for t in range(5):
+        nxt = torch.empty_like(cur)
+        hip.ca_step_b1(cur, None, nxt, mask, None, 0)
+        cur_np, _, _ = O.c_env_step(cur_np, None, mask)
+        cur = nxt
+    assert np.array_equal(cur.cpu().numpy(), np_pack(cur_np))
+
+
+def _b1_cases():
+    return [nm for nm in G.ca_case_names()
+            if G.ca_case(nm).size in (64, 128, 256, 512) and G.ca_case(nm).asize % 64 == 0
+            and G.ca_case(nm).meta["actions_binary"] and G.ca_case(nm).meta["action_kind"] != "oversize"]
+
+
+@pytest.mark.parametrize("name", _b1_cases())
+def test_b1_replays_golden_case(name):
+    """pack(fp32 action, publishes the predicates) -> packed step -> finish; grids of the genuine
+    reference reproduced bit for bit, master reset and counters included."""
+    from carle_amd import hip
+    c = G.ca_case(name)
+    mask = O.rule_mask(c.birth, c.survive)
+    cur = hip.pack_f32_b1(torch.from_numpy(c.init.copy()).cuda())
+    st = hip.new_status("cuda:0")
+    rec = 0
+    for t in range(c.steps):
+        slot = t & 1
+        a = hip.pack_f32_b1(torch.from_numpy(c.actions[t].copy()).cuda(), st, slot)
+        nxt = torch.empty_like(cur)
+        hip.ca_step_b1(cur, a, nxt, mask, None, slot)
+        hip.ca_finish(nxt, None, st, slot, True)
+        cur = nxt
+        if (t + 1) in c.record:
+            got = hip.unpack_b1_f32(cur).cpu().numpy()
+            assert np.array_equal(got, c.obs[rec]), f"grid mismatch at step {t + 1}"
+            host = st.cpu()
+            assert int(host[6:8].view(torch.int64)) == c.step_number[t]
+            assert int(host[8:10].view(torch.int64)) == c.steps_since_action[t]
+            rec += 1
+
+
+def test_b1_full_size_round_trip():
+    """BASELINE configs[4]: B36/S23, N=4096 would be 128 MiB/array; here N=512 at 512x512 and
+    N=4096 at 64x64: packed step == pack(f32 step(unpack)) on the same inputs."""
+    from carle_amd import hip
+    high = O.rule_mask([3, 6], [2, 3])
+    for n, size in ((512, 512), (4096, 64)):
+        g = torch.Generator(device="cuda").manual_seed(size)
+        u = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.5).float()
+        ub = hip.pack_f32_b1(u)
+        o_b = torch.empty_like(ub)
+        hip.ca_step_b1(ub, None, o_b, high, None, 0)
+        o_f = torch.empty_like(u)
+        hip.ca_step_f32(u, None, o_f, high, None, 0)
+        assert torch.equal(hip.pack_f32_b1(o_f), o_b)
+        assert torch.equal(hip.unpack_b1_f32(o_b), o_f)
