@@ -38,8 +38,15 @@ def parse():
     ap.add_argument("--instances", type=int, default=4096, help="instances PER GPU")
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--rule", default="B3/S23")
+    ap.add_argument("--format", default="f32", choices=["f32", "b1"],
+                    help="grid storage: f32 = the reference's drop-in format (headline), "
+                         "b1 = bit-packed state and actions (secondary configurations)")
     ap.add_argument("--action-ring", type=int, default=6,
                     help="number of distinct device action buffers cycled through")
+    ap.add_argument("--rnd", action="store_true",
+                    help="configs[3]: also run the RND2D intrinsic-reward forward (eval mode) on "
+                         "every observation and feed ITS reward to the running statistics")
+    ap.add_argument("--ae", action="store_true", help="additionally the AE2D forward")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1")
     ap.add_argument("--stats-every", type=int, default=16,
                     help="steps between reward-statistics all-gathers (reporting interval)")
@@ -83,6 +90,16 @@ def cpu_baseline(size, rule, seconds):
                       f"{k} steps in {dt:.1f} s, torch {torch.__version__} {cores} threads"}
 
 
+def cfg_name(args, n, size):
+    if args.format == "f32" and size == 64 and n == 4096:
+        return "BASELINE configs[3] (CA + RND2D forward)" if args.rnd else "BASELINE configs[1]"
+    if args.format == "b1" and size == 512 and n == 4096:
+        return "BASELINE configs[4] (bit-packed)"
+    if size == 256:
+        return "BASELINE configs[2] shape (4096 instances per GPU)"
+    return "custom"
+
+
 def pmc_traffic(size, n):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py).  The
@@ -111,8 +128,9 @@ def main():
 
     n, size = args.instances, args.size
     asize = min(64, size)
+    packed = args.format == "b1"
     env = CARLE(width=size, height=size, action_width=asize, action_height=asize, instances=n,
-                device=str(dev))
+                device=str(dev), storage=args.format)
     env.rules_from_string(args.rule)
     env.reset()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -120,6 +138,8 @@ def main():
     ga = torch.Generator(device=dev).manual_seed(4321 + rank)
     ring = [(torch.rand(n, 1, asize, asize, device=dev, generator=ga) <= 0.1).float()
             for _ in range(args.action_ring)]
+    if packed:                      # actions handed over already packed (1 bit per toggle)
+        ring = [hip.pack_f32_b1(a) for a in ring]
 
     # reward statistics shared by all shards: local moments every step (HIP kernel), one 24-B
     # all-gather per rank every --stats-every steps (the only collective of the path)
@@ -131,8 +151,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    rnd = ae = None
+    if args.rnd or args.ae:
+        from carle_amd.mcl import RND2D, AE2D
+        torch.manual_seed(0)                 # construction order predictor -> random (mcl.py:248)
+        rnd = RND2D(env)
+        rnd.eval()
+        rnd.to(dev)
+        if args.ae:
+            ae = AE2D(rnd)
+            ae.eval()
+            ae.to(dev)
+
     def one_step(i):
         obs, reward, done, info = env.step(ring[i % len(ring)])
+        if rnd is not None:
+            if obs.dtype != torch.float32:
+                obs = env.universe
+            reward += rnd.get_bonus_only(obs).unsqueeze(1)
+            if ae is not None:
+                reward += ae.get_bonus_only(obs).unsqueeze(1)
         stats.update(reward)
 
     for i in range(args.warmup):
@@ -151,30 +189,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     pop = float(env.universe.sum().item())      # keeps the result live / sanity
+    state = env.universe_bits if packed else env.universe
+    step_fn = hip.ca_step_b1 if packed else hip.ca_step_f32
 
     # ---- roofline of the dominant kernel: back-to-back launches of the step kernel alone,
     # HIP events on the launch stream (torch's current stream is the stream the ABI is given)
     rule = env.rule_mask()
-    a_buf, b_buf = env.universe, torch.empty_like(env.universe)
+    a_buf, b_buf = state, torch.empty_like(state)
     reps = max(32, min(args.steps, 256))
     for i in range(4):
-        hip.ca_step_f32(a_buf, ring[i % len(ring)], b_buf, rule, env._status, 0)
+        step_fn(a_buf, ring[i % len(ring)], b_buf, rule, env._status, 0)
         a_buf, b_buf = b_buf, a_buf
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
     e0.record()
     for i in range(reps):
-        hip.ca_step_f32(a_buf, ring[i % len(ring)], b_buf, rule, env._status, 0)
+        step_fn(a_buf, ring[i % len(ring)], b_buf, rule, env._status, 0)
         a_buf, b_buf = b_buf, a_buf
     e1.record()
     torch.cuda.synchronize(dev)
     k_ms = e0.elapsed_time(e1) / reps
-    alg_bytes = n * (size * size * 8 + asize * asize * 4)
+    alg_bytes = n * (size * size * 8 + asize * asize * 4) if not packed else \
+        n * (size * size * 2 + asize * asize) // 8
     achieved = alg_bytes / (k_ms * 1e-3)
 
     if rank == 0:
         out = {
-            "metric": "env-steps/sec at N=4096x64x64 (B3/S23, fp32 drop-in grids, action every step)",
+            "metric": "env-steps/sec at N=4096x64x64 (B3/S23, fp32 drop-in grids, action every step)"
+                      if not packed and size == 64 else
+                      f"env-steps/sec at N={n}x{size}x{size} ({args.rule}, {args.format} grids, action every step)",
             "value": world * n * args.steps / dt,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -184,20 +227,22 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not packed else "u64 bit-planes",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {args.rule} N={n}/GPU {size}x{size} "
-                                   f"fp32 grids, Bernoulli(0.1) {asize}x{asize} fp32 action per step "
+            "config": {"workload": f"{cfg_name(args, n, size)}: {args.rule} N={n}/GPU {size}x{size} "
+                                   f"{args.format} grids, Bernoulli(0.1) {asize}x{asize} {args.format} action per step "
                                    f"(ring of {len(ring)} device buffers), CARLE.step drop-in surface",
                        "instances_per_gpu": n, "height": size, "width": size,
                        "action": asize, "rule": args.rule, "sharding": f"batch x{world}",
+                       "reward_nets": ("RND2D" if args.rnd else "") + ("+AE2D" if args.ae else ""),
                        "collective": f"all-gather of 24 B/rank reward moments every {args.stats_every} steps"},
             "cell_updates_per_s": world * n * args.steps * size * size / dt,
             "final_population_rank0": pop,
-            "roofline": {"bound": "hbm", "kernel": "ca_step_f32_64_kernel<true>" if size == 64
-                         else "ca_step_f32 (see DESIGN.md)",
+            "roofline": {"bound": "hbm", "kernel": ("ca_step_b1_kernel" if packed else
+                                    "ca_step_f32_64_kernel<true>" if size == 64 else
+                                    "ca_step_f32_wide_kernel<true>"),
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, **pmc_traffic(size, n),
+                         "frac": achieved / HBM_PEAK, **(pmc_traffic(size, n) if not packed else {"traffic": None}),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": k_ms * 1e3, "launches_timed": reps},
         }

@@ -26,7 +26,9 @@ SIGNATURES = {
                                      _c_vp]),
     "carle_rnd2d_workspace_floats": (_c_i64, [_c_i64, _c_int, _c_int]),
     "carle_rnd2d_bonus_f32": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
-                                       _c_vp, _c_vp, _c_vp]),
+                                       _c_vp, _c_vp, _c_int, _c_vp]),
+    "carle_rnd2d_bonus_b1": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
+                                      _c_vp, _c_vp, _c_vp]),
     "carle_ae2d_workspace_floats": (_c_i64, [_c_i64, _c_int, _c_int]),
     "carle_ae2d_bonus_f32": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
                                       _c_vp]),
@@ -35,6 +37,8 @@ SIGNATURES = {
     "carle_normalize_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp, ctypes.c_double, _c_vp]),
     "carle_env_step_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
                                     _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp]),
+    "carle_env_step_b1": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
+                                   _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp]),
     "carle_ca_finish": (_c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_int, _c_int, _c_vp]),
 }
 

@@ -102,3 +102,19 @@ extern "C" int carle_env_step_f32(const float *u_in, const float *action, float 
     return carle_ca_finish(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status,
                            slot, action != nullptr, stream);
 }
+
+extern "C" int carle_ca_step_b1(const uint64_t *, const uint64_t *, uint64_t *, int64_t, int, int, int,
+                                int, uint32_t, int32_t *, int, void *);
+
+// Whole CARLE.step on bit-packed state: packed step kernel + epilogue, one call.
+extern "C" int carle_env_step_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out,
+                                 float *reward, int64_t n, int h, int w, int ah, int aw,
+                                 uint32_t rule, int32_t *status, int slot, int publish_flags,
+                                 void *stream) {
+    if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_b1: status is NULL");
+    if (int e = carle_ca_step_b1(u_in, action, u_out, n, h, w, ah, aw, rule,
+                                 publish_flags ? status : nullptr, slot, stream))
+        return e;
+    return carle_ca_finish(u_out, (int64_t)n * h * (w / 8), reward, n, status, slot,
+                           action != nullptr, stream);
+}

@@ -1,0 +1,266 @@
+// nets_fused.hip -- RND2D forward for 64x64 BINARY grids, fused into one kernel per batch.
+//
+// Same networks and numerics as nets_staged.hip (carle/mcl.py:262-296, 343-352; eval mode), but
+// nothing leaves the CU between the observation read and the 4-byte bonus write:
+//   * the observation is binary, so conv1 (3x3, 1->4 and 1->2 channels) + bias + relu is a
+//     512-entry table per channel, indexed by the 9-bit neighbourhood pattern.  The tables are
+//     built once per call by rnd_prepare_kernel (1.5k patterns x 9 fma) and sit in LDS;
+//   * one wavefront per grid: lane (q,k) owns rows 16q..16q+15, cols 4k..4k+3 (a 16x4 patch =
+//     four 4x4 pooling windows), the 1-pixel halo comes from lanes k-1,k+1,q-1,q+1 by shuffles;
+//   * pooled conv1 maps (6 x 16x16) go to a wave-private, zero-bordered LDS image; conv2 + relu
+//     + 2x2 pool, the 64->16 linear layers + tanh and the bonus reduction run from LDS;
+//   * HBM traffic per grid: 16 KiB in (fp32 obs) or 512 B (bit-packed obs), 4 B out.
+// Blocks are persistent-ish: 4 waves share one copy of the tables and each wave strides over
+// grids, so the 21 KiB table load is amortised.
+#include "common.hpp"
+
+namespace carle {
+
+static constexpr int kLutFloats = 512 * 4 + 512 * 2;          // predictor float4 + random float2
+static constexpr int kLinStride = 68;                          // padded row of the 16x64 weights
+static constexpr int kLinFloats = 16 * kLinStride + 16;        // weights + bias, per net
+static constexpr int kFusedWsFloats = kLutFloats + 2 * kLinFloats;
+static constexpr int kPlaneStride = 24, kPlaneRows = 18;
+static constexpr int kPlaneFloats = kPlaneRows * kPlaneStride; // zero-bordered 16x16 map
+
+// ---------------------------------------------------------------------------------------------
+// per-call table build: conv1 LUTs (relu applied) + padded copy of the linear layers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void rnd_prepare_kernel(const float *__restrict__ pp,
+                                                          const float *__restrict__ rp,
+                                                          float *__restrict__ ws) {
+    const int p = threadIdx.x;                                  // neighbourhood pattern, bit ky*3+kx
+    float *lut_p = ws, *lut_r = ws + 2048;
+#pragma unroll
+    for (int ch = 0; ch < 6; ++ch) {
+        const float *wt = ch < 4 ? pp + ch * 9 : rp + (ch - 4) * 9;
+        const float bias = ch < 4 ? pp[36 + ch] : rp[18 + (ch - 4)];
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc = fmaf(wt[t], (float)((p >> t) & 1), acc);
+        const float v = fmaxf(acc + bias, 0.0f);
+        if (ch < 4) lut_p[p * 4 + ch] = v; else lut_r[p * 2 + (ch - 4)] = v;
+    }
+    float *lin = ws + kLutFloats;
+    for (int i = p; i < 2 * kLinFloats; i += 512) {
+        const int net = i / kLinFloats, j = i % kLinFloats;
+        const float *src = (net == 0 ? pp + 77 : rp + 39);      // lin.w[16][64] then lin.b[16]
+        float v;
+        if (j < 16 * kLinStride) {
+            const int k = j / kLinStride, d = j % kLinStride;
+            v = d < 64 ? src[k * 64 + d] : 0.0f;
+        } else {
+            v = src[16 * 64 + (j - 16 * kLinStride)];
+        }
+        lin[i] = v;
+    }
+    // conv2 parameters behind the tables: pred w[36] b[1] at +0, rand w[18] b[1] at +40
+    float *c2 = ws + kFusedWsFloats;
+    if (p < 37) c2[p] = pp[40 + p];
+    if (p >= 40 && p < 59) c2[p] = rp[20 + (p - 40)];
+}
+
+__device__ __forceinline__ uint32_t nz_bit(uint32_t bits) { return min(bits & 0x7FFFFFFFu, 1u); }
+
+// 8 nibbles (32 bits) -> 8 bytes
+__device__ __forceinline__ uint64_t spread_nibbles(uint32_t x) {
+    uint64_t t = x;
+    t = (t | (t << 16)) & 0x0000FFFF0000FFFFull;
+    t = (t | (t << 8)) & 0x00FF00FF00FF00FFull;
+    t = (t | (t << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    return t;
+}
+
+template <bool PACKED_OBS>
+__global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict__ obs_v,
+                                                          const float *__restrict__ ws,
+                                                          float *__restrict__ bonus,
+                                                          float *__restrict__ pred_out,
+                                                          float *__restrict__ target_out, int64_t n) {
+    __shared__ float4 s_lut_p[512];
+    __shared__ float2 s_lut_r[512];
+    __shared__ float s_lin[2 * kLinFloats];
+    __shared__ float s_planes[4][6][kPlaneFloats];
+    __shared__ float s_feat[4][2][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // tables -> LDS (coalesced copies), zero the plane borders once
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(ws);
+        for (int i = tid; i < 512; i += 256) s_lut_p[i] = src[i];
+        const float2 *src2 = reinterpret_cast<const float2 *>(ws + 2048);
+        for (int i = tid; i < 512; i += 256) s_lut_r[i] = src2[i];
+        for (int i = tid; i < 2 * kLinFloats; i += 256) s_lin[i] = ws[kLutFloats + i];
+        float *pl = &s_planes[0][0][0];
+        for (int i = tid; i < 4 * 6 * kPlaneFloats; i += 256) pl[i] = 0.0f;
+    }
+    __syncthreads();
+
+    const int q = lane >> 4, k = lane & 15;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t g = wave_id; g < n; g += nwaves) {
+        // ---- 1. the lane's 16x4 patch as one nibble per row
+        uint64_t c = 0;
+        if (PACKED_OBS) {
+            const uint64_t *rows = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + 16 * q;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c |= ((rows[i] >> (4 * k)) & 0xFull) << (4 * i);
+        } else {
+            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + (16 * q) * 16 + k;
+            uint4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = gin[i * 16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t nib = nz_bit(v[i].x) | (nz_bit(v[i].y) << 1) | (nz_bit(v[i].z) << 2) |
+                                     (nz_bit(v[i].w) << 3);
+                c |= (uint64_t)nib << (4 * i);
+            }
+        }
+        // ---- 2. 6-bit row segments [west | 4 cells | east], one byte per row; zero padding at
+        //         the grid border (conv1 uses zero padding, mcl.py:263)
+        uint64_t cw = ((uint64_t)__shfl((uint32_t)(c >> 32), lane - 1, 64) << 32) | __shfl((uint32_t)c, lane - 1, 64);
+        uint64_t ce = ((uint64_t)__shfl((uint32_t)(c >> 32), lane + 1, 64) << 32) | __shfl((uint32_t)c, lane + 1, 64);
+        if (k == 0) cw = 0;
+        if (k == 15) ce = 0;
+        const uint64_t wb = (cw >> 3) & 0x1111111111111111ull, eb = ce & 0x1111111111111111ull;
+        const uint64_t ea = (spread_nibbles((uint32_t)c) << 1) | spread_nibbles((uint32_t)wb) |
+                            (spread_nibbles((uint32_t)eb) << 5);                    // rows 0..7
+        const uint64_t ebb = (spread_nibbles((uint32_t)(c >> 32)) << 1) | spread_nibbles((uint32_t)(wb >> 32)) |
+                             (spread_nibbles((uint32_t)(eb >> 32)) << 5);           // rows 8..15
+        uint32_t top = __shfl((uint32_t)(ebb >> 56), lane - 16, 64);               // row 16q-1
+        uint32_t bot = __shfl((uint32_t)ea & 0xFFu, lane + 16, 64);                // row 16q+16
+        if (q == 0) top = 0;
+        if (q == 3) bot = 0;
+        uint32_t seg[18];
+        seg[0] = top;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            seg[1 + r] = (uint32_t)(ea >> (8 * r)) & 0xFFu;
+            seg[9 + r] = (uint32_t)(ebb >> (8 * r)) & 0xFFu;
+        }
+        seg[17] = bot;
+
+        // ---- 3. conv1 (table lookup) + relu + 4x4 max-pool -> zero-bordered planes in LDS
+        float *planes = &s_planes[wv][0][0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) {
+                    const uint32_t p = ((seg[4 * j + dy] >> dx) & 7u) |
+                                       (((seg[4 * j + dy + 1] >> dx) & 7u) << 3) |
+                                       (((seg[4 * j + dy + 2] >> dx) & 7u) << 6);
+                    const float4 a = s_lut_p[p];
+                    const float2 b = s_lut_r[p];
+                    m0 = fmaxf(m0, a.x); m1 = fmaxf(m1, a.y); m2 = fmaxf(m2, a.z); m3 = fmaxf(m3, a.w);
+                    m4 = fmaxf(m4, b.x); m5 = fmaxf(m5, b.y);
+                }
+            }
+            const int off = (4 * q + j + 1) * kPlaneStride + k + 1;
+            planes[0 * kPlaneFloats + off] = m0;
+            planes[1 * kPlaneFloats + off] = m1;
+            planes[2 * kPlaneFloats + off] = m2;
+            planes[3 * kPlaneFloats + off] = m3;
+            planes[4 * kPlaneFloats + off] = m4;
+            planes[5 * kPlaneFloats + off] = m5;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 4. conv2 (C->1, 3x3, zero pad) + relu + 2x2 pool: lane = pooled output (fy, fx)
+        const int fy = lane >> 3, fx = lane & 7;
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            const int nch = net == 0 ? 4 : 2, chbase = net == 0 ? 0 : 4;
+            const float *cw2 = ws + kFusedWsFloats + (net == 0 ? 0 : 40);   // uniform -> SGPR loads
+            float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                if (cc < nch) {
+                    const float *pl = planes + (chbase + cc) * kPlaneFloats + (2 * fy) * kPlaneStride + 2 * fx;
+                    float patch[4][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride);
+                        const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride + 2);
+                        patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+                    }
+                    // same accumulation order as the staged kernel (channel, oy, ox, ky, kx)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) o00 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][kx], o00);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) o01 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][1 + kx], o01);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) o10 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][kx], o10);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) o11 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][1 + kx], o11);
+                }
+            }
+            const float mx = fmaxf(fmaxf(o00, o01), fmaxf(o10, o11)) + cw2[net == 0 ? 36 : 18];
+            s_feat[wv][net][fy * 8 + fx] = fmaxf(mx, 0.0f);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 5. linear(64->16) + tanh for both nets; lane = (net, k16, half)
+        {
+            const int half = lane & 1, kk = (lane >> 1) & 15, net = lane >> 5;
+            const float4 *f4 = reinterpret_cast<const float4 *>(&s_feat[wv][net][32 * half]);
+            const float4 *w4 = reinterpret_cast<const float4 *>(&s_lin[net * kLinFloats + kk * kLinStride + 32 * half]);
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 f = f4[i], w = w4[i];
+                acc = fmaf(w.x, f.x, acc); acc = fmaf(w.y, f.y, acc);
+                acc = fmaf(w.z, f.z, acc); acc = fmaf(w.w, f.w, acc);
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            const float out = tanhf(acc + s_lin[net * kLinFloats + 16 * kLinStride + kk]);
+            if (half == 0) {
+                if (net == 0 && pred_out) pred_out[g * 16 + kk] = out;
+                if (net == 1 && target_out) target_out[g * 16 + kk] = out;
+            }
+            const float other = __shfl_xor(out, 32, 64);
+            float sq = (out - other) * (out - other);
+#pragma unroll
+            for (int s = 2; s < 32; s <<= 1) sq += __shfl_xor(sq, s, 64);
+            if (lane == 0) bonus[g] = sq * (1.0f / 16.0f);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace carle
+
+using namespace carle;
+
+namespace carle {
+
+// workspace: [tables + padded linear layers (kFusedWsFloats)] [conv2 parameters (64)]
+int64_t rnd2d_fused_workspace_floats() { return kFusedWsFloats + 64; }
+
+int rnd2d_fused64(const void *obs, bool packed, int64_t n, const float *pp, const float *rp,
+                  float *ws, float *bonus, float *pred_out, float *target_out, hipStream_t s) {
+    hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
+    int64_t blocks = (n + 7) / 8;                     // two grids per wave when the batch allows
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (packed)
+        hipLaunchKernelGGL(rnd_fused64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
+                           bonus, pred_out, target_out, n);
+    else
+        hipLaunchKernelGGL(rnd_fused64_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
+                           bonus, pred_out, target_out, n);
+    return check_launch("carle_rnd2d_bonus(fused 64x64)");
+}
+
+}  // namespace carle

@@ -48,6 +48,12 @@ _PLAIN_ATTRS = frozenset(("universe", "action", "_slot", "log"))
 class CARLE(nn.Module):
     """Batched toroidal Life-like cellular automaton with a gym-style interface."""
 
+    def __new__(cls, **kwargs):
+        # storage="b1" selects the bit-packed state variant (same surface, 1 bit per cell in HBM)
+        if cls is CARLE and kwargs.get("storage", "f32") == "b1":
+            return super().__new__(CARLEPacked)
+        return super().__new__(cls)
+
     def __setattr__(self, name, value):
         if name in _PLAIN_ATTRS:
             object.__setattr__(self, name, value)
@@ -70,6 +76,9 @@ class CARLE(nn.Module):
         # reference behaviour for an empty birth/survive list is a TypeError (env.py:221-224);
         # by default this build treats an empty list as "never" (a superset); strict mirrors it
         self.strict_reference_errors = kwargs.get("strict_reference_errors", False)
+        self.storage = kwargs.get("storage", "f32")
+        if self.storage not in ("f32", "b1"):
+            raise ValueError("storage must be 'f32' (reference format) or 'b1' (bit-packed)")
 
         self.set_neighborhood()
         self.set_action_padding()
@@ -288,6 +297,126 @@ class CARLE(nn.Module):
     def log_universe(self):
         raise NotImplementedError(
             "universe logging (RLE, carle/env.py:466-491) is outside the hot path of this build")
+
+
+class CARLEPacked(CARLE):
+    """CARLE with bit-packed state in HBM (``CARLE(storage="b1")``).
+
+    Same gym surface and semantics as ``CARLE``; the universe lives as int64 words
+    ``universe_bits`` (N,1,H,W/64), bit j of word i = column 64*i+j, and every step moves 1/32 of
+    the bytes of the fp32 format.  ``obs="b1"`` (default) returns the packed tensor from
+    ``reset``/``step``; ``obs="f32"`` materialises the reference-format observation with the
+    unpack kernel.  ``universe`` stays readable/writable as fp32 (unpacked / packed on demand).
+    Actions may be fp32 (packed on the fly, exact predicates) or already packed int64.
+    """
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.obs_format = kwargs.get("obs", "b1")
+        if self.obs_format not in ("f32", "b1"):
+            raise ValueError("obs must be 'f32' or 'b1'")
+        self.__dict__["_bits"] = None
+        self.__dict__["_f32"] = None
+
+    def _check_domain(self):
+        super()._check_domain()
+        if self.width not in (64, 128, 256, 512) or self.action_width % 64:
+            raise ValueError("storage='b1' needs H == W in {64,128,256,512} and AW % 64 == 0")
+
+    # fp32 view of record: unpacked lazily, packed on assignment
+    @property
+    def universe(self):
+        d = self.__dict__
+        if d["_bits"] is None:
+            return None
+        if d["_f32"] is None:
+            d["_f32"] = hip.unpack_b1_f32(d["_bits"])
+        return d["_f32"]
+
+    @universe.setter
+    def universe(self, value):
+        d = self.__dict__
+        if value is None:
+            d["_bits"], d["_f32"] = None, None
+            return
+        hip.require_gpu()
+        u = value if isinstance(value, torch.Tensor) else torch.as_tensor(value, dtype=torch.float32)
+        if tuple(u.shape) != (self.instances, 1, self.height, self.width):
+            raise ValueError(f"universe has shape {tuple(u.shape)}")
+        u = u.to(self.my_device, torch.float32).contiguous()
+        d["_bits"] = hip.pack_f32_b1(u)
+        d["_f32"] = None
+
+    @property
+    def universe_bits(self):
+        return self.__dict__["_bits"]
+
+    @universe_bits.setter
+    def universe_bits(self, value):
+        self.__dict__["_bits"] = value
+        self.__dict__["_f32"] = None
+
+    def _obs(self):
+        return self.universe if self.obs_format == "f32" else self.__dict__["_bits"]
+
+    def reset(self):
+        hip.require_gpu()
+        self._check_domain()
+        self.__dict__["_bits"] = torch.zeros(self.instances, 1, self.height, self.width // 64,
+                                             dtype=torch.int64, device=self.my_device)
+        self.__dict__["_f32"] = None
+        self._ensure_status()
+        self._status.zero_()
+        self._slot = 0
+        self.instance_id = str(int(time.time()))
+        self.log = []
+        return self._obs()
+
+    def get_observation(self):
+        return self._obs()
+
+    def apply_action(self, action):
+        a, _, _ = self._device_action(action)
+        out = torch.empty_like(self.universe)
+        hip.ca_toggle_f32(self.universe, a, out)
+        self.universe = out
+
+    def step(self, action):
+        hip.require_gpu()
+        self._check_domain()
+        self._ensure_status()
+        self.action = action
+        d = self.__dict__
+        bits = d["_bits"]
+        if bits is None:
+            raise RuntimeError("call reset() before step()")
+        slot = self._slot
+        publish = True
+        if isinstance(action, torch.Tensor) and action.dtype == torch.int64:
+            act = action                                   # already packed (N,1,AH,AW/64)
+            if act.device != self.my_device:
+                act = act.to(self.my_device, non_blocking=True)
+            if tuple(act.shape) != (self.instances, 1, self.action_height, self.action_width // 64):
+                raise AssertionError(f"packed action has shape {tuple(act.shape)}")
+            act = act.contiguous()
+        else:
+            a32, cropped, full = self._device_action(action)
+            if cropped:
+                self._status[slot] = (full != 0).any().to(torch.int32)
+                self._status[2 + slot] = (full != 1).any().to(torch.int32)
+                act = hip.pack_f32_b1(a32)
+            else:
+                act = hip.pack_f32_b1(a32, self._status, slot)   # exact fp32 predicates
+            publish = False
+        out = torch.empty_like(bits)
+        reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
+        hip.env_step_b1(bits, act, out, reward, self.rule_mask(), self._status, slot, publish)
+        self._slot = slot ^ 1
+        d["_bits"] = out
+        d["_f32"] = None
+        done = torch.zeros(self.instances, 1)
+        info = [{}] * self.instances
+        return self._obs(), reward, done, info
 
 
 def _check_moore(module, incompatible_keys):

@@ -131,11 +131,15 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=False):
-    """RND2D bonus (N,) for fp32 obs (N,1,H,W); params = flat fp32 blobs (see carle_hip.h)."""
+def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=False, binary=False):
+    """RND2D bonus (N,) for obs (N,1,H,W) fp32 -- or int64 bit-packed (N,1,64,1).  params = flat
+    fp32 blobs (see carle_hip.h).  binary=True: obs values are exactly 0/1 (fused 64x64 path)."""
     lib = _lib.load()
-    _chk_grid(obs, "obs", torch.float32)
+    packed = obs.dtype == torch.int64
+    _chk_grid(obs, "obs", torch.int64 if packed else torch.float32)
     n, _, h, w = obs.shape
+    if packed:
+        w *= 64
     need = lib.carle_rnd2d_workspace_floats(n, h, w)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 1), dtype=torch.float32, device=obs.device)
@@ -143,10 +147,16 @@ def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=
     pred = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
     targ = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
     with _on_device(obs.device):
-        rc = lib.carle_rnd2d_bonus_f32(obs.data_ptr(), n, h, w, pred_params.data_ptr(),
-                                       rand_params.data_ptr(), workspace.data_ptr(),
-                                       bonus.data_ptr(), _ptr(pred), _ptr(targ), _stream(obs))
-    _lib.check(rc, "carle_rnd2d_bonus_f32")
+        if packed:
+            rc = lib.carle_rnd2d_bonus_b1(obs.data_ptr(), n, h, w, pred_params.data_ptr(),
+                                          rand_params.data_ptr(), workspace.data_ptr(),
+                                          bonus.data_ptr(), _ptr(pred), _ptr(targ), _stream(obs))
+        else:
+            rc = lib.carle_rnd2d_bonus_f32(obs.data_ptr(), n, h, w, pred_params.data_ptr(),
+                                           rand_params.data_ptr(), workspace.data_ptr(),
+                                           bonus.data_ptr(), _ptr(pred), _ptr(targ),
+                                           1 if binary else 0, _stream(obs))
+    _lib.check(rc, "carle_rnd2d_bonus")
     return (bonus, pred, targ, workspace) if want_outputs else (bonus, workspace)
 
 
@@ -266,3 +276,19 @@ def ca_step_b1(u_in, action, u_out, rule, status=None, slot=0):
         rc = lib.carle_ca_step_b1(u_in.data_ptr(), ap, u_out.data_ptr(), n, h, ww * 64, ah, aw, rule,
                                   _ptr(status), slot, _stream(u_in))
     _lib.check(rc, "carle_ca_step_b1")
+
+
+def env_step_b1(u_in, action, u_out, reward, rule, status, slot, publish_flags=True):
+    """CARLE.step hot path on packed state: packed step kernel + epilogue, one library call."""
+    lib = _lib.load()
+    n, _, h, ww = u_in.shape
+    if action is None:
+        ap, ah, aw = None, 0, 0
+    else:
+        ap, ah, aw = action.data_ptr(), action.shape[2], action.shape[3] * 64
+    with _on_device(u_in.device):
+        rc = lib.carle_env_step_b1(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h,
+                                   ww * 64, ah, aw, rule, status.data_ptr(), slot,
+                                   1 if publish_flags else 0, _stream(u_in))
+    if rc != 0:
+        _lib.check(rc, "carle_env_step_b1")

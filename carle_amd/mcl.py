@@ -99,6 +99,9 @@ class RND2D(Motivator):
         self.updates = 0
         self._window = []                    # observations of the current update window
         self._ws = None                      # kernel workspace, reused across steps
+        # obs values are exactly 0/1 (always true for what CARLE.step returns; detected by
+        # identity with inner_env.universe).  Set True to assert it for foreign tensors.
+        self.assume_binary_obs = False
         self.accumulate_loss = 0.0
 
     # ------------------------------------------------------------------ networks
@@ -150,20 +153,30 @@ class RND2D(Motivator):
             p.requires_grad = False
 
     # ------------------------------------------------------------------ HIP forward passes
-    def _obs(self, obs):
+    def _obs(self, obs, allow_packed=False):
+        """-> (device tensor, binary?)  fp32 (N,1,H,W), or int64 bit-packed when allowed."""
         hip.require_gpu()
         dev = self.inner_env.my_device
+        env = self.inner_env
+        if obs.dtype == torch.int64:                      # bit-packed observation (storage="b1")
+            if obs.device != dev or not obs.is_contiguous():
+                obs = obs.to(dev).contiguous()
+            if allow_packed and obs.shape[2] == 64 and obs.shape[3] == 1:
+                return obs, True
+            return hip.unpack_b1_f32(obs), True
+        binary = self.assume_binary_obs or (getattr(env, "storage", "f32") == "f32" and
+                                            obs is env.__dict__.get("universe"))
         if obs.device != dev or obs.dtype != torch.float32 or not obs.is_contiguous():
             obs = obs.to(dev, torch.float32).contiguous()
         if obs.dim() == 3:
             obs = obs.unsqueeze(1)
-        return obs
+        return obs, binary
 
     def _hip_forward(self, obs, want_outputs=False):
-        obs = self._obs(obs)
+        obs, binary = self._obs(obs, allow_packed=True)
         dev = obs.device
         res = hip.rnd2d_bonus_f32(obs, self._pred_blob.get(dev), self._rand_blob.get(dev),
-                                  self._ws, want_outputs)
+                                  self._ws, want_outputs, binary)
         self._ws = res[-1]
         return res
 
@@ -211,7 +224,7 @@ class RND2D(Motivator):
         """Bonus + immediate predictor update on this observation (mcl.py:354-366)."""
         self.predictor.zero_grad()
         bonus = self.get_bonus(obs)
-        self._window = [self._obs(obs)]
+        self._window = [self._obs(obs)[0]]
         self._replay_window(1.0)
         self.optimizer.step()
         self._after_update()
@@ -224,7 +237,7 @@ class RND2D(Motivator):
             self.accumulate_loss = 0.0
             self._window = []
         bonus = self.get_bonus(obs)
-        self._window.append(self._obs(obs))
+        self._window.append(self._obs(obs)[0])
         self.buffer_length += 1
         if self.buffer_length >= self.batch_size:
             self.accumulate_loss = self._replay_window(1.0 / self.batch_size)
@@ -293,7 +306,7 @@ class AE2D(RND2D):
             p.requires_grad = False
 
     def _hip_forward(self, obs, want_outputs=False):
-        obs = self._obs(obs)
+        obs, binary = self._obs(obs)
         res = hip.ae2d_bonus_f32(obs, self._pred_blob.get(obs.device), self._ws, want_outputs)
         self._ws = res[-1]
         return res

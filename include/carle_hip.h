@@ -129,6 +129,11 @@ int carle_env_step_f32(const float *u_in, const float *action, float *u_out, flo
                        int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                        int32_t *status, int slot, int publish_flags, void *stream);
 
+/* The same on bit-packed state: carle_ca_step_b1 + carle_ca_finish. */
+int carle_env_step_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out, float *reward,
+                      int64_t n, int h, int w, int ah, int aw, uint32_t rule,
+                      int32_t *status, int slot, int publish_flags, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Intrinsic-reward forward passes (eval mode: Dropout = identity), fp32, tolerance 1e-5 abs.
  * Parameter blobs are flat fp32 arrays in the state_dict order of the reference's
@@ -144,10 +149,19 @@ int carle_env_step_f32(const float *u_in, const float *action, float *u_out, flo
 /* RND2D.get_bonus (carle/mcl.py:319-330,343-352): bonus[i] = mean_k (random(obs_i)_k -
  * predictor(obs_i)_k)^2.  pred_out / target_out: optional (N,16) network outputs, may be NULL. */
 int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w);
+/* flags: CARLE_NET_OBS_BINARY = the caller guarantees every obs value is exactly 0.0f or 1.0f
+ * (true for anything CARLE.step returned); enables the fused 64x64 kernel whose first conv is a
+ * table lookup on the binary image.  Without the flag obs values are used as fp32 numbers. */
+#define CARLE_NET_OBS_BINARY 1
 int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
                           const float *pred_params, const float *rand_params,
                           float *workspace, float *bonus, float *pred_out, float *target_out,
-                          void *stream);
+                          int flags, void *stream);
+/* the same on bit-packed observations (CARLE_FMT_B1), 64x64 grids */
+int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
+                         const float *pred_params, const float *rand_params,
+                         float *workspace, float *bonus, float *pred_out, float *target_out,
+                         void *stream);
 
 /* AE2D.get_bonus (carle/mcl.py:436-443,504-512): bonus[i] = mean_{h,w} (obs_i - decoder(obs_i))^2.
  * recon_out: optional (N,1,H,W) reconstruction, may be NULL. */

@@ -119,3 +119,45 @@ def test_b1_full_size_round_trip():
         hip.ca_step_f32(u, None, o_f, high, None, 0)
         assert torch.equal(hip.pack_f32_b1(o_f), o_b)
         assert torch.equal(hip.unpack_b1_f32(o_b), o_f)
+
+
+@pytest.mark.parametrize("name", ["tog64a64_life", "tog256a64_daynight", "reset64_life", "reset256_life",
+                                  "tog512a64_highlife", "crop256_life", "values64_life"])
+def test_packed_env_replays_golden_case(name):
+    """CARLE(storage="b1") through the gym surface: fp32 actions in, packed state inside."""
+    from carle_amd.env import CARLE
+    c = G.ca_case(name)
+    for obs_fmt in ("b1", "f32"):
+        env = CARLE(width=c.size, height=c.size, action_width=c.asize, action_height=c.asize,
+                    instances=c.n, device="cuda:0", storage="b1", obs=obs_fmt)
+        env.birth, env.survive = list(c.birth), list(c.survive)
+        env.reset()
+        env.universe = torch.from_numpy(c.init.copy())
+        rec = 0
+        for t in range(c.steps):
+            obs, reward, done, info = env.step(torch.from_numpy(c.actions[t].copy()))
+            if obs_fmt == "b1":
+                assert obs.dtype == torch.int64 and tuple(obs.shape) == (c.n, 1, c.size, c.size // 64)
+            if (t + 1) in c.record:
+                assert np.array_equal(env.universe.cpu().numpy(), c.obs[rec])
+                if obs_fmt == "f32":
+                    assert np.array_equal(obs.cpu().numpy(), c.obs[rec])
+                assert env.step_number == c.step_number[t]
+                assert env.steps_since_action == c.steps_since_action[t]
+                rec += 1
+
+
+def test_packed_env_packed_actions():
+    from carle_amd.env import CARLE
+    from carle_amd import hip
+    env = CARLE(width=64, height=64, instances=5, device="cuda:0", storage="b1")
+    ref = CARLE(width=64, height=64, instances=5, device="cuda:0")
+    env.reset(); ref.reset()
+    for t in range(6):
+        a = (torch.rand(5, 1, 64, 64, device="cuda") < 0.2).float()
+        if t == 3:
+            a.fill_(1.0)
+        ob = env.step(hip.pack_f32_b1(a))[0]
+        of = ref.step(a)[0]
+        assert torch.equal(hip.unpack_b1_f32(ob), of)
+        assert env.step_number == ref.step_number
