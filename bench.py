@@ -47,6 +47,8 @@ def parse():
                     help="configs[3]: also run the RND2D intrinsic-reward forward (eval mode) on "
                          "every observation and feed ITS reward to the running statistics")
     ap.add_argument("--ae", action="store_true", help="additionally the AE2D forward")
+    ap.add_argument("--sync-reward", action="store_true",
+                    help="run the reward nets on the CA stream instead of the reward stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1")
     ap.add_argument("--stats-every", type=int, default=16,
                     help="steps between reward-statistics all-gathers (reporting interval)")
@@ -151,35 +153,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    rnd = ae = None
+    wenv = env
     if args.rnd or args.ae:
         from carle_amd.mcl import RND2D, AE2D
         torch.manual_seed(0)                 # construction order predictor -> random (mcl.py:248)
-        rnd = RND2D(env)
-        rnd.eval()
-        rnd.to(dev)
+        kw = dict(async_reward=not args.sync_reward, train_predictor=False)   # forward passes only
+        wenv = RND2D(env, **kw)
         if args.ae:
-            ae = AE2D(rnd)
-            ae.eval()
-            ae.to(dev)
+            wenv = AE2D(wenv, **kw)
+        wenv.eval()
+        wenv.to(dev)
+    rs = None
 
     def one_step(i):
-        obs, reward, done, info = env.step(ring[i % len(ring)])
-        if rnd is not None:
-            if obs.dtype != torch.float32:
-                obs = env.universe
-            reward += rnd.get_bonus_only(obs).unsqueeze(1)
-            if ae is not None:
-                reward += ae.get_bonus_only(obs).unsqueeze(1)
-        stats.update(reward)
+        nonlocal rs
+        obs, reward, done, info = wenv.step(ring[i % len(ring)])
+        rs = env.__dict__.get("reward_stream")
+        if rs is not None:                   # reward consumers live on the reward stream
+            with torch.cuda.stream(rs):
+                stats.update(reward)
+        else:
+            stats.update(reward)
+
+    def join_rewards():
+        if rs is not None:
+            torch.cuda.current_stream(dev).wait_stream(rs)
 
     for i in range(args.warmup):
         one_step(i)
+    join_rewards()
     stats.flush()                       # first collective (RCCL setup) stays out of the timing
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+    join_rewards()
     stats.flush()
     torch.cuda.synchronize(dev)
     barrier()
@@ -234,7 +242,9 @@ def main():
                                    f"(ring of {len(ring)} device buffers), CARLE.step drop-in surface",
                        "instances_per_gpu": n, "height": size, "width": size,
                        "action": asize, "rule": args.rule, "sharding": f"batch x{world}",
-                       "reward_nets": ("RND2D" if args.rnd else "") + ("+AE2D" if args.ae else ""),
+                       "reward_nets": ("RND2D" if args.rnd else "") + ("+AE2D" if args.ae else "") +
+                                      (" forward, on the reward stream" if (args.rnd or args.ae) and
+                                       not args.sync_reward else ""),
                        "collective": f"all-gather of 24 B/rank reward moments every {args.stats_every} steps"},
             "cell_updates_per_s": world * n * args.steps * size * size / dt,
             "final_population_rank0": pop,

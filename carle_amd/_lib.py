@@ -28,7 +28,7 @@ SIGNATURES = {
     "carle_rnd2d_bonus_f32": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
                                        _c_vp, _c_vp, _c_int, _c_vp]),
     "carle_rnd2d_bonus_b1": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
-                                      _c_vp, _c_vp, _c_vp]),
+                                      _c_vp, _c_vp, _c_int, _c_vp]),
     "carle_ae2d_workspace_floats": (_c_i64, [_c_i64, _c_int, _c_int]),
     "carle_ae2d_bonus_f32": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
                                       _c_vp]),

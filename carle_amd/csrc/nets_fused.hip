@@ -98,6 +98,14 @@ __global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict
 
     const int q = lane >> 4, k = lane & 15;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    // software prefetch: the fp32 loads of the NEXT grid are issued right after the current
+    // grid's words have been converted, so their latency hides under the compute phases
+    uint4 v[16];
+    if (!PACKED_OBS && wave_id < n) {
+        const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + wave_id * 1024 + (16 * q) * 16 + k;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = gin[i * 16];
+    }
     for (int64_t g = wave_id; g < n; g += nwaves) {
         // ---- 1. the lane's 16x4 patch as one nibble per row
         uint64_t c = 0;
@@ -106,15 +114,16 @@ __global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict
 #pragma unroll
             for (int i = 0; i < 16; ++i) c |= ((rows[i] >> (4 * k)) & 0xFull) << (4 * i);
         } else {
-            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + (16 * q) * 16 + k;
-            uint4 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = gin[i * 16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const uint32_t nib = nz_bit(v[i].x) | (nz_bit(v[i].y) << 1) | (nz_bit(v[i].z) << 2) |
                                      (nz_bit(v[i].w) << 3);
                 c |= (uint64_t)nib << (4 * i);
+            }
+            if (g + nwaves < n) {
+                const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + (g + nwaves) * 1024 + (16 * q) * 16 + k;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = gin[i * 16];
             }
         }
         // ---- 2. 6-bit row segments [west | 4 cells | east], one byte per row; zero padding at
@@ -249,8 +258,9 @@ namespace carle {
 int64_t rnd2d_fused_workspace_floats() { return kFusedWsFloats + 64; }
 
 int rnd2d_fused64(const void *obs, bool packed, int64_t n, const float *pp, const float *rp,
-                  float *ws, float *bonus, float *pred_out, float *target_out, hipStream_t s) {
-    hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
+                  float *ws, float *bonus, float *pred_out, float *target_out, bool tables_valid,
+                  hipStream_t s) {
+    if (!tables_valid) hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
     int64_t blocks = (n + 7) / 8;                     // two grids per wave when the batch allows
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;

@@ -321,7 +321,8 @@ static inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 25
 namespace carle {
 int64_t rnd2d_fused_workspace_floats();
 int rnd2d_fused64(const void *obs, bool packed, int64_t n, const float *pp, const float *rp,
-                  float *ws, float *bonus, float *pred_out, float *target_out, hipStream_t s);
+                  float *ws, float *bonus, float *pred_out, float *target_out, bool tables_valid,
+                  hipStream_t s);
 }
 
 using namespace carle;
@@ -336,7 +337,7 @@ extern "C" int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w) {
 extern "C" int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
                                     const float *pred_params, const float *rand_params,
                                     float *workspace, float *bonus, float *pred_out,
-                                    float *target_out, void *stream) {
+                                    float *target_out, int flags, void *stream) {
     if (!obs || !pred_params || !rand_params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_rnd2d_bonus_b1: NULL pointer");
     if (h != 64 || w != 64 || n < 0)
@@ -344,7 +345,8 @@ extern "C" int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w
                                       "for 64x64 grids (unpack larger grids first)");
     if (n == 0) return 0;
     return rnd2d_fused64(obs, true, n, pred_params, rand_params, workspace, bonus, pred_out,
-                         target_out, static_cast<hipStream_t>(stream));
+                         target_out, (flags & CARLE_NET_TABLES_VALID) != 0,
+                         static_cast<hipStream_t>(stream));
 }
 
 extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
@@ -358,7 +360,7 @@ extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (h == 64 && w == 64 && (flags & CARLE_NET_OBS_BINARY) && aligned16(obs))
         return rnd2d_fused64(obs, false, n, pred_params, rand_params, workspace, bonus, pred_out,
-                             target_out, s);
+                             target_out, (flags & CARLE_NET_TABLES_VALID) != 0, s);
     const int64_t p1 = n * (int64_t)(h / 4) * (w / 4);
     const int d = (h / 8) * (w / 8);
     if (p1 * 6 / 256 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_rnd2d_bonus_f32: batch too large");

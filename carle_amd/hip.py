@@ -131,6 +131,9 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+_ws_tables = {}      # workspace data_ptr -> (pred blob id, rand blob id) the fused tables hold
+
+
 def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=False, binary=False):
     """RND2D bonus (N,) for obs (N,1,H,W) fp32 -- or int64 bit-packed (N,1,64,1).  params = flat
     fp32 blobs (see carle_hip.h).  binary=True: obs values are exactly 0/1 (fused 64x64 path)."""
@@ -146,16 +149,31 @@ def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=
     bonus = torch.empty(n, dtype=torch.float32, device=obs.device)
     pred = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
     targ = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
+    flags = 1 if binary else 0
+    fused = h == 64 and w == 64 and (packed or binary)
+    if fused:
+        # parameter blobs are immutable tensors rebuilt on every parameter change (_ParamBlob), so
+        # their identity tells whether the tables in this workspace are still valid
+        key = (id(pred_params), id(rand_params), pred_params.data_ptr(), rand_params.data_ptr())
+        if _ws_tables.get(workspace.data_ptr()) == key:
+            flags |= 2
+        else:
+            if len(_ws_tables) > 64:
+                _ws_tables.clear()
+            _ws_tables[workspace.data_ptr()] = key
+    else:
+        _ws_tables.pop(workspace.data_ptr(), None)        # staged path overwrites the workspace
     with _on_device(obs.device):
         if packed:
             rc = lib.carle_rnd2d_bonus_b1(obs.data_ptr(), n, h, w, pred_params.data_ptr(),
                                           rand_params.data_ptr(), workspace.data_ptr(),
-                                          bonus.data_ptr(), _ptr(pred), _ptr(targ), _stream(obs))
+                                          bonus.data_ptr(), _ptr(pred), _ptr(targ), flags,
+                                          _stream(obs))
         else:
             rc = lib.carle_rnd2d_bonus_f32(obs.data_ptr(), n, h, w, pred_params.data_ptr(),
                                            rand_params.data_ptr(), workspace.data_ptr(),
-                                           bonus.data_ptr(), _ptr(pred), _ptr(targ),
-                                           1 if binary else 0, _stream(obs))
+                                           bonus.data_ptr(), _ptr(pred), _ptr(targ), flags,
+                                           _stream(obs))
     _lib.check(rc, "carle_rnd2d_bonus")
     return (bonus, pred, targ, workspace) if want_outputs else (bonus, workspace)
 

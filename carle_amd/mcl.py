@@ -72,10 +72,15 @@ class _ParamBlob:
         self.module = module
         self.key = None
         self.blob = None
+        self.params = None
 
     def get(self, device):
-        ps = list(self.module.parameters())
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in ps)
+        # the Parameter objects of an nn.Sequential are stable (.to()/load_state_dict/optimisers
+        # mutate them in place): enumerate the module tree once, not on every step
+        ps = self.params
+        if ps is None:
+            ps = self.params = list(self.module.parameters())
+        key = (device,) + tuple([(p.data_ptr(), p._version) for p in ps])
         if key != self.key:
             with torch.no_grad():
                 self.blob = torch.cat([p.detach().reshape(-1).to(device, torch.float32) for p in ps])
@@ -102,6 +107,9 @@ class RND2D(Motivator):
         # obs values are exactly 0/1 (always true for what CARLE.step returns; detected by
         # identity with inner_env.universe).  Set True to assert it for foreign tensors.
         self.assume_binary_obs = False
+        self.async_reward = bool(kwargs.get("async_reward", False))
+        # False: step() only evaluates the bonus (forward pass), no window retention / Adam update
+        self.train_predictor = bool(kwargs.get("train_predictor", True))
         self.accumulate_loss = 0.0
 
     # ------------------------------------------------------------------ networks
@@ -251,13 +259,50 @@ class RND2D(Motivator):
         self.updates += 1
 
     # ------------------------------------------------------------------ gym surface
+    def _bonus_into(self, obs, reward):
+        if self.train_predictor:
+            bonus = self.get_bonus_accumulate(obs)
+        else:
+            bonus = self.get_bonus_only(obs)
+        reward += self.reward_scale * bonus.unsqueeze(1)
+
     def step(self, action):
+        """env.step, then reward += reward_scale * bonus(obs)  (mcl.py:398-407).
+
+        With ``async_reward=True`` the bonus runs on a dedicated HIP stream
+        (``inner_env.reward_stream``): the compute-bound reward networks of step t then overlap
+        the bandwidth-bound CA kernel of step t+1.  ``obs`` is ready on the caller's stream as
+        usual; ``reward`` must be consumed on the reward stream or after ``wait_rewards()``.
+        """
         if isinstance(action, torch.Tensor):
             action = action.to(self.inner_env.my_device)
         obs, reward, done, info = self.env.step(action)
-        bonus = self.get_bonus_accumulate(obs).unsqueeze(1)
-        reward += self.reward_scale * bonus
+        rs = self._reward_stream()
+        if rs is None:
+            self._bonus_into(obs, reward)
+        else:
+            rs.wait_stream(torch.cuda.current_stream(obs.device))
+            with torch.cuda.stream(rs):
+                self._bonus_into(obs, reward)
+            obs.record_stream(rs)
+            reward.record_stream(rs)
         return obs, reward, done, info
+
+    def _reward_stream(self):
+        if not self.async_reward:
+            return None
+        env = self.inner_env
+        rs = env.__dict__.get("reward_stream")
+        if rs is None:
+            rs = torch.cuda.Stream(device=env.my_device)
+            env.__dict__["reward_stream"] = rs
+        return rs
+
+    def wait_rewards(self):
+        """Make the caller's current stream wait for all reward work enqueued so far."""
+        rs = self.inner_env.__dict__.get("reward_stream")
+        if rs is not None:
+            torch.cuda.current_stream(self.inner_env.my_device).wait_stream(rs)
 
     def reset(self):
         obs = self.env.reset()

@@ -153,6 +153,9 @@ int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w);
  * (true for anything CARLE.step returned); enables the fused 64x64 kernel whose first conv is a
  * table lookup on the binary image.  Without the flag obs values are used as fp32 numbers. */
 #define CARLE_NET_OBS_BINARY 1
+/* CARLE_NET_TABLES_VALID: `workspace` still holds the lookup tables a previous fused call built
+ * from the SAME parameter values (the caller tracks parameter updates); skips the table build. */
+#define CARLE_NET_TABLES_VALID 2
 int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
                           const float *pred_params, const float *rand_params,
                           float *workspace, float *bonus, float *pred_out, float *target_out,
@@ -161,7 +164,7 @@ int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
 int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
                          const float *pred_params, const float *rand_params,
                          float *workspace, float *bonus, float *pred_out, float *target_out,
-                         void *stream);
+                         int flags, void *stream);
 
 /* AE2D.get_bonus (carle/mcl.py:436-443,504-512): bonus[i] = mean_{h,w} (obs_i - decoder(obs_i))^2.
  * recon_out: optional (N,1,H,W) reconstruction, may be NULL. */

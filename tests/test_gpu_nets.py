@@ -151,3 +151,28 @@ def test_fused_path_is_taken_through_the_env():
     assert binary and o is obs
     o2, binary2 = rnd._obs(obs.clone(), allow_packed=True)
     assert not binary2
+
+
+def test_async_reward_stream_matches_sync():
+    """Rewards computed on the dedicated reward stream equal the same-stream rewards."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D
+    outs = []
+    for async_reward in (False, True):
+        torch.manual_seed(3)
+        env = CARLE(width=64, height=64, instances=32, device="cuda:0")
+        w = AE2D(RND2D(env, async_reward=async_reward, train_predictor=False),
+                 async_reward=async_reward, train_predictor=False)
+        w.eval()
+        w.reset()
+        g = torch.Generator().manual_seed(5)
+        rews = []
+        for t in range(6):
+            a = (torch.rand(32, 1, 64, 64, generator=g) < 0.2).float()
+            obs, reward, done, info = w.step(a)
+            rews.append(reward)
+        w.wait_rewards()
+        torch.cuda.synchronize()
+        outs.append(torch.stack(rews).cpu().numpy())
+        assert (env.__dict__.get("reward_stream") is not None) == async_reward
+    assert np.array_equal(outs[0], outs[1]) and outs[0].max() > 0
