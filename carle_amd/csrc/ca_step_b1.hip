@@ -26,6 +26,18 @@ __device__ __forceinline__ uint64_t dpp64_rol1(uint64_t x) {      // lane i <- l
     return ((uint64_t)hi << 32) | lo;
 }
 
+// lane i <- lane i-1, lane 0 keeps `old` (wave_shr:1); lane i <- lane i+1, lane 63 keeps `old`
+__device__ __forceinline__ uint64_t dpp64_shr1(uint64_t x, uint64_t old) {
+    const uint32_t lo = __builtin_amdgcn_update_dpp((uint32_t)old, (uint32_t)x, 0x138, 0xF, 0xF, false);
+    const uint32_t hi = __builtin_amdgcn_update_dpp((uint32_t)(old >> 32), (uint32_t)(x >> 32), 0x138, 0xF, 0xF, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t dpp64_shl1(uint64_t x, uint64_t old) {
+    const uint32_t lo = __builtin_amdgcn_update_dpp((uint32_t)old, (uint32_t)x, 0x130, 0xF, 0xF, false);
+    const uint32_t hi = __builtin_amdgcn_update_dpp((uint32_t)(old >> 32), (uint32_t)(x >> 32), 0x130, 0xF, 0xF, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 template <int WW>
 __device__ __forceinline__ void load_row(const uint64_t *__restrict__ p, uint64_t (&r)[WW]) {
     if constexpr (WW == 1) {
@@ -56,72 +68,75 @@ __device__ __forceinline__ void store_row(uint64_t *__restrict__ p, const uint64
 }
 
 // XOR the packed action row (AWW words at column offset ox = 32*(WW-AWW)) into a grid row.
-// `ok` = this lane's row is inside the window.  Returns the OR / AND of the action words seen.
+// `ok` = this lane's row is inside the window.  Register-light on purpose: each target word
+// re-reads the (at most two) action words that overlap it (L1 hits) instead of staging the action
+// row in a register array, so the action path does not raise the kernel's VGPR allocation.
 template <int WW>
 __device__ __forceinline__ void toggle_row(uint64_t (&c)[WW], const uint64_t *__restrict__ arow,
                                            int aww, bool ok, uint64_t &seen_or, uint64_t &seen_and) {
-    uint64_t a[WW];
-#pragma unroll
-    for (int j = 0; j < WW; ++j) {
-        a[j] = (ok && j < aww) ? arow[j] : 0ull;
-        if (ok && j < aww) { seen_or |= a[j]; seen_and &= a[j]; }
-    }
-    const int shift_words = (WW - aww) >> 1;               // uniform
+    const int wo = (WW - aww) >> 1;                         // uniform word offset of the window
     const bool half = ((WW - aww) & 1) != 0;                // ox % 64 == 32
 #pragma unroll
-    for (int wo = 0; wo <= WW / 2; ++wo) {
-        if (wo == shift_words) {                            // uniform select of the word offset
-#pragma unroll
-            for (int j = 0; j < WW; ++j) {
-                const uint64_t cur = (j - wo >= 0 && j - wo < WW) ? a[j - wo >= 0 && j - wo < WW ? j - wo : 0] : 0ull;
-                const uint64_t prv = (j - wo - 1 >= 0 && j - wo - 1 < WW) ? a[j - wo - 1 >= 0 && j - wo - 1 < WW ? j - wo - 1 : 0] : 0ull;
-                c[j] ^= half ? ((cur << 32) | (prv >> 32)) : cur;
-            }
+    for (int j = 0; j < WW; ++j) {
+        const int i = j - wo;                               // action word aligned with grid word j
+        uint64_t cur = 0ull, prv = 0ull;
+        if (ok && i >= 0 && i < aww) {
+            cur = arow[i];
+            seen_or |= cur;
+            seen_and &= cur;
         }
+        if (half && ok && i - 1 >= 0 && i - 1 < aww) prv = arow[i - 1];
+        c[j] ^= half ? ((cur << 32) | (prv >> 32)) : cur;
     }
 }
 
 template <int WW, bool HAS_ACT>
 __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     const uint64_t *__restrict__ u_in, const uint64_t *__restrict__ act, uint64_t *__restrict__ u_out,
-    int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot) {
+    int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot,
+    int strip_first, int strip_count) {
+    // the launch covers strips [strip_first, strip_first + strip_count) (mod WW) of every grid:
+    // the host launches the strips that can meet the action window with HAS_ACT = true and the
+    // others with the leaner HAS_ACT = false instantiation (half the registers)
     constexpr int H = 64 * WW;
     constexpr bool MULTI = WW > 1;                          // more than one 64-row strip per grid
     const int lane = threadIdx.x;
     const int64_t wid = blockIdx.x;
-    const int64_t g = wid / WW;
-    const int r0 = (int)(wid % WW) * 64;
+    const int64_t g = wid / strip_count;
+    const int r0 = ((strip_first + (int)(wid % strip_count)) % WW) * 64;
     if (g >= n) return;
     const int r = r0 + lane;
     const uint64_t *gin = u_in + g * (int64_t)H * WW;
+    const int rt = (r0 + H - 1) % H, rb = (r0 + 64) % H;   // rows bordering the strip (y torus)
+    const int hr = lane == 0 ? rt : (lane == 63 ? rb : -1);
 
     uint64_t c[WW], hal[WW];
     load_row<WW>(gin + (int64_t)r * WW, c);
 #pragma unroll
     for (int j = 0; j < WW; ++j) hal[j] = 0ull;
-    int hr = -1;                                            // halo row of this lane (lanes 0, 63)
-    if (MULTI) {
-        if (lane == 0) hr = (r0 + H - 1) % H;
-        if (lane == 63) hr = (r0 + 64) % H;
-        if (hr >= 0) load_row<WW>(gin + (int64_t)hr * WW, hal);
-    }
+    if (MULTI && hr >= 0) load_row<WW>(gin + (int64_t)hr * WW, hal);
 
     if (HAS_ACT) {
         const int oy = (H - ah) >> 1, aww = aw >> 6;
-        const uint64_t *ga = act + g * (int64_t)ah * aww;
-        uint64_t s_or = 0ull, s_and = ~0ull, d0 = 0ull, d1 = ~0ull;
-        const bool in = r >= oy && r < oy + ah;
-        toggle_row<WW>(c, ga + (int64_t)(in ? r - oy : 0) * aww, aww, in, s_or, s_and);
-        if (MULTI) {
-            const bool hin = hr >= oy && hr < oy + ah;
-            toggle_row<WW>(hal, ga + (int64_t)(hin ? hr - oy : 0) * aww, aww, hin, d0, d1);
-        }
-        if (status != nullptr) {
-            const bool any = __ballot(s_or != 0ull) != 0ull;
-            const bool notone = __ballot(in && s_and != ~0ull) != 0ull;
-            if (lane == 0) {
-                if (any) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
-                if (notone) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
+        // wave-uniform: does the strip or one of its halo rows meet the action window at all?
+        const bool touches = (r0 < oy + ah && r0 + 64 > oy) ||
+                             (MULTI && ((rt >= oy && rt < oy + ah) || (rb >= oy && rb < oy + ah)));
+        if (touches) {
+            const uint64_t *ga = act + g * (int64_t)ah * aww;
+            uint64_t s_or = 0ull, s_and = ~0ull, d0 = 0ull, d1 = ~0ull;
+            const bool in = r >= oy && r < oy + ah;
+            toggle_row<WW>(c, ga + (int64_t)(in ? r - oy : 0) * aww, aww, in, s_or, s_and);
+            if (MULTI) {
+                const bool hin = hr >= oy && hr < oy + ah;
+                toggle_row<WW>(hal, ga + (int64_t)(hin ? hr - oy : 0) * aww, aww, hin, d0, d1);
+            }
+            if (status != nullptr) {
+                const bool any = __ballot(s_or != 0ull) != 0ull;
+                const bool notone = __ballot(in && s_and != ~0ull) != 0ull;
+                if (lane == 0) {
+                    if (any) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
+                    if (notone) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
+                }
             }
         }
     }
@@ -144,11 +159,14 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     uint64_t nx[WW];
 #pragma unroll
     for (int j = 0; j < WW; ++j) {
-        uint64_t a0 = dpp64_ror1(h0[j]), a1 = dpp64_ror1(h1[j]);     // row above
-        uint64_t b0 = dpp64_rol1(h0[j]), b1 = dpp64_rol1(h1[j]);     // row below
+        uint64_t a0, a1, b0, b1;
         if (MULTI) {
-            if (lane == 0) { a0 = g0[j]; a1 = g1[j]; }
-            if (lane == 63) { b0 = g0[j]; b1 = g1[j]; }
+            // lanes with no source keep `old` = the sums of the halo row they loaded themselves
+            a0 = dpp64_shr1(h0[j], g0[j]); a1 = dpp64_shr1(h1[j], g1[j]);     // row above
+            b0 = dpp64_shl1(h0[j], g0[j]); b1 = dpp64_shl1(h1[j], g1[j]);     // row below
+        } else {
+            a0 = dpp64_ror1(h0[j]); a1 = dpp64_ror1(h1[j]);                   // rotate = y torus seam
+            b0 = dpp64_rol1(h0[j]); b1 = dpp64_rol1(h1[j]);
         }
         nx[j] = apply_rule_auto(neighbour_count(a0, a1, b0, b1, p0[j], p1[j]), c[j], rule);
     }
@@ -204,14 +222,26 @@ __global__ __launch_bounds__(256) void unpack_b1_f32_kernel(const uint64_t *__re
 template <int WW>
 static int launch_b1(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
                      int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
-    const int64_t wgs = n * WW;
-    if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1: batch too large");
-    if (act)
-        hipLaunchKernelGGL((ca_step_b1_kernel<WW, true>), dim3((unsigned)wgs), dim3(64), 0, s, u_in,
-                           act, u_out, n, ah, aw, rule, status, slot);
-    else
-        hipLaunchKernelGGL((ca_step_b1_kernel<WW, false>), dim3((unsigned)wgs), dim3(64), 0, s, u_in,
-                           act, u_out, n, 0, 0, rule, status, slot);
+    if (n * WW > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1: batch too large");
+    if (!act) {
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, false>), dim3((unsigned)(n * WW)), dim3(64), 0, s,
+                           u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW);
+        return check_launch("carle_ca_step_b1");
+    }
+    // strips whose rows, or whose two bordering rows, intersect the window rows [oy, oy+ah)
+    constexpr int H = 64 * WW;
+    const int oy = (H - ah) / 2;
+    int first = (oy > 0 ? oy - 1 : H - 1) / 64;              // strip of the row just above the window
+    int last = ((oy + ah) % H) / 64;                          // strip of the row just below it
+    if (ah == H) { first = 0; last = WW - 1; }
+    int count = ((last - first + WW) % WW) + 1;
+    if (count > WW) count = WW;
+    hipLaunchKernelGGL((ca_step_b1_kernel<WW, true>), dim3((unsigned)(n * count)), dim3(64), 0, s,
+                       u_in, act, u_out, n, ah, aw, rule, status, slot, first, count);
+    if (count < WW)
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, false>), dim3((unsigned)(n * (WW - count))), dim3(64),
+                           0, s, u_in, act, u_out, n, 0, 0, rule, status, slot, (first + count) % WW,
+                           WW - count);
     return check_launch("carle_ca_step_b1");
 }
 

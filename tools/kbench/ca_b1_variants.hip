@@ -1,0 +1,81 @@
+// A/B microbenchmark for the bit-packed 512x512 step kernel (development tool).
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/kbench/ca_b1_variants tools/kbench/ca_b1_variants.hip
+#include "../../carle_amd/csrc/abi.hip"
+#include "../../carle_amd/csrc/ca_step_b1.hip"
+#include "../../carle_amd/csrc/ca_step_f32.hip"
+#include <algorithm>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+using namespace carle;
+
+using v4u = __attribute__((ext_vector_type(4))) unsigned int;
+template <int WW, bool VIA_LDS>
+__global__ __launch_bounds__(64) void copy_strip_kernel(const uint64_t *in, uint64_t *out, int64_t n) {
+    const int lane = threadIdx.x;
+    const int64_t wid = blockIdx.x;
+    const v4u *s4 = reinterpret_cast<const v4u *>(in + wid * 64 * WW);
+    v4u *d4 = reinterpret_cast<v4u *>(out + wid * 64 * WW);
+    if (VIA_LDS) {   // lane = row access pattern (4 x 16 B at stride 64 B)
+#pragma unroll
+        for (int i = 0; i < WW / 2; ++i) d4[lane * (WW / 2) + i] = s4[lane * (WW / 2) + i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < WW / 2; ++i) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + 64 * i + lane), d4 + 64 * i + lane);
+    }
+}
+// big-block flat copy (reference ceiling)
+__global__ __launch_bounds__(256) void copy_flat_kernel(const v4u *in, v4u *out, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+
+int main(int argc, char **argv) {
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 4096;
+    const int rounds = 12, reps = 20;
+    constexpr int WW = 8;
+    const size_t words = (size_t)n * 512 * WW;
+    uint64_t *a, *b, *act; int32_t *st;
+    CK(hipMalloc(&a, words * 8)); CK(hipMalloc(&b, words * 8)); CK(hipMalloc(&st, 64)); CK(hipMemset(st, 0, 64));
+    CK(hipMalloc(&act, (size_t)n * 64 * 8));
+    std::vector<uint64_t> h(words);
+    srand(1);
+    for (auto &v : h) v = ((uint64_t)rand() << 33) ^ ((uint64_t)rand() << 11) ^ rand();
+    CK(hipMemcpy(a, h.data(), words * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(act, 0x11, (size_t)n * 64 * 8));
+    const uint32_t high = (1u << 12) | (1u << 15) | 0xC, life = (1u << 12) | 0xC;
+    struct V { const char *name; int id; } vs[] = {{"flat_copy", 0}, {"strip_copy_direct", 1}, {"strip_copy_rowlane", 2},
+        {"step_noact_highlife", 3}, {"step_act_highlife", 4}, {"step_act_nostatus", 7}, {"step_noact_life", 5}, {"step_noact_dense", 6}};
+    const int nv = sizeof(vs) / sizeof(vs[0]);
+    std::vector<std::vector<float>> t(nv);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < rounds; ++r)
+        for (int v = 0; v < nv; ++v) {
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < reps; ++i) {
+                switch (vs[v].id) {
+                    case 0: hipLaunchKernelGGL(copy_flat_kernel, dim3(2048), dim3(256), 0, 0, (const v4u *)a, (v4u *)b, (int64_t)(words / 2)); break;
+                    case 1: hipLaunchKernelGGL((copy_strip_kernel<WW, false>), dim3((unsigned)(n * WW)), dim3(64), 0, 0, a, b, n); break;
+                    case 2: hipLaunchKernelGGL((copy_strip_kernel<WW, true>), dim3((unsigned)(n * WW)), dim3(64), 0, 0, a, b, n); break;
+                    case 3: carle_ca_step_b1(a, nullptr, b, n, 512, 512, 0, 0, high, st, 0, nullptr); break;
+                    case 4: carle_ca_step_b1(a, act, b, n, 512, 512, 64, 64, high, st, 0, nullptr); break;
+                    case 7: carle_ca_step_b1(a, act, b, n, 512, 512, 64, 64, high, nullptr, 0, nullptr); break;
+                    case 5: carle_ca_step_b1(a, nullptr, b, n, 512, 512, 0, 0, life, st, 0, nullptr); break;
+                    case 6: carle_ca_step_b1(a, nullptr, b, n, 512, 512, 0, 0, 0x3FFFF, st, 0, nullptr); break;
+                }
+                std::swap(a, b);
+            }
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) t[v].push_back(ms * 1000.f / reps);
+        }
+    const double bytes = (double)words * 16;
+    for (int v = 0; v < nv; ++v) {
+        std::sort(t[v].begin(), t[v].end());
+        float med = t[v][t[v].size() / 2];
+        printf("%-22s median %7.2f us  %6.3f TB/s\n", vs[v].name, med, bytes / med * 1e-6);
+    }
+    return 0;
+}
