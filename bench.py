@@ -43,6 +43,10 @@ def parse():
                          "b1 = bit-packed state and actions (secondary configurations)")
     ap.add_argument("--action-ring", type=int, default=6,
                     help="number of distinct device action buffers cycled through")
+    ap.add_argument("--agent", default="ring", choices=["ring", "random", "fused"],
+                    help="action source: ring = pre-generated device tensors (BASELINE definition); "
+                         "random = device-side RandomAgent tensor per step; fused = RandomAgent "
+                         "toggles drawn inside the step kernel (no action tensor)")
     ap.add_argument("--rnd", action="store_true",
                     help="configs[3]: also run the RND2D intrinsic-reward forward (eval mode) on "
                          "every observation and feed ITS reward to the running statistics")
@@ -165,9 +169,16 @@ def main():
         wenv.to(dev)
     rs = None
 
+    agent = None
+    if args.agent != "ring":
+        from carle_amd.agents import RandomAgent
+        agent = RandomAgent(action_width=asize, action_height=asize, fused=args.agent == "fused",
+                            seed=4321 + rank)
+
     def one_step(i):
         nonlocal rs
-        obs, reward, done, info = wenv.step(ring[i % len(ring)])
+        action = ring[i % len(ring)] if agent is None else agent(env.universe)
+        obs, reward, done, info = wenv.step(action)
         rs = env.__dict__.get("reward_stream")
         if rs is not None:                   # reward consumers live on the reward stream
             with torch.cuda.stream(rs):
@@ -242,6 +253,7 @@ def main():
                                    f"(ring of {len(ring)} device buffers), CARLE.step drop-in surface",
                        "instances_per_gpu": n, "height": size, "width": size,
                        "action": asize, "rule": args.rule, "sharding": f"batch x{world}",
+                       "action_source": args.agent,
                        "reward_nets": ("RND2D" if args.rnd else "") + ("+AE2D" if args.ae else "") +
                                       (" forward, on the reward stream" if (args.rnd or args.ae) and
                                        not args.sync_reward else ""),

@@ -18,6 +18,7 @@
 // Generic path (any even square size): one thread per cell, neighbours through L1/L2.
 #include "ca_bits.hpp"
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace carle {
 
@@ -93,10 +94,18 @@ __device__ __forceinline__ void st16(uint4 *p, const uint4 &v) {
     }
 }
 
-template <bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256>
+// parameters of the fused device-side random agent (RAND_ACT instantiation): toggles are drawn
+// in-kernel with the counter layout of philox.hpp instead of being read from an action tensor
+struct RandAct {
+    float p;
+    uint64_t seed, offset;
+    float *action_out;      // optional: also materialise the (N,1,AW,AW) action (may be NULL)
+};
+
+template <bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256, bool RAND_ACT = false>
 __global__ __launch_bounds__(BLOCK) void ca_step_f32_64_kernel(
     const uint4 *__restrict__ u_in, const float *__restrict__ act, uint4 *__restrict__ u_out,
-    int64_t n, int aw, uint32_t rule, int32_t *__restrict__ status, int slot) {
+    int64_t n, int aw, uint32_t rule, int32_t *__restrict__ status, int slot, RandAct ra = RandAct()) {
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (g >= n) return;                              // wave-uniform
@@ -123,9 +132,23 @@ __global__ __launch_bounds__(BLOCK) void ca_step_f32_64_kernel(
         for (int i = 0; i < 16; ++i) {
             const int ay = 4 * i + q - o;
             if (col_in && ay >= 0 && ay < aw) {
-                const uint4 a = ld16<NT_LD>(reinterpret_cast<const uint4 *>(abase + (int64_t)ay * aw));
-                seen.add(a);
-                tog |= (uint64_t)nibble_of(a) << (4 * i);
+                if (RAND_ACT) {
+                    const uint64_t quad = (uint64_t)((g * aw + ay) * (int64_t)aw + ax) >> 2;
+                    const uint32_t nib = bernoulli_nibble(quad, ra.seed, ra.offset, ra.p);
+                    uint4 a;
+                    a.x = (nib & 1u) ? kOneBits : 0u;
+                    a.y = (nib & 2u) ? kOneBits : 0u;
+                    a.z = (nib & 4u) ? kOneBits : 0u;
+                    a.w = (nib & 8u) ? kOneBits : 0u;
+                    seen.add(a);
+                    tog |= (uint64_t)nib << (4 * i);
+                    if (ra.action_out)
+                        *reinterpret_cast<uint4 *>(ra.action_out + (g * aw + ay) * (int64_t)aw + ax) = a;
+                } else {
+                    const uint4 a = ld16<NT_LD>(reinterpret_cast<const uint4 *>(abase + (int64_t)ay * aw));
+                    seen.add(a);
+                    tog |= (uint64_t)nibble_of(a) << (4 * i);
+                }
             }
         }
         c ^= tog;                                    // toggle, env.py:182
@@ -457,4 +480,32 @@ extern "C" int carle_ca_toggle_f32(const float *u_in, const float *action, float
     hipLaunchKernelGGL(ca_toggle_f32_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), u_in, action, u_out, n, h, w, ah, aw);
     return check_launch("carle_ca_toggle_f32");
+}
+
+// CARLE.step with the device-side RandomAgent fused in (carle/agents.py:35-42 + env.py:188-242):
+// Bernoulli(p) toggles over the centred AW x AW window, drawn in the step kernel.
+extern "C" int carle_ca_step_f32_rand(const float *u_in, float *u_out, int64_t n, int h, int w,
+                                      int ah, int aw, uint32_t rule, float p, uint64_t seed,
+                                      uint64_t offset, float *action_out, int32_t *status, int slot,
+                                      void *stream) {
+    if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_step_f32_rand: u_in/u_out is NULL");
+    if (int e = check_dims(n, h, w, true, ah, aw)) return e;
+    if (h != 64 || (aw % 8) != 0)
+        return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: fused random toggles need 64x64 grids "
+                                      "and AW % 8 == 0 (generate the action with carle_bernoulli_f32 otherwise)");
+    if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_ca_step_f32_rand: rule mask exceeds 18 bits");
+    if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: slot must be 0 or 1");
+    if (!aligned16(u_in) || !aligned16(u_out) || (action_out && !aligned16(action_out)))
+        return fail_arg(CARLE_E_ALIGN, "carle_ca_step_f32_rand: pointers must be 16-byte aligned");
+    const size_t bytes = (size_t)n * h * w * sizeof(float);
+    if (overlap(u_in, bytes, u_out, bytes))
+        return fail_arg(CARLE_E_ALIAS, "carle_ca_step_f32_rand: u_in and u_out overlap");
+    if (n == 0) return 0;
+    if (n > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: batch too large");
+    RandAct ra;
+    ra.p = p; ra.seed = seed; ra.offset = offset; ra.action_out = action_out;
+    hipLaunchKernelGGL((ca_step_f32_64_kernel<true, true, true, 64, true>), dim3((unsigned)n), dim3(64), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const uint4 *>(u_in),
+                       (const float *)nullptr, reinterpret_cast<uint4 *>(u_out), n, aw, rule, status, slot, ra);
+    return check_launch("carle_ca_step_f32_rand");
 }

@@ -270,11 +270,22 @@ class CARLE(nn.Module):
         if self.logging:
             self.log_universe()
         u_in = self._device_universe()
-        act, cropped, full = self._device_action(action)
         rule = self.rule_mask()
         slot = self._slot
         out = torch.empty_like(u_in)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
+        if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
+            if tuple(action.shape) != (self.instances, 1, self.action_width, self.action_height):
+                raise AssertionError(f"action shape {action.shape} does not match the environment")
+            if self.height == 64 and self.action_width % 8 == 0:
+                # the toggles are drawn inside the step kernel: no action tensor exists
+                hip.env_step_f32_rand(u_in, out, reward, rule, self._status, slot, self.action_height,
+                                      self.action_width, action.p, action.seed, action.offset)
+                self._slot = slot ^ 1
+                self.universe = out
+                return self.universe, reward, torch.zeros(self.instances, 1), [{}] * self.instances
+            action = action.materialize()
+        act, cropped, full = self._device_action(action)
         if cropped:
             # the two whole-batch predicates are defined on the action AS PASSED (env.py:191,208);
             # for an oversize action evaluate them on the uncropped tensor (cold path, no sync)

@@ -310,3 +310,31 @@ def env_step_b1(u_in, action, u_out, reward, rule, status, slot, publish_flags=T
                                    1 if publish_flags else 0, _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_step_b1")
+
+
+# ---------------------------------------------------------------------------------------------
+# device-side agents
+# ---------------------------------------------------------------------------------------------
+
+def bernoulli_f32(shape, p, seed, offset, device, out=None):
+    """Bernoulli(p) 0.0/1.0 tensor drawn on the device (Philox4x32-10, see carle_hip.h)."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+    with _on_device(out.device):
+        rc = lib.carle_bernoulli_f32(out.data_ptr(), out.numel(), float(p), int(seed), int(offset),
+                                     _stream(out))
+    _lib.check(rc, "carle_bernoulli_f32")
+    return out
+
+
+def env_step_f32_rand(u_in, u_out, reward, rule, status, slot, ah, aw, p, seed, offset, action_out=None):
+    """CARLE.step with Bernoulli(p) toggles drawn inside the step kernel (64x64 grids)."""
+    lib = _lib.load()
+    n, _, h, w = u_in.shape
+    with _on_device(u_in.device):
+        rc = lib.carle_env_step_f32_rand(u_in.data_ptr(), u_out.data_ptr(), reward.data_ptr(), n, h, w,
+                                         ah, aw, rule, float(p), int(seed), int(offset),
+                                         _ptr(action_out), status.data_ptr(), slot, _stream(u_in))
+    if rc != 0:
+        _lib.check(rc, "carle_env_step_f32_rand")

@@ -173,6 +173,26 @@ int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float 
                          float *workspace, float *bonus, float *recon_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Device-side agents.  The reference's RandomAgent draws its toggles with
+ * torch.rand on the CPU and copies them to the device every step (carle/agents.py:35-42,
+ * carle/mcl.py:400).  Philox4x32-10, counter = (quad index of the flattened action, offset),
+ * key = seed: element 4q+j toggles iff (word_j >> 8) * 2^-24 <= p  (csrc/philox.hpp).
+ * ------------------------------------------------------------------------------------------- */
+/* out[0..count) := Bernoulli(p) as 0.0f / 1.0f; count % 4 == 0 */
+int carle_bernoulli_f32(float *out, int64_t count, float p, uint64_t seed, uint64_t offset,
+                        void *stream);
+/* carle_ca_step_f32 with the action drawn IN the kernel (identical to generating the action with
+ * carle_bernoulli_f32(seed, offset) and passing it in): no action tensor is read; 64x64 grids,
+ * AW % 8 == 0.  action_out (nullable): also write the drawn (N,1,AW,AW) action. */
+int carle_ca_step_f32_rand(const float *u_in, float *u_out, int64_t n, int h, int w, int ah, int aw,
+                           uint32_t rule, float p, uint64_t seed, uint64_t offset, float *action_out,
+                           int32_t *status, int slot, void *stream);
+/* ... followed by carle_ca_finish: the whole CARLE.step for a RandomAgent-driven environment */
+int carle_env_step_f32_rand(const float *u_in, float *u_out, float *reward, int64_t n, int h, int w,
+                            int ah, int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset,
+                            float *action_out, int32_t *status, int slot, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Reward statistics for batch-sharded runs (build-side feature required by the north star; the
  * reference has none).  out3 / moments3 = fp64 (count, mean, M2) on the device.  The triples of
  * all ranks are all-gathered over RCCL and Chan-merged by carle_amd/dist.py; the merged triple

@@ -1,0 +1,82 @@
+"""GPU tests of the device-side agents: the Philox Bernoulli kernel bit-exact against
+oracle/philox.py (pinned by the Random123 known answers), the fused random-toggle step against
+the materialised action, and the toggle rate of the reference's RandomAgent (agents.py:33,38-40)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ca as O
+from oracle.philox import bernoulli_f32 as np_bernoulli
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("count,p,seed,offset", [(4, 0.1, 0, 0), (4096, 0.1, 1, 7), (65536 + 8, 0.5, 0xDEADBEEFCAFE, 2 ** 40 + 3),
+                                                  (1024, 0.0, 5, 5), (1024, 1.0, 5, 5)])
+def test_bernoulli_kernel_matches_oracle(count, p, seed, offset):
+    from carle_amd import hip
+    got = hip.bernoulli_f32((count,), p, seed, offset, "cuda:0").cpu().numpy()
+    assert np.array_equal(got, np_bernoulli(count, p, seed, offset))
+
+
+def test_random_agent_surface_and_rate():
+    from carle_amd.agents import RandomAgent, SubmissionAgent, DeviceRandomAction
+    agent = RandomAgent(action_width=64, action_height=64, seed=3)
+    obs = torch.zeros(128, 1, 64, 64, device="cuda")
+    a0, a1 = agent(obs), agent(obs)
+    assert tuple(a0.shape) == (128, 1, 64, 64) and a0.is_cuda and a0.dtype == torch.float32
+    assert set(torch.unique(a0).cpu().tolist()) <= {0.0, 1.0}
+    assert not torch.equal(a0, a1)                         # fresh draw per call
+    rate = float(torch.cat([a0, a1]).mean())
+    assert abs(rate - 0.1) < 0.002                         # toggle_rate = 0.1 (agents.py:33)
+    tok = RandomAgent(fused=True, seed=3)(obs)
+    assert isinstance(tok, DeviceRandomAction) and torch.equal(tok.materialize(), a0)
+    assert tuple(SubmissionAgent()(obs).shape) == (128, 1, 64, 64)
+
+
+@pytest.mark.parametrize("n,asize", [(1, 64), (37, 64), (5, 32)])
+def test_fused_random_step_equals_materialised(n, asize):
+    """step(DeviceRandomAction) == step(token.materialize()) bit for bit, and == the oracle."""
+    from carle_amd.agents import RandomAgent
+    from carle_amd.env import CARLE
+    envs = [CARLE(width=64, height=64, action_width=asize, action_height=asize, instances=n, device="cuda:0")
+            for _ in range(2)]
+    u0 = (torch.rand(n, 1, 64, 64) < 0.4).float()
+    for e in envs:
+        e.rules_from_string("B36/S23")
+        e.reset()
+        e.universe = u0.clone().cuda()
+    fused = RandomAgent(action_width=asize, action_height=asize, fused=True, seed=11)
+    plain = RandomAgent(action_width=asize, action_height=asize, fused=False, seed=11)
+    u_np = u0.numpy()
+    mask = O.rule_mask([3, 6], [2, 3])
+    for t in range(5):
+        o0 = envs[0].step(fused(envs[0].universe))[0]
+        a = plain(envs[1].universe)
+        o1 = envs[1].step(a)[0]
+        u_np, _, _ = O.c_env_step(u_np, a.cpu().numpy(), mask)
+        assert torch.equal(o0, o1)
+        assert np.array_equal(o0.cpu().numpy(), u_np)
+    assert envs[0].step_number == envs[1].step_number == 5
+    assert envs[0].steps_since_action == envs[1].steps_since_action
+
+
+def test_fused_token_on_other_geometries_falls_back_to_materialise():
+    from carle_amd.agents import RandomAgent
+    from carle_amd.env import CARLE
+    env = CARLE(width=256, height=256, instances=2, device="cuda:0")
+    env.reset()
+    agent = RandomAgent(fused=True, seed=1)
+    obs = env.step(agent(env.universe))[0]
+    exp, _, _ = O.c_env_step(np.zeros((2, 1, 256, 256), np.float32),
+                             np_bernoulli(2 * 64 * 64, 0.1, 1, 0).reshape(2, 1, 64, 64), O.rule_mask([3], [2, 3]))
+    assert np.array_equal(obs.cpu().numpy(), exp)
+
+
+def test_random_network_agent():
+    from carle_amd.agents import RandomNetworkAgent
+    torch.manual_seed(0)
+    agent = RandomNetworkAgent(observation_width=64, observation_height=64)
+    a = agent((torch.rand(3, 1, 64, 64, device="cuda") < 0.3).float())
+    assert tuple(a.shape) == (3, 1, 64, 64) and a.is_cuda
+    assert set(torch.unique(a).cpu().tolist()) <= {0.0, 1.0}

@@ -112,3 +112,15 @@ def test_torch_port_matches_golden(name):
         if (t + 1) in c.record:
             assert np.array_equal(obs.numpy(), c.obs[rec])
             rec += 1
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10 pin oracle/philox.py."""
+    from oracle.philox import philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, exp in kat:
+        got = philox4x32_10(np.array([ctr], dtype=np.uint32), key)[0]
+        assert tuple(int(v) for v in got) == exp
