@@ -47,6 +47,7 @@ SIGNATURES = {
     "carle_env_step_f32_rand": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int,
                                          _c_u32, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64,
                                          _c_vp, _c_vp, _c_int, _c_vp]),
+    "carle_instance_sums_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "carle_ca_finish": (_c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_int, _c_int, _c_vp]),
 }
 

@@ -1,0 +1,95 @@
+"""carle_amd.harness -- the reference's two harness loops on the HIP path.
+
+``train`` follows carle/train_mcl.py:15-89 (reward-wrapper training under an agent, ruleset
+cycling, state_dict + reward-trace dumps) and ``evaluate`` follows evaluation/eval.py:17-79
+(stack wrappers, optional weights, score = mean summed reward).  Same signatures and return
+values; differences: the per-step ``reward.sum().cpu()`` host round trips of the reference
+(train_mcl.py:68-69, eval.py:69-70) are deferred to the end of each inner loop, wrappers listed in
+``mcl`` are actually used (the reference hard-codes RND2D+AE2D), and environment kwargs can be
+passed through for small test geometries.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from .env import CARLE
+from .mcl import RND2D, AE2D
+
+
+def _drain(sums):
+    return torch.stack(sums).detach().cpu().numpy() if sums else np.zeros(0, np.float32)
+
+
+def train(agent_fn, instances=16, steps=(64, 2048), rules=(((3,), (2, 3)),), mcl=(RND2D, AE2D),
+          out_dir="./logs/mcl", verbose=True, **env_kwargs):
+    env_kwargs.setdefault("use_cuda", True)
+    env = CARLE(instances=instances, **env_kwargs)
+    for wrapper in mcl:
+        env = wrapper(env)
+    agent = agent_fn(observation_width=env.inner_env.width, observation_height=env.inner_env.height,
+                     action_width=env.inner_env.action_width, action_height=env.inner_env.action_height)
+    exp_id = "mcl" + str(int(time.time()))
+    rewards = []
+    for epoch in range(steps[0]):
+        for ruleset in rules:
+            env.inner_env.birth = list(ruleset[0])
+            env.inner_env.survive = list(ruleset[1])
+            obs = env.reset()
+            t1 = time.time()
+            sums = []
+            for step in range(steps[1]):
+                action = agent(obs)
+                obs, reward, done, info = env.step(action)
+                sums.append(reward.detach().sum())
+            trace = _drain(sums)                       # one host sync per inner loop
+            rewards.extend(list(trace))
+            t2 = time.time()
+            if verbose:
+                print("steps / second = {:.3f}".format((steps[1] * instances) / max(t2 - t1, 1e-9)))
+                print("round {}, ruleset {}, mean reward = {:.3e}".format(
+                    epoch, ruleset, float(trace.sum()) / max(steps[1] * instances, 1)))
+            if out_dir is not None:
+                os.makedirs(os.path.join(out_dir, "models"), exist_ok=True)
+                node = env
+                while getattr(node, "env", None) is not None:      # every wrapper, outermost first
+                    if hasattr(node, "my_name"):
+                        torch.save(node.state_dict(),
+                                   os.path.join(out_dir, "models", "{}_{}.pt".format(node.my_name, exp_id)))
+                    node = node.env
+        if out_dir is not None:
+            os.makedirs(os.path.join(out_dir, "metrics"), exist_ok=True)
+            np.save(os.path.join(out_dir, "metrics", "mcl_rewards_{}".format(exp_id)), rewards)
+    return rewards
+
+
+def evaluate(Agent, rules, wrappers, params_path=None, steps=1024, verbose=True, **env_kwargs):
+    agent = Agent()
+    if params_path is not None:
+        agent.load_state_dict(torch.load(params_path))
+    env = CARLE(**env_kwargs)
+    for wrapper in wrappers:
+        env = wrapper[0](env)
+        env.reward_scale = wrapper[1]
+        env.batch_size = steps * len(rules)
+        if wrapper[2] is not None:
+            env.load_state_dict(torch.load(wrapper[2], map_location="cpu"))
+        env.eval()
+    score, total_steps, score_trace = 0.0, 0, []
+    for ruleset in rules:
+        env.inner_env.birth = list(ruleset[0])
+        env.inner_env.survive = list(ruleset[0])     # sic: the reference assigns ruleset[0] twice (eval.py:59)
+        obs = env.reset()
+        sums = []
+        for step in range(steps):
+            action = agent(obs)
+            obs, reward, done, info = env.step(action)
+            sums.append(reward.detach().sum())
+            total_steps += 1
+        trace = _drain(sums)
+        score += float(trace.sum())
+        score_trace.extend(list(trace))
+        if verbose:
+            print("cumulative score = {:.3e} at total steps = {}, rulset = {}".format(score, total_steps, ruleset))
+    return score / max(total_steps, 1), score_trace

@@ -338,3 +338,26 @@ def env_step_f32_rand(u_in, u_out, reward, rule, status, slot, ah, aw, p, seed, 
                                          _ptr(action_out), status.data_ptr(), slot, _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_step_f32_rand")
+
+
+def instance_sums_f32(x, w0=None, w1=None, w2=None):
+    """(N,4) fp32: per-instance [sum x, sum x*w0, sum x*w1, sum x*w2] over all trailing dims; the
+    weight planes (same element count as one instance) are optional."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        x = x.to(torch.float32).contiguous()
+    n = x.shape[0]
+    elems = x.numel() // max(n, 1)
+    ws = []
+    for wt in (w0, w1, w2):
+        if wt is not None:
+            wt = wt.to(x.device, torch.float32).contiguous()
+            if wt.numel() != elems:
+                raise ValueError("weight plane size differs from one instance")
+        ws.append(wt)
+    out = torch.empty(n, 4, dtype=torch.float32, device=x.device)
+    with _on_device(x.device):
+        rc = lib.carle_instance_sums_f32(x.data_ptr(), n, elems, _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]),
+                                         out.data_ptr(), _stream(x))
+    _lib.check(rc, "carle_instance_sums_f32")
+    return out

@@ -376,3 +376,159 @@ class AE2D(RND2D):
     def _after_update(self):
         self.updates += 0                    # AE2D.update_predictor neither zeroes grads nor
         # counts updates (mcl.py:498-502); grads are zeroed at the start of the next window
+
+
+# ---------------------------------------------------------------------------------------------
+# hand-coded reward wrappers: one HIP reduction pass per step
+# (carle_instance_sums_f32); the remaining arithmetic is on (N,)-sized tensors
+# ---------------------------------------------------------------------------------------------
+
+def _as_device_f32(x, device):
+    if not isinstance(x, torch.Tensor):
+        if getattr(x, "materialize", None) is not None:          # agents.DeviceRandomAction
+            return x.materialize()
+        x = torch.as_tensor(x, dtype=torch.float32)
+    return x.to(device, torch.float32)
+
+
+class ParsimonyBonus(Motivator):
+    """Scales the reward down when many cells are toggled (mcl.py:86-105).
+
+    reward <- 100 * reward / max(sum(action_i), 100), per instance.  (The reference divides the
+    (N,1) reward by an (N,) vector, which broadcasts to (N,N) for N > 1; this implementation keeps
+    the per-instance meaning and is identical for N == 1, the only case the reference exercises.)
+    """
+
+    def __init__(self, env, **kwargs):
+        super().__init__(env, **kwargs)
+        self.parsimony_threshold = 128
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        a = _as_device_f32(action, self.inner_env.my_device)
+        while a.dim() < 4:
+            a = a.unsqueeze(0)
+        toggles = hip.instance_sums_f32(a.contiguous())[:, 0:1]
+        if toggles.shape[0] != reward.shape[0]:
+            toggles = toggles.expand(reward.shape[0], 1)
+        reward = 100.0 * reward / torch.clamp(toggles, min=100.0)
+        return obs, reward, done, info
+
+
+class CornerBonus(Motivator):
+    """Masked-sum reward / punishment regions (mcl.py:197-231)."""
+
+    def __init__(self, env, **kwargs):
+        super().__init__(env, **kwargs)
+        self.my_name = "CornerBonus"
+        self.reward_scale = 1.0
+        h, w = self.inner_env.height, self.inner_env.width
+        self.reward_mask = torch.zeros(1, 1, h, w)
+        self.punish_mask = torch.zeros(1, 1, h, w)
+        self.reward_mask[:, :, :16, :16] = 1.0
+        for ii in range(96):
+            self.reward_mask[:, :, ii - 4:ii + 4, ii - 4:ii + 4] = 1.0
+        self.punish_mask[:, :, -64:, -64:] = -1.0
+        self.punish_mask[:, :, :64, -64:] = -1.0
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        sums = hip.instance_sums_f32(_as_device_f32(obs, self.inner_env.my_device), self.reward_mask,
+                                     self.punish_mask)
+        reward += self.reward_scale * sums[:, 1:2]
+        reward += self.reward_scale * sums[:, 2:3]
+        return obs, reward, done, info
+
+
+class SpeedDetector(Motivator):
+    """Rewards centre-of-mass motion outside the action window (mcl.py:730-799)."""
+
+    def __init__(self, env, **kwargs):
+        super().__init__(env, **kwargs)
+        self.reward_scale = 1.0
+        self.center_of_mass = None
+        self.speed_modulator = 32.0
+        mass_weight_w = torch.arange(self.inner_env.height).reshape(1, -1)
+        mass_weight_h = torch.arange(self.inner_env.width).reshape(-1, 1)
+        action_mask = torch.ones(1, 1, self.action_height, self.action_width)
+        action_mask = self.inner_env.action_padding(action_mask)
+        action_mask = torch.ones_like(action_mask) - action_mask
+        self.mass_weight_h = (mass_weight_h * action_mask).to(torch.float32)
+        self.mass_weight_w = (mass_weight_w * action_mask).to(torch.float32)
+        self.growing_steps = 0
+        self.smooth_velocity = None
+        self.speed = None
+        self.velocity = torch.tensor([self.inner_env.instances, 1, 0., 0.])
+        self.live_cells = None
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        dev = self.inner_env.my_device
+        universe = self.inner_env.universe
+        # sum(obs * w) over the whole grid with the action window masked out of the weights;
+        # live cells are counted on the inner universe (= obs) as in the reference (mcl.py:769)
+        sums = hip.instance_sums_f32(_as_device_f32(obs, dev), self.mass_weight_h, self.mass_weight_w)
+        live_cells = sums[:, 0] if universe is obs else hip.instance_sums_f32(universe)[:, 0]
+        center_of_mass_h = sums[:, 1] / (live_cells + 1e-7)
+        center_of_mass_w = sums[:, 2] / (live_cells + 1e-7)
+        center_of_mass = torch.cat([center_of_mass_h.unsqueeze(0), center_of_mass_w.unsqueeze(0)])
+        if self.center_of_mass is None:
+            self.center_of_mass = center_of_mass
+        else:
+            velocity = self.center_of_mass - center_of_mass
+            speed = torch.sqrt(torch.sum(torch.pow(velocity, 2)))
+            self.speed = speed
+            self.velocity = velocity
+            self.center_of_mass = center_of_mass
+            reward += speed
+        self.live_cells = live_cells
+        return obs, reward, done, info
+
+
+class PufferDetector(Motivator):
+    """Rewards sustained growth in the absence of actions (mcl.py:804-853).  Host-synchronising
+    by construction, exactly like the reference (live-cell total and action sum are read on the
+    host every step to drive a Python list)."""
+
+    def __init__(self, env, **kwargs):
+        super().__init__(env, **kwargs)
+        self.my_name = "PufferDetector"
+        self.cells = []
+        self.live_cells = 0.0
+        self.reward_scale = 1.0
+        self.growth_threshold = 512
+        self.growing_steps = 0
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        self.live_cells = float(hip.instance_sums_f32(self.inner_env.universe)[:, 0].sum().item())
+        a = _as_device_f32(action, self.inner_env.my_device)
+        if not bool(torch.sum(a)):
+            self.cells.append(self.live_cells)
+            if len(self.cells) > self.growth_threshold:
+                slope = self.cells[-1] - self.cells[0]
+                self.cells.pop(0)
+                if slope > 0.01:
+                    reward += 1
+        else:
+            self.growing_steps = 0
+            self.cells = []
+        return obs, reward, done, info
+
+
+def get_glider():
+    """The glider used throughout the reference's demos (mcl.py:872-879)."""
+    action = torch.zeros(1, 1, 64, 64)
+    for r, c in ((32, 32), (33, 32), (33, 33), (34, 31), (34, 33)):
+        action[0, 0, r, c] = 1.0
+    return action
+
+
+def get_morley_puffer():
+    """Common puffer of the Move/Morley rule B368/S245 (mcl.py:881-893)."""
+    action = torch.zeros(1, 1, 64, 64)
+    cells = [(31, 32), (32, 32), (30, 33), (33, 33)] + [(r, 34) for r in range(29, 35)] + \
+            [(30, 35), (30, 36), (33, 35), (33, 36), (31, 37), (32, 37)]
+    for r, c in cells:
+        action[0, 0, r, c] = 1.0
+    return action

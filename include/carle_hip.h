@@ -193,6 +193,16 @@ int carle_env_step_f32_rand(const float *u_in, float *u_out, float *reward, int6
                             float *action_out, int32_t *status, int slot, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-instance sums for the hand-coded reward wrappers: for every instance i
+ * of x (n x elems floats): out4[4i] = sum x, out4[4i+k+1] = sum x * w_k for the (nullable) weight
+ * planes w0..w2 of `elems` floats each.  Replaces torch.sum(universe, dim=[1,2,3]) (mcl.py:769),
+ * the masked sums of CornerBonus (mcl.py:222-223), the centre-of-mass numerators of SpeedDetector
+ * (mcl.py:772-775) and action.sum(axis=[1,2,3]) of ParsimonyBonus (mcl.py:102-103).
+ * ------------------------------------------------------------------------------------------- */
+int carle_instance_sums_f32(const float *x, int64_t n, int64_t elems, const float *w0,
+                            const float *w1, const float *w2, float *out4, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Reward statistics for batch-sharded runs (build-side feature required by the north star; the
  * reference has none).  out3 / moments3 = fp64 (count, mean, M2) on the device.  The triples of
  * all ranks are all-gathered over RCCL and Chan-merged by carle_amd/dist.py; the merged triple

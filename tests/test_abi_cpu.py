@@ -95,3 +95,13 @@ def test_compute_fails_loudly_without_gpu():
     env = CARLE(width=64, height=64)
     with pytest.raises(CarleHipError):
         env.reset()
+
+
+def test_reference_import_paths_resolve_to_this_build():
+    import carle.env, carle.mcl, carle.agents, carle.train_mcl
+    import evaluation.eval, evaluation.submission
+    import carle_amd.env, carle_amd.mcl
+    assert carle.env.CARLE is carle_amd.env.CARLE
+    assert carle.mcl.RND2D is carle_amd.mcl.RND2D and carle.mcl.AE2D is carle_amd.mcl.AE2D
+    assert callable(carle.train_mcl.train) and callable(evaluation.eval.evaluate)
+    assert issubclass(evaluation.submission.SubmissionAgent, carle.agents.RandomAgent)

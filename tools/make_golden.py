@@ -24,6 +24,8 @@ Fixture files
                    wrapper rewards over a few steps, and a predictor-update trajectory
   nets_256.npz     the shipped evaluation/*.pt weights (256x256): state_dicts (as arrays),
                    4 input grids, get_bonus_only outputs (eval mode)
+  wrappers.npz     CornerBonus / SpeedDetector / PufferDetector / ParsimonyBonus and the eval.py
+                   wrapper stack: inputs and per-step rewards
 """
 import argparse
 import io
@@ -400,6 +402,71 @@ def make_nets(torch, ref_env, ref_mcl, outdir):
     print("nets_256.npz written")
 
 
+def make_wrappers(torch, ref_env, ref_mcl, outdir):
+    """Hand-coded reward wrappers: CornerBonus, SpeedDetector, PufferDetector,
+    ParsimonyBonus driven by the genuine reference; inputs + rewards per step."""
+    import contextlib
+    sink = io.StringIO()
+    out = {}
+    rng = np.random.default_rng(99)
+
+    def run(name, build, n, size, steps, act_fn, init_p=0.2, post=None):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(sink):
+            env = ref_env.CARLE(width=size, height=size, instances=n, device="cpu")
+            w = build(env)
+        if post:
+            post(w)
+        w.eval()
+        w.reset()
+        init = (rng.random((n, 1, size, size)) < init_p).astype(np.float32)
+        env.universe = torch.from_numpy(init.copy())
+        acts, rews = [], []
+        for t in range(steps):
+            a = act_fn(t, n)
+            obs, reward, done, info = w.step(torch.from_numpy(a.copy()))
+            acts.append(a)
+            rews.append(np.asarray(reward.detach().numpy(), dtype=np.float32).reshape(n, -1).copy())
+        out[f"{name}/init"], _ = pack(init)
+        out[f"{name}/actions"], _ = pack(np.stack(acts))
+        out[f"{name}/rewards"] = np.stack(rews)
+        out[f"{name}/final_obs"], _ = pack(obs.detach().numpy())
+        out[f"{name}/meta"] = np.frombuffer(json.dumps(dict(n=n, size=size, steps=steps)).encode(), dtype=np.uint8)
+        return w
+
+    p10 = lambda t, n: (rng.random((n, 1, 64, 64)) <= 0.1).astype(np.float32)
+    sparse = lambda t, n: (p10(t, n) if t < 2 else np.zeros((n, 1, 64, 64), np.float32))
+    run("corner", lambda e: ref_mcl.CornerBonus(e), 2, 256, 6, p10)
+    run("speed", lambda e: ref_mcl.SpeedDetector(e), 2, 256, 8, sparse)
+
+    def small_threshold(w):
+        w.growth_threshold = 6
+    run("puffer", lambda e: ref_mcl.PufferDetector(e), 1, 256, 20, sparse, init_p=0.3, post=small_threshold)
+    # eval.py stacking: RND2D -> AE2D -> SpeedDetector -> PufferDetector (eval.py:83-87), N=1, 64x64
+    def stack(e):
+        w = ref_mcl.RND2D(e)
+        w = ref_mcl.AE2D(w)
+        w.batch_size = 10 ** 6
+        w.env.batch_size = 10 ** 6
+        w = ref_mcl.SpeedDetector(w)
+        w.reward_scale = 1e-2
+        w = ref_mcl.PufferDetector(w)
+        w.reward_scale = 1e-3
+        return w
+    w = run("evalstack", stack, 1, 64, 6, sparse)
+    sd_to_npz("evalstack_sd", w.state_dict(), out)
+    # ParsimonyBonus over RND2D, N=1 (the reference divides (N,1) by (N,): only N=1 is meaningful)
+    def pars(e):
+        w = ref_mcl.RND2D(e)
+        w.batch_size = 10 ** 6
+        return ref_mcl.ParsimonyBonus(w)
+    dense = lambda t, n: (rng.random((n, 1, 64, 64)) <= (0.5 if t % 2 else 0.01)).astype(np.float32)
+    w = run("parsimony", pars, 1, 64, 4, dense)
+    sd_to_npz("parsimony_sd", w.state_dict(), out)
+    np.savez_compressed(os.path.join(outdir, "wrappers.npz"), **out)
+    print("wrappers.npz written")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="/root/repo/tests/golden")
@@ -408,13 +475,15 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch, ref_env, ref_mcl = import_reference()
     torch.set_num_threads(8)
-    todo = args.only.split(",") if args.only else ["ca", "known", "nets"]
+    todo = args.only.split(",") if args.only else ["ca", "known", "nets", "wrappers"]
     if "ca" in todo:
         make_ca(torch, ref_env, args.out)
     if "known" in todo:
         make_known(torch, ref_env, ref_mcl, args.out)
     if "nets" in todo:
         make_nets(torch, ref_env, ref_mcl, args.out)
+    if "wrappers" in todo:
+        make_wrappers(torch, ref_env, ref_mcl, args.out)
 
 
 if __name__ == "__main__":
