@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
+from .rle import RLEMixin
 
 _MOORE = ((1.0, 1.0, 1.0), (1.0, 0.0, 1.0), (1.0, 1.0, 1.0))
 
@@ -45,7 +46,7 @@ def _resolve_device(kwargs):
 _PLAIN_ATTRS = frozenset(("universe", "action", "_slot", "log"))
 
 
-class CARLE(nn.Module):
+class CARLE(RLEMixin, nn.Module):
     """Batched toroidal Life-like cellular automaton with a gym-style interface."""
 
     def __new__(cls, **kwargs):
@@ -304,10 +305,6 @@ class CARLE(nn.Module):
         print("\n CA Universe")
         for r in rows:
             print("".join("o" if v else " " for v in r.tolist()))
-
-    def log_universe(self):
-        raise NotImplementedError(
-            "universe logging (RLE, carle/env.py:466-491) is outside the hot path of this build")
 
 
 class CARLEPacked(CARLE):

@@ -217,6 +217,16 @@ int carle_merge_moments(const double *gathered, int world, double *state3, doubl
 int carle_normalize_f32(const float *x, float *y, int64_t n, const double *moments3, double eps,
                         void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Run-length codec.  HOST pointers, synchronous, no HIP calls.
+ * encode: body of CARLE.get_rle (carle/env.py:431-462) for h x w byte cells (non-zero = alive);
+ *         returns the number of bytes of the body, writes at most `cap` of them (call with
+ *         out = NULL to size the buffer).  Byte-compatible with the reference, quirks included.
+ * decode: CARLE.rle_to_grid (carle/env.py:260-328) into h x w byte cells.
+ * ------------------------------------------------------------------------------------------- */
+int64_t carle_rle_encode_body(const uint8_t *cells, int h, int w, char *out, int64_t cap);
+int carle_rle_decode_body(const char *rle, int64_t len, uint8_t *cells, int h, int w);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,3 +199,25 @@ def test_action_forms():
         assert obs[i, 0].nonzero().cpu().tolist() == k["action_2d_out"]
     with pytest.raises(AssertionError):
         env.step(torch.zeros(3, 1, 32, 32))
+
+
+def test_logging_and_rle_round_trip(tmp_path):
+    """logging=True (env.py:194-195,466-491): every step records [action rle, universe rle];
+    load_universe (env.py:390-406) restores a pattern from a file."""
+    env = _env(width=64, height=64, instances=2, logging=True)
+    env.reset()
+    a = torch.zeros(2, 1, 64, 64)
+    a[0, 0, 10, 10:13] = 1
+    env.step(a)
+    env.step(torch.zeros(2, 1, 64, 64))
+    assert len(env.log) == 2 and "(action)" in env.log[0][0] and "(universe)" in env.log[0][1]
+    assert "step=1 (universe)" in env.log[1][1] and "rule = B3/S23:T64, 64" in env.log[1][1]
+    env.save_log(str(tmp_path))
+    env.save_frame(str(tmp_path))
+    assert any(f.startswith("carle_log") for f in __import__("os").listdir(tmp_path))
+    p = tmp_path / "blinker.rle"
+    p.write_text("x = 3, y = 1, rule = B3/S23\n3o!\n")
+    env.load_universe(str(p), universe_index=1)
+    assert env.universe[1, 0].nonzero().cpu().tolist() == [[0, 0], [0, 1], [0, 2]]
+    obs = env.step(torch.zeros(2, 1, 64, 64))[0]
+    assert obs[1, 0].nonzero().cpu().tolist() == [[0, 1], [1, 1], [63, 1]]

@@ -467,6 +467,40 @@ def make_wrappers(torch, ref_env, ref_mcl, outdir):
     print("wrappers.npz written")
 
 
+def make_rle(torch, ref_env, outdir):
+    """RLE codec: get_rle strings and rle_to_grid grids of the reference."""
+    import base64
+    rng = np.random.default_rng(5)
+    cases = []
+    for (size, p, rule, step, action) in [(64, 0.5, "life", 3, False), (64, 0.02, "morley", 0, True),
+                                          (64, 0.0, "life", 7, False), (64, 1.0, "b2s0", 1, False),
+                                          (256, 0.1, "daynight", 12, False), (32, 0.3, "life", 2, False)]:
+        env = ref_env.CARLE(width=size, height=size, device="cpu")
+        env.birth, env.survive = list(RULES[rule][0]), list(RULES[rule][1])
+        env.reset()
+        env.instance_id = "1700000000"
+        env.step_number = step
+        g = (rng.random((size, size)) < p).astype(np.float32)
+        rle = env.get_rle(torch.from_numpy(g), action=action)
+        back = env.rle_to_grid(rle[rle.index("\n", rle.index("rule")) + 1:]).numpy()
+        cases.append(dict(size=size, birth=env.birth, survive=env.survive, step=step, action=action,
+                          instance_id=env.instance_id,
+                          grid=base64.b64encode(np.packbits(g != 0, bitorder="little").tobytes()).decode(),
+                          rle=rle,
+                          decoded=base64.b64encode(np.packbits(back != 0, bitorder="little").tobytes()).decode()))
+    # standard (Golly-style) RLE bodies through rle_to_grid
+    decodes = []
+    for body, size in [("3b2o$3ob2o$5o$b3o!", 64), ("bo$2bo$3o!", 64), ("2o$2o3$4bo$5bo$3b3o!", 32),
+                       ("10b3o\n2$o!", 64), ("64o$64b$o62bo!", 64)]:
+        env = ref_env.CARLE(width=size, height=size, device="cpu")
+        g = env.rle_to_grid(body).numpy()
+        decodes.append(dict(size=size, rle=body,
+                            grid=base64.b64encode(np.packbits(g != 0, bitorder="little").tobytes()).decode()))
+    with open(os.path.join(outdir, "rle.json"), "w") as f:
+        json.dump(dict(encode=cases, decode=decodes), f, indent=1)
+    print("rle.json written")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="/root/repo/tests/golden")
@@ -475,7 +509,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch, ref_env, ref_mcl = import_reference()
     torch.set_num_threads(8)
-    todo = args.only.split(",") if args.only else ["ca", "known", "nets", "wrappers"]
+    todo = args.only.split(",") if args.only else ["ca", "known", "nets", "wrappers", "rle"]
     if "ca" in todo:
         make_ca(torch, ref_env, args.out)
     if "known" in todo:
@@ -484,6 +518,8 @@ def main():
         make_nets(torch, ref_env, ref_mcl, args.out)
     if "wrappers" in todo:
         make_wrappers(torch, ref_env, ref_mcl, args.out)
+    if "rle" in todo:
+        make_rle(torch, ref_env, args.out)
 
 
 if __name__ == "__main__":
