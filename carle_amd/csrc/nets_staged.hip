@@ -323,6 +323,9 @@ int64_t rnd2d_fused_workspace_floats();
 int rnd2d_fused64(const void *obs, bool packed, int64_t n, const float *pp, const float *rp,
                   float *ws, float *bonus, float *pred_out, float *target_out, bool tables_valid,
                   hipStream_t s);
+int64_t ae2d_fused_workspace_floats();
+int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
+                 float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s);
 }
 
 using namespace carle;
@@ -377,17 +380,37 @@ extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
 extern "C" int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w) {
     if (n < 0 || h < 8 || w < 8) return 0;
     const int64_t q = (int64_t)(h / 2) * (w / 2);
-    return n * (4 * q + 2 * (q / 4) + q);                 // A1 (4ch) + A2 (2ch) + A3
+    const int64_t staged = n * (4 * q + 2 * (q / 4) + q);    // A1 (4ch) + A2 (2ch) + A3
+    const int64_t fused = ae2d_fused_workspace_floats();
+    return staged > fused ? staged : fused;
+}
+
+extern "C" int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const float *params,
+                                   float *workspace, float *bonus, float *recon_out, int flags,
+                                   void *stream) {
+    if (!obs || !params || !workspace || !bonus)
+        return fail_arg(CARLE_E_NULL, "carle_ae2d_bonus_b1: NULL pointer");
+    if (h != 64 || w != 64 || n < 0)
+        return fail_arg(CARLE_E_DIMS, "carle_ae2d_bonus_b1: bit-packed observations are supported "
+                                      "for 64x64 grids (unpack larger grids first)");
+    if (recon_out && !aligned16(recon_out)) return fail_arg(CARLE_E_ALIGN, "carle_ae2d_bonus_b1: recon_out alignment");
+    if (n == 0) return 0;
+    return ae2d_fused64(obs, true, n, params, workspace, bonus, recon_out, nullptr, 0.0f,
+                        (flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float *params,
-                                    float *workspace, float *bonus, float *recon_out,
+                                    float *workspace, float *bonus, float *recon_out, int flags,
                                     void *stream) {
     if (!obs || !params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_ae2d_bonus_f32: NULL pointer");
     if (int e = check_net_dims(n, h, w, "carle_ae2d_bonus_f32")) return e;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h == 64 && w == 64 && (flags & CARLE_NET_OBS_BINARY) && aligned16(obs) &&
+        (!recon_out || aligned16(recon_out)))
+        return ae2d_fused64(obs, false, n, params, workspace, bonus, recon_out, nullptr, 0.0f,
+                            (flags & CARLE_NET_TABLES_VALID) != 0, s);
     const int64_t q = (int64_t)(h / 2) * (w / 2);
     if (n * q / 256 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ae2d_bonus_f32: batch too large");
     float *a1 = workspace, *a2 = a1 + n * 4 * q, *a3 = a2 + n * 2 * (q / 4);

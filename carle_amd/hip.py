@@ -178,21 +178,36 @@ def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=
     return (bonus, pred, targ, workspace) if want_outputs else (bonus, workspace)
 
 
-def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False):
-    """AE2D bonus (N,) for fp32 obs (N,1,H,W); params = flat 164-float blob."""
+def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False):
+    """AE2D bonus (N,) for obs (N,1,H,W) fp32 -- or int64 bit-packed (N,1,64,1); params = flat
+    164-float blob.  binary=True: obs values are exactly 0/1 (fused 64x64 path)."""
     lib = _lib.load()
-    _chk_grid(obs, "obs", torch.float32)
+    packed = obs.dtype == torch.int64
+    _chk_grid(obs, "obs", torch.int64 if packed else torch.float32)
     n, _, h, w = obs.shape
+    if packed:
+        w *= 64
     need = lib.carle_ae2d_workspace_floats(n, h, w)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 1), dtype=torch.float32, device=obs.device)
     bonus = torch.empty(n, dtype=torch.float32, device=obs.device)
-    recon = torch.empty_like(obs) if want_recon else None
+    recon = torch.empty(n, 1, h, w, dtype=torch.float32, device=obs.device) if want_recon else None
+    flags = 1 if binary else 0
+    if h == 64 and w == 64 and (packed or binary):
+        key = (id(params), params.data_ptr())
+        if _ws_tables.get(workspace.data_ptr()) == key:
+            flags |= 2
+        else:
+            if len(_ws_tables) > 64:
+                _ws_tables.clear()
+            _ws_tables[workspace.data_ptr()] = key
+    else:
+        _ws_tables.pop(workspace.data_ptr(), None)
     with _on_device(obs.device):
-        rc = lib.carle_ae2d_bonus_f32(obs.data_ptr(), n, h, w, params.data_ptr(),
-                                      workspace.data_ptr(), bonus.data_ptr(), _ptr(recon),
-                                      _stream(obs))
-    _lib.check(rc, "carle_ae2d_bonus_f32")
+        fn = lib.carle_ae2d_bonus_b1 if packed else lib.carle_ae2d_bonus_f32
+        rc = fn(obs.data_ptr(), n, h, w, params.data_ptr(), workspace.data_ptr(), bonus.data_ptr(),
+                _ptr(recon), flags, _stream(obs))
+    _lib.check(rc, "carle_ae2d_bonus")
     return (bonus, recon, workspace) if want_recon else (bonus, workspace)
 
 

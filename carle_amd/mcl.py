@@ -351,8 +351,8 @@ class AE2D(RND2D):
             p.requires_grad = False
 
     def _hip_forward(self, obs, want_outputs=False):
-        obs, binary = self._obs(obs)
-        res = hip.ae2d_bonus_f32(obs, self._pred_blob.get(obs.device), self._ws, want_outputs)
+        obs, binary = self._obs(obs, allow_packed=True)
+        res = hip.ae2d_bonus_f32(obs, self._pred_blob.get(obs.device), self._ws, want_outputs, binary)
         self._ws = res[-1]
         return res
 

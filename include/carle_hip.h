@@ -170,7 +170,10 @@ int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
  * recon_out: optional (N,1,H,W) reconstruction, may be NULL. */
 int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w);
 int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float *params,
-                         float *workspace, float *bonus, float *recon_out, void *stream);
+                         float *workspace, float *bonus, float *recon_out, int flags, void *stream);
+/* the same on bit-packed observations (CARLE_FMT_B1), 64x64 grids */
+int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const float *params,
+                        float *workspace, float *bonus, float *recon_out, int flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-side agents.  The reference's RandomAgent draws its toggles with

@@ -176,3 +176,34 @@ def test_async_reward_stream_matches_sync():
         outs.append(torch.stack(rews).cpu().numpy())
         assert (env.__dict__.get("reward_stream") is not None) == async_reward
     assert np.array_equal(outs[0], outs[1]) and outs[0].max() > 0
+
+
+def test_ae_fused64_matches_reference_and_staged():
+    """Fused 64x64 AE2D kernel on binary observations vs the genuine reference and the staged path."""
+    from carle_amd import hip
+    z = G.nets(64)
+    env, rnd, ae = _stack(64, 16, G.load_sd(z, "rnd_sd"), G.load_sd(z, "ae_sd"))
+    ae.reset()
+    g = torch.from_numpy(G.unpack(z["grids"], (16, 1, 64, 64))).cuda()
+    staged = ae.get_bonus_only(g)
+    staged_rec = ae.forward(g)
+    ae.assume_binary_obs = True
+    fused = ae.get_bonus_only(g)
+    np.testing.assert_allclose(fused.cpu().numpy(), z["ae_bonus"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(fused.cpu().numpy(), staged.cpu().numpy(), rtol=0, atol=1e-6)
+    rec = ae.forward(g)
+    np.testing.assert_allclose(rec.cpu().numpy(), z["ae_pred"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(rec.cpu().numpy(), staged_rec.cpu().numpy(), rtol=0, atol=1e-6)
+    packed = hip.pack_f32_b1(g)
+    np.testing.assert_allclose(ae.get_bonus_only(packed).cpu().numpy(), fused.cpu().numpy(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 770, 4096 + 3])
+def test_ae_fused64_batch_sizes(n):
+    torch.manual_seed(100 + n)
+    env, rnd, ae = _stack(64, n)
+    g = (torch.rand(n, 1, 64, 64, device="cuda") < 0.3).float()
+    staged = ae.get_bonus_only(g)
+    ae.assume_binary_obs = True
+    fused = ae.get_bonus_only(g)
+    np.testing.assert_allclose(fused.cpu().numpy(), staged.cpu().numpy(), rtol=0, atol=1e-6)
