@@ -181,8 +181,11 @@ def main():
         obs, reward, done, info = wenv.step(action)
         rs = env.__dict__.get("reward_stream")
         if rs is not None:                   # reward consumers live on the reward stream
-            with torch.cuda.stream(rs):
-                stats.update(reward)
+            if stats._pending_steps + 1 >= stats.sync_every:
+                with torch.cuda.stream(rs):  # the periodic all-gather + merge (torch/RCCL ops)
+                    stats.update(reward)
+            else:
+                stats.update(reward, rs.cuda_stream)
         else:
             stats.update(reward)
 

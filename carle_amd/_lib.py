@@ -26,14 +26,15 @@ SIGNATURES = {
                                      _c_vp]),
     "carle_rnd2d_workspace_floats": (_c_i64, [_c_i64, _c_int, _c_int]),
     "carle_rnd2d_bonus_f32": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
-                                       _c_vp, _c_vp, _c_int, _c_vp]),
+                                       _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_vp]),
     "carle_rnd2d_bonus_b1": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
-                                      _c_vp, _c_vp, _c_int, _c_vp]),
+                                      _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_vp]),
+    "carle_stream_fork": (_c_int, [_c_vp, _c_vp, _c_vp]),
     "carle_ae2d_workspace_floats": (_c_i64, [_c_i64, _c_int, _c_int]),
     "carle_ae2d_bonus_f32": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
-                                      _c_int, _c_vp]),
+                                      _c_vp, ctypes.c_float, _c_int, _c_vp]),
     "carle_ae2d_bonus_b1": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
-                                     _c_int, _c_vp]),
+                                     _c_vp, ctypes.c_float, _c_int, _c_vp]),
     "carle_batch_moments_f32": (_c_int, [_c_vp, _c_i64, _c_vp, _c_vp, _c_vp]),
     "carle_merge_moments": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "carle_normalize_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp, ctypes.c_double, _c_vp]),

@@ -134,3 +134,14 @@ extern "C" int carle_env_step_f32_rand(const float *u_in, float *u_out, float *r
     return carle_ca_finish(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot, 1,
                            stream);
 }
+
+// Orders `to_stream` after everything enqueued so far on `from_stream` (event record + wait):
+// lets the reward networks of step t run on their own stream beside the CA kernel of step t+1.
+extern "C" int carle_stream_fork(void *event, void *from_stream, void *to_stream) {
+    if (!event) return fail_arg(CARLE_E_NULL, "carle_stream_fork: event is NULL");
+    hipError_t e = hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(from_stream));
+    if (e != hipSuccess) return fail_hip(e, "carle_stream_fork(record)");
+    e = hipStreamWaitEvent(static_cast<hipStream_t>(to_stream), static_cast<hipEvent_t>(event), 0);
+    if (e != hipSuccess) return fail_hip(e, "carle_stream_fork(wait)");
+    return 0;
+}

@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict
                                                           const float *__restrict__ ws,
                                                           float *__restrict__ bonus,
                                                           float *__restrict__ pred_out,
-                                                          float *__restrict__ target_out, int64_t n) {
+                                                          float *__restrict__ target_out,
+                                                          float *__restrict__ reward, float reward_scale,
+                                                          int64_t n) {
     __shared__ float4 s_lut_p[512];
     __shared__ float2 s_lut_r[512];
     __shared__ float s_lin[2 * kLinFloats];
@@ -242,7 +244,11 @@ __global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict
             float sq = (out - other) * (out - other);
 #pragma unroll
             for (int s = 2; s < 32; s <<= 1) sq += __shfl_xor(sq, s, 64);
-            if (lane == 0) bonus[g] = sq * (1.0f / 16.0f);
+            if (lane == 0) {
+                const float b = sq * (1.0f / 16.0f);
+                bonus[g] = b;
+                if (reward) reward[g] += reward_scale * b;       // mcl.py:403-405
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -258,18 +264,18 @@ namespace carle {
 int64_t rnd2d_fused_workspace_floats() { return kFusedWsFloats + 64; }
 
 int rnd2d_fused64(const void *obs, bool packed, int64_t n, const float *pp, const float *rp,
-                  float *ws, float *bonus, float *pred_out, float *target_out, bool tables_valid,
-                  hipStream_t s) {
+                  float *ws, float *bonus, float *pred_out, float *target_out, float *reward,
+                  float reward_scale, bool tables_valid, hipStream_t s) {
     if (!tables_valid) hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
     int64_t blocks = (n + 7) / 8;                     // two grids per wave when the batch allows
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     if (packed)
         hipLaunchKernelGGL(rnd_fused64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
-                           bonus, pred_out, target_out, n);
+                           bonus, pred_out, target_out, reward, reward_scale, n);
     else
         hipLaunchKernelGGL(rnd_fused64_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
-                           bonus, pred_out, target_out, n);
+                           bonus, pred_out, target_out, reward, reward_scale, n);
     return check_launch("carle_rnd2d_bonus(fused 64x64)");
 }
 

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void rnd_conv2_pool2_kernel(
 __global__ __launch_bounds__(64) void rnd_linear_bonus_kernel(
     const float *__restrict__ ws2, const float *__restrict__ pp, const float *__restrict__ rp,
     float *__restrict__ bonus, float *__restrict__ pred_out, float *__restrict__ target_out,
-    int64_t n, int d) {
+    float *__restrict__ reward, float reward_scale, int64_t n, int d) {
     const int64_t g = blockIdx.x;
     const int lane = threadIdx.x;
     const int quarter = lane & 1, k = (lane >> 1) & 15, net = lane >> 5;   // 2 partials per output
@@ -139,7 +139,11 @@ __global__ __launch_bounds__(64) void rnd_linear_bonus_kernel(
     // sum over k within lanes 0..31 (each k appears on two lanes: quarter 0/1 -> halve)
 #pragma unroll
     for (int s = 2; s < 32; s <<= 1) sq += __shfl_xor(sq, s, 64);
-    if (lane == 0) bonus[g] = sq * (1.0f / kRndDim);
+    if (lane == 0) {
+        const float b = sq * (1.0f / kRndDim);
+        bonus[g] = b;
+        if (reward) reward[g] += reward_scale * b;        // mcl.py:403-405
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -269,7 +273,8 @@ __global__ __launch_bounds__(256) void ae_convt1_kernel(
 // one 256-thread block per grid, deterministic tree reduction.
 __global__ __launch_bounds__(256) void ae_convt2_mse_kernel(
     const float *__restrict__ obs, const float *__restrict__ a3, const float *__restrict__ ap,
-    float *__restrict__ bonus, float *__restrict__ recon, int64_t n, int h, int w) {
+    float *__restrict__ bonus, float *__restrict__ recon, float *__restrict__ reward,
+    float reward_scale, int64_t n, int h, int w) {
     __shared__ float red[256];
     const int h2 = h >> 1, w2 = w >> 1;
     const int64_t g = blockIdx.x;
@@ -302,7 +307,11 @@ __global__ __launch_bounds__(256) void ae_convt2_mse_kernel(
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) bonus[g] = red[0] / (float)(h * w);
+    if (threadIdx.x == 0) {
+        const float b = red[0] / (float)(h * w);
+        bonus[g] = b;
+        if (reward) reward[g] += reward_scale * b;
+    }
 }
 
 static inline int check_net_dims(int64_t n, int h, int w, const char *who) {
@@ -321,8 +330,8 @@ static inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 25
 namespace carle {
 int64_t rnd2d_fused_workspace_floats();
 int rnd2d_fused64(const void *obs, bool packed, int64_t n, const float *pp, const float *rp,
-                  float *ws, float *bonus, float *pred_out, float *target_out, bool tables_valid,
-                  hipStream_t s);
+                  float *ws, float *bonus, float *pred_out, float *target_out, float *reward,
+                  float reward_scale, bool tables_valid, hipStream_t s);
 int64_t ae2d_fused_workspace_floats();
 int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s);
@@ -340,7 +349,8 @@ extern "C" int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w) {
 extern "C" int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
                                     const float *pred_params, const float *rand_params,
                                     float *workspace, float *bonus, float *pred_out,
-                                    float *target_out, int flags, void *stream) {
+                                    float *target_out, float *reward_accum, float reward_scale,
+                                    int flags, void *stream) {
     if (!obs || !pred_params || !rand_params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_rnd2d_bonus_b1: NULL pointer");
     if (h != 64 || w != 64 || n < 0)
@@ -348,14 +358,15 @@ extern "C" int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w
                                       "for 64x64 grids (unpack larger grids first)");
     if (n == 0) return 0;
     return rnd2d_fused64(obs, true, n, pred_params, rand_params, workspace, bonus, pred_out,
-                         target_out, (flags & CARLE_NET_TABLES_VALID) != 0,
+                         target_out, reward_accum, reward_scale, (flags & CARLE_NET_TABLES_VALID) != 0,
                          static_cast<hipStream_t>(stream));
 }
 
 extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
                                      const float *pred_params, const float *rand_params,
                                      float *workspace, float *bonus, float *pred_out,
-                                     float *target_out, int flags, void *stream) {
+                                     float *target_out, float *reward_accum, float reward_scale,
+                                     int flags, void *stream) {
     if (!obs || !pred_params || !rand_params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_rnd2d_bonus_f32: NULL pointer");
     if (int e = check_net_dims(n, h, w, "carle_rnd2d_bonus_f32")) return e;
@@ -363,7 +374,8 @@ extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (h == 64 && w == 64 && (flags & CARLE_NET_OBS_BINARY) && aligned16(obs))
         return rnd2d_fused64(obs, false, n, pred_params, rand_params, workspace, bonus, pred_out,
-                             target_out, (flags & CARLE_NET_TABLES_VALID) != 0, s);
+                             target_out, reward_accum, reward_scale,
+                             (flags & CARLE_NET_TABLES_VALID) != 0, s);
     const int64_t p1 = n * (int64_t)(h / 4) * (w / 4);
     const int d = (h / 8) * (w / 8);
     if (p1 * 6 / 256 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_rnd2d_bonus_f32: batch too large");
@@ -373,7 +385,7 @@ extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
     hipLaunchKernelGGL(rnd_conv2_pool2_kernel, dim3(blocks_for(n * 2 * (int64_t)d)), dim3(256), 0, s,
                        ws1, pred_params, rand_params, ws2, n, h, w);
     hipLaunchKernelGGL(rnd_linear_bonus_kernel, dim3((unsigned)n), dim3(64), 0, s, ws2, pred_params,
-                       rand_params, bonus, pred_out, target_out, n, d);
+                       rand_params, bonus, pred_out, target_out, reward_accum, reward_scale, n, d);
     return check_launch("carle_rnd2d_bonus_f32");
 }
 
@@ -386,8 +398,8 @@ extern "C" int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w) {
 }
 
 extern "C" int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const float *params,
-                                   float *workspace, float *bonus, float *recon_out, int flags,
-                                   void *stream) {
+                                   float *workspace, float *bonus, float *recon_out,
+                                   float *reward_accum, float reward_scale, int flags, void *stream) {
     if (!obs || !params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_ae2d_bonus_b1: NULL pointer");
     if (h != 64 || w != 64 || n < 0)
@@ -395,13 +407,13 @@ extern "C" int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
                                       "for 64x64 grids (unpack larger grids first)");
     if (recon_out && !aligned16(recon_out)) return fail_arg(CARLE_E_ALIGN, "carle_ae2d_bonus_b1: recon_out alignment");
     if (n == 0) return 0;
-    return ae2d_fused64(obs, true, n, params, workspace, bonus, recon_out, nullptr, 0.0f,
+    return ae2d_fused64(obs, true, n, params, workspace, bonus, recon_out, reward_accum, reward_scale,
                         (flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float *params,
-                                    float *workspace, float *bonus, float *recon_out, int flags,
-                                    void *stream) {
+                                    float *workspace, float *bonus, float *recon_out,
+                                    float *reward_accum, float reward_scale, int flags, void *stream) {
     if (!obs || !params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_ae2d_bonus_f32: NULL pointer");
     if (int e = check_net_dims(n, h, w, "carle_ae2d_bonus_f32")) return e;
@@ -409,8 +421,8 @@ extern "C" int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, c
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (h == 64 && w == 64 && (flags & CARLE_NET_OBS_BINARY) && aligned16(obs) &&
         (!recon_out || aligned16(recon_out)))
-        return ae2d_fused64(obs, false, n, params, workspace, bonus, recon_out, nullptr, 0.0f,
-                            (flags & CARLE_NET_TABLES_VALID) != 0, s);
+        return ae2d_fused64(obs, false, n, params, workspace, bonus, recon_out, reward_accum,
+                            reward_scale, (flags & CARLE_NET_TABLES_VALID) != 0, s);
     const int64_t q = (int64_t)(h / 2) * (w / 2);
     if (n * q / 256 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ae2d_bonus_f32: batch too large");
     float *a1 = workspace, *a2 = a1 + n * 4 * q, *a3 = a2 + n * 2 * (q / 4);
@@ -421,6 +433,6 @@ extern "C" int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, c
     hipLaunchKernelGGL(ae_convt1_kernel, dim3(blocks_for(n * q)), dim3(256), 0, s, a2, params, a3, n,
                        h, w);
     hipLaunchKernelGGL(ae_convt2_mse_kernel, dim3((unsigned)n), dim3(256), 0, s, obs, a3, params,
-                       bonus, recon_out, n, h, w);
+                       bonus, recon_out, reward_accum, reward_scale, n, h, w);
     return check_launch("carle_ae2d_bonus_f32");
 }

@@ -114,11 +114,12 @@ class RunningRewardStats:
         self.state = chan_merge(torch.stack([self.state, self.last_batch]))
         return self.last_batch
 
-    def update(self, reward):
+    def update(self, reward, stream=None):
         """One HIP kernel per call: batch moments, merged on the device into the pending triple;
-        every ``sync_every`` calls the pending triple is exchanged (``flush``)."""
+        every ``sync_every`` calls the pending triple is exchanged (``flush``).  ``stream``: raw
+        hipStream_t to launch on (e.g. the reward stream of the wrappers)."""
         from . import hip
-        hip.batch_moments_f32(reward.reshape(-1), self._batch, self._pending)
+        hip.batch_moments_f32(reward.reshape(-1), self._batch, self._pending, stream)
         self._pending_steps += 1
         if self._pending_steps >= self.sync_every:
             return self.flush()

@@ -134,9 +134,12 @@ def _ptr(t):
 _ws_tables = {}      # workspace data_ptr -> (pred blob id, rand blob id) the fused tables hold
 
 
-def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=False, binary=False):
+def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=False, binary=False,
+                    reward=None, reward_scale=1.0, bonus_out=None, stream=None):
     """RND2D bonus (N,) for obs (N,1,H,W) fp32 -- or int64 bit-packed (N,1,64,1).  params = flat
-    fp32 blobs (see carle_hip.h).  binary=True: obs values are exactly 0/1 (fused 64x64 path)."""
+    fp32 blobs (see carle_hip.h).  binary=True: obs values are exactly 0/1 (fused 64x64 path).
+    reward (N,1): additionally reward += reward_scale * bonus inside the kernel.  stream: raw
+    hipStream_t to launch on (default: torch's current stream)."""
     lib = _lib.load()
     packed = obs.dtype == torch.int64
     _chk_grid(obs, "obs", torch.int64 if packed else torch.float32)
@@ -146,7 +149,7 @@ def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=
     need = lib.carle_rnd2d_workspace_floats(n, h, w)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 1), dtype=torch.float32, device=obs.device)
-    bonus = torch.empty(n, dtype=torch.float32, device=obs.device)
+    bonus = bonus_out if bonus_out is not None else torch.empty(n, dtype=torch.float32, device=obs.device)
     pred = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
     targ = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
     flags = 1 if binary else 0
@@ -164,23 +167,19 @@ def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=
     else:
         _ws_tables.pop(workspace.data_ptr(), None)        # staged path overwrites the workspace
     with _on_device(obs.device):
-        if packed:
-            rc = lib.carle_rnd2d_bonus_b1(obs.data_ptr(), n, h, w, pred_params.data_ptr(),
-                                          rand_params.data_ptr(), workspace.data_ptr(),
-                                          bonus.data_ptr(), _ptr(pred), _ptr(targ), flags,
-                                          _stream(obs))
-        else:
-            rc = lib.carle_rnd2d_bonus_f32(obs.data_ptr(), n, h, w, pred_params.data_ptr(),
-                                           rand_params.data_ptr(), workspace.data_ptr(),
-                                           bonus.data_ptr(), _ptr(pred), _ptr(targ), flags,
-                                           _stream(obs))
-    _lib.check(rc, "carle_rnd2d_bonus")
+        fn = lib.carle_rnd2d_bonus_b1 if packed else lib.carle_rnd2d_bonus_f32
+        rc = fn(obs.data_ptr(), n, h, w, pred_params.data_ptr(), rand_params.data_ptr(),
+                workspace.data_ptr(), bonus.data_ptr(), _ptr(pred), _ptr(targ), _ptr(reward),
+                float(reward_scale), flags, stream if stream is not None else _stream(obs))
+    if rc != 0:
+        _lib.check(rc, "carle_rnd2d_bonus")
     return (bonus, pred, targ, workspace) if want_outputs else (bonus, workspace)
 
 
-def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False):
+def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False,
+                   reward=None, reward_scale=1.0, bonus_out=None, stream=None):
     """AE2D bonus (N,) for obs (N,1,H,W) fp32 -- or int64 bit-packed (N,1,64,1); params = flat
-    164-float blob.  binary=True: obs values are exactly 0/1 (fused 64x64 path)."""
+    164-float blob.  binary / reward / stream as for rnd2d_bonus_f32."""
     lib = _lib.load()
     packed = obs.dtype == torch.int64
     _chk_grid(obs, "obs", torch.int64 if packed else torch.float32)
@@ -190,7 +189,7 @@ def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False):
     need = lib.carle_ae2d_workspace_floats(n, h, w)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 1), dtype=torch.float32, device=obs.device)
-    bonus = torch.empty(n, dtype=torch.float32, device=obs.device)
+    bonus = bonus_out if bonus_out is not None else torch.empty(n, dtype=torch.float32, device=obs.device)
     recon = torch.empty(n, 1, h, w, dtype=torch.float32, device=obs.device) if want_recon else None
     flags = 1 if binary else 0
     if h == 64 and w == 64 and (packed or binary):
@@ -206,12 +205,21 @@ def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False):
     with _on_device(obs.device):
         fn = lib.carle_ae2d_bonus_b1 if packed else lib.carle_ae2d_bonus_f32
         rc = fn(obs.data_ptr(), n, h, w, params.data_ptr(), workspace.data_ptr(), bonus.data_ptr(),
-                _ptr(recon), flags, _stream(obs))
-    _lib.check(rc, "carle_ae2d_bonus")
+                _ptr(recon), _ptr(reward), float(reward_scale), flags,
+                stream if stream is not None else _stream(obs))
+    if rc != 0:
+        _lib.check(rc, "carle_ae2d_bonus")
     return (bonus, recon, workspace) if want_recon else (bonus, workspace)
 
 
-def batch_moments_f32(x, out=None, acc=None):
+def stream_fork(event_handle, from_stream, to_stream):
+    """to_stream waits for everything enqueued so far on from_stream (raw handles)."""
+    rc = _lib.load().carle_stream_fork(event_handle, from_stream, to_stream)
+    if rc != 0:
+        _lib.check(rc, "carle_stream_fork")
+
+
+def batch_moments_f32(x, out=None, acc=None, stream=None):
     """(count, mean, M2) of a fp32 device vector as a fp64[3] device tensor (no host sync);
     ``acc`` (fp64[3] device) is additionally Chan-merged with the batch inside the kernel."""
     lib = _lib.load()
@@ -221,7 +229,7 @@ def batch_moments_f32(x, out=None, acc=None):
         out = torch.empty(3, dtype=torch.float64, device=x.device)
     with _on_device(x.device):
         rc = lib.carle_batch_moments_f32(x.data_ptr(), x.numel(), out.data_ptr(), _ptr(acc),
-                                         _stream(x))
+                                         stream if stream is not None else _stream(x))
     _lib.check(rc, "carle_batch_moments_f32")
     return out
 

@@ -108,6 +108,7 @@ class RND2D(Motivator):
         # identity with inner_env.universe).  Set True to assert it for foreign tensors.
         self.assume_binary_obs = False
         self.async_reward = bool(kwargs.get("async_reward", False))
+        self._bonus_buf = None
         # False: step() only evaluates the bonus (forward pass), no window retention / Adam update
         self.train_predictor = bool(kwargs.get("train_predictor", True))
         self.accumulate_loss = 0.0
@@ -180,11 +181,12 @@ class RND2D(Motivator):
             obs = obs.unsqueeze(1)
         return obs, binary
 
-    def _hip_forward(self, obs, want_outputs=False):
+    def _hip_forward(self, obs, want_outputs=False, reward=None, bonus_out=None, stream=None):
         obs, binary = self._obs(obs, allow_packed=True)
         dev = obs.device
         res = hip.rnd2d_bonus_f32(obs, self._pred_blob.get(dev), self._rand_blob.get(dev),
-                                  self._ws, want_outputs, binary)
+                                  self._ws, want_outputs, binary, reward, self.reward_scale,
+                                  bonus_out, stream)
         self._ws = res[-1]
         return res
 
@@ -259,12 +261,24 @@ class RND2D(Motivator):
         self.updates += 1
 
     # ------------------------------------------------------------------ gym surface
-    def _bonus_into(self, obs, reward):
+    def _bonus_into(self, obs, reward, stream=None):
+        """reward += reward_scale * bonus(obs), fused into the bonus kernel (mcl.py:403-405)."""
         if self.train_predictor:
-            bonus = self.get_bonus_accumulate(obs)
-        else:
-            bonus = self.get_bonus_only(obs)
-        reward += self.reward_scale * bonus.unsqueeze(1)
+            if self.buffer_length == 0:
+                self.predictor.zero_grad()
+                self.accumulate_loss = 0.0
+                self._window = []
+            self._window.append(self._obs(obs)[0])
+            self.buffer_length += 1
+        n = reward.shape[0]
+        if self._bonus_buf is None or self._bonus_buf.shape[0] != n or self._bonus_buf.device != reward.device:
+            self._bonus_buf = torch.empty(n, dtype=torch.float32, device=reward.device)
+        self._hip_forward(obs, False, reward, self._bonus_buf, stream)
+        if self.train_predictor and self.buffer_length >= self.batch_size:
+            self.accumulate_loss = self._replay_window(1.0 / self.batch_size)
+            self.optimizer.step()
+            self._after_update()
+            self.buffer_length = 0
 
     def step(self, action):
         """env.step, then reward += reward_scale * bonus(obs)  (mcl.py:398-407).
@@ -280,12 +294,23 @@ class RND2D(Motivator):
         rs = self._reward_stream()
         if rs is None:
             self._bonus_into(obs, reward)
+            return obs, reward, done, info
+        env = self.inner_env
+        d = env.__dict__
+        main_raw = hip._stream(reward)
+        rs_raw = rs.cuda_stream
+        hip.stream_fork(d["_reward_event"].cuda_event, main_raw, rs_raw)   # rs after CA step t
+        if self.train_predictor and self.buffer_length + 1 >= self.batch_size:
+            with torch.cuda.stream(rs):                  # the Adam replay uses torch ops: rare path
+                self._bonus_into(obs, reward, rs_raw)
         else:
-            rs.wait_stream(torch.cuda.current_stream(obs.device))
-            with torch.cuda.stream(rs):
-                self._bonus_into(obs, reward)
-            obs.record_stream(rs)
-            reward.record_stream(rs)
+            self._bonus_into(obs, reward, rs_raw)
+        # tensors touched on the reward stream stay referenced until the next cross-stream join
+        hold = d.setdefault("_reward_hold", [])
+        hold.append((obs, reward))
+        if len(hold) >= 8:
+            hip.stream_fork(d["_reward_event2"].cuda_event, rs_raw, main_raw)  # main waits for rs
+            d["_reward_hold"] = hold[-1:]
         return obs, reward, done, info
 
     def _reward_stream(self):
@@ -296,6 +321,10 @@ class RND2D(Motivator):
         if rs is None:
             rs = torch.cuda.Stream(device=env.my_device)
             env.__dict__["reward_stream"] = rs
+            for name in ("_reward_event", "_reward_event2"):
+                ev = torch.cuda.Event()
+                ev.record()                              # materialises the hipEvent_t handle
+                env.__dict__[name] = ev
         return rs
 
     def wait_rewards(self):
@@ -350,9 +379,10 @@ class AE2D(RND2D):
         for p in self.predictor.parameters():
             p.requires_grad = False
 
-    def _hip_forward(self, obs, want_outputs=False):
+    def _hip_forward(self, obs, want_outputs=False, reward=None, bonus_out=None, stream=None):
         obs, binary = self._obs(obs, allow_packed=True)
-        res = hip.ae2d_bonus_f32(obs, self._pred_blob.get(obs.device), self._ws, want_outputs, binary)
+        res = hip.ae2d_bonus_f32(obs, self._pred_blob.get(obs.device), self._ws, want_outputs, binary,
+                                 reward, self.reward_scale, bonus_out, stream)
         self._ws = res[-1]
         return res
 

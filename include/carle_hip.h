@@ -146,6 +146,9 @@ int carle_env_step_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_
  * carle_*_workspace_floats(n,h,w) floats.  H == W, multiple of 8.
  * ------------------------------------------------------------------------------------------- */
 
+/* reward_accum (nullable, N floats): additionally reward_accum[i] += reward_scale * bonus[i], the
+ * wrapper's `reward += reward_scale * bonus` (carle/mcl.py:403-405) fused into the last kernel. */
+
 /* RND2D.get_bonus (carle/mcl.py:319-330,343-352): bonus[i] = mean_k (random(obs_i)_k -
  * predictor(obs_i)_k)^2.  pred_out / target_out: optional (N,16) network outputs, may be NULL. */
 int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w);
@@ -159,21 +162,28 @@ int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w);
 int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
                           const float *pred_params, const float *rand_params,
                           float *workspace, float *bonus, float *pred_out, float *target_out,
-                          int flags, void *stream);
+                          float *reward_accum, float reward_scale, int flags, void *stream);
 /* the same on bit-packed observations (CARLE_FMT_B1), 64x64 grids */
 int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
                          const float *pred_params, const float *rand_params,
                          float *workspace, float *bonus, float *pred_out, float *target_out,
-                         int flags, void *stream);
+                         float *reward_accum, float reward_scale, int flags, void *stream);
 
 /* AE2D.get_bonus (carle/mcl.py:436-443,504-512): bonus[i] = mean_{h,w} (obs_i - decoder(obs_i))^2.
  * recon_out: optional (N,1,H,W) reconstruction, may be NULL. */
 int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w);
 int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float *params,
-                         float *workspace, float *bonus, float *recon_out, int flags, void *stream);
+                         float *workspace, float *bonus, float *recon_out,
+                         float *reward_accum, float reward_scale, int flags, void *stream);
 /* the same on bit-packed observations (CARLE_FMT_B1), 64x64 grids */
 int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const float *params,
-                        float *workspace, float *bonus, float *recon_out, int flags, void *stream);
+                        float *workspace, float *bonus, float *recon_out,
+                        float *reward_accum, float reward_scale, int flags, void *stream);
+
+/* Orders `to_stream` after everything enqueued so far on `from_stream` (hipEventRecord on
+ * from_stream + hipStreamWaitEvent on to_stream; `event` is a caller-owned hipEvent_t).  Used to
+ * run the reward networks of step t on a second stream beside the CA kernel of step t+1. */
+int carle_stream_fork(void *event, void *from_stream, void *to_stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-side agents.  The reference's RandomAgent draws its toggles with
