@@ -12,6 +12,7 @@
 // (ca_bits.hpp).  No MFMA, no LDS.
 #include "ca_bits.hpp"
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace carle {
 
@@ -67,30 +68,59 @@ __device__ __forceinline__ void store_row(uint64_t *__restrict__ p, const uint64
     }
 }
 
-// XOR the packed action row (AWW words at column offset ox = 32*(WW-AWW)) into a grid row.
-// `ok` = this lane's row is inside the window.  Register-light on purpose: each target word
-// re-reads the (at most two) action words that overlap it (L1 hits) instead of staging the action
-// row in a register array, so the action path does not raise the kernel's VGPR allocation.
+// XOR the packed action row (AWW words at column offset ox = 32*(WW-AWW), a multiple of 32 bits)
+// into a grid row.  `ok` = this lane's row is inside the window.  Every 32-bit half of every grid
+// word reads "its" action dword with an UNCONDITIONAL load from a clamped (always valid) address
+// and masks the result: 2*WW independent loads that issue back to back (one latency, not 2*WW
+// dependent ones as with per-word branches).
 template <int WW>
 __device__ __forceinline__ void toggle_row(uint64_t (&c)[WW], const uint64_t *__restrict__ arow,
                                            int aww, bool ok, uint64_t &seen_or, uint64_t &seen_and) {
-    const int wo = (WW - aww) >> 1;                         // uniform word offset of the window
-    const bool half = ((WW - aww) & 1) != 0;                // ox % 64 == 32
+    const uint32_t *a32 = reinterpret_cast<const uint32_t *>(arow);
+    const int shift_dwords = WW - aww;                      // ox / 32
+    const int ndw = 2 * aww;                                // dwords in the action row
+    uint32_t v[2 * WW];
 #pragma unroll
-    for (int j = 0; j < WW; ++j) {
-        const int i = j - wo;                               // action word aligned with grid word j
-        uint64_t cur = 0ull, prv = 0ull;
-        if (ok && i >= 0 && i < aww) {
-            cur = arow[i];
-            seen_or |= cur;
-            seen_and &= cur;
-        }
-        if (half && ok && i - 1 >= 0 && i - 1 < aww) prv = arow[i - 1];
-        c[j] ^= half ? ((cur << 32) | (prv >> 32)) : cur;
+    for (int d = 0; d < 2 * WW; ++d) {
+        const int i = d - shift_dwords;                     // action dword under grid dword d
+        const bool in = ok && i >= 0 && i < ndw;
+        const uint32_t x = a32[in ? i : 0];
+        v[d] = in ? x : 0u;
+    }
+    uint32_t o = 0u, n = 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 0; d < 2 * WW; ++d) {
+        const int i = d - shift_dwords;
+        if (ok && i >= 0 && i < ndw) { o |= v[d]; n &= v[d]; }
+    }
+#pragma unroll
+    for (int j = 0; j < WW; ++j) c[j] ^= ((uint64_t)v[2 * j + 1] << 32) | v[2 * j];
+    seen_or |= o;
+    if (ok) seen_and &= (n == 0xFFFFFFFFu) ? ~0ull : 0ull;
+}
+
+// RULE_MODE: the two rules of the BASELINE configs get a 2-instruction closed form; everything
+// else goes through the rule-independent 17-instruction multiplexer tree (no per-rule branches,
+// no extra live registers -- the branchy sparse form measured slower here: 142 VGPRs).
+enum { kRuleGeneric = 0, kRuleLife = 1, kRuleHighLife = 2 };
+static constexpr uint32_t kLifeMask = (1u << 12) | 0xCu;                  // B3/S23
+static constexpr uint32_t kHighLifeMask = (1u << 12) | (1u << 15) | 0xCu;  // B36/S23
+
+template <int RULE_MODE>
+__device__ __forceinline__ uint32_t next_state(const Count4<uint32_t> &n, uint32_t c, uint32_t rule) {
+    if constexpr (RULE_MODE == kRuleLife) {
+        // count==3, or alive and count==2:  s1 & ~s2 & (s0 | c)   (count 8 has s1 == 0)
+        return bop3<(kA & ~kB & kC) & 0xFF>(n.s1, n.s2, n.s0 | c);
+    } else if constexpr (RULE_MODE == kRuleHighLife) {
+        // Life, plus dead and count==6:  s1 & ((~s2 & (s0 | c)) | (s2 & ~s0 & ~c))
+        const uint32_t x = bop3<((~kB & (kA | kC)) | (kB & ~kA & ~kC)) & 0xFF>(n.s0, n.s2, c);
+        return n.s1 & x;
+    } else {
+        return apply_rule(n, c, rule);
     }
 }
 
-template <int WW, bool HAS_ACT>
+template <int WW, bool HAS_ACT, int RULE_MODE>
 __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     const uint64_t *__restrict__ u_in, const uint64_t *__restrict__ act, uint64_t *__restrict__ u_out,
     int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot,
@@ -117,7 +147,8 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     if (MULTI && hr >= 0) load_row<WW>(gin + (int64_t)hr * WW, hal);
 
     if (HAS_ACT) {
-        const int oy = (H - ah) >> 1, aww = aw >> 6;
+        __builtin_amdgcn_sched_barrier(0);      // keep the toggle phase's registers out of the
+        const int oy = (H - ah) >> 1, aww = aw >> 6;    // compute phase (occupancy: <= 64 VGPRs)
         // wave-uniform: does the strip or one of its halo rows meet the action window at all?
         const bool touches = (r0 < oy + ah && r0 + 64 > oy) ||
                              (MULTI && ((rt >= oy && rt < oy + ah) || (rb >= oy && rb < oy + ah)));
@@ -126,6 +157,7 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
             uint64_t s_or = 0ull, s_and = ~0ull, d0 = 0ull, d1 = ~0ull;
             const bool in = r >= oy && r < oy + ah;
             toggle_row<WW>(c, ga + (int64_t)(in ? r - oy : 0) * aww, aww, in, s_or, s_and);
+            __builtin_amdgcn_sched_barrier(0);
             if (MULTI) {
                 const bool hin = hr >= oy && hr < oy + ah;
                 toggle_row<WW>(hal, ga + (int64_t)(hin ? hr - oy : 0) * aww, aww, hin, d0, d1);
@@ -141,35 +173,49 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
         }
     }
 
-    // horizontal sums of the own row and (lanes 0/63) of the halo row
-    uint64_t h0[WW], h1[WW], p0[WW], p1[WW], g0[WW], g1[WW];
+    if (HAS_ACT) __builtin_amdgcn_sched_barrier(0);
+
+    // ---- compute phase on 32-bit chunks (NC = 2*WW per row): every operation below is a single
+    // full-rate VALU instruction -- v_alignbit_b32 for the 1-bit funnel shifts across chunk
+    // borders (the wrap j-1 / j+1 is the x torus seam), v_bitop3_b32 for the adders and the rule,
+    // v_mov_b32_dpp for the rows above / below.
+    constexpr int NC = 2 * WW;
+    uint32_t cc[NC], hc[NC];
 #pragma unroll
     for (int j = 0; j < WW; ++j) {
-        const uint64_t wst = (c[j] << 1) | (c[(j + WW - 1) % WW] >> 63);
-        const uint64_t est = (c[j] >> 1) | (c[(j + 1) % WW] << 63);
-        row_sums(wst, c[j], est, h0[j], h1[j], p0[j], p1[j]);
-        if (MULTI) {
-            const uint64_t hw = (hal[j] << 1) | (hal[(j + WW - 1) % WW] >> 63);
-            const uint64_t he = (hal[j] >> 1) | (hal[(j + 1) % WW] << 63);
-            uint64_t q0, q1;
-            row_sums(hw, hal[j], he, g0[j], g1[j], q0, q1);
-        }
+        cc[2 * j] = (uint32_t)c[j]; cc[2 * j + 1] = (uint32_t)(c[j] >> 32);
+        hc[2 * j] = (uint32_t)hal[j]; hc[2 * j + 1] = (uint32_t)(hal[j] >> 32);
     }
-
+    uint32_t nx32[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const uint32_t prev = cc[(k + NC - 1) % NC], next = cc[(k + 1) % NC];
+        const uint32_t wst = __builtin_amdgcn_alignbit(cc[k], prev, 31);     // (c << 1) | (prev >> 31)
+        const uint32_t est = __builtin_amdgcn_alignbit(next, cc[k], 1);      // (c >> 1) | (next << 31)
+        uint32_t h0, h1, p0, p1;
+        row_sums(wst, cc[k], est, h0, h1, p0, p1);
+        uint32_t a0, a1, b0, b1;
+        if (MULTI) {
+            const uint32_t hprev = hc[(k + NC - 1) % NC], hnext = hc[(k + 1) % NC];
+            const uint32_t hw = __builtin_amdgcn_alignbit(hc[k], hprev, 31);
+            const uint32_t he = __builtin_amdgcn_alignbit(hnext, hc[k], 1);
+            const uint32_t g0 = bop3<kXor3>(hw, hc[k], he), g1 = bop3<kMaj>(hw, hc[k], he);
+            // lanes with no source keep `old` = the sums of the halo row they loaded themselves
+            a0 = __builtin_amdgcn_update_dpp(g0, h0, 0x138, 0xF, 0xF, false);   // wave_shr:1, row above
+            a1 = __builtin_amdgcn_update_dpp(g1, h1, 0x138, 0xF, 0xF, false);
+            b0 = __builtin_amdgcn_update_dpp(g0, h0, 0x130, 0xF, 0xF, false);   // wave_shl:1, row below
+            b1 = __builtin_amdgcn_update_dpp(g1, h1, 0x130, 0xF, 0xF, false);
+        } else {
+            a0 = __builtin_amdgcn_update_dpp(0u, h0, 0x13C, 0xF, 0xF, false);   // wave_ror:1 = y seam
+            a1 = __builtin_amdgcn_update_dpp(0u, h1, 0x13C, 0xF, 0xF, false);
+            b0 = __builtin_amdgcn_update_dpp(0u, h0, 0x134, 0xF, 0xF, false);   // wave_rol:1
+            b1 = __builtin_amdgcn_update_dpp(0u, h1, 0x134, 0xF, 0xF, false);
+        }
+        nx32[k] = next_state<RULE_MODE>(neighbour_count(a0, a1, b0, b1, p0, p1), cc[k], rule);
+    }
     uint64_t nx[WW];
 #pragma unroll
-    for (int j = 0; j < WW; ++j) {
-        uint64_t a0, a1, b0, b1;
-        if (MULTI) {
-            // lanes with no source keep `old` = the sums of the halo row they loaded themselves
-            a0 = dpp64_shr1(h0[j], g0[j]); a1 = dpp64_shr1(h1[j], g1[j]);     // row above
-            b0 = dpp64_shl1(h0[j], g0[j]); b1 = dpp64_shl1(h1[j], g1[j]);     // row below
-        } else {
-            a0 = dpp64_ror1(h0[j]); a1 = dpp64_ror1(h1[j]);                   // rotate = y torus seam
-            b0 = dpp64_rol1(h0[j]); b1 = dpp64_rol1(h1[j]);
-        }
-        nx[j] = apply_rule_auto(neighbour_count(a0, a1, b0, b1, p0[j], p1[j]), c[j], rule);
-    }
+    for (int j = 0; j < WW; ++j) nx[j] = ((uint64_t)nx32[2 * j + 1] << 32) | nx32[2 * j];
     store_row<WW>(u_out + (g * (int64_t)H + r) * WW, nx);
 }
 
@@ -219,13 +265,13 @@ __global__ __launch_bounds__(256) void unpack_b1_f32_kernel(const uint64_t *__re
     dst[i] = o;
 }
 
-template <int WW>
-static int launch_b1(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
-                     int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
+template <int WW, int RULE_MODE>
+static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
+                          int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
     if (n * WW > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1: batch too large");
     if (!act) {
-        hipLaunchKernelGGL((ca_step_b1_kernel<WW, false>), dim3((unsigned)(n * WW)), dim3(64), 0, s,
-                           u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW);
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, false, RULE_MODE>), dim3((unsigned)(n * WW)), dim3(64), 0,
+                           s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW);
         return check_launch("carle_ca_step_b1");
     }
     // strips whose rows, or whose two bordering rows, intersect the window rows [oy, oy+ah)
@@ -236,13 +282,23 @@ static int launch_b1(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out,
     if (ah == H) { first = 0; last = WW - 1; }
     int count = ((last - first + WW) % WW) + 1;
     if (count > WW) count = WW;
-    hipLaunchKernelGGL((ca_step_b1_kernel<WW, true>), dim3((unsigned)(n * count)), dim3(64), 0, s,
+    hipLaunchKernelGGL((ca_step_b1_kernel<WW, true, RULE_MODE>), dim3((unsigned)(n * count)), dim3(64), 0, s,
                        u_in, act, u_out, n, ah, aw, rule, status, slot, first, count);
     if (count < WW)
-        hipLaunchKernelGGL((ca_step_b1_kernel<WW, false>), dim3((unsigned)(n * (WW - count))), dim3(64),
-                           0, s, u_in, act, u_out, n, 0, 0, rule, status, slot, (first + count) % WW,
-                           WW - count);
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, false, RULE_MODE>), dim3((unsigned)(n * (WW - count))),
+                           dim3(64), 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot,
+                           (first + count) % WW, WW - count);
     return check_launch("carle_ca_step_b1");
+}
+
+template <int WW>
+static int launch_b1(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
+                     int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
+    if (rule == kLifeMask)
+        return launch_b1_mode<WW, kRuleLife>(u_in, act, u_out, n, ah, aw, rule, status, slot, s);
+    if (rule == kHighLifeMask)
+        return launch_b1_mode<WW, kRuleHighLife>(u_in, act, u_out, n, ah, aw, rule, status, slot, s);
+    return launch_b1_mode<WW, kRuleGeneric>(u_in, act, u_out, n, ah, aw, rule, status, slot, s);
 }
 
 }  // namespace carle
