@@ -408,6 +408,8 @@ class CARLEPacked(CARLE):
                 raise AssertionError(f"packed action has shape {tuple(act.shape)}")
             act = act.contiguous()
         else:
+            if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
+                action = action.materialize()
             a32, cropped, full = self._device_action(action)
             if cropped:
                 self._status[slot] = (full != 0).any().to(torch.int32)

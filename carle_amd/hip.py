@@ -131,11 +131,8 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-_ws_tables = {}      # workspace data_ptr -> (pred blob id, rand blob id) the fused tables hold
-
-
 def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=False, binary=False,
-                    reward=None, reward_scale=1.0, bonus_out=None, stream=None):
+                    reward=None, reward_scale=1.0, bonus_out=None, stream=None, tables_valid=False):
     """RND2D bonus (N,) for obs (N,1,H,W) fp32 -- or int64 bit-packed (N,1,64,1).  params = flat
     fp32 blobs (see carle_hip.h).  binary=True: obs values are exactly 0/1 (fused 64x64 path).
     reward (N,1): additionally reward += reward_scale * bonus inside the kernel.  stream: raw
@@ -149,23 +146,11 @@ def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=
     need = lib.carle_rnd2d_workspace_floats(n, h, w)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 1), dtype=torch.float32, device=obs.device)
+        tables_valid = False
     bonus = bonus_out if bonus_out is not None else torch.empty(n, dtype=torch.float32, device=obs.device)
     pred = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
     targ = torch.empty(n, 16, dtype=torch.float32, device=obs.device) if want_outputs else None
-    flags = 1 if binary else 0
-    fused = h == 64 and w == 64 and (packed or binary)
-    if fused:
-        # parameter blobs are immutable tensors rebuilt on every parameter change (_ParamBlob), so
-        # their identity tells whether the tables in this workspace are still valid
-        key = (id(pred_params), id(rand_params), pred_params.data_ptr(), rand_params.data_ptr())
-        if _ws_tables.get(workspace.data_ptr()) == key:
-            flags |= 2
-        else:
-            if len(_ws_tables) > 64:
-                _ws_tables.clear()
-            _ws_tables[workspace.data_ptr()] = key
-    else:
-        _ws_tables.pop(workspace.data_ptr(), None)        # staged path overwrites the workspace
+    flags = (1 if binary else 0) | (2 if tables_valid else 0)
     with _on_device(obs.device):
         fn = lib.carle_rnd2d_bonus_b1 if packed else lib.carle_rnd2d_bonus_f32
         rc = fn(obs.data_ptr(), n, h, w, pred_params.data_ptr(), rand_params.data_ptr(),
@@ -177,7 +162,7 @@ def rnd2d_bonus_f32(obs, pred_params, rand_params, workspace=None, want_outputs=
 
 
 def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False,
-                   reward=None, reward_scale=1.0, bonus_out=None, stream=None):
+                   reward=None, reward_scale=1.0, bonus_out=None, stream=None, tables_valid=False):
     """AE2D bonus (N,) for obs (N,1,H,W) fp32 -- or int64 bit-packed (N,1,64,1); params = flat
     164-float blob.  binary / reward / stream as for rnd2d_bonus_f32."""
     lib = _lib.load()
@@ -189,19 +174,10 @@ def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False,
     need = lib.carle_ae2d_workspace_floats(n, h, w)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 1), dtype=torch.float32, device=obs.device)
+        tables_valid = False
     bonus = bonus_out if bonus_out is not None else torch.empty(n, dtype=torch.float32, device=obs.device)
     recon = torch.empty(n, 1, h, w, dtype=torch.float32, device=obs.device) if want_recon else None
-    flags = 1 if binary else 0
-    if h == 64 and w == 64 and (packed or binary):
-        key = (id(params), params.data_ptr())
-        if _ws_tables.get(workspace.data_ptr()) == key:
-            flags |= 2
-        else:
-            if len(_ws_tables) > 64:
-                _ws_tables.clear()
-            _ws_tables[workspace.data_ptr()] = key
-    else:
-        _ws_tables.pop(workspace.data_ptr(), None)
+    flags = (1 if binary else 0) | (2 if tables_valid else 0)
     with _on_device(obs.device):
         fn = lib.carle_ae2d_bonus_b1 if packed else lib.carle_ae2d_bonus_f32
         rc = fn(obs.data_ptr(), n, h, w, params.data_ptr(), workspace.data_ptr(), bonus.data_ptr(),

@@ -207,3 +207,39 @@ def test_ae_fused64_batch_sizes(n):
     ae.assume_binary_obs = True
     fused = ae.get_bonus_only(g)
     np.testing.assert_allclose(fused.cpu().numpy(), staged.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_fused_tables_follow_parameter_updates():
+    """The fused kernels cache their lookup tables in the workspace; every parameter change (Adam
+    step, load_state_dict, in-place edit) must invalidate them.  Checked against the CPU oracle
+    after each change, on observations the wrappers recognise as binary."""
+    torch.manual_seed(21)
+    env, rnd, ae = _stack(64, 6)
+    rnd.assume_binary_obs = True
+    ae.assume_binary_obs = True
+    g = (torch.rand(6, 1, 64, 64) < 0.3).float()
+    gd = g.cuda()
+
+    def check():
+        sd_r = {k: v.detach().cpu().numpy() for k, v in rnd.state_dict().items()}
+        sd_a = {k: v.detach().cpu().numpy() for k, v in ae.state_dict().items()}
+        with torch.no_grad():
+            er, ea = ON.rnd_bonus(g, sd_r).numpy(), ON.ae_bonus(g, sd_a).numpy()
+        for _ in range(2):                      # second call reuses the tables
+            np.testing.assert_allclose(rnd.get_bonus(gd).cpu().numpy(), er, rtol=0, atol=TOL)
+            np.testing.assert_allclose(ae.get_bonus(gd).cpu().numpy(), ea, rtol=0, atol=TOL)
+    ae.reset()
+    check()
+    for _ in range(3):                          # Adam updates through the wrappers
+        rnd.get_bonus_update(gd)
+        ae.get_bonus_update(gd)
+        check()
+    with torch.no_grad():                       # in-place edits
+        rnd.random_network[0].weight.mul_(1.5)
+        ae.predictor[0].bias.add_(0.25)
+    check()
+    torch.manual_seed(5)
+    env2, rnd2, ae2 = _stack(64, 6)             # fresh weights via load_state_dict
+    rnd.load_state_dict(rnd2.state_dict())
+    ae.load_state_dict(ae2.state_dict())
+    check()
