@@ -35,7 +35,10 @@ def _resolve_device(kwargs):
     """
     dev = kwargs.get("device", None)
     if dev is not None:
-        return torch.device(dev)
+        dev = torch.device(dev)
+        if dev.type == "cuda" and dev.index is None:     # "cuda" -> the current device, indexed:
+            dev = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        return dev                                       # tensor.device comparisons need the index
     if kwargs.get("use_cuda", False) or torch.cuda.is_available():
         return torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
     return torch.device("cpu")

@@ -221,3 +221,15 @@ def test_logging_and_rle_round_trip(tmp_path):
     assert env.universe[1, 0].nonzero().cpu().tolist() == [[0, 0], [0, 1], [0, 2]]
     obs = env.step(torch.zeros(2, 1, 64, 64))[0]
     assert obs[1, 0].nonzero().cpu().tolist() == [[0, 1], [1, 1], [63, 1]]
+
+
+def test_unindexed_cuda_device_and_use_cuda():
+    """device="cuda" / use_cuda=True (carle/env.py:28-37): counters must survive across steps."""
+    from carle_amd.env import CARLE
+    for kw in (dict(device="cuda"), dict(use_cuda=True), dict()):
+        env = CARLE(width=64, height=64, instances=2, **kw)
+        assert env.my_device.type == "cuda" and env.my_device.index is not None
+        env.reset()
+        for _ in range(3):
+            env.step(torch.zeros(2, 1, 64, 64))
+        assert env.step_number == 3 and env.steps_since_action == 3
