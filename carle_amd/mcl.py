@@ -314,22 +314,12 @@ class RND2D(Motivator):
         if rs is None:
             self._bonus_into(obs, reward)
             return obs, reward, done, info
-        env = self.inner_env
-        d = env.__dict__
-        main_raw = hip._stream(reward)
-        rs_raw = rs.cuda_stream
-        hip.stream_fork(d["_reward_event"].cuda_event, main_raw, rs_raw)   # rs after CA step t
+        rs_raw = rs.fork(obs, reward)                    # reward stream ordered after CA step t
         if self.train_predictor and self.buffer_length + 1 >= self.batch_size:
-            with torch.cuda.stream(rs):                  # the Adam replay uses torch ops: rare path
+            with rs.context():                           # the Adam replay uses torch ops: rare path
                 self._bonus_into(obs, reward, rs_raw)
         else:
             self._bonus_into(obs, reward, rs_raw)
-        # tensors touched on the reward stream stay referenced until the next cross-stream join
-        hold = d.setdefault("_reward_hold", [])
-        hold.append((obs, reward))
-        if len(hold) >= 8:
-            hip.stream_fork(d["_reward_event2"].cuda_event, rs_raw, main_raw)  # main waits for rs
-            d["_reward_hold"] = hold[-1:]
         return obs, reward, done, info
 
     def _reward_stream(self):
@@ -338,19 +328,16 @@ class RND2D(Motivator):
         env = self.inner_env
         rs = env.__dict__.get("reward_stream")
         if rs is None:
-            rs = torch.cuda.Stream(device=env.my_device)
+            from .streams import RewardStream
+            rs = RewardStream(env.my_device)
             env.__dict__["reward_stream"] = rs
-            for name in ("_reward_event", "_reward_event2"):
-                ev = torch.cuda.Event()
-                ev.record()                              # materialises the hipEvent_t handle
-                env.__dict__[name] = ev
         return rs
 
     def wait_rewards(self):
         """Make the caller's current stream wait for all reward work enqueued so far."""
         rs = self.inner_env.__dict__.get("reward_stream")
         if rs is not None:
-            torch.cuda.current_stream(self.inner_env.my_device).wait_stream(rs)
+            rs.join()
 
     def reset(self):
         obs = self.env.reset()

@@ -1,0 +1,49 @@
+"""carle_amd.streams -- the reward stream: a second HIP stream for everything that consumes
+observations / rewards of step t while the CA kernel of step t+1 already runs on the caller's
+stream (the bandwidth-bound CA step and the compute/latency-bound reward work overlap).
+
+Ordering uses ``carle_stream_fork`` (hipEventRecord + hipStreamWaitEvent inside the library: one
+cheap ctypes call, no torch stream context switches).  Tensors touched on the reward stream are
+kept referenced until the next cross-stream join (every ``join_every`` forks), so torch's caching
+allocator cannot recycle them while the reward stream may still use them.
+"""
+import torch
+
+from . import hip
+
+
+class RewardStream:
+    def __init__(self, device, join_every=8):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.raw = self.stream.cuda_stream
+        self._ev_fork = torch.cuda.Event()
+        self._ev_join = torch.cuda.Event()
+        with torch.cuda.device(self.device):
+            self._ev_fork.record()           # materialise the hipEvent_t handles
+            self._ev_join.record()
+        self._held = []
+        self.join_every = join_every
+
+    def fork(self, *tensors):
+        """Reward stream waits for everything enqueued so far on the caller's current stream;
+        ``tensors`` are the buffers the reward stream is about to touch."""
+        if hip._raw_stream is not None:
+            main_raw = hip._raw_stream(self.device.index)
+        else:
+            main_raw = torch.cuda.current_stream(self.device).cuda_stream
+        hip.stream_fork(self._ev_fork.cuda_event, main_raw, self.raw)
+        self._held.append(tensors)
+        if len(self._held) >= self.join_every:
+            hip.stream_fork(self._ev_join.cuda_event, self.raw, main_raw)   # bound the lag
+            self._held = self._held[-1:]
+        return self.raw
+
+    def join(self):
+        """The caller's current stream waits for all reward work enqueued so far."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self._held = []
+
+    def context(self):
+        """torch stream context for the rare torch-op work that must run on the reward stream."""
+        return torch.cuda.stream(self.stream)
