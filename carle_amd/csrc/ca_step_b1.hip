@@ -308,6 +308,7 @@ using namespace carle;
 extern "C" int carle_ca_step_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out,
                                 int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                                 int32_t *status, int slot, void *stream) {
+    if (n == 0) return 0;
     if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_step_b1: u_in/u_out is NULL");
     if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
     if (w != 64 && w != 128 && w != 256 && w != 512)

@@ -428,6 +428,7 @@ using namespace carle;
 extern "C" int carle_ca_step_f32(const float *u_in, const float *action, float *u_out, int64_t n,
                                  int h, int w, int ah, int aw, uint32_t rule, int32_t *status,
                                  int slot, void *stream) {
+    if (n == 0) return 0;                      // empty batch: nothing to launch, pointers may be NULL
     if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_step_f32: u_in/u_out is NULL");
     if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
     if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_ca_step_f32: rule mask exceeds 18 bits");
@@ -488,6 +489,7 @@ extern "C" int carle_ca_step_f32_rand(const float *u_in, float *u_out, int64_t n
                                       int ah, int aw, uint32_t rule, float p, uint64_t seed,
                                       uint64_t offset, float *action_out, int32_t *status, int slot,
                                       void *stream) {
+    if (n == 0) return 0;
     if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_step_f32_rand: u_in/u_out is NULL");
     if (int e = check_dims(n, h, w, true, ah, aw)) return e;
     if (h != 64 || (aw % 8) != 0)

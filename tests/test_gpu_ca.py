@@ -233,3 +233,33 @@ def test_unindexed_cuda_device_and_use_cuda():
         for _ in range(3):
             env.step(torch.zeros(2, 1, 64, 64))
         assert env.step_number == 3 and env.steps_since_action == 3
+
+
+def test_index_width_beyond_2_31_cells():
+    """BASELINE configs[2] has N*H*W = 2^31 cells: offsets must be 64-bit.  N=32769 x 256x256
+    (8 GiB per array) through the ABI; first / middle / last instances against the oracle."""
+    from carle_amd import hip
+    n = 32769
+    g = torch.Generator(device="cuda").manual_seed(7)
+    u = torch.empty(n, 1, 256, 256, device="cuda")
+    for i in range(0, n, 4096):                       # fill in slices: bounded temporaries
+        m = min(4096, n - i)
+        u[i:i + m] = (torch.rand(m, 1, 256, 256, device="cuda", generator=g) < 0.4).float()
+    a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
+    out = torch.empty_like(u)
+    life = O.rule_mask([3], [2, 3])
+    hip.ca_step_f32(u, a, out, life, None, 0)
+    idx = [0, 1, 16383, 16384, 32767, 32768]
+    exp, _, _ = O.c_env_step(u[idx].cpu().numpy(), a[idx].cpu().numpy(), life)
+    assert np.array_equal(out[idx].cpu().numpy(), exp)
+    del u, out, a
+    torch.cuda.empty_cache()
+
+
+def test_zero_instances_and_tiny_batches():
+    env = _env(width=64, height=64, instances=0)
+    obs = env.reset()
+    assert tuple(obs.shape) == (0, 1, 64, 64)
+    obs, reward, done, info = env.step(torch.zeros(0, 1, 64, 64))
+    assert tuple(obs.shape) == (0, 1, 64, 64) and tuple(reward.shape) == (0, 1) and info == []
+    assert env.step_number == 1

@@ -124,3 +124,21 @@ def test_philox_known_answers():
     for ctr, key, exp in kat:
         got = philox4x32_10(np.array([ctr], dtype=np.uint32), key)[0]
         assert tuple(int(v) for v in got) == exp
+
+
+def test_c_and_numpy_oracles_agree_on_random_rules():
+    """Property check (seeded): the two independent restatements agree for random rules, sizes,
+    window sizes and densities, including the master-reset branch."""
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        size = int(rng.choice([2, 4, 6, 10, 16, 30, 64]))
+        asize = int(rng.choice([s for s in range(2, size + 1, 2)]))
+        n = int(rng.integers(1, 4))
+        rule = int(rng.integers(0, 1 << 18))
+        u = (rng.random((n, 1, size, size)) < rng.random()).astype(np.float32)
+        a = (rng.random((n, 1, asize, asize)) < rng.random()).astype(np.float32)
+        if trial % 15 == 0:
+            a[:] = 1.0
+        c_out, c_reset, _ = O.c_env_step(u, a, rule)
+        n_out, n_reset = O.np_env_step(u, a, rule)
+        assert c_reset == n_reset and np.array_equal(c_out, n_out), (trial, size, asize, rule)
