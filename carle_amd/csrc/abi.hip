@@ -15,7 +15,8 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
                                                         unsigned char *__restrict__ tail,
                                                         int tail_bytes, float *__restrict__ reward,
                                                         int64_t n, int32_t *__restrict__ st,
-                                                        int slot, int has_action) {
+                                                        int slot, int has_action,
+                                                        uint4 *__restrict__ extra, int64_t extra16) {
     // the whole status block in one round trip (it is one 64-byte line)
     const uint4 *st4 = reinterpret_cast<const uint4 *>(st);
     const uint4 w0 = st4[0], w1 = st4[1], w2 = st4[2];
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
         const uint4 z = {0u, 0u, 0u, 0u};
         for (int64_t i = tid; i < n16; i += nthreads) out[i] = z;
         if (tid < tail_bytes) tail[tid] = 0;
+        for (int64_t i = tid; i < extra16; i += nthreads) extra[i] = z;   // side copy of the state
     }
     if (reward)
         for (int64_t i = tid; i < n; i += nthreads) reward[i] = 0.0f;
@@ -71,8 +73,19 @@ extern "C" const char *carle_build_arch(void) {
 #endif
 }
 
+namespace carle {
+int ca_finish_impl(void *u_out, int64_t u_out_bytes, float *reward, int64_t n, int32_t *status, int slot,
+                   int has_action, void *extra, int64_t extra_bytes, void *stream);
+}
+
 extern "C" int carle_ca_finish(void *u_out, int64_t u_out_bytes, float *reward, int64_t n,
                                int32_t *status, int slot, int has_action, void *stream) {
+    return ca_finish_impl(u_out, u_out_bytes, reward, n, status, slot, has_action, nullptr, 0, stream);
+}
+
+// `extra` (16-byte multiple): a second buffer zeroed together with u_out on a master reset
+int carle::ca_finish_impl(void *u_out, int64_t u_out_bytes, float *reward, int64_t n, int32_t *status,
+                          int slot, int has_action, void *extra, int64_t extra_bytes, void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_ca_finish: status is NULL");
     if (!u_out && u_out_bytes > 0) return fail_arg(CARLE_E_NULL, "carle_ca_finish: u_out is NULL");
     if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_ca_finish: slot must be 0 or 1");
@@ -85,7 +98,8 @@ extern "C" int carle_ca_finish(void *u_out, int64_t u_out_bytes, float *reward, 
     hipLaunchKernelGGL(ca_finish_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<uint4 *>(u_out), n16,
                        reinterpret_cast<unsigned char *>(u_out) + n16 * 16, tail, reward, n, status,
-                       slot, (n > 0 && has_action) ? 1 : 0);
+                       slot, (n > 0 && has_action) ? 1 : 0, reinterpret_cast<uint4 *>(extra),
+                       extra_bytes / 16);
     return check_launch("carle_ca_finish");
 }
 
@@ -144,4 +158,56 @@ extern "C" int carle_stream_fork(void *event, void *from_stream, void *to_stream
     e = hipStreamWaitEvent(static_cast<hipStream_t>(to_stream), static_cast<hipEvent_t>(event), 0);
     if (e != hipSuccess) return fail_hip(e, "carle_stream_fork(wait)");
     return 0;
+}
+
+extern "C" int carle_rnd2d_bonus_f32(const float *, int64_t, int, int, const float *, const float *,
+                                     float *, float *, float *, float *, float *, float, int, void *);
+
+// CARLE.step followed by the RND2D wrapper's reward bonus on the fresh observation
+// (carle/env.py:188-242 + carle/mcl.py:398-407) in ONE library call: step + epilogue on
+// `stream_env`; the bonus (reward += scale * bonus fused into its last kernel) on `stream_reward`,
+// ordered behind the step through `event` -- or on `stream_env` itself when stream_reward is
+// NULL / equal.  The observation is the kernel's own 0/1 output, so the fused table-lookup path
+// of the reward net applies.  One call instead of four keeps the host below the GPU time.
+namespace carle {
+int ca_step_f32_impl(const float *u_in, const float *action, float *u_out, int64_t n, int h, int w,
+                     int ah, int aw, uint32_t rule, int32_t *status, int slot, uint64_t *patch_out,
+                     void *stream);
+int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp,
+                  float *ws, float *bonus, float *pred_out, float *target_out, float *reward,
+                  float reward_scale, bool tables_valid, hipStream_t s);
+}
+
+extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out,
+                                      float *reward, int64_t n, int h, int w, int ah, int aw,
+                                      uint32_t rule, int32_t *status, int slot, int publish_flags,
+                                      const float *pred_params, const float *rand_params,
+                                      float *workspace, float *bonus, float reward_scale,
+                                      int net_flags, uint64_t *patch_scratch, void *event,
+                                      void *stream_env, void *stream_reward) {
+    if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: status is NULL");
+    if (!pred_params || !rand_params || !workspace || !bonus)
+        return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: NULL reward-net pointer");
+    // 64x64 grids with an aligned action window take the fast CA kernel, which can hand the
+    // fresh state to the reward net as 512-B "patch" words instead of the 16-KiB fp32 grid
+    const bool patch = patch_scratch && h == 64 && w == 64 && (!action || (aw % 8) == 0) && n > 0;
+    if (int e = ca_step_f32_impl(u_in, action, u_out, n, h, w, ah, aw, rule,
+                                 publish_flags ? status : nullptr, slot, patch ? patch_scratch : nullptr,
+                                 stream_env))
+        return e;
+    if (int e = ca_finish_impl(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot,
+                               action != nullptr, patch ? patch_scratch : nullptr,
+                               patch ? n * 64 * 8 : 0, stream_env))
+        return e;
+    void *rs = stream_env;
+    if (stream_reward && stream_reward != stream_env) {
+        if (int e = carle_stream_fork(event, stream_env, stream_reward)) return e;
+        rs = stream_reward;
+    }
+    if (patch)
+        return rnd2d_fused64(patch_scratch, 2, n, pred_params, rand_params, workspace, bonus, nullptr,
+                             nullptr, reward, reward_scale, (net_flags & CARLE_NET_TABLES_VALID) != 0,
+                             static_cast<hipStream_t>(rs));
+    return carle_rnd2d_bonus_f32(u_out, n, h, w, pred_params, rand_params, workspace, bonus, nullptr,
+                                 nullptr, reward, reward_scale, net_flags | CARLE_NET_OBS_BINARY, rs);
 }

@@ -97,9 +97,13 @@ __device__ __forceinline__ void st16(uint4 *p, const uint4 &v) {
 // parameters of the fused device-side random agent (RAND_ACT instantiation): toggles are drawn
 // in-kernel with the counter layout of philox.hpp instead of being read from an action tensor
 struct RandAct {
-    float p;
-    uint64_t seed, offset;
-    float *action_out;      // optional: also materialise the (N,1,AW,AW) action (may be NULL)
+    float p = 0.0f;
+    uint64_t seed = 0, offset = 0;
+    float *action_out = nullptr;   // optional: also materialise the (N,1,AW,AW) action
+    // optional side output for the fused reward nets: the lane's 64-bit result word ("patch"
+    // layout: word g*64 + lane, nibble i = row 4i + lane/16, cols 4*(lane%16)..+3), 512 B per
+    // grid instead of the 16 KiB fp32 observation
+    uint64_t *patch_out = nullptr;
 };
 
 template <bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256, bool RAND_ACT = false>
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(BLOCK) void ca_step_f32_64_kernel(
         o4.w = (nib & 8u) ? kOneBits : 0u;
         st16<NT_ST>(gout + i * 64, o4);
     }
+    if (ra.patch_out) ra.patch_out[g * 64 + lane] = nxt;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -425,9 +430,22 @@ __global__ __launch_bounds__(256) void ca_toggle_f32_kernel(
 
 using namespace carle;
 
+namespace carle {
+int ca_step_f32_impl(const float *u_in, const float *action, float *u_out, int64_t n, int h, int w,
+                     int ah, int aw, uint32_t rule, int32_t *status, int slot, uint64_t *patch_out,
+                     void *stream);
+}
+
 extern "C" int carle_ca_step_f32(const float *u_in, const float *action, float *u_out, int64_t n,
                                  int h, int w, int ah, int aw, uint32_t rule, int32_t *status,
                                  int slot, void *stream) {
+    return ca_step_f32_impl(u_in, action, u_out, n, h, w, ah, aw, rule, status, slot, nullptr, stream);
+}
+
+// patch_out: only honoured by the 64x64 fast path (callers check can_patch first)
+int carle::ca_step_f32_impl(const float *u_in, const float *action, float *u_out, int64_t n, int h,
+                            int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
+                            uint64_t *patch_out, void *stream) {
     if (n == 0) return 0;                      // empty batch: nothing to launch, pointers may be NULL
     if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_step_f32: u_in/u_out is NULL");
     if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
@@ -446,14 +464,16 @@ extern "C" int carle_ca_step_f32(const float *u_in, const float *action, float *
         // {plain, nt} x {64,128,256,512}-thread variants (tools/kbench, profiles/r01_kbench.txt)
         if (n > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32: batch too large");
         const unsigned blocks = (unsigned)n;
+        RandAct ra;
+        ra.patch_out = patch_out;
         if (action)
             hipLaunchKernelGGL((ca_step_f32_64_kernel<true, true, true, 64>), dim3(blocks), dim3(64),
                                0, s, reinterpret_cast<const uint4 *>(u_in), action,
-                               reinterpret_cast<uint4 *>(u_out), n, aw, rule, status, slot);
+                               reinterpret_cast<uint4 *>(u_out), n, aw, rule, status, slot, ra);
         else
             hipLaunchKernelGGL((ca_step_f32_64_kernel<false, true, true, 64>), dim3(blocks), dim3(64),
                                0, s, reinterpret_cast<const uint4 *>(u_in), action,
-                               reinterpret_cast<uint4 *>(u_out), n, 0, rule, status, slot);
+                               reinterpret_cast<uint4 *>(u_out), n, 0, rule, status, slot, ra);
         return check_launch("carle_ca_step_f32(64x64)");
     }
     // 256x256 / 512x512: wavefront-per-strip path; needs a 16-byte aligned action window

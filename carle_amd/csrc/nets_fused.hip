@@ -71,7 +71,15 @@ __device__ __forceinline__ uint64_t spread_nibbles(uint32_t x) {
     return t;
 }
 
-template <bool PACKED_OBS>
+// nibble j of a 16-bit field -> nibble 4j of a 64-bit word
+__device__ __forceinline__ uint64_t spread_field(uint32_t x) {
+    return (uint64_t)(x & 0xFu) | ((uint64_t)(x & 0xF0u) << 12) | ((uint64_t)(x & 0xF00u) << 24) |
+           ((uint64_t)(x & 0xF000u) << 36);
+}
+
+// OBS_MODE: 0 = fp32 grid, 1 = bit-packed rows (CARLE_FMT_B1), 2 = "patch" words written by the
+// 64x64 CA kernel (word g*64 + lane', nibble i = row 4i + lane'/16, cols 4*(lane'%16)..+3)
+template <int OBS_MODE>
 __global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict__ obs_v,
                                                           const float *__restrict__ ws,
                                                           float *__restrict__ bonus,
@@ -102,6 +110,7 @@ __global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
     // software prefetch: the fp32 loads of the NEXT grid are issued right after the current
     // grid's words have been converted, so their latency hides under the compute phases
+    constexpr bool PACKED_OBS = OBS_MODE != 0;
     uint4 v[16];
     if (!PACKED_OBS && wave_id < n) {
         const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + wave_id * 1024 + (16 * q) * 16 + k;
@@ -111,7 +120,13 @@ __global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict
     for (int64_t g = wave_id; g < n; g += nwaves) {
         // ---- 1. the lane's 16x4 patch as one nibble per row
         uint64_t c = 0;
-        if (PACKED_OBS) {
+        if (OBS_MODE == 2) {
+            // rows 16q+i' of this lane are nibbles 4q..4q+3 of the CA lanes (q' = i' % 4, k)
+            const uint64_t *pw = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + k;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                c |= spread_field((uint32_t)(pw[16 * qq] >> (16 * q)) & 0xFFFFu) << (4 * qq);
+        } else if (OBS_MODE == 1) {
             const uint64_t *rows = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + 16 * q;
 #pragma unroll
             for (int i = 0; i < 16; ++i) c |= ((rows[i] >> (4 * k)) & 0xFull) << (4 * i);
@@ -263,18 +278,21 @@ namespace carle {
 // workspace: [tables + padded linear layers (kFusedWsFloats)] [conv2 parameters (64)]
 int64_t rnd2d_fused_workspace_floats() { return kFusedWsFloats + 64; }
 
-int rnd2d_fused64(const void *obs, bool packed, int64_t n, const float *pp, const float *rp,
+int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp,
                   float *ws, float *bonus, float *pred_out, float *target_out, float *reward,
                   float reward_scale, bool tables_valid, hipStream_t s) {
     if (!tables_valid) hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
     int64_t blocks = (n + 7) / 8;                     // two grids per wave when the batch allows
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    if (packed)
-        hipLaunchKernelGGL(rnd_fused64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
+    if (obs_mode == 2)
+        hipLaunchKernelGGL(rnd_fused64_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
+                           bonus, pred_out, target_out, reward, reward_scale, n);
+    else if (obs_mode == 1)
+        hipLaunchKernelGGL(rnd_fused64_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
                            bonus, pred_out, target_out, reward, reward_scale, n);
     else
-        hipLaunchKernelGGL(rnd_fused64_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
+        hipLaunchKernelGGL(rnd_fused64_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
                            bonus, pred_out, target_out, reward, reward_scale, n);
     return check_launch("carle_rnd2d_bonus(fused 64x64)");
 }

@@ -329,7 +329,7 @@ static inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 25
 
 namespace carle {
 int64_t rnd2d_fused_workspace_floats();
-int rnd2d_fused64(const void *obs, bool packed, int64_t n, const float *pp, const float *rp,
+int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp,
                   float *ws, float *bonus, float *pred_out, float *target_out, float *reward,
                   float reward_scale, bool tables_valid, hipStream_t s);
 int64_t ae2d_fused_workspace_floats();
@@ -357,7 +357,7 @@ extern "C" int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w
         return fail_arg(CARLE_E_DIMS, "carle_rnd2d_bonus_b1: bit-packed observations are supported "
                                       "for 64x64 grids (unpack larger grids first)");
     if (n == 0) return 0;
-    return rnd2d_fused64(obs, true, n, pred_params, rand_params, workspace, bonus, pred_out,
+    return rnd2d_fused64(obs, 1, n, pred_params, rand_params, workspace, bonus, pred_out,
                          target_out, reward_accum, reward_scale, (flags & CARLE_NET_TABLES_VALID) != 0,
                          static_cast<hipStream_t>(stream));
 }
@@ -373,7 +373,7 @@ extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (h == 64 && w == 64 && (flags & CARLE_NET_OBS_BINARY) && aligned16(obs))
-        return rnd2d_fused64(obs, false, n, pred_params, rand_params, workspace, bonus, pred_out,
+        return rnd2d_fused64(obs, 0, n, pred_params, rand_params, workspace, bonus, pred_out,
                              target_out, reward_accum, reward_scale,
                              (flags & CARLE_NET_TABLES_VALID) != 0, s);
     const int64_t p1 = n * (int64_t)(h / 4) * (w / 4);

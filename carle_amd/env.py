@@ -267,6 +267,11 @@ class CARLE(RLEMixin, nn.Module):
         device, ``reward`` zeros (N,1) on the device, ``done`` zeros (N,1) on the CPU and
         ``info`` a list of N dicts -- the reference's exact return structure (env.py:236-242).
         """
+        return self._step(action, None)
+
+    def _step(self, action, launch):
+        """``launch`` (optional): replaces the plain library call -- a wrapper that sits directly on
+        this environment passes a closure that enqueues step + its reward bonus in one call."""
         hip.require_gpu()
         self._check_domain()
         self._ensure_status()
@@ -295,7 +300,10 @@ class CARLE(RLEMixin, nn.Module):
             # for an oversize action evaluate them on the uncropped tensor (cold path, no sync)
             self._status[slot] = (full != 0).any().to(torch.int32)
             self._status[2 + slot] = (full != 1).any().to(torch.int32)
-        hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, not cropped)
+        if launch is None:
+            hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, not cropped)
+        else:
+            launch(u_in, act, out, reward, rule, self._status, slot, not cropped)
         self._slot = slot ^ 1
         self.universe = out
         done = torch.zeros(self.instances, 1)

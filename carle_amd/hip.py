@@ -360,3 +360,21 @@ def instance_sums_f32(x, w0=None, w1=None, w2=None):
                                          out.data_ptr(), _stream(x))
     _lib.check(rc, "carle_instance_sums_f32")
     return out
+
+
+def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_flags, pred_params,
+                     rand_params, workspace, bonus, reward_scale, tables_valid, patch_scratch,
+                     event_handle, stream_env, stream_reward):
+    """CARLE.step + RND2D bonus of the fresh observation in one library call (see carle_hip.h)."""
+    lib = _lib.load()
+    n, _, h, w = u_in.shape
+    with _on_device(u_in.device):
+        rc = lib.carle_env_step_f32_rnd(u_in.data_ptr(), action.data_ptr(), u_out.data_ptr(),
+                                        reward.data_ptr(), n, h, w, action.shape[2], action.shape[3],
+                                        rule, status.data_ptr(), slot, 1 if publish_flags else 0,
+                                        pred_params.data_ptr(), rand_params.data_ptr(),
+                                        workspace.data_ptr(), bonus.data_ptr(), float(reward_scale),
+                                        2 if tables_valid else 0, _ptr(patch_scratch), event_handle,
+                                        stream_env, stream_reward)
+    if rc != 0:
+        _lib.check(rc, "carle_env_step_f32_rnd")

@@ -113,6 +113,8 @@ class RND2D(Motivator):
         self.assume_binary_obs = False
         self.async_reward = bool(kwargs.get("async_reward", False))
         self._bonus_buf = None
+        self._patch = None                   # scratch ring: CA kernel -> reward net hand-off
+        self._patch_turn = 0
         # False: step() only evaluates the bonus (forward pass), no window retention / Adam update
         self.train_predictor = bool(kwargs.get("train_predictor", True))
         self.accumulate_loss = 0.0
@@ -309,6 +311,8 @@ class RND2D(Motivator):
         """
         if isinstance(action, torch.Tensor):
             action = action.to(self.inner_env.my_device)
+        if self._can_fuse_step(action):
+            return self._fused_step(action)
         obs, reward, done, info = self.env.step(action)
         rs = self._reward_stream()
         if rs is None:
@@ -321,6 +325,48 @@ class RND2D(Motivator):
         else:
             self._bonus_into(obs, reward, rs_raw)
         return obs, reward, done, info
+
+    # -- one-call fast path: this wrapper sits directly on a 64x64 fp32 CARLE, forward only ----
+    def _can_fuse_step(self, action):
+        env = self.env
+        return (type(self) is RND2D and env is self.inner_env and not self.train_predictor and
+                isinstance(action, torch.Tensor) and env.height == 64 and
+                getattr(env, "storage", "f32") == "f32" and not env.logging)
+
+    def _fused_step(self, action):
+        env = self.inner_env
+        dev = env.my_device
+        pb, rb = self._pred_blob.get(dev), self._rand_blob.get(dev)
+        from . import _lib
+        need = _lib.load().carle_rnd2d_workspace_floats(env.instances, 64, 64)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.float32, device=dev)
+            self._tables_key = None
+        n = env.instances
+        if self._bonus_buf is None or self._bonus_buf.shape[0] != n or self._bonus_buf.device != dev:
+            self._bonus_buf = torch.empty(n, dtype=torch.float32, device=dev)
+        # hand-off scratch ring: the reward stream may lag the CA stream by up to join_every steps
+        # (streams.RewardStream), so step t must not reuse the words step t-1..t-8 handed over
+        if self._patch is None or self._patch[0].shape[0] != n or self._patch[0].device != dev:
+            self._patch = [torch.empty(n, 64, dtype=torch.int64, device=dev) for _ in range(10)]
+        patch = self._patch[self._patch_turn % len(self._patch)]
+        self._patch_turn += 1
+        versions = (self._pred_blob.version, self._rand_blob.version)
+        valid = self._tables_key == (id(self._ws), versions)
+        rs = self._reward_stream()
+
+        def launch(u_in, act, out, reward, rule, status, slot, publish):
+            main_raw = hip._stream(u_in)
+            if rs is None:
+                ev, rs_raw = None, None
+            else:
+                rs_raw = rs.raw
+                ev = rs.event_for_fork(main_raw, out, reward)
+            hip.env_step_f32_rnd(u_in, act, out, reward, rule, status, slot, publish, pb, rb, self._ws,
+                                 self._bonus_buf, self.reward_scale, valid, patch, ev, main_raw, rs_raw)
+        result = env._step(action, launch)
+        self._tables_key = (id(self._ws), versions)
+        return result
 
     def _reward_stream(self):
         if not self.async_reward:

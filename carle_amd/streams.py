@@ -39,6 +39,15 @@ class RewardStream:
             self._held = self._held[-1:]
         return self.raw
 
+    def event_for_fork(self, main_raw, *tensors):
+        """For library calls that perform the fork themselves (carle_env_step_f32_rnd): hands out
+        the fork event, keeps ``tensors`` referenced and bounds the lag like ``fork``."""
+        self._held.append(tensors)
+        if len(self._held) >= self.join_every:
+            hip.stream_fork(self._ev_join.cuda_event, self.raw, main_raw)
+            self._held = self._held[-1:]
+        return self._ev_fork.cuda_event
+
     def join(self):
         """The caller's current stream waits for all reward work enqueued so far."""
         torch.cuda.current_stream(self.device).wait_stream(self.stream)

@@ -180,6 +180,20 @@ int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const floa
                         float *workspace, float *bonus, float *recon_out,
                         float *reward_accum, float reward_scale, int flags, void *stream);
 
+/* CARLE.step + the RND2D wrapper's bonus on the fresh observation (carle/env.py:188-242 +
+ * carle/mcl.py:398-407) in one call: step and epilogue on stream_env; the bonus, with
+ * reward += reward_scale * bonus fused in, on stream_reward behind `event` (or on stream_env when
+ * stream_reward is NULL).  net_flags: CARLE_NET_TABLES_VALID as for carle_rnd2d_bonus_f32.
+ * patch_scratch (nullable, N*64 uint64): caller-owned scratch through which the 64x64 CA kernel
+ * hands the fresh state to the reward net as 512 B per grid instead of the 16-KiB fp32 grid. */
+int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out, float *reward,
+                           int64_t n, int h, int w, int ah, int aw, uint32_t rule,
+                           int32_t *status, int slot, int publish_flags,
+                           const float *pred_params, const float *rand_params, float *workspace,
+                           float *bonus, float reward_scale, int net_flags,
+                           uint64_t *patch_scratch, void *event, void *stream_env,
+                           void *stream_reward);
+
 /* Orders `to_stream` after everything enqueued so far on `from_stream` (hipEventRecord on
  * from_stream + hipStreamWaitEvent on to_stream; `event` is a caller-owned hipEvent_t).  Used to
  * run the reward networks of step t on a second stream beside the CA kernel of step t+1. */

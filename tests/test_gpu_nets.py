@@ -243,3 +243,33 @@ def test_fused_tables_follow_parameter_updates():
     rnd.load_state_dict(rnd2.state_dict())
     ae.load_state_dict(ae2.state_dict())
     check()
+
+
+@pytest.mark.parametrize("async_reward", [False, True])
+def test_one_call_step_plus_rnd_matches_generic_path(async_reward):
+    """RND2D directly on a 64x64 CARLE, forward only: the single-library-call fast path
+    (carle_env_step_f32_rnd) returns exactly what env.step + get_bonus_only + reward add return."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D
+    torch.manual_seed(9)
+    env_a = CARLE(width=64, height=64, instances=9, device="cuda:0")
+    fast = RND2D(env_a, async_reward=async_reward, train_predictor=False)
+    env_b = CARLE(width=64, height=64, instances=9, device="cuda:0")
+    slow = RND2D(env_b, train_predictor=False)
+    slow.load_state_dict(fast.state_dict())
+    slow._can_fuse_step = lambda action: False          # force the generic path
+    fast.eval(); slow.eval(); fast.reset(); slow.reset()
+    assert fast._can_fuse_step(torch.zeros(1))
+    g = torch.Generator().manual_seed(1)
+    for t in range(7):
+        a = (torch.rand(9, 1, 64, 64, generator=g) < 0.2).float()
+        if t == 4:
+            a.fill_(1.0)                                 # master reset goes through both paths
+        of, rf, _, _ = fast.step(a)
+        os_, rs_, _, _ = slow.step(a)
+        fast.wait_rewards()
+        torch.cuda.synchronize()
+        assert torch.equal(of, os_)
+        assert torch.equal(rf, rs_) and float(rf.abs().sum()) > 0
+        assert of is env_a.universe
+    assert env_a.step_number == env_b.step_number
