@@ -579,3 +579,336 @@ int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float
 }
 
 }  // namespace carle
+
+// =============================================================================================
+// RND2D forward + BACKWARD for 64x64 binary grids: the predictor's gradient
+// of  sum_t mean_n mean_k (target - prediction)^2 / batch_size  (carle/mcl.py:343-386), computed
+// in the same kernel that evaluates the bonus -- no observation window to retain, no autograd
+// replay.  Eval-mode semantics (Dropout = identity).  Per grid and wavefront:
+//   forward as rnd_fused64_kernel, additionally remembering, per 4x4 pooling window and predictor
+//   channel, the 9-bit input pattern of the arg-max pixel (ties only occur between equal
+//   patterns or at the relu floor, where the routing does not matter);
+//   backward: dtanh -> linear (dW = dy p2^T in registers of lane (k, half)) -> dp2 -> arg-max of
+//   the 2x2 pool and relu gate -> conv2 weight gradients + scatter of dp1 into LDS planes
+//   (ds_add_f32) -> relu gate at the arg-max pixel of each 4x4 window -> conv1 weight gradients
+//   as gated sums of the remembered pattern bits.
+// Every lane accumulates its share of the 1117 gradient entries in registers over all grids of
+// the wave; one reduction + one partial-row store per wave at the end; rnd_grad_reduce_kernel adds
+// the partial rows in fixed order into the running gradient (deterministic).
+// =============================================================================================
+namespace carle {
+
+static constexpr int kRndPredParams = 36 + 4 + 36 + 1 + 16 * 64 + 16;   // 1117
+static constexpr int kTrainWaves = 2;
+
+template <int OBS_MODE>
+__global__ __launch_bounds__(64 * kTrainWaves) void rnd_train64_kernel(
+    const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
+    float *__restrict__ reward, float reward_scale, float grad_scale, float *__restrict__ partial,
+    int64_t n) {
+    __shared__ float4 s_lut_p[512];
+    __shared__ float2 s_lut_r[512];
+    __shared__ float s_lin[2 * kLinFloats];
+    __shared__ float s_planes[kTrainWaves][6][kPlaneFloats];
+    __shared__ float s_dplanes[kTrainWaves][4][kPlaneFloats];
+    __shared__ float s_feat[kTrainWaves][2][64];
+    __shared__ float s_dy[kTrainWaves][16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NT = 64 * kTrainWaves;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(ws);
+        for (int i = tid; i < 512; i += NT) s_lut_p[i] = src[i];
+        const float2 *src2 = reinterpret_cast<const float2 *>(ws + 2048);
+        for (int i = tid; i < 512; i += NT) s_lut_r[i] = src2[i];
+        for (int i = tid; i < 2 * kLinFloats; i += NT) s_lin[i] = ws[kLutFloats + i];
+        float *pl = &s_planes[0][0][0];
+        for (int i = tid; i < kTrainWaves * 6 * kPlaneFloats; i += NT) pl[i] = 0.0f;
+    }
+    __syncthreads();
+    const float *cw2p = ws + kFusedWsFloats;          // predictor conv2.w[36], b at [36]
+    const float *cw2r = ws + kFusedWsFloats + 40;     // random conv2.w[18], b at [18]
+
+    const int q = lane >> 4, k = lane & 15;
+    const int fy = lane >> 3, fx = lane & 7;
+    const int half = lane & 1, kk = (lane >> 1) & 15, net = lane >> 5;
+    float *planes = &s_planes[wv][0][0];
+    float *dpl = &s_dplanes[wv][0][0];
+
+    // gradient accumulators of this lane (over all grids of the wave)
+    float gW[32], gB = 0.0f, gw2[36], gb2 = 0.0f, gw1[36], gb1[4];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) gW[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { gw2[i] = 0.0f; gw1[i] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gb1[i] = 0.0f;
+
+    const int64_t wave_id = (int64_t)blockIdx.x * kTrainWaves + wv, nwaves = (int64_t)gridDim.x * kTrainWaves;
+    for (int64_t g = wave_id; g < n; g += nwaves) {
+        // ---- observation -> 16x4 patch of this lane
+        uint64_t c = 0;
+        if (OBS_MODE == 2) {
+            const uint64_t *pw = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + k;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                c |= spread_field((uint32_t)(pw[16 * qq] >> (16 * q)) & 0xFFFFu) << (4 * qq);
+        } else if (OBS_MODE == 1) {
+            const uint64_t *rows = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + 16 * q;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c |= ((rows[i] >> (4 * k)) & 0xFull) << (4 * i);
+        } else {
+            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + (16 * q) * 16 + k;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint4 v = gin[i * 16];
+                const uint32_t nib = nz_bit(v.x) | (nz_bit(v.y) << 1) | (nz_bit(v.z) << 2) | (nz_bit(v.w) << 3);
+                c |= (uint64_t)nib << (4 * i);
+            }
+        }
+        uint64_t cw = ((uint64_t)__shfl((uint32_t)(c >> 32), lane - 1, 64) << 32) | __shfl((uint32_t)c, lane - 1, 64);
+        uint64_t ce = ((uint64_t)__shfl((uint32_t)(c >> 32), lane + 1, 64) << 32) | __shfl((uint32_t)c, lane + 1, 64);
+        if (k == 0) cw = 0;
+        if (k == 15) ce = 0;
+        const uint64_t wb = (cw >> 3) & 0x1111111111111111ull, eb = ce & 0x1111111111111111ull;
+        const uint64_t ea = (spread_nibbles((uint32_t)c) << 1) | spread_nibbles((uint32_t)wb) |
+                            (spread_nibbles((uint32_t)eb) << 5);
+        const uint64_t ebb = (spread_nibbles((uint32_t)(c >> 32)) << 1) | spread_nibbles((uint32_t)(wb >> 32)) |
+                             (spread_nibbles((uint32_t)(eb >> 32)) << 5);
+        uint32_t top = __shfl((uint32_t)(ebb >> 56), lane - 16, 64);
+        uint32_t bot = __shfl((uint32_t)ea & 0xFFu, lane + 16, 64);
+        if (q == 0) top = 0;
+        if (q == 3) bot = 0;
+        uint32_t seg[18];
+        seg[0] = top;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            seg[1 + r] = (uint32_t)(ea >> (8 * r)) & 0xFFu;
+            seg[9 + r] = (uint32_t)(ebb >> (8 * r)) & 0xFFu;
+        }
+        seg[17] = bot;
+
+        // ---- conv1 + relu + 4x4 pool, remembering the arg-max pattern per predictor channel
+        float pm[4][4];                               // [window][channel] pooled value
+        uint32_t pat[4][4];                           // [window][channel] arg-max pattern
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) {
+                    const uint32_t p = ((seg[4 * j + dy] >> dx) & 7u) | (((seg[4 * j + dy + 1] >> dx) & 7u) << 3) |
+                                       (((seg[4 * j + dy + 2] >> dx) & 7u) << 6);
+                    const float4 a = s_lut_p[p];
+                    const float2 b = s_lut_r[p];
+                    if (a.x > m0) { m0 = a.x; a0 = p; }
+                    if (a.y > m1) { m1 = a.y; a1 = p; }
+                    if (a.z > m2) { m2 = a.z; a2 = p; }
+                    if (a.w > m3) { m3 = a.w; a3 = p; }
+                    m4 = fmaxf(m4, b.x); m5 = fmaxf(m5, b.y);
+                }
+            pm[j][0] = m0; pm[j][1] = m1; pm[j][2] = m2; pm[j][3] = m3;
+            pat[j][0] = a0; pat[j][1] = a1; pat[j][2] = a2; pat[j][3] = a3;
+            const int off = (4 * q + j + 1) * kPlaneStride + k + 1;
+            planes[0 * kPlaneFloats + off] = m0;
+            planes[1 * kPlaneFloats + off] = m1;
+            planes[2 * kPlaneFloats + off] = m2;
+            planes[3 * kPlaneFloats + off] = m3;
+            planes[4 * kPlaneFloats + off] = m4;
+            planes[5 * kPlaneFloats + off] = m5;
+        }
+        for (int i = lane; i < 4 * kPlaneFloats; i += 64) dpl[i] = 0.0f;     // gradient planes
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- conv2 + relu + 2x2 pool (both nets); predictor: arg-max position and relu gate
+        int amax = 0;
+        bool active = false;
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+            const int nch = nn == 0 ? 4 : 2, chbase = nn == 0 ? 0 : 4;
+            const float *cw2 = nn == 0 ? cw2p : cw2r;
+            float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                if (cc < nch) {
+                    const float *pl = planes + (chbase + cc) * kPlaneFloats + (2 * fy) * kPlaneStride + 2 * fx;
+                    float patch[4][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride);
+                        const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride + 2);
+                        patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+                    }
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) o00 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][kx], o00);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) o01 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][1 + kx], o01);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) o10 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][kx], o10);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) o11 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][1 + kx], o11);
+                }
+            }
+            float mx = o00; int am = 0;
+            if (o01 > mx) { mx = o01; am = 1; }
+            if (o10 > mx) { mx = o10; am = 2; }
+            if (o11 > mx) { mx = o11; am = 3; }
+            mx += cw2[nn == 0 ? 36 : 18];
+            s_feat[wv][nn][fy * 8 + fx] = fmaxf(mx, 0.0f);
+            if (nn == 0) { amax = am; active = mx > 0.0f; }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- linear + tanh, bonus, dL/dy of the predictor
+        float dyk = 0.0f;
+        {
+            const float4 *f4 = reinterpret_cast<const float4 *>(&s_feat[wv][net][32 * half]);
+            const float4 *w4 = reinterpret_cast<const float4 *>(&s_lin[net * kLinFloats + kk * kLinStride + 32 * half]);
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 f = f4[i], w = w4[i];
+                acc = fmaf(w.x, f.x, acc); acc = fmaf(w.y, f.y, acc);
+                acc = fmaf(w.z, f.z, acc); acc = fmaf(w.w, f.w, acc);
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            const float out = tanhf(acc + s_lin[net * kLinFloats + 16 * kLinStride + kk]);
+            const float other = __shfl_xor(out, 32, 64);
+            const float diff = out - other;                      // net 0 lanes: prediction - target
+            float sq = diff * diff;
+#pragma unroll
+            for (int s = 2; s < 32; s <<= 1) sq += __shfl_xor(sq, s, 64);
+            if (lane == 0) {
+                const float b = sq * (1.0f / 16.0f);
+                bonus[g] = b;
+                if (reward) reward[g] += reward_scale * b;
+            }
+            if (net == 0) {
+                dyk = grad_scale * diff * (1.0f - out * out);    // d loss / d y_k
+                // linear layer gradients: this lane owns W[kk][32*half .. +32)
+                const float *fp = &s_feat[wv][0][32 * half];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) gW[i] = fmaf(dyk, fp[i], gW[i]);
+                if (half == 0) { gB += dyk; s_dy[wv][kk] = dyk; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- back through linear, 2x2 pool, relu and conv2 (lane = pooled position fy, fx)
+        {
+            float dp2 = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) dp2 = fmaf(s_lin[o * kLinStride + lane], s_dy[wv][o], dp2);
+            const float dz2 = active ? dp2 : 0.0f;
+            gb2 += dz2;
+            const int Y = 2 * fy + (amax >> 1), X = 2 * fx + (amax & 1);   // conv2 output position
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const float *pl = planes + cc * kPlaneFloats + Y * kPlaneStride + X;   // padded: +ky, +kx
+                float *dp = dpl + cc * kPlaneFloats + Y * kPlaneStride + X;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        gw2[cc * 9 + ky * 3 + kx] = fmaf(dz2, pl[ky * kPlaneStride + kx], gw2[cc * 9 + ky * 3 + kx]);
+                        atomicAdd(dp + ky * kPlaneStride + kx, cw2p[cc * 9 + ky * 3 + kx] * dz2);
+                    }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- back through the 4x4 pool, relu and conv1 (lane = owner of 4 windows)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = (4 * q + j + 1) * kPlaneStride + k + 1;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const float gz = pm[j][cc] > 0.0f ? dpl[cc * kPlaneFloats + off] : 0.0f;
+                gb1[cc] += gz;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    gw1[cc * 9 + t] = fmaf(gz, (float)((pat[j][cc] >> t) & 1u), gw1[cc * 9 + t]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- one partial gradient row per wave, parameter order of the predictor blob
+    if (wave_id < nwaves) {
+        float *row = partial + wave_id * kRndPredParams;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) {
+            float a = gw1[i], b = gw2[i];
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) { a += __shfl_xor(a, s, 64); b += __shfl_xor(b, s, 64); }
+            if (lane == 0) { row[i] = a; row[40 + i] = b; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a = gb1[i];
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) a += __shfl_xor(a, s, 64);
+            if (lane == 0) row[36 + i] = a;
+        }
+        {
+            float a = gb2;
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) a += __shfl_xor(a, s, 64);
+            if (lane == 0) row[76] = a;
+        }
+        if (net == 0) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) row[77 + kk * 64 + 32 * half + i] = gW[i];
+            if (half == 0) row[77 + 1024 + kk] = gB;
+        }
+    }
+}
+
+// grad[p] += sum over wave rows (fixed order): deterministic accumulation across the window
+__global__ __launch_bounds__(256) void rnd_grad_reduce_kernel(const float *__restrict__ partial, int rows,
+                                                              float *__restrict__ grad, int nparams) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nparams) return;
+    float s = 0.0f;
+    for (int r = 0; r < rows; ++r) s += partial[(int64_t)r * nparams + p];
+    grad[p] += s;
+}
+
+int rnd2d_train64_rows(int64_t n) {
+    int64_t blocks = (n + kTrainWaves - 1) / kTrainWaves;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    return (int)(blocks * kTrainWaves);
+}
+
+int rnd2d_train64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp, float *ws,
+                  float *bonus, float *reward, float reward_scale, float grad_scale, float *partial,
+                  float *grad, bool tables_valid, hipStream_t s) {
+    if (!tables_valid) hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
+    const int rows = rnd2d_train64_rows(n);
+    const unsigned blocks = (unsigned)(rows / kTrainWaves);
+    if (obs_mode == 2)
+        hipLaunchKernelGGL(rnd_train64_kernel<2>, dim3(blocks), dim3(64 * kTrainWaves), 0, s, obs, ws, bonus,
+                           reward, reward_scale, grad_scale, partial, n);
+    else if (obs_mode == 1)
+        hipLaunchKernelGGL(rnd_train64_kernel<1>, dim3(blocks), dim3(64 * kTrainWaves), 0, s, obs, ws, bonus,
+                           reward, reward_scale, grad_scale, partial, n);
+    else
+        hipLaunchKernelGGL(rnd_train64_kernel<0>, dim3(blocks), dim3(64 * kTrainWaves), 0, s, obs, ws, bonus,
+                           reward, reward_scale, grad_scale, partial, n);
+    hipLaunchKernelGGL(rnd_grad_reduce_kernel, dim3((kRndPredParams + 255) / 256), dim3(256), 0, s, partial,
+                       rows, grad, kRndPredParams);
+    return check_launch("carle_rnd2d_train(fused 64x64)");
+}
+
+}  // namespace carle

@@ -115,6 +115,9 @@ class RND2D(Motivator):
         self._bonus_buf = None
         self._patch = None                   # scratch ring: CA kernel -> reward net hand-off
         self._patch_turn = 0
+        self._grad = None                    # flat gradient the fused training kernel accumulates
+        self._grad_used = False
+        self._partial = None                 # per-wave partial gradient rows (scratch)
         # False: step() only evaluates the bonus (forward pass), no window retention / Adam update
         self.train_predictor = bool(kwargs.get("train_predictor", True))
         self.accumulate_loss = 0.0
@@ -263,18 +266,19 @@ class RND2D(Motivator):
 
     def get_bonus_accumulate(self, obs):
         """Bonus now, predictor update every ``batch_size`` calls (mcl.py:368-386)."""
+        o = self._obs(obs, allow_packed=True)[0]
+        n = o.shape[0]
+        bonus = torch.empty(n, dtype=torch.float32, device=o.device)
         if self.buffer_length == 0:
             self.predictor.zero_grad()
             self.accumulate_loss = 0.0
             self._window = []
-        bonus = self.get_bonus(obs)
-        self._window.append(self._obs(obs)[0])
+        if not self._fused_train(obs, None, bonus, None):
+            self._window.append(self._obs(obs)[0])
+            bonus = self.get_bonus(obs)
         self.buffer_length += 1
         if self.buffer_length >= self.batch_size:
-            self.accumulate_loss = self._replay_window(1.0 / self.batch_size)
-            self.optimizer.step()
-            self._after_update()
-            self.buffer_length = 0
+            self._finish_window()
         return bonus
 
     def _after_update(self):
@@ -283,23 +287,72 @@ class RND2D(Motivator):
 
     # ------------------------------------------------------------------ gym surface
     def _bonus_into(self, obs, reward, stream=None):
-        """reward += reward_scale * bonus(obs), fused into the bonus kernel (mcl.py:403-405)."""
-        if self.train_predictor:
-            if self.buffer_length == 0:
-                self.predictor.zero_grad()
-                self.accumulate_loss = 0.0
-                self._window = []
-            self._window.append(self._obs(obs)[0])
-            self.buffer_length += 1
+        """reward += reward_scale * bonus(obs), fused into the bonus kernel (mcl.py:403-405); in
+        training mode the predictor's gradient is accumulated on the way (fused kernel) or the
+        observation is retained for the autograd replay."""
         n = reward.shape[0]
         if self._bonus_buf is None or self._bonus_buf.shape[0] != n or self._bonus_buf.device != reward.device:
             self._bonus_buf = torch.empty(n, dtype=torch.float32, device=reward.device)
-        self._hip_forward(obs, False, reward, self._bonus_buf, stream)
-        if self.train_predictor and self.buffer_length >= self.batch_size:
+        if not self.train_predictor:
+            self._hip_forward(obs, False, reward, self._bonus_buf, stream)
+            return
+        if self.buffer_length == 0:
+            self.predictor.zero_grad()
+            self.accumulate_loss = 0.0
+            self._window = []
+        if not self._fused_train(obs, reward, self._bonus_buf, stream):
+            self._window.append(self._obs(obs)[0])
+            self._hip_forward(obs, False, reward, self._bonus_buf, stream)
+        self.buffer_length += 1
+        if self.buffer_length >= self.batch_size:
+            self._finish_window()
+
+    def _finish_window(self):
+        """End of an update window: replay retained observations (if any), add the gradient the
+        fused kernel accumulated, Adam step (mcl.py:380-384, 333-341)."""
+        if self._window:
             self.accumulate_loss = self._replay_window(1.0 / self.batch_size)
-            self.optimizer.step()
-            self._after_update()
-            self.buffer_length = 0
+        if self._grad_used:
+            off = 0
+            for p in self._pred_blob.params:
+                gslice = self._grad[off:off + p.numel()].view_as(p)
+                p.grad = gslice.clone() if p.grad is None else p.grad + gslice
+                off += p.numel()
+            self._grad.zero_()
+            self._grad_used = False
+        self.optimizer.step()
+        self._after_update()
+        self.buffer_length = 0
+
+    def _fused_train(self, obs, reward, bonus_out, stream):
+        """Bonus + gradient in one HIP pass (carle_rnd2d_train_*): RND2D proper, 64x64 binary obs.
+        Returns False when the fused kernel does not apply (the caller then retains the obs)."""
+        if type(self) is not RND2D:
+            return False
+        o, binary = self._obs(obs, allow_packed=True)
+        if not binary or o.shape[2] != 64 or (o.dtype != torch.int64 and o.shape[3] != 64):
+            return False
+        from . import _lib
+        lib = _lib.load()
+        dev, n = o.device, o.shape[0]
+        pb, rb = self._pred_blob.get(dev), self._rand_blob.get(dev)
+        need = lib.carle_rnd2d_workspace_floats(n, 64, 64)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.float32, device=dev)
+            self._tables_key = None
+        pneed = lib.carle_rnd2d_train_partial_floats(n)
+        if self._partial is None or self._partial.numel() < pneed or self._partial.device != dev:
+            self._partial = torch.empty(pneed, dtype=torch.float32, device=dev)
+        if self._grad is None or self._grad.device != dev:
+            self._grad = torch.zeros(pb.numel(), dtype=torch.float32, device=dev)
+        versions = (self._pred_blob.version, self._rand_blob.version)
+        valid = self._tables_key == (id(self._ws), versions)
+        grad_scale = 2.0 / (self.rnd_dim * n * self.batch_size)
+        hip.rnd2d_train(o, pb, rb, self._ws, self._partial, self._grad, bonus_out, reward,
+                        self.reward_scale, grad_scale, valid, stream)
+        self._tables_key = (id(self._ws), versions)
+        self._grad_used = True
+        return True
 
     def step(self, action):
         """env.step, then reward += reward_scale * bonus(obs)  (mcl.py:398-407).

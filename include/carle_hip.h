@@ -169,6 +169,22 @@ int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
                          float *workspace, float *bonus, float *pred_out, float *target_out,
                          float *reward_accum, float reward_scale, int flags, void *stream);
 
+/* RND2D bonus AND the predictor's gradient in one pass: replaces the autograd
+ * graph the reference keeps alive across the update window (carle/mcl.py:343-386).  64x64 binary
+ * observations, eval-mode semantics.  grad[0..1117) (predictor blob order) is ACCUMULATED:
+ *   grad += d/dtheta [ grad_scale/2 * sum_i sum_k (target_ik - prediction_ik)^2 ],
+ * so grad_scale = 2 / (16 * N * batch_size) reproduces sum_t mean_n mean_k(.)^2 / batch_size.
+ * partial: scratch of carle_rnd2d_train_partial_floats(n) floats; workspace: as for the bonus. */
+int64_t carle_rnd2d_train_partial_floats(int64_t n);
+int carle_rnd2d_train_f32(const float *obs, int64_t n, int h, int w, const float *pred_params,
+                          const float *rand_params, float *workspace, float *partial, float *grad,
+                          float *bonus, float *reward_accum, float reward_scale, float grad_scale,
+                          int flags, void *stream);
+int carle_rnd2d_train_b1(const uint64_t *obs, int64_t n, int h, int w, const float *pred_params,
+                         const float *rand_params, float *workspace, float *partial, float *grad,
+                         float *bonus, float *reward_accum, float reward_scale, float grad_scale,
+                         int flags, void *stream);
+
 /* AE2D.get_bonus (carle/mcl.py:436-443,504-512): bonus[i] = mean_{h,w} (obs_i - decoder(obs_i))^2.
  * recon_out: optional (N,1,H,W) reconstruction, may be NULL. */
 int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w);

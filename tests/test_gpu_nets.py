@@ -273,3 +273,58 @@ def test_one_call_step_plus_rnd_matches_generic_path(async_reward):
         assert torch.equal(rf, rs_) and float(rf.abs().sum()) > 0
         assert of is env_a.universe
     assert env_a.step_number == env_b.step_number
+
+
+@pytest.mark.parametrize("n,packed", [(1, False), (5, False), (37, True), (1030, False)])
+def test_fused_rnd_gradient_matches_autograd(n, packed):
+    """carle_rnd2d_train_*: the gradient the fused forward+backward kernel accumulates equals
+    torch autograd's gradient of  mean_n mean_k (target - prediction)^2 / batch_size  (eval mode),
+    and the bonus it returns equals the forward-only kernel's."""
+    from carle_amd import hip
+    torch.manual_seed(40 + n)
+    env, rnd, ae = _stack(64, n)
+    ae.reset()                                             # moves the nets to the device
+    rnd.eval()
+    rnd.assume_binary_obs = True
+    rnd.batch_size = 4
+    g = (torch.rand(n, 1, 64, 64, device="cuda") < 0.35).float()
+    obs = hip.pack_f32_b1(g) if packed else g
+    expected_bonus = rnd.get_bonus_only(g).clone()
+    bonus = torch.empty(n, device="cuda")
+    reward = torch.zeros(n, 1, device="cuda")
+    for rep in range(2):                                   # accumulation across two calls
+        assert rnd._fused_train(obs, reward, bonus, None)
+    np.testing.assert_allclose(bonus.cpu().numpy(), expected_bonus.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(reward.cpu().numpy()[:, 0], 2 * expected_bonus.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    rnd.predictor.zero_grad()
+    loss = torch.mean(rnd._torch_loss(g)) / rnd.batch_size * 2.0
+    loss.backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in rnd.predictor.parameters()]).cpu().numpy()
+    got = rnd._grad.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert scale > 0
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+
+
+def test_fused_training_window_updates_like_autograd():
+    """A whole update window through get_bonus_accumulate: fused-kernel gradients + torch Adam
+    give the same parameters as the retained-window autograd replay."""
+    torch.manual_seed(77)
+    env_a, fused, _ = _stack(64, 6)
+    env_b, replay, _ = _stack(64, 6)
+    replay.load_state_dict(fused.state_dict())
+    fused.assume_binary_obs = True                        # fused gradient kernel
+    replay._fused_train = lambda *a, **k: False           # force retention + autograd replay
+    for w in (fused, replay):
+        w.reset()
+        w.eval()
+        w.batch_size = 3
+    g = torch.Generator().manual_seed(3)
+    for t in range(7):                                     # two updates + one pending step
+        obs = (torch.rand(6, 1, 64, 64, generator=g) < 0.3).float().cuda()
+        bf = fused.get_bonus_accumulate(obs)
+        br = replay.get_bonus_accumulate(obs)
+        np.testing.assert_allclose(bf.cpu().numpy(), br.cpu().numpy(), rtol=0, atol=2e-5)
+    assert fused.updates == replay.updates == 2
+    for (k, a), (_, b) in zip(fused.state_dict().items(), replay.state_dict().items()):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-3, err_msg=k)
