@@ -874,14 +874,30 @@ __global__ __launch_bounds__(64 * kTrainWaves) void rnd_train64_kernel(
     }
 }
 
-// grad[p] += sum over wave rows (fixed order): deterministic accumulation across the window
+// grad[p] += sum over wave rows, fixed order: 32 parameters x 8 row groups per block (128-byte
+// coalesced row segments), the 8 group sums combined in a fixed order -> deterministic
 __global__ __launch_bounds__(256) void rnd_grad_reduce_kernel(const float *__restrict__ partial, int rows,
                                                               float *__restrict__ grad, int nparams) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nparams) return;
-    float s = 0.0f;
-    for (int r = 0; r < rows; ++r) s += partial[(int64_t)r * nparams + p];
-    grad[p] += s;
+    __shared__ float part[8][32];
+    const int pl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int p = blockIdx.x * 32 + pl;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (p < nparams) {
+        int r = rl;
+        for (; r + 8 < rows; r += 16) {
+            s0 += partial[(int64_t)r * nparams + p];
+            s1 += partial[(int64_t)(r + 8) * nparams + p];
+        }
+        if (r < rows) s0 += partial[(int64_t)r * nparams + p];
+    }
+    part[rl][pl] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && p < nparams) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += part[i][pl];
+        grad[p] += s;
+    }
 }
 
 int rnd2d_train64_rows(int64_t n) {
@@ -906,7 +922,7 @@ int rnd2d_train64(const void *obs, int obs_mode, int64_t n, const float *pp, con
     else
         hipLaunchKernelGGL(rnd_train64_kernel<0>, dim3(blocks), dim3(64 * kTrainWaves), 0, s, obs, ws, bonus,
                            reward, reward_scale, grad_scale, partial, n);
-    hipLaunchKernelGGL(rnd_grad_reduce_kernel, dim3((kRndPredParams + 255) / 256), dim3(256), 0, s, partial,
+    hipLaunchKernelGGL(rnd_grad_reduce_kernel, dim3((kRndPredParams + 31) / 32), dim3(256), 0, s, partial,
                        rows, grad, kRndPredParams);
     return check_launch("carle_rnd2d_train(fused 64x64)");
 }
