@@ -928,3 +928,398 @@ int rnd2d_train64(const void *obs, int obs_mode, int64_t n, const float *pp, con
 }
 
 }  // namespace carle
+
+// =============================================================================================
+// AE2D forward + BACKWARD for 64x64 binary grids: gradient of
+//   sum_t mean_n mean_hw (obs - decoder(obs))^2 / batch_size   (carle/mcl.py:504-547)
+// with respect to the 164 predictor parameters, in the pass that evaluates the bonus.
+// One wavefront per workgroup (the LDS holds A1, A2, A3 and their gradient planes: 54 KiB):
+//   convT2/sigmoid backward on the lane's own 16x4 pixels -> scatter into dA3 (ds_add_f32)
+//   -> relu gate, convT1 backward -> scatter into dA2 -> 2x2 pool arg-max + relu gate, conv2
+//   backward (weight gradients from the A1 planes, scatter into dA1) -> 2x2 pool arg-max pattern +
+//   relu gate, conv1 weight gradients as gated sums of pattern bits.
+// =============================================================================================
+namespace carle {
+
+static constexpr int kAeParams = 164;
+
+template <bool PACKED_OBS>
+__global__ __launch_bounds__(64) void ae_train64_kernel(
+    const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
+    float *__restrict__ reward, float reward_scale, float grad_scale, float *__restrict__ partial,
+    int64_t n) {
+    __shared__ float4 s_lut[512];
+    __shared__ float s_a1[4 * kA1Plane], s_d1[4 * kA1Plane];
+    __shared__ float s_a2[2 * kA2Plane], s_d2[2 * kA2Plane];
+    __shared__ float s_a3[kA1Plane], s_d3[kA1Plane];
+
+    const int lane = threadIdx.x;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(ws);
+        for (int i = lane; i < 512; i += 64) s_lut[i] = src[i];
+        for (int i = lane; i < 4 * kA1Plane; i += 64) s_a1[i] = 0.0f;
+        for (int i = lane; i < 2 * kA2Plane; i += 64) s_a2[i] = 0.0f;
+        for (int i = lane; i < kA1Plane; i += 64) s_a3[i] = 0.0f;
+    }
+    __syncthreads();
+    const float *prm = ws + kAeLutFloats;
+    const float *w2 = prm, *b2 = prm + 72, *wt1 = prm + 74, *wt2 = prm + 107;
+    const float bt1 = prm[106], bt2 = prm[123];
+    const int q = lane >> 4, k = lane & 15;
+
+    float gw1[36], gb1[4], gw2[72], gb2[2], gwt1[32], gbt1 = 0.0f, gwt2[16], gbt2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) gw1[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gb1[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 72; ++i) gw2[i] = 0.0f;
+    gb2[0] = gb2[1] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) gwt1[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gwt2[i] = 0.0f;
+
+    const int64_t wave_id = blockIdx.x, nwaves = gridDim.x;
+    for (int64_t g = wave_id; g < n; g += nwaves) {
+        // ---- observation patch and row segments (as in ae_fused64_kernel)
+        uint64_t c = 0;
+        if (PACKED_OBS) {
+            const uint64_t *rows = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + 16 * q;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c |= ((rows[i] >> (4 * k)) & 0xFull) << (4 * i);
+        } else {
+            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + (16 * q) * 16 + k;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint4 v = gin[i * 16];
+                const uint32_t nib = nz_bit(v.x) | (nz_bit(v.y) << 1) | (nz_bit(v.z) << 2) | (nz_bit(v.w) << 3);
+                c |= (uint64_t)nib << (4 * i);
+            }
+        }
+        uint64_t cw = ((uint64_t)__shfl((uint32_t)(c >> 32), lane - 1, 64) << 32) | __shfl((uint32_t)c, lane - 1, 64);
+        uint64_t ce = ((uint64_t)__shfl((uint32_t)(c >> 32), lane + 1, 64) << 32) | __shfl((uint32_t)c, lane + 1, 64);
+        if (k == 0) cw = 0;
+        if (k == 15) ce = 0;
+        const uint64_t wb = (cw >> 3) & 0x1111111111111111ull, eb = ce & 0x1111111111111111ull;
+        const uint64_t ea = (spread_nibbles((uint32_t)c) << 1) | spread_nibbles((uint32_t)wb) |
+                            (spread_nibbles((uint32_t)eb) << 5);
+        const uint64_t ebb = (spread_nibbles((uint32_t)(c >> 32)) << 1) | spread_nibbles((uint32_t)(wb >> 32)) |
+                             (spread_nibbles((uint32_t)(eb >> 32)) << 5);
+        uint32_t top = __shfl((uint32_t)(ebb >> 56), lane - 16, 64);
+        uint32_t bot = __shfl((uint32_t)ea & 0xFFu, lane + 16, 64);
+        if (q == 0) top = 0;
+        if (q == 3) bot = 0;
+        uint32_t seg[18];
+        seg[0] = top;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            seg[1 + r] = (uint32_t)(ea >> (8 * r)) & 0xFFu;
+            seg[9 + r] = (uint32_t)(ebb >> (8 * r)) & 0xFFu;
+        }
+        seg[17] = bot;
+
+        // ---- zero the gradient planes of this grid
+        {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 *d1 = reinterpret_cast<float4 *>(s_d1);
+            for (int i = lane; i < kA1Plane; i += 64) d1[i] = z;                // 4 planes = kA1Plane float4
+            float4 *d2 = reinterpret_cast<float4 *>(s_d2);
+            for (int i = lane; i < kA2Plane / 2; i += 64) d2[i] = z;           // 2 planes
+            float4 *d3 = reinterpret_cast<float4 *>(s_d3);
+            for (int i = lane; i < kA1Plane / 4; i += 64) d3[i] = z;
+        }
+
+        // ---- conv1 (table) + relu + 2x2 pool -> A1 (rows 8q+j, cols 2k+i); arg-max patterns
+        uint32_t patlo[8][2], pathi[8][2];            // ch0 | ch1<<9 | ch2<<18 ; ch3
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+                uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int r = 2 * j + dy, cx = 2 * i + dx;
+                        const uint32_t p = ((seg[r] >> cx) & 7u) | (((seg[r + 1] >> cx) & 7u) << 3) |
+                                           (((seg[r + 2] >> cx) & 7u) << 6);
+                        const float4 a = s_lut[p];
+                        if (a.x > m0) { m0 = a.x; p0 = p; }
+                        if (a.y > m1) { m1 = a.y; p1 = p; }
+                        if (a.z > m2) { m2 = a.z; p2 = p; }
+                        if (a.w > m3) { m3 = a.w; p3 = p; }
+                    }
+                patlo[j][i] = p0 | (p1 << 9) | (p2 << 18);
+                pathi[j][i] = p3;
+                const int off = (8 * q + j + 1) * kA1Stride + 2 * k + i + 1;
+                s_a1[0 * kA1Plane + off] = m0;
+                s_a1[1 * kA1Plane + off] = m1;
+                s_a1[2 * kA1Plane + off] = m2;
+                s_a1[3 * kA1Plane + off] = m3;
+            }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- conv2 (4->2) + relu + 2x2 pool -> A2 (rows 4q+t, col k); arg-max + gate
+        float acc2[2][4][2][2];
+#pragma unroll
+        for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { acc2[oc][t][0][0] = 0.f; acc2[oc][t][0][1] = 0.f; acc2[oc][t][1][0] = 0.f; acc2[oc][t][1][1] = 0.f; }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const float *pl = s_a1 + cc * kA1Plane + (8 * q) * kA1Stride + 2 * k;
+            float patch[10][4];
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+                const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
+                const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
+                patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+            }
+#pragma unroll
+            for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                                for (int kx = 0; kx < 3; ++kx)
+                                    acc2[oc][t][dy][dx] = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx],
+                                                               patch[2 * t + dy + ky][dx + kx], acc2[oc][t][dy][dx]);
+        }
+        int am2[2][4];
+        bool on2[2][4];
+#pragma unroll
+        for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float mx = acc2[oc][t][0][0]; int am = 0;
+                if (acc2[oc][t][0][1] > mx) { mx = acc2[oc][t][0][1]; am = 1; }
+                if (acc2[oc][t][1][0] > mx) { mx = acc2[oc][t][1][0]; am = 2; }
+                if (acc2[oc][t][1][1] > mx) { mx = acc2[oc][t][1][1]; am = 3; }
+                mx += b2[oc];
+                am2[oc][t] = am;
+                on2[oc][t] = mx > 0.0f;
+                s_a2[oc * kA2Plane + (4 * q + t + 1) * kA2Stride + k + 1] = fmaxf(mx, 0.0f);
+            }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- convT1 (2->1) + relu -> A3 (rows 8q+j, cols 2k+i)
+        float r2[2][6][3];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+                    r2[cc][r][x] = s_a2[cc * kA2Plane + (4 * q + r) * kA2Stride + k + x];
+        float a3[8][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = j >> 1;
+                const int ry0 = m + 1, ky0 = (j & 1) ? 2 : 1;
+                const int ry1 = (j & 1) ? m + 2 : m, ky1 = (j & 1) ? 0 : 3;
+                const int cx0 = 1, kx0 = i ? 2 : 1;
+                const int cx1 = i ? 2 : 0, kx1 = i ? 0 : 3;
+                float acc = 0.0f;
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    acc = fmaf(r2[cc][ry0][cx0], wt1[cc * 16 + ky0 * 4 + kx0], acc);
+                    acc = fmaf(r2[cc][ry0][cx1], wt1[cc * 16 + ky0 * 4 + kx1], acc);
+                    acc = fmaf(r2[cc][ry1][cx0], wt1[cc * 16 + ky1 * 4 + kx0], acc);
+                    acc = fmaf(r2[cc][ry1][cx1], wt1[cc * 16 + ky1 * 4 + kx1], acc);
+                }
+                a3[j][i] = fmaxf(acc + bt1, 0.0f);
+                s_a3[(8 * q + j + 1) * kA1Stride + 2 * k + i + 1] = a3[j][i];
+            }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- convT2 + sigmoid + loss; backward of convT2 on the lane's own pixels
+        float t3[10][4], dt3[10][4];
+        {
+            const float *pl = s_a3 + (8 * q) * kA1Stride + 2 * k;
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+                const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
+                const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
+                t3[r][0] = lo.x; t3[r][1] = lo.y; t3[r][2] = hi.x; t3[r][3] = hi.y;
+                dt3[r][0] = 0.f; dt3[r][1] = 0.f; dt3[r][2] = 0.f; dt3[r][3] = 0.f;
+            }
+        }
+        float sq = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int cx = 0; cx < 4; ++cx) {
+                const int my = r >> 1, mx = cx >> 1;
+                const int ry0 = my + 1, ky0 = (r & 1) ? 2 : 1;
+                const int ry1 = (r & 1) ? my + 2 : my, ky1 = (r & 1) ? 0 : 3;
+                const int cx0 = mx + 1, kx0 = (cx & 1) ? 2 : 1;
+                const int cx1 = (cx & 1) ? mx + 2 : mx, kx1 = (cx & 1) ? 0 : 3;
+                float acc = 0.0f;
+                acc = fmaf(t3[ry0][cx0], wt2[ky0 * 4 + kx0], acc);
+                acc = fmaf(t3[ry0][cx1], wt2[ky0 * 4 + kx1], acc);
+                acc = fmaf(t3[ry1][cx0], wt2[ky1 * 4 + kx0], acc);
+                acc = fmaf(t3[ry1][cx1], wt2[ky1 * 4 + kx1], acc);
+                const float pr = 1.0f / (1.0f + expf(-(acc + bt2)));
+                const float ob = (float)((c >> (4 * r + cx)) & 1ull);
+                const float df = ob - pr;
+                sq = fmaf(df, df, sq);
+                const float dz = grad_scale * (pr - ob) * pr * (1.0f - pr);     // d loss / d (pre-sigmoid)
+                gbt2 += dz;
+                gwt2[ky0 * 4 + kx0] = fmaf(dz, t3[ry0][cx0], gwt2[ky0 * 4 + kx0]);
+                gwt2[ky0 * 4 + kx1] = fmaf(dz, t3[ry0][cx1], gwt2[ky0 * 4 + kx1]);
+                gwt2[ky1 * 4 + kx0] = fmaf(dz, t3[ry1][cx0], gwt2[ky1 * 4 + kx0]);
+                gwt2[ky1 * 4 + kx1] = fmaf(dz, t3[ry1][cx1], gwt2[ky1 * 4 + kx1]);
+                dt3[ry0][cx0] = fmaf(dz, wt2[ky0 * 4 + kx0], dt3[ry0][cx0]);
+                dt3[ry0][cx1] = fmaf(dz, wt2[ky0 * 4 + kx1], dt3[ry0][cx1]);
+                dt3[ry1][cx0] = fmaf(dz, wt2[ky1 * 4 + kx0], dt3[ry1][cx0]);
+                dt3[ry1][cx1] = fmaf(dz, wt2[ky1 * 4 + kx1], dt3[ry1][cx1]);
+            }
+        sq = wave_sum_f32(sq);
+        if (lane == 0) {
+            const float b = sq * (1.0f / 4096.0f);
+            bonus[g] = b;
+            if (reward) reward[g] += reward_scale * b;
+        }
+        {
+            float *dp = s_d3 + (8 * q) * kA1Stride + 2 * k;
+#pragma unroll
+            for (int r = 0; r < 10; ++r)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) atomicAdd(dp + r * kA1Stride + x, dt3[r][x]);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- relu gate of A3, convT1 backward
+        {
+            float dr2[2][6][3];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { dr2[cc][r][0] = 0.f; dr2[cc][r][1] = 0.f; dr2[cc][r][2] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float gz = a3[j][i] > 0.0f ? s_d3[(8 * q + j + 1) * kA1Stride + 2 * k + i + 1] : 0.0f;
+                    gbt1 += gz;
+                    const int m = j >> 1;
+                    const int ry0 = m + 1, ky0 = (j & 1) ? 2 : 1;
+                    const int ry1 = (j & 1) ? m + 2 : m, ky1 = (j & 1) ? 0 : 3;
+                    const int cx0 = 1, kx0 = i ? 2 : 1;
+                    const int cx1 = i ? 2 : 0, kx1 = i ? 0 : 3;
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        gwt1[cc * 16 + ky0 * 4 + kx0] = fmaf(gz, r2[cc][ry0][cx0], gwt1[cc * 16 + ky0 * 4 + kx0]);
+                        gwt1[cc * 16 + ky0 * 4 + kx1] = fmaf(gz, r2[cc][ry0][cx1], gwt1[cc * 16 + ky0 * 4 + kx1]);
+                        gwt1[cc * 16 + ky1 * 4 + kx0] = fmaf(gz, r2[cc][ry1][cx0], gwt1[cc * 16 + ky1 * 4 + kx0]);
+                        gwt1[cc * 16 + ky1 * 4 + kx1] = fmaf(gz, r2[cc][ry1][cx1], gwt1[cc * 16 + ky1 * 4 + kx1]);
+                        dr2[cc][ry0][cx0] = fmaf(gz, wt1[cc * 16 + ky0 * 4 + kx0], dr2[cc][ry0][cx0]);
+                        dr2[cc][ry0][cx1] = fmaf(gz, wt1[cc * 16 + ky0 * 4 + kx1], dr2[cc][ry0][cx1]);
+                        dr2[cc][ry1][cx0] = fmaf(gz, wt1[cc * 16 + ky1 * 4 + kx0], dr2[cc][ry1][cx0]);
+                        dr2[cc][ry1][cx1] = fmaf(gz, wt1[cc * 16 + ky1 * 4 + kx1], dr2[cc][ry1][cx1]);
+                    }
+                }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x)
+                        atomicAdd(&s_d2[cc * kA2Plane + (4 * q + r) * kA2Stride + k + x], dr2[cc][r][x]);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 2x2 pool arg-max + relu gate of A2, conv2 backward (A1 planes in LDS)
+#pragma unroll
+        for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float gz = on2[oc][t] ? s_d2[oc * kA2Plane + (4 * q + t + 1) * kA2Stride + k + 1] : 0.0f;
+                gb2[oc] += gz;
+                // conv2 output (2a+dy, 2k+dx) with a = 4q+t: padded A1 origin row 8q+2t+dy, col 2k+dx
+                const int base = (8 * q + 2 * t + (am2[oc][t] >> 1)) * kA1Stride + 2 * k + (am2[oc][t] & 1);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int o = cc * kA1Plane + base + ky * kA1Stride + kx;
+                            gw2[(oc * 4 + cc) * 9 + ky * 3 + kx] = fmaf(gz, s_a1[o], gw2[(oc * 4 + cc) * 9 + ky * 3 + kx]);
+                            atomicAdd(&s_d1[o], w2[(oc * 4 + cc) * 9 + ky * 3 + kx] * gz);
+                        }
+            }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 2x2 pool arg-max pattern + relu gate of A1, conv1 weight gradients
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (8 * q + j + 1) * kA1Stride + 2 * k + i + 1;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float gz = s_a1[cc * kA1Plane + off] > 0.0f ? s_d1[cc * kA1Plane + off] : 0.0f;
+                    const uint32_t pt = cc < 3 ? (patlo[j][i] >> (9 * cc)) & 0x1FFu : pathi[j][i];
+                    gb1[cc] += gz;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        gw1[cc * 9 + t] = fmaf(gz, (float)((pt >> t) & 1u), gw1[cc * 9 + t]);
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- one partial gradient row per wave, parameter order of the AE blob
+    float *row = partial + wave_id * kAeParams;
+    auto put = [&](int idx, float v) {
+        v = wave_sum_f32(v);
+        if (lane == 0) row[idx] = v;
+    };
+#pragma unroll
+    for (int i = 0; i < 36; ++i) put(i, gw1[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put(36 + i, gb1[i]);
+#pragma unroll
+    for (int i = 0; i < 72; ++i) put(40 + i, gw2[i]);
+    put(112, gb2[0]);
+    put(113, gb2[1]);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) put(114 + i, gwt1[i]);
+    put(146, gbt1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) put(147 + i, gwt2[i]);
+    put(163, gbt2);
+}
+
+int ae2d_train64_rows(int64_t n) {
+    int64_t rows = n < 512 ? n : 512;
+    return (int)(rows < 1 ? 1 : rows);
+}
+
+int ae2d_train64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
+                 float *reward, float reward_scale, float grad_scale, float *partial, float *grad,
+                 bool tables_valid, hipStream_t s) {
+    if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
+    const int rows = ae2d_train64_rows(n);
+    if (packed)
+        hipLaunchKernelGGL(ae_train64_kernel<true>, dim3((unsigned)rows), dim3(64), 0, s, obs, ws, bonus, reward,
+                           reward_scale, grad_scale, partial, n);
+    else
+        hipLaunchKernelGGL(ae_train64_kernel<false>, dim3((unsigned)rows), dim3(64), 0, s, obs, ws, bonus, reward,
+                           reward_scale, grad_scale, partial, n);
+    hipLaunchKernelGGL(rnd_grad_reduce_kernel, dim3((kAeParams + 31) / 32), dim3(256), 0, s, partial, rows, grad,
+                       kAeParams);
+    return check_launch("carle_ae2d_train(fused 64x64)");
+}
+
+}  // namespace carle

@@ -336,6 +336,10 @@ int rnd2d_train64_rows(int64_t n);
 int rnd2d_train64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp, float *ws,
                   float *bonus, float *reward, float reward_scale, float grad_scale, float *partial,
                   float *grad, bool tables_valid, hipStream_t s);
+int ae2d_train64_rows(int64_t n);
+int ae2d_train64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
+                 float *reward, float reward_scale, float grad_scale, float *partial, float *grad,
+                 bool tables_valid, hipStream_t s);
 int64_t ae2d_fused_workspace_floats();
 int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s);
@@ -478,4 +482,42 @@ extern "C" int carle_rnd2d_train_b1(const uint64_t *obs, int64_t n, int h, int w
                                     float grad_scale, int flags, void *stream) {
     return rnd2d_train_common(obs, 1, n, h, w, pred_params, rand_params, workspace, partial, grad, bonus,
                               reward_accum, reward_scale, grad_scale, flags, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// AE2D bonus + predictor gradient in one pass (64x64 binary observations), SURVEY 8(f) row 2
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t carle_ae2d_train_partial_floats(int64_t n) {
+    return n < 0 ? 0 : (int64_t)ae2d_train64_rows(n) * 164;
+}
+
+static int ae2d_train_common(const void *obs, bool packed, int64_t n, int h, int w, const float *params,
+                             float *workspace, float *partial, float *grad, float *bonus,
+                             float *reward_accum, float reward_scale, float grad_scale, int flags,
+                             void *stream) {
+    if (!obs || !params || !workspace || !partial || !grad || !bonus)
+        return fail_arg(CARLE_E_NULL, "carle_ae2d_train: NULL pointer");
+    if (h != 64 || w != 64 || n < 0)
+        return fail_arg(CARLE_E_DIMS, "carle_ae2d_train: the fused gradient kernel supports 64x64 grids");
+    if (!packed && (!(flags & CARLE_NET_OBS_BINARY) || !aligned16(obs)))
+        return fail_arg(CARLE_E_FORMAT, "carle_ae2d_train: fp32 observations must be binary (flag) and aligned");
+    if (n == 0) return 0;
+    return ae2d_train64(obs, packed, n, params, workspace, bonus, reward_accum, reward_scale, grad_scale,
+                        partial, grad, (flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int carle_ae2d_train_f32(const float *obs, int64_t n, int h, int w, const float *params,
+                                    float *workspace, float *partial, float *grad, float *bonus,
+                                    float *reward_accum, float reward_scale, float grad_scale, int flags,
+                                    void *stream) {
+    return ae2d_train_common(obs, false, n, h, w, params, workspace, partial, grad, bonus, reward_accum,
+                             reward_scale, grad_scale, flags, stream);
+}
+
+extern "C" int carle_ae2d_train_b1(const uint64_t *obs, int64_t n, int h, int w, const float *params,
+                                   float *workspace, float *partial, float *grad, float *bonus,
+                                   float *reward_accum, float reward_scale, float grad_scale, int flags,
+                                   void *stream) {
+    return ae2d_train_common(obs, true, n, h, w, params, workspace, partial, grad, bonus, reward_accum,
+                             reward_scale, grad_scale, flags, stream);
 }

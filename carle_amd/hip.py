@@ -395,3 +395,19 @@ def rnd2d_train(obs, pred_params, rand_params, workspace, partial, grad, bonus, 
                 stream if stream is not None else _stream(obs))
     if rc != 0:
         _lib.check(rc, "carle_rnd2d_train")
+
+
+def ae2d_train(obs, params, workspace, partial, grad, bonus, reward, reward_scale, grad_scale,
+               tables_valid, stream=None):
+    """AE2D bonus + accumulated predictor gradient in one pass (64x64 binary obs, fp32 or packed)."""
+    lib = _lib.load()
+    packed = obs.dtype == torch.int64
+    n = obs.shape[0]
+    flags = 1 | (2 if tables_valid else 0)
+    with _on_device(obs.device):
+        fn = lib.carle_ae2d_train_b1 if packed else lib.carle_ae2d_train_f32
+        rc = fn(obs.data_ptr(), n, 64, 64, params.data_ptr(), workspace.data_ptr(), partial.data_ptr(),
+                grad.data_ptr(), bonus.data_ptr(), _ptr(reward), float(reward_scale), float(grad_scale),
+                flags, stream if stream is not None else _stream(obs))
+    if rc != 0:
+        _lib.check(rc, "carle_ae2d_train")

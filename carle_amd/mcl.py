@@ -325,9 +325,11 @@ class RND2D(Motivator):
         self.buffer_length = 0
 
     def _fused_train(self, obs, reward, bonus_out, stream):
-        """Bonus + gradient in one HIP pass (carle_rnd2d_train_*): RND2D proper, 64x64 binary obs.
-        Returns False when the fused kernel does not apply (the caller then retains the obs)."""
-        if type(self) is not RND2D:
+        """Bonus + gradient in one HIP pass (carle_rnd2d_train_* / carle_ae2d_train_*): 64x64
+        binary observations.  Returns False when the fused kernel does not apply (the caller then
+        retains the observation for the autograd replay)."""
+        is_ae = type(self) is AE2D
+        if not is_ae and type(self) is not RND2D:
             return False
         o, binary = self._obs(obs, allow_packed=True)
         if not binary or o.shape[2] != 64 or (o.dtype != torch.int64 and o.shape[3] != 64):
@@ -335,21 +337,27 @@ class RND2D(Motivator):
         from . import _lib
         lib = _lib.load()
         dev, n = o.device, o.shape[0]
-        pb, rb = self._pred_blob.get(dev), self._rand_blob.get(dev)
-        need = lib.carle_rnd2d_workspace_floats(n, 64, 64)
+        pb = self._pred_blob.get(dev)
+        rb = None if is_ae else self._rand_blob.get(dev)
+        need = (lib.carle_ae2d_workspace_floats if is_ae else lib.carle_rnd2d_workspace_floats)(n, 64, 64)
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, dtype=torch.float32, device=dev)
             self._tables_key = None
-        pneed = lib.carle_rnd2d_train_partial_floats(n)
+        pneed = (lib.carle_ae2d_train_partial_floats if is_ae else lib.carle_rnd2d_train_partial_floats)(n)
         if self._partial is None or self._partial.numel() < pneed or self._partial.device != dev:
             self._partial = torch.empty(pneed, dtype=torch.float32, device=dev)
         if self._grad is None or self._grad.device != dev:
             self._grad = torch.zeros(pb.numel(), dtype=torch.float32, device=dev)
-        versions = (self._pred_blob.version, self._rand_blob.version)
+        versions = (self._pred_blob.version,) if is_ae else (self._pred_blob.version, self._rand_blob.version)
         valid = self._tables_key == (id(self._ws), versions)
-        grad_scale = 2.0 / (self.rnd_dim * n * self.batch_size)
-        hip.rnd2d_train(o, pb, rb, self._ws, self._partial, self._grad, bonus_out, reward,
-                        self.reward_scale, grad_scale, valid, stream)
+        if is_ae:
+            grad_scale = 2.0 / (64 * 64 * n * self.batch_size)
+            hip.ae2d_train(o, pb, self._ws, self._partial, self._grad, bonus_out, reward,
+                           self.reward_scale, grad_scale, valid, stream)
+        else:
+            grad_scale = 2.0 / (self.rnd_dim * n * self.batch_size)
+            hip.rnd2d_train(o, pb, rb, self._ws, self._partial, self._grad, bonus_out, reward,
+                            self.reward_scale, grad_scale, valid, stream)
         self._tables_key = (id(self._ws), versions)
         self._grad_used = True
         return True

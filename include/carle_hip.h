@@ -185,6 +185,18 @@ int carle_rnd2d_train_b1(const uint64_t *obs, int64_t n, int h, int w, const flo
                          float *bonus, float *reward_accum, float reward_scale, float grad_scale,
                          int flags, void *stream);
 
+/* The same for AE2D (carle/mcl.py:504-547): grad[0..164) accumulates
+ * d/dtheta [ grad_scale/2 * sum_i sum_hw (obs_i - decoder(obs_i))^2 ]; grad_scale = 2/(H*W*N*batch_size). */
+int64_t carle_ae2d_train_partial_floats(int64_t n);
+int carle_ae2d_train_f32(const float *obs, int64_t n, int h, int w, const float *params,
+                         float *workspace, float *partial, float *grad, float *bonus,
+                         float *reward_accum, float reward_scale, float grad_scale, int flags,
+                         void *stream);
+int carle_ae2d_train_b1(const uint64_t *obs, int64_t n, int h, int w, const float *params,
+                        float *workspace, float *partial, float *grad, float *bonus,
+                        float *reward_accum, float reward_scale, float grad_scale, int flags,
+                        void *stream);
+
 /* AE2D.get_bonus (carle/mcl.py:436-443,504-512): bonus[i] = mean_{h,w} (obs_i - decoder(obs_i))^2.
  * recon_out: optional (N,1,H,W) reconstruction, may be NULL. */
 int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w);

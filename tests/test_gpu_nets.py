@@ -328,3 +328,32 @@ def test_fused_training_window_updates_like_autograd():
     assert fused.updates == replay.updates == 2
     for (k, a), (_, b) in zip(fused.state_dict().items(), replay.state_dict().items()):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("n,packed", [(1, False), (4, False), (19, True), (600, False)])
+def test_fused_ae_gradient_matches_autograd(n, packed):
+    """carle_ae2d_train_*: gradient of mean_n mean_hw (obs - decoder)^2 / batch_size vs autograd."""
+    from carle_amd import hip
+    torch.manual_seed(90 + n)
+    env, rnd, ae = _stack(64, n)
+    ae.reset()
+    ae.eval()
+    ae.assume_binary_obs = True
+    ae.batch_size = 4
+    g = (torch.rand(n, 1, 64, 64, device="cuda") < 0.35).float()
+    obs = hip.pack_f32_b1(g) if packed else g
+    expected_bonus = ae.get_bonus_only(g).clone()
+    bonus = torch.empty(n, device="cuda")
+    reward = torch.zeros(n, 1, device="cuda")
+    for rep in range(2):
+        assert ae._fused_train(obs, reward, bonus, None)
+    np.testing.assert_allclose(bonus.cpu().numpy(), expected_bonus.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(reward.cpu().numpy()[:, 0], 2 * expected_bonus.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    ae.predictor.zero_grad()
+    loss = torch.mean(ae._torch_loss(g)) / ae.batch_size * 2.0
+    loss.backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in ae.predictor.parameters()]).cpu().numpy()
+    got = ae._grad.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert scale > 0
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * scale + 1e-9)
