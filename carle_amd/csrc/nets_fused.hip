@@ -949,7 +949,7 @@ __global__ __launch_bounds__(64) void ae_train64_kernel(
     float *__restrict__ reward, float reward_scale, float grad_scale, float *__restrict__ partial,
     int64_t n) {
     __shared__ float4 s_lut[512];
-    __shared__ float s_a1[4 * kA1Plane], s_d1[4 * kA1Plane];
+    __shared__ float s_a1[4 * kA1Plane], s_dz2[2 * kA1Plane];   // s_dz2: conv2-output gradient map
     __shared__ float s_a2[2 * kA2Plane], s_d2[2 * kA2Plane];
     __shared__ float s_a3[kA1Plane], s_d3[kA1Plane];
 
@@ -1022,8 +1022,8 @@ __global__ __launch_bounds__(64) void ae_train64_kernel(
         // ---- zero the gradient planes of this grid
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 *d1 = reinterpret_cast<float4 *>(s_d1);
-            for (int i = lane; i < kA1Plane; i += 64) d1[i] = z;                // 4 planes = kA1Plane float4
+            float4 *d1 = reinterpret_cast<float4 *>(s_dz2);
+            for (int i = lane; i < kA1Plane / 2; i += 64) d1[i] = z;            // 2 planes = kA1Plane/2 float4
             float4 *d2 = reinterpret_cast<float4 *>(s_d2);
             for (int i = lane; i < kA2Plane / 2; i += 64) d2[i] = z;           // 2 planes
             float4 *d3 = reinterpret_cast<float4 *>(s_d3);
@@ -1238,15 +1238,17 @@ __global__ __launch_bounds__(64) void ae_train64_kernel(
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- 2x2 pool arg-max + relu gate of A2, conv2 backward (A1 planes in LDS)
+        // ---- 2x2 pool arg-max + relu gate of A2, conv2 weight gradients (A1 planes in LDS); the
+        //      gradient w.r.t. the conv2 outputs goes to a sparse 32x32 map (one entry per 2x2 block)
 #pragma unroll
         for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float gz = on2[oc][t] ? s_d2[oc * kA2Plane + (4 * q + t + 1) * kA2Stride + k + 1] : 0.0f;
                 gb2[oc] += gz;
-                // conv2 output (2a+dy, 2k+dx) with a = 4q+t: padded A1 origin row 8q+2t+dy, col 2k+dx
+                // conv2 output (Y, X) = (2a+dy, 2k+dx), a = 4q+t: padded A1 origin row 8q+2t+dy, col 2k+dx
                 const int base = (8 * q + 2 * t + (am2[oc][t] >> 1)) * kA1Stride + 2 * k + (am2[oc][t] & 1);
+                s_dz2[oc * kA1Plane + base + kA1Stride + 1] = gz;          // padded (Y+1, X+1)
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
@@ -1255,27 +1257,50 @@ __global__ __launch_bounds__(64) void ae_train64_kernel(
                         for (int kx = 0; kx < 3; ++kx) {
                             const int o = cc * kA1Plane + base + ky * kA1Stride + kx;
                             gw2[(oc * 4 + cc) * 9 + ky * 3 + kx] = fmaf(gz, s_a1[o], gw2[(oc * 4 + cc) * 9 + ky * 3 + kx]);
-                            atomicAdd(&s_d1[o], w2[(oc * 4 + cc) * 9 + ky * 3 + kx] * gz);
                         }
             }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- 2x2 pool arg-max pattern + relu gate of A1, conv1 weight gradients
+        // ---- dA1 by gathering the conv2-output gradients (transposed convolution), then the
+        //      2x2 pool arg-max pattern + relu gate of A1 and the conv1 weight gradients
+        {
+            float dzp[2][10][4];                      // map rows 8q-1..8q+8, cols 2k-1..2k+2 (padded)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+            for (int oc = 0; oc < 2; ++oc) {
+                const float *pl = s_dz2 + oc * kA1Plane + (8 * q) * kA1Stride + 2 * k;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = (8 * q + j + 1) * kA1Stride + 2 * k + i + 1;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const float gz = s_a1[cc * kA1Plane + off] > 0.0f ? s_d1[cc * kA1Plane + off] : 0.0f;
-                    const uint32_t pt = cc < 3 ? (patlo[j][i] >> (9 * cc)) & 0x1FFu : pathi[j][i];
-                    gb1[cc] += gz;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t)
-                        gw1[cc * 9 + t] = fmaf(gz, (float)((pt >> t) & 1u), gw1[cc * 9 + t]);
+                for (int r = 0; r < 10; ++r) {
+                    const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
+                    const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
+                    dzp[oc][r][0] = lo.x; dzp[oc][r][1] = lo.y; dzp[oc][r][2] = hi.x; dzp[oc][r][3] = hi.y;
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int off = (8 * q + j + 1) * kA1Stride + 2 * k + i + 1;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        // A1 position P receives w2[oc][cc][ky][kx] * dz2[oc][P - k + 1]; local map
+                        // index of output row (8q+j) - ky + 1 is j + 2 - ky, column i + 2 - kx
+                        float d = 0.0f;
+#pragma unroll
+                        for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                                for (int kx = 0; kx < 3; ++kx)
+                                    d = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx], dzp[oc][j + 2 - ky][i + 2 - kx], d);
+                        const float gz = s_a1[cc * kA1Plane + off] > 0.0f ? d : 0.0f;
+                        const uint32_t pt = cc < 3 ? (patlo[j][i] >> (9 * cc)) & 0x1FFu : pathi[j][i];
+                        gb1[cc] += gz;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t)
+                            gw1[cc * 9 + t] = fmaf(gz, (float)((pt >> t) & 1u), gw1[cc * 9 + t]);
+                    }
+                }
+        }
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -1302,7 +1327,7 @@ __global__ __launch_bounds__(64) void ae_train64_kernel(
 }
 
 int ae2d_train64_rows(int64_t n) {
-    int64_t rows = n < 512 ? n : 512;
+    int64_t rows = n < 768 ? n : 768;                  // 3 one-wave workgroups (53 KiB LDS) per CU
     return (int)(rows < 1 ? 1 : rows);
 }
 
