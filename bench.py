@@ -38,9 +38,10 @@ def parse():
     ap.add_argument("--instances", type=int, default=4096, help="instances PER GPU")
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--rule", default="B3/S23")
-    ap.add_argument("--format", default="f32", choices=["f32", "b1"],
+    ap.add_argument("--format", default="f32", choices=["f32", "u8", "b1"],
                     help="grid storage: f32 = the reference's drop-in format (headline), "
-                         "b1 = bit-packed state and actions (secondary configurations)")
+                         "u8 = uint8 state and actions, b1 = bit-packed state and actions "
+                         "(secondary configurations)")
     ap.add_argument("--action-ring", type=int, default=6,
                     help="number of distinct device action buffers cycled through")
     ap.add_argument("--agent", default="ring", choices=["ring", "random", "fused"],
@@ -136,6 +137,7 @@ def main():
     n, size = args.instances, args.size
     asize = min(64, size)
     packed = args.format == "b1"
+    bytes_fmt = args.format == "u8"
     env = CARLE(width=size, height=size, action_width=asize, action_height=asize, instances=n,
                 device=str(dev), storage=args.format)
     env.rules_from_string(args.rule)
@@ -147,6 +149,8 @@ def main():
             for _ in range(args.action_ring)]
     if packed:                      # actions handed over already packed (1 bit per toggle)
         ring = [hip.pack_f32_b1(a) for a in ring]
+    elif bytes_fmt:                 # ... or as uint8 (1 byte per toggle)
+        ring = [a.to(torch.uint8) for a in ring]
 
     # reward statistics shared by all shards: local moments every step (HIP kernel), one 24-B
     # all-gather per rank every --stats-every steps (the only collective of the path)
@@ -223,7 +227,7 @@ def main():
         dt = float(t.item())
     pop = float(env.universe.sum().item())      # keeps the result live / sanity
     state = env.universe_bits if packed else env.universe
-    step_fn = hip.ca_step_b1 if packed else hip.ca_step_f32
+    step_fn = hip.ca_step_b1 if packed else hip.ca_step_u8 if bytes_fmt else hip.ca_step_f32
 
     # ---- roofline of the dominant kernel: back-to-back launches of the step kernel alone,
     # HIP events on the launch stream (torch's current stream is the stream the ABI is given)
@@ -242,14 +246,19 @@ def main():
     e1.record()
     torch.cuda.synchronize(dev)
     k_ms = e0.elapsed_time(e1) / reps
-    alg_bytes = n * (size * size * 8 + asize * asize * 4) if not packed else \
-        n * (size * size * 2 + asize * asize) // 8
+    if packed:
+        alg_bytes = n * (size * size * 2 + asize * asize) // 8
+    elif bytes_fmt:
+        alg_bytes = n * (size * size * 2 + asize * asize)
+    else:
+        alg_bytes = n * (size * size * 8 + asize * asize * 4)
     achieved = alg_bytes / (k_ms * 1e-3)
 
+    cells = "carle::U8Cells" if bytes_fmt else "carle::F32Cells"
     if rank == 0:
         out = {
             "metric": "env-steps/sec at N=4096x64x64 (B3/S23, fp32 drop-in grids, action every step)"
-                      if not packed and size == 64 else
+                      if args.format == "f32" and size == 64 else
                       f"env-steps/sec at N={n}x{size}x{size} ({args.rule}, {args.format} grids, action every step)",
             "value": world * n * args.steps / dt,
             "unit": "env-steps/s",
@@ -260,7 +269,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if not packed else "u64 bit-planes",
+            "dtype": "u64 bit-planes" if packed else args.format,
             "data": "synthetic",
             "config": {"workload": f"{cfg_name(args, n, size)}: {args.rule} N={n}/GPU {size}x{size} "
                                    f"{args.format} grids, Bernoulli(0.1) {asize}x{asize} {args.format} action per step "
@@ -275,10 +284,11 @@ def main():
             "cell_updates_per_s": world * n * args.steps * size * size / dt,
             "final_population_rank0": pop,
             "roofline": {"bound": "hbm", "kernel": ("ca_step_b1_kernel" if packed else
-                                    "ca_step_f32_64_kernel<true>" if size == 64 else
-                                    "ca_step_f32_wide_kernel<true>"),
+                                    f"ca_step_64_kernel<{cells}, {cells}, true, ...>" if size == 64 else
+                                    f"ca_step_wide_kernel<{cells}, {cells}, true, ...>"),
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, **(pmc_traffic(size, n) if not packed else {"traffic": None}),
+                         "frac": achieved / HBM_PEAK,
+                         **(pmc_traffic(size, n) if args.format == "f32" else {"traffic": None}),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": k_ms * 1e3, "launches_timed": reps},
         }

@@ -133,6 +133,20 @@ extern "C" int carle_env_step_b1(const uint64_t *u_in, const uint64_t *action, u
                            action != nullptr, stream);
 }
 
+extern "C" int carle_ca_step_u8(const uint8_t *, const void *, int, uint8_t *, int64_t, int, int, int, int,
+                                uint32_t, int32_t *, int, void *);
+
+// Whole CARLE.step on uint8 state (fp32 or uint8 action): step kernel + epilogue, one call.
+extern "C" int carle_env_step_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out,
+                                 float *reward, int64_t n, int h, int w, int ah, int aw, uint32_t rule,
+                                 int32_t *status, int slot, int publish_flags, void *stream) {
+    if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_u8: status is NULL");
+    if (int e = carle_ca_step_u8(u_in, action, action_fmt, u_out, n, h, w, ah, aw, rule,
+                                 publish_flags ? status : nullptr, slot, stream))
+        return e;
+    return carle_ca_finish(u_out, (int64_t)n * h * w, reward, n, status, slot, action != nullptr, stream);
+}
+
 extern "C" int carle_ca_step_f32_rand(const float *, float *, int64_t, int, int, int, int, uint32_t, float,
                                       uint64_t, uint64_t, float *, int32_t *, int, void *);
 

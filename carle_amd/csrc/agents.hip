@@ -4,7 +4,7 @@
 // wrappers copy the action to the device every step (carle/agents.py:35-42, carle/mcl.py:400):
 // 64 MiB of PCIe traffic per step at N=4096.  Here the toggles are generated where they are used:
 // a stand-alone Bernoulli kernel (this file) and a fused variant inside the 64x64 step kernel
-// (ca_step_f32.hip) that never materialises the action at all.
+// (ca_step_cells.hip) that never materialises the action at all.
 #include "common.hpp"
 #include "philox.hpp"
 

@@ -1,4 +1,5 @@
-// ca_step_f32.hip -- one CA generation on fp32 (N,1,H,W) grids: the reference's own format.
+// ca_step_cells.hip -- one CA generation on cell-per-element (N,1,H,W) grids: fp32 (the
+// reference's own format) and uint8 (CARLE_FMT_U8: the same layout at 1 B per cell).
 //
 // Replaces CARLE.apply_action + the update branch of CARLE.step (carle/env.py:150-182,219-229):
 // ~19 ATen launches and ~15 full-grid passes become ONE pass: read state (+ action), write state.
@@ -14,6 +15,10 @@
 //   - 3x3 count by bit-sliced adders, rule as a mux tree with the 18 rule bits in SGPRs
 //     (ca_bits.hpp); no MFMA: the stencil is not a contraction.
 // Algorithmic HBM traffic: 4 B read + 4 B written per cell (+ 4 B per action cell).
+//
+// uint8 grids use the SAME lane <-> cell mapping with dword (4 cells) instead of dwordx4 accesses:
+// every kernel here is a template over the cell traits of the state (F32Cells / U8Cells) and of
+// the action (fp32 as the reference's agents produce it, or uint8); 1 B + 1 B per cell update.
 //
 // Generic path (any even square size): one thread per cell, neighbours through L1/L2.
 #include "ca_bits.hpp"
@@ -41,35 +46,6 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t x, int src_lane) {
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int s) { return (x << s) | (x >> (64 - s)); }
 __device__ __forceinline__ uint64_t rotr64(uint64_t x, int s) { return (x >> s) | (x << (64 - s)); }
 
-// Per-lane summary of the action elements a lane has seen, for the two whole-batch predicates
-// of CARLE.step: any element non-zero (env.py:191), every element == 1.0 (env.py:208).
-struct ActionSeen {
-    uint32_t all_and = 0xFFFFFFFFu, all_or = 0u;
-    __device__ __forceinline__ void add(const uint4 &a) {
-        all_and &= a.x & a.y & a.z & a.w;
-        all_or |= a.x | a.y | a.z | a.w;
-    }
-    __device__ __forceinline__ void add(uint32_t a) { all_and &= a; all_or |= a; }
-    __device__ __forceinline__ bool any_nonzero() const { return (all_or & 0x7FFFFFFFu) != 0; }
-    __device__ __forceinline__ bool not_all_ones() const {
-        const bool seen = !(all_and == 0xFFFFFFFFu && all_or == 0u);
-        return seen && (all_and != kOneBits || all_or != kOneBits);
-    }
-};
-
-__device__ __forceinline__ void publish_flags(const ActionSeen &s, int32_t *status, int slot) {
-    if (status == nullptr) return;
-    const bool any = __ballot(s.any_nonzero()) != 0ull;
-    const bool notone = __ballot(s.not_all_ones()) != 0ull;
-    if ((threadIdx.x & 63) == 0) {      // every writer stores the same value: benign
-        if (any) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
-        if (notone) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// 64x64 fast path: one wavefront per grid
-// ---------------------------------------------------------------------------------------------
 template <bool NT>
 __device__ __forceinline__ uint4 ld16(const uint4 *p) {
     if (NT) {
@@ -94,6 +70,91 @@ __device__ __forceinline__ void st16(uint4 *p, const uint4 &v) {
     }
 }
 
+// Per-lane summary of the action elements a lane has seen, for the two whole-batch predicates
+// of CARLE.step: any element non-zero (env.py:191), every element == 1 (env.py:208).  Raw bit
+// patterns are folded with AND / OR; the cell traits say what "non-zero" and "one" look like.
+struct ActionSeen {
+    uint32_t all_and = 0xFFFFFFFFu, all_or = 0u;
+    __device__ __forceinline__ void add(const uint4 &a) {
+        all_and &= a.x & a.y & a.z & a.w;
+        all_or |= a.x | a.y | a.z | a.w;
+    }
+    __device__ __forceinline__ void add(uint32_t a) { all_and &= a; all_or |= a; }
+    template <class A>
+    __device__ __forceinline__ bool any_nonzero() const { return (all_or & A::kNonzeroMask) != 0; }
+    template <class A>
+    __device__ __forceinline__ bool not_all_ones() const {
+        const bool seen = !(all_and == 0xFFFFFFFFu && all_or == 0u);
+        return seen && (all_and != A::kOnes || all_or != A::kOnes);
+    }
+};
+
+// Cell traits: how four horizontally adjacent cells travel between memory and a 4-bit nibble.
+struct F32Cells {
+    using T = float;
+    using Quad = uint4;
+    static constexpr uint32_t kOnes = kOneBits;             // raw pattern of an all-ones word
+    static constexpr uint32_t kNonzeroMask = 0x7FFFFFFFu;   // -0.0 is zero (env.py:182 truthiness)
+    template <bool NT>
+    static __device__ __forceinline__ Quad load(const T *p) { return ld16<NT>(reinterpret_cast<const uint4 *>(p)); }
+    static __device__ __forceinline__ uint32_t nibble(const Quad &v) { return nibble_of(v); }
+    template <bool NT>
+    static __device__ __forceinline__ void store(T *p, uint32_t nib) {
+        uint4 o4;
+        o4.x = (nib & 1u) ? kOneBits : 0u;
+        o4.y = (nib & 2u) ? kOneBits : 0u;
+        o4.z = (nib & 4u) ? kOneBits : 0u;
+        o4.w = (nib & 8u) ? kOneBits : 0u;
+        st16<NT>(reinterpret_cast<uint4 *>(p), o4);
+    }
+    static __device__ __forceinline__ uint32_t alive(T v) { return nonzero_bit(__float_as_uint(v)); }
+    static __device__ __forceinline__ uint32_t raw(T v) { return __float_as_uint(v); }
+    static __device__ __forceinline__ T make(uint32_t bit) { return bit ? 1.0f : 0.0f; }
+};
+
+struct U8Cells {
+    using T = uint8_t;
+    using Quad = uint32_t;
+    static constexpr uint32_t kOnes = 0x01010101u;
+    static constexpr uint32_t kNonzeroMask = 0xFFFFFFFFu;
+    template <bool NT>
+    static __device__ __forceinline__ Quad load(const T *p) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+        return NT ? __builtin_nontemporal_load(q) : *q;
+    }
+    // byte j non-zero -> bit j: high bit of every non-zero byte, then a multiply gathers them
+    static __device__ __forceinline__ uint32_t nibble(Quad x) {
+        const uint32_t t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+        return (((t >> 7) * 0x01020408u) >> 24) & 0xFu;
+    }
+    template <bool NT>
+    static __device__ __forceinline__ void store(T *p, uint32_t nib) {
+        const uint32_t v = ((nib & 0xFu) * 0x00204081u) & 0x01010101u;     // bit j -> byte j
+        uint32_t *q = reinterpret_cast<uint32_t *>(p);
+        if (NT) __builtin_nontemporal_store(v, q);
+        else *q = v;
+    }
+    static __device__ __forceinline__ uint32_t alive(T v) { return v != 0; }
+    static __device__ __forceinline__ uint32_t raw(T v) { return (uint32_t)v * 0x01010101u; }
+    static __device__ __forceinline__ T make(uint32_t bit) { return (T)bit; }
+};
+__device__ __forceinline__ void see(ActionSeen &s, const uint4 &a) { s.add(a); }
+__device__ __forceinline__ void see(ActionSeen &s, uint32_t a) { s.add(a); }
+
+template <class A>
+__device__ __forceinline__ void publish_flags(const ActionSeen &s, int32_t *status, int slot) {
+    if (status == nullptr) return;
+    const bool any = __ballot(s.any_nonzero<A>()) != 0ull;
+    const bool notone = __ballot(s.not_all_ones<A>()) != 0ull;
+    if ((threadIdx.x & 63) == 0) {      // every writer stores the same value: benign
+        if (any) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
+        if (notone) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 64x64 fast path: one wavefront per grid
+// ---------------------------------------------------------------------------------------------
 // parameters of the fused device-side random agent (RAND_ACT instantiation): toggles are drawn
 // in-kernel with the counter layout of philox.hpp instead of being read from an action tensor
 struct RandAct {
@@ -106,22 +167,24 @@ struct RandAct {
     uint64_t *patch_out = nullptr;
 };
 
-template <bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256, bool RAND_ACT = false>
-__global__ __launch_bounds__(BLOCK) void ca_step_f32_64_kernel(
-    const uint4 *__restrict__ u_in, const float *__restrict__ act, uint4 *__restrict__ u_out,
-    int64_t n, int aw, uint32_t rule, int32_t *__restrict__ status, int slot, RandAct ra = RandAct()) {
+template <class C, class A, bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256,
+          bool RAND_ACT = false>
+__global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
+    const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
+    typename C::T *__restrict__ u_out, int64_t n, int aw, uint32_t rule, int32_t *__restrict__ status,
+    int slot, RandAct ra = RandAct()) {
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (g >= n) return;                              // wave-uniform
     const int q = lane >> 4, k = lane & 15;
-    const uint4 *gin = u_in + g * 1024 + lane;       // 4096 floats = 1024 x 16 B per grid
+    const typename C::T *gin = u_in + g * 4096 + 4 * lane;   // 1024 quads per grid, 64 per load
 
-    uint4 v[16];
+    typename C::Quad v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = ld16<NT_LD>(gin + i * 64);
+    for (int i = 0; i < 16; ++i) v[i] = C::template load<NT_LD>(gin + i * 256);
     uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c |= (uint64_t)nibble_of(v[i]) << (4 * i);
+    for (int i = 0; i < 16; ++i) c |= (uint64_t)C::nibble(v[i]) << (4 * i);
 
     if (HAS_ACT) {
         // window offset o = (64-aw)/2 is a multiple of 4 (host guarantees aw % 8 == 0), so a
@@ -129,7 +192,7 @@ __global__ __launch_bounds__(BLOCK) void ca_step_f32_64_kernel(
         const int o = (64 - aw) >> 1;
         const int ax = 4 * k - o;
         const bool col_in = ax >= 0 && ax < aw;
-        const float *abase = act + g * (int64_t)aw * aw + ax;
+        const typename A::T *abase = act + g * (int64_t)aw * aw + ax;
         ActionSeen seen;
         uint64_t tog = 0;
 #pragma unroll
@@ -149,14 +212,14 @@ __global__ __launch_bounds__(BLOCK) void ca_step_f32_64_kernel(
                     if (ra.action_out)
                         *reinterpret_cast<uint4 *>(ra.action_out + (g * aw + ay) * (int64_t)aw + ax) = a;
                 } else {
-                    const uint4 a = ld16<NT_LD>(reinterpret_cast<const uint4 *>(abase + (int64_t)ay * aw));
-                    seen.add(a);
-                    tog |= (uint64_t)nibble_of(a) << (4 * i);
+                    const typename A::Quad a = A::template load<NT_LD>(abase + (int64_t)ay * aw);
+                    see(seen, a);
+                    tog |= (uint64_t)A::nibble(a) << (4 * i);
                 }
             }
         }
         c ^= tog;                                    // toggle, env.py:182
-        publish_flags(seen, status, slot);
+        publish_flags<A>(seen, status, slot);
     }
 
     // horizontal: west/east neighbour of every cell
@@ -177,17 +240,9 @@ __global__ __launch_bounds__(BLOCK) void ca_step_f32_64_kernel(
 
     const uint64_t nxt = apply_rule(neighbour_count(a0, a1, b0, b1, p0, p1), c, rule);
 
-    uint4 *gout = u_out + g * 1024 + lane;
+    typename C::T *gout = u_out + g * 4096 + 4 * lane;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t nib = (uint32_t)(nxt >> (4 * i));
-        uint4 o4;
-        o4.x = (nib & 1u) ? kOneBits : 0u;
-        o4.y = (nib & 2u) ? kOneBits : 0u;
-        o4.z = (nib & 4u) ? kOneBits : 0u;
-        o4.w = (nib & 8u) ? kOneBits : 0u;
-        st16<NT_ST>(gout + i * 64, o4);
-    }
+    for (int i = 0; i < 16; ++i) C::template store<NT_ST>(gout + i * 256, (uint32_t)(nxt >> (4 * i)) & 0xFu);
     if (ra.patch_out) ra.patch_out[g * 64 + lane] = nxt;
 }
 
@@ -216,10 +271,11 @@ __device__ __forceinline__ void horiz_neighbours(uint64_t c, uint64_t cw, uint64
     est = ((c >> 1) & 0x7777777777777777ull) | ((ce << 3) & 0x8888888888888888ull);
 }
 
-template <bool HAS_ACT, int NS, int RW>
-__global__ __launch_bounds__(64) void ca_step_f32_wide_kernel(
-    const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out,
-    int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot) {
+template <class C, class A, bool HAS_ACT, int NS, int RW>
+__global__ __launch_bounds__(64) void ca_step_wide_kernel(
+    const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
+    typename C::T *__restrict__ u_out, int64_t n, int ah, int aw, uint32_t rule,
+    int32_t *__restrict__ status, int slot) {
     constexpr int W = WideGeom<NS, RW>::kW, H = W, R = WideGeom<NS, RW>::kR;
     constexpr int kStrips = H / R;
     const int k = threadIdx.x;                       // lane = column quad
@@ -230,7 +286,7 @@ __global__ __launch_bounds__(64) void ca_step_f32_wide_kernel(
     const int64_t g = wid / kStrips;
     const int r0 = (int)(wid % kStrips) * R;
     if (g >= n) return;
-    const float *gin = u_in + g * (int64_t)H * W;
+    const typename C::T *gin = u_in + g * (int64_t)H * W;
     const int rt = (r0 + H - 1) % H, rb = (r0 + R) % H;      // halo rows (torus in y)
 
     uint64_t c[NS][RW];
@@ -239,19 +295,19 @@ __global__ __launch_bounds__(64) void ca_step_f32_wide_kernel(
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
         for (int m = 0; m < RW; ++m) {
-            uint4 v[16];
+            typename C::Quad v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                v[i] = ld16<true>(reinterpret_cast<const uint4 *>(gin + (int64_t)(r0 + 16 * m + i) * W + 256 * s) + k);
+                v[i] = C::template load<true>(gin + (int64_t)(r0 + 16 * m + i) * W + 256 * s + 4 * k);
             uint64_t acc = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc |= (uint64_t)nibble_of(v[i]) << (4 * i);
+            for (int i = 0; i < 16; ++i) acc |= (uint64_t)C::nibble(v[i]) << (4 * i);
             c[s][m] = acc;
         }
         // halo rows are re-read by the neighbouring strip: default cache policy keeps them in L2
-        const uint4 vt = *(reinterpret_cast<const uint4 *>(gin + (int64_t)rt * W + 256 * s) + k);
-        const uint4 vb = *(reinterpret_cast<const uint4 *>(gin + (int64_t)rb * W + 256 * s) + k);
-        halo[s] = nibble_of(vt) | (nibble_of(vb) << 4);
+        const typename C::Quad vt = C::template load<false>(gin + (int64_t)rt * W + 256 * s + 4 * k);
+        const typename C::Quad vb = C::template load<false>(gin + (int64_t)rb * W + 256 * s + 4 * k);
+        halo[s] = C::nibble(vt) | (C::nibble(vb) << 4);
     }
 
     if (HAS_ACT) {
@@ -260,7 +316,7 @@ __global__ __launch_bounds__(64) void ca_step_f32_wide_kernel(
         const bool touches = (r0 + R > oy && r0 < oy + ah) || (rt >= oy && rt < oy + ah) ||
                              (rb >= oy && rb < oy + ah);
         if (touches) {
-            const float *ga = act + g * (int64_t)ah * aw;
+            const typename A::T *ga = act + g * (int64_t)ah * aw;
             ActionSeen seen;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -273,20 +329,20 @@ __global__ __launch_bounds__(64) void ca_step_f32_wide_kernel(
                     for (int i = 0; i < 16; ++i) {
                         const int ay = r0 + 16 * m + i - oy;
                         if (col_in && ay >= 0 && ay < ah) {
-                            const uint4 a = ld16<true>(reinterpret_cast<const uint4 *>(ga + (int64_t)ay * aw + ax));
-                            seen.add(a);
-                            tog |= (uint64_t)nibble_of(a) << (4 * i);
+                            const typename A::Quad a = A::template load<true>(ga + (int64_t)ay * aw + ax);
+                            see(seen, a);
+                            tog |= (uint64_t)A::nibble(a) << (4 * i);
                         }
                     }
                     c[s][m] ^= tog;
                 }
                 const int ayt = rt - oy, ayb = rb - oy;
                 if (col_in && ayt >= 0 && ayt < ah)
-                    halo[s] ^= nibble_of(*reinterpret_cast<const uint4 *>(ga + (int64_t)ayt * aw + ax));
+                    halo[s] ^= A::nibble(A::template load<false>(ga + (int64_t)ayt * aw + ax));
                 if (col_in && ayb >= 0 && ayb < ah)
-                    halo[s] ^= nibble_of(*reinterpret_cast<const uint4 *>(ga + (int64_t)ayb * aw + ax)) << 4;
+                    halo[s] ^= A::nibble(A::template load<false>(ga + (int64_t)ayb * aw + ax)) << 4;
             }
-            publish_flags(seen, status, slot);
+            publish_flags<A>(seen, status, slot);
         } else if (status != nullptr && k == 0) {
             // a strip outside the window sees no action element; the flags describe the whole
             // action, which the in-window strips publish.  Nothing to do.
@@ -327,7 +383,7 @@ __global__ __launch_bounds__(64) void ca_step_f32_wide_kernel(
         }
     }
 
-    float *gout = u_out + g * (int64_t)H * W;
+    typename C::T *gout = u_out + g * (int64_t)H * W;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
@@ -342,40 +398,36 @@ __global__ __launch_bounds__(64) void ca_step_f32_wide_kernel(
             const uint64_t nx = apply_rule(neighbour_count(up0, up1, dn0, dn1, p0[s][m], p1[s][m]),
                                            c[s][m], rule);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint32_t nib = (uint32_t)(nx >> (4 * i));
-                uint4 o4;
-                o4.x = (nib & 1u) ? kOneBits : 0u;
-                o4.y = (nib & 2u) ? kOneBits : 0u;
-                o4.z = (nib & 4u) ? kOneBits : 0u;
-                o4.w = (nib & 8u) ? kOneBits : 0u;
-                st16<true>(reinterpret_cast<uint4 *>(gout + (int64_t)(r0 + 16 * m + i) * W + 256 * s) + k, o4);
-            }
+            for (int i = 0; i < 16; ++i)
+                C::template store<true>(gout + (int64_t)(r0 + 16 * m + i) * W + 256 * s + 4 * k,
+                                        (uint32_t)(nx >> (4 * i)) & 0xFu);
         }
     }
 }
 
-template <int NS, int RW>
-static int launch_wide(const float *u_in, const float *action, float *u_out, int64_t n, int ah,
-                       int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
+template <class C, class A, int NS, int RW>
+static int launch_wide(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
+                       int64_t n, int ah, int aw, uint32_t rule, int32_t *status, int slot,
+                       hipStream_t s) {
     const int64_t wgs = n * (WideGeom<NS, RW>::kW / WideGeom<NS, RW>::kR);
-    if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32: batch too large");
+    if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step: batch too large");
     if (action)
-        hipLaunchKernelGGL((ca_step_f32_wide_kernel<true, NS, RW>), dim3((unsigned)wgs), dim3(64), 0,
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW>), dim3((unsigned)wgs), dim3(64), 0,
                            s, u_in, action, u_out, n, ah, aw, rule, status, slot);
     else
-        hipLaunchKernelGGL((ca_step_f32_wide_kernel<false, NS, RW>), dim3((unsigned)wgs), dim3(64), 0,
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, false, NS, RW>), dim3((unsigned)wgs), dim3(64), 0,
                            s, u_in, action, u_out, n, 0, 0, rule, status, slot);
-    return check_launch("carle_ca_step_f32(wide)");
+    return check_launch("carle_ca_step(wide)");
 }
 
 // ---------------------------------------------------------------------------------------------
 // generic path: any even square grid, one thread per cell
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ca_step_f32_generic_kernel(
-    const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out,
-    int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *__restrict__ status,
-    int slot) {
+template <class C, class A>
+__global__ __launch_bounds__(256) void ca_step_generic_kernel(
+    const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
+    typename C::T *__restrict__ u_out, int64_t n, int h, int w, int ah, int aw, uint32_t rule,
+    int32_t *__restrict__ status, int slot) {
     const int64_t cells = n * (int64_t)h * w;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int oy = (h - ah) >> 1, ox = (w - aw) >> 1;
@@ -384,13 +436,12 @@ __global__ __launch_bounds__(256) void ca_step_f32_generic_kernel(
         const int x = (int)(idx % w);
         const int y = (int)((idx / w) % h);
         const int64_t g = idx / ((int64_t)h * w);
-        const float *gu = u_in + g * (int64_t)h * w;
-        const float *ga = act ? act + g * (int64_t)ah * aw : nullptr;
+        const typename C::T *gu = u_in + g * (int64_t)h * w;
+        const typename A::T *ga = act ? act + g * (int64_t)ah * aw : nullptr;
         auto alive = [&](int yy, int xx) -> uint32_t {
-            uint32_t a = nonzero_bit(__float_as_uint(gu[yy * w + xx]));
+            uint32_t a = C::alive(gu[yy * w + xx]);
             const int ay = yy - oy, ax = xx - ox;
-            if (ga && ay >= 0 && ay < ah && ax >= 0 && ax < aw)
-                a ^= nonzero_bit(__float_as_uint(ga[ay * aw + ax]));
+            if (ga && ay >= 0 && ay < ah && ax >= 0 && ax < aw) a ^= A::alive(ga[ay * aw + ax]);
             return a;
         };
         const int ym = y == 0 ? h - 1 : y - 1, yp = y == h - 1 ? 0 : y + 1;
@@ -399,31 +450,30 @@ __global__ __launch_bounds__(256) void ca_step_f32_generic_kernel(
                              alive(y, xp) + alive(yp, xm) + alive(yp, x) + alive(yp, xp);
         const uint32_t c = alive(y, x);
         const uint32_t nxt = (rule >> (c ? cnt : 9 + cnt)) & 1u;
-        u_out[idx] = nxt ? 1.0f : 0.0f;
+        u_out[idx] = C::make(nxt);
         const int ay = y - oy, ax = x - ox;           // this cell owns its own action element
-        if (ga && ay >= 0 && ay < ah && ax >= 0 && ax < aw)
-            seen.add(__float_as_uint(ga[ay * aw + ax]));
+        if (ga && ay >= 0 && ay < ah && ax >= 0 && ax < aw) seen.add(A::raw(ga[ay * aw + ax]));
     }
-    if (act) publish_flags(seen, status, slot);
+    if (act) publish_flags<A>(seen, status, slot);
 }
 
 // ---------------------------------------------------------------------------------------------
 // toggle only (CARLE.apply_action called on its own, carle/env.py:150-182): elementwise
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ca_toggle_f32_kernel(
-    const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out,
-    int64_t n, int h, int w, int ah, int aw) {
+template <class C, class A>
+__global__ __launch_bounds__(256) void ca_toggle_kernel(
+    const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
+    typename C::T *__restrict__ u_out, int64_t n, int h, int w, int ah, int aw) {
     const int64_t cells = n * (int64_t)h * w;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= cells) return;
     const int x = (int)(idx % w);
     const int y = (int)((idx / w) % h);
     const int64_t g = idx / ((int64_t)h * w);
-    uint32_t a = nonzero_bit(__float_as_uint(u_in[idx]));
+    uint32_t a = C::alive(u_in[idx]);
     const int ay = y - ((h - ah) >> 1), ax = x - ((w - aw) >> 1);
-    if (ay >= 0 && ay < ah && ax >= 0 && ax < aw)
-        a ^= nonzero_bit(__float_as_uint(act[(g * ah + ay) * (int64_t)aw + ax]));
-    u_out[idx] = a ? 1.0f : 0.0f;
+    if (ay >= 0 && ay < ah && ax >= 0 && ax < aw) a ^= A::alive(act[(g * ah + ay) * (int64_t)aw + ax]);
+    u_out[idx] = C::make(a);
 }
 
 }  // namespace carle
@@ -434,7 +484,71 @@ namespace carle {
 int ca_step_f32_impl(const float *u_in, const float *action, float *u_out, int64_t n, int h, int w,
                      int ah, int aw, uint32_t rule, int32_t *status, int slot, uint64_t *patch_out,
                      void *stream);
+
+// validation + dispatch shared by the fp32 and uint8 entry points (`who` prefixes error texts)
+template <class C, class A>
+static int ca_step_cells(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
+                         int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status,
+                         int slot, uint64_t *patch_out, void *stream, const char *who) {
+    auto fail = [&](int code, const char *what) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "%s: %s", who, what);
+        return fail_arg(code, buf);
+    };
+    if (n == 0) return 0;                      // empty batch: nothing to launch, pointers may be NULL
+    if (!u_in || !u_out) return fail(CARLE_E_NULL, "u_in/u_out is NULL");
+    if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
+    if (rule >> 18) return fail(CARLE_E_RULE, "rule mask exceeds 18 bits");
+    if (slot != 0 && slot != 1) return fail(CARLE_E_DIMS, "slot must be 0 or 1");
+    if (!aligned16(u_in) || !aligned16(u_out) || (action && !aligned16(action)))
+        return fail(CARLE_E_ALIGN, "pointers must be 16-byte aligned");
+    const size_t bytes = (size_t)n * h * w * sizeof(typename C::T);
+    if (overlap(u_in, bytes, u_out, bytes)) return fail(CARLE_E_ALIAS, "u_in and u_out overlap");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    if (h == 64 && w == 64 && (!action || (aw % 8) == 0)) {
+        // one wavefront per workgroup, non-temporal loads and stores: measured best of the
+        // {plain, nt} x {64,128,256,512}-thread variants (tools/kbench, profiles/r01_kbench_f32_64.txt)
+        if (n > 0x7FFFFFFFll) return fail(CARLE_E_DIMS, "batch too large");
+        const unsigned blocks = (unsigned)n;
+        RandAct ra;
+        ra.patch_out = patch_out;
+        if (action)
+            hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, true, 64>), dim3(blocks), dim3(64), 0,
+                               s, u_in, action, u_out, n, aw, rule, status, slot, ra);
+        else
+            hipLaunchKernelGGL((ca_step_64_kernel<C, A, false, true, true, 64>), dim3(blocks), dim3(64), 0,
+                               s, u_in, action, u_out, n, 0, rule, status, slot, ra);
+        return check_launch(who);
+    }
+    // 256x256 / 512x512: wavefront-per-strip path; needs a 16-byte aligned action window
+    if ((w == 256 || w == 512) && (!action || ((aw % 4) == 0 && ((w - aw) % 8) == 0))) {
+        if (w == 256)
+            return launch_wide<C, A, 1, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
+        return launch_wide<C, A, 2, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
+    }
+    const int64_t cells = n * (int64_t)h * w;
+    const int64_t blocks = (cells + 255) / 256;
+    if (blocks > 0x7FFFFFFFll) return fail(CARLE_E_DIMS, "batch too large");
+    hipLaunchKernelGGL((ca_step_generic_kernel<C, A>), dim3((unsigned)blocks), dim3(256), 0, s, u_in,
+                       action, u_out, n, h, w, action ? ah : 0, action ? aw : 0, rule, status, slot);
+    return check_launch(who);
 }
+
+template <class C, class A>
+static int ca_toggle_cells(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
+                           int64_t n, int h, int w, int ah, int aw, void *stream, const char *who) {
+    if (!u_in || !u_out || !action) return fail_arg(CARLE_E_NULL, "carle_ca_toggle: NULL pointer");
+    if (int e = check_dims(n, h, w, true, ah, aw)) return e;
+    if (n == 0) return 0;
+    const int64_t cells = n * (int64_t)h * w;
+    const int64_t blocks = (cells + 255) / 256;
+    if (blocks > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_toggle: batch too large");
+    hipLaunchKernelGGL((ca_toggle_kernel<C, A>), dim3((unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), u_in, action, u_out, n, h, w, ah, aw);
+    return check_launch(who);
+}
+}  // namespace carle
 
 extern "C" int carle_ca_step_f32(const float *u_in, const float *action, float *u_out, int64_t n,
                                  int h, int w, int ah, int aw, uint32_t rule, int32_t *status,
@@ -446,61 +560,40 @@ extern "C" int carle_ca_step_f32(const float *u_in, const float *action, float *
 int carle::ca_step_f32_impl(const float *u_in, const float *action, float *u_out, int64_t n, int h,
                             int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
                             uint64_t *patch_out, void *stream) {
-    if (n == 0) return 0;                      // empty batch: nothing to launch, pointers may be NULL
-    if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_step_f32: u_in/u_out is NULL");
-    if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
-    if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_ca_step_f32: rule mask exceeds 18 bits");
-    if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32: slot must be 0 or 1");
-    if (!aligned16(u_in) || !aligned16(u_out) || (action && !aligned16(action)))
-        return fail_arg(CARLE_E_ALIGN, "carle_ca_step_f32: pointers must be 16-byte aligned");
-    const size_t bytes = (size_t)n * h * w * sizeof(float);
-    if (overlap(u_in, bytes, u_out, bytes))
-        return fail_arg(CARLE_E_ALIAS, "carle_ca_step_f32: u_in and u_out overlap");
-    if (n == 0) return 0;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    return ca_step_cells<F32Cells, F32Cells>(u_in, action, u_out, n, h, w, ah, aw, rule, status, slot,
+                                             patch_out, stream, "carle_ca_step_f32");
+}
 
-    if (h == 64 && w == 64 && (!action || (aw % 8) == 0)) {
-        // one wavefront per workgroup, non-temporal loads and stores: measured best of the
-        // {plain, nt} x {64,128,256,512}-thread variants (tools/kbench, profiles/r01_kbench.txt)
-        if (n > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32: batch too large");
-        const unsigned blocks = (unsigned)n;
-        RandAct ra;
-        ra.patch_out = patch_out;
-        if (action)
-            hipLaunchKernelGGL((ca_step_f32_64_kernel<true, true, true, 64>), dim3(blocks), dim3(64),
-                               0, s, reinterpret_cast<const uint4 *>(u_in), action,
-                               reinterpret_cast<uint4 *>(u_out), n, aw, rule, status, slot, ra);
-        else
-            hipLaunchKernelGGL((ca_step_f32_64_kernel<false, true, true, 64>), dim3(blocks), dim3(64),
-                               0, s, reinterpret_cast<const uint4 *>(u_in), action,
-                               reinterpret_cast<uint4 *>(u_out), n, 0, rule, status, slot, ra);
-        return check_launch("carle_ca_step_f32(64x64)");
-    }
-    // 256x256 / 512x512: wavefront-per-strip path; needs a 16-byte aligned action window
-    if ((w == 256 || w == 512) && (!action || ((aw % 4) == 0 && ((w - aw) % 8) == 0))) {
-        if (w == 256) return launch_wide<1, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
-        return launch_wide<2, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
-    }
-    const int64_t cells = n * (int64_t)h * w;
-    const int64_t blocks = (cells + 255) / 256;
-    if (blocks > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32: batch too large");
-    hipLaunchKernelGGL(ca_step_f32_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, s, u_in,
-                       action, u_out, n, h, w, action ? ah : 0, action ? aw : 0, rule, status, slot);
-    return check_launch("carle_ca_step_f32(generic)");
+// uint8 state; the action is fp32 (what the reference's agents emit) or uint8
+extern "C" int carle_ca_step_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out,
+                                int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status,
+                                int slot, void *stream) {
+    if (action_fmt == CARLE_FMT_U8)
+        return ca_step_cells<U8Cells, U8Cells>(u_in, static_cast<const uint8_t *>(action), u_out, n, h, w,
+                                               ah, aw, rule, status, slot, nullptr, stream,
+                                               "carle_ca_step_u8");
+    if (action_fmt == CARLE_FMT_F32)
+        return ca_step_cells<U8Cells, F32Cells>(u_in, static_cast<const float *>(action), u_out, n, h, w,
+                                                ah, aw, rule, status, slot, nullptr, stream,
+                                                "carle_ca_step_u8");
+    return fail_arg(CARLE_E_FORMAT, "carle_ca_step_u8: action_fmt must be CARLE_FMT_F32 or CARLE_FMT_U8");
 }
 
 extern "C" int carle_ca_toggle_f32(const float *u_in, const float *action, float *u_out,
                                    int64_t n, int h, int w, int ah, int aw, void *stream) {
-    if (!u_in || !u_out || !action)
-        return fail_arg(CARLE_E_NULL, "carle_ca_toggle_f32: NULL pointer");
-    if (int e = check_dims(n, h, w, true, ah, aw)) return e;
-    if (n == 0) return 0;
-    const int64_t cells = n * (int64_t)h * w;
-    const int64_t blocks = (cells + 255) / 256;
-    if (blocks > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_toggle_f32: batch too large");
-    hipLaunchKernelGGL(ca_toggle_f32_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), u_in, action, u_out, n, h, w, ah, aw);
-    return check_launch("carle_ca_toggle_f32");
+    return ca_toggle_cells<F32Cells, F32Cells>(u_in, action, u_out, n, h, w, ah, aw, stream,
+                                               "carle_ca_toggle_f32");
+}
+
+extern "C" int carle_ca_toggle_u8(const uint8_t *u_in, const void *action, int action_fmt,
+                                  uint8_t *u_out, int64_t n, int h, int w, int ah, int aw, void *stream) {
+    if (action_fmt == CARLE_FMT_U8)
+        return ca_toggle_cells<U8Cells, U8Cells>(u_in, static_cast<const uint8_t *>(action), u_out, n, h,
+                                                 w, ah, aw, stream, "carle_ca_toggle_u8");
+    if (action_fmt == CARLE_FMT_F32)
+        return ca_toggle_cells<U8Cells, F32Cells>(u_in, static_cast<const float *>(action), u_out, n, h,
+                                                  w, ah, aw, stream, "carle_ca_toggle_u8");
+    return fail_arg(CARLE_E_FORMAT, "carle_ca_toggle_u8: action_fmt must be CARLE_FMT_F32 or CARLE_FMT_U8");
 }
 
 // CARLE.step with the device-side RandomAgent fused in (carle/agents.py:35-42 + env.py:188-242):
@@ -526,8 +619,8 @@ extern "C" int carle_ca_step_f32_rand(const float *u_in, float *u_out, int64_t n
     if (n > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: batch too large");
     RandAct ra;
     ra.p = p; ra.seed = seed; ra.offset = offset; ra.action_out = action_out;
-    hipLaunchKernelGGL((ca_step_f32_64_kernel<true, true, true, 64, true>), dim3((unsigned)n), dim3(64), 0,
-                       static_cast<hipStream_t>(stream), reinterpret_cast<const uint4 *>(u_in),
-                       (const float *)nullptr, reinterpret_cast<uint4 *>(u_out), n, aw, rule, status, slot, ra);
+    hipLaunchKernelGGL((ca_step_64_kernel<F32Cells, F32Cells, true, true, true, 64, true>),
+                       dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), u_in,
+                       (const float *)nullptr, u_out, n, aw, rule, status, slot, ra);
     return check_launch("carle_ca_step_f32_rand");
 }

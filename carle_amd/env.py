@@ -53,9 +53,12 @@ class CARLE(RLEMixin, nn.Module):
     """Batched toroidal Life-like cellular automaton with a gym-style interface."""
 
     def __new__(cls, **kwargs):
-        # storage="b1" selects the bit-packed state variant (same surface, 1 bit per cell in HBM)
+        # storage="b1" / "u8" select the bit-packed / uint8 state variants (same surface, 1 bit or
+        # 1 byte per cell in HBM instead of 4 bytes)
         if cls is CARLE and kwargs.get("storage", "f32") == "b1":
             return super().__new__(CARLEPacked)
+        if cls is CARLE and kwargs.get("storage", "f32") == "u8":
+            return super().__new__(CARLEBytes)
         return super().__new__(cls)
 
     def __setattr__(self, name, value):
@@ -81,8 +84,8 @@ class CARLE(RLEMixin, nn.Module):
         # by default this build treats an empty list as "never" (a superset); strict mirrors it
         self.strict_reference_errors = kwargs.get("strict_reference_errors", False)
         self.storage = kwargs.get("storage", "f32")
-        if self.storage not in ("f32", "b1"):
-            raise ValueError("storage must be 'f32' (reference format) or 'b1' (bit-packed)")
+        if self.storage not in ("f32", "u8", "b1"):
+            raise ValueError("storage must be 'f32' (reference format), 'u8' or 'b1' (bit-packed)")
 
         self.set_neighborhood()
         self.set_action_padding()
@@ -298,8 +301,7 @@ class CARLE(RLEMixin, nn.Module):
         if cropped:
             # the two whole-batch predicates are defined on the action AS PASSED (env.py:191,208);
             # for an oversize action evaluate them on the uncropped tensor (cold path, no sync)
-            self._status[slot] = (full != 0).any().to(torch.int32)
-            self._status[2 + slot] = (full != 1).any().to(torch.int32)
+            hip.action_flags_f32(full.contiguous(), self._status, slot)
         if launch is None:
             hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, not cropped)
         else:
@@ -423,8 +425,7 @@ class CARLEPacked(CARLE):
                 action = action.materialize()
             a32, cropped, full = self._device_action(action)
             if cropped:
-                self._status[slot] = (full != 0).any().to(torch.int32)
-                self._status[2 + slot] = (full != 1).any().to(torch.int32)
+                hip.action_flags_f32(full.contiguous(), self._status, slot)
                 act = hip.pack_f32_b1(a32)
             else:
                 act = hip.pack_f32_b1(a32, self._status, slot)   # exact fp32 predicates
@@ -438,6 +439,90 @@ class CARLEPacked(CARLE):
         done = torch.zeros(self.instances, 1)
         info = [{}] * self.instances
         return self._obs(), reward, done, info
+
+
+class CARLEBytes(CARLE):
+    """CARLE with uint8 state in HBM (``CARLE(storage="u8")``): the reference layout at one byte
+    per cell, a quarter of the fp32 traffic, still an ordinary (N,1,H,W) tensor.
+
+    ``universe`` IS the uint8 tensor (``obs is env.universe`` holds as in the reference);
+    ``obs="f32"`` makes ``reset``/``step`` return an fp32 copy instead.  Assigning an fp32 (or
+    bool) universe converts it with the truthiness of carle/env.py:182.  Actions may be fp32
+    (what the reference's agents emit) or uint8.
+    """
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.obs_format = kwargs.get("obs", "u8")
+        if self.obs_format not in ("f32", "u8"):
+            raise ValueError("obs must be 'f32' or 'u8'")
+
+    def _obs(self):
+        return self.universe.float() if self.obs_format == "f32" else self.universe
+
+    def reset(self):
+        hip.require_gpu()
+        self._check_domain()
+        self.universe = torch.zeros(self.instances, 1, self.height, self.width, dtype=torch.uint8,
+                                    device=self.my_device)
+        self._ensure_status()
+        self._status.zero_()
+        self._slot = 0
+        self.instance_id = str(int(time.time()))
+        self.log = []
+        return self._obs()
+
+    def get_observation(self):
+        return self._obs()
+
+    def _device_universe(self):
+        u = self.universe
+        if u is None:
+            raise RuntimeError("call reset() before step()/apply_action()")
+        if not isinstance(u, torch.Tensor):
+            u = torch.as_tensor(u)
+        if u.dim() != 4 or tuple(u.shape) != (self.instances, 1, self.height, self.width):
+            raise ValueError(f"universe has shape {tuple(u.shape)}, expected "
+                             f"{(self.instances, 1, self.height, self.width)}")
+        if u.dtype != torch.uint8:
+            u = (u != 0).to(torch.uint8)
+        if u.device != self.my_device or not u.is_contiguous():
+            u = u.to(self.my_device).contiguous()
+        return u
+
+    def apply_action(self, action):
+        hip.require_gpu()
+        self._check_domain()
+        a, _, _ = self._device_action(action)
+        u = self._device_universe()
+        out = torch.empty_like(u)
+        hip.ca_toggle_u8(u, a, out)
+        self.universe = out
+
+    def step(self, action):
+        hip.require_gpu()
+        self._check_domain()
+        self._ensure_status()
+        self.action = action
+        if self.logging:
+            self.log_universe()
+        u_in = self._device_universe()
+        slot = self._slot
+        if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
+            action = action.materialize()
+        if (isinstance(action, torch.Tensor) and action.dtype == torch.uint8 and action.is_cuda
+                and tuple(action.shape) == (self.instances, 1, self.action_width, self.action_height)):
+            act, cropped = action.contiguous(), False              # hot path: uint8 on the device
+        else:
+            act, cropped, full = self._device_action(action)
+            if cropped:
+                hip.action_flags_f32(full.contiguous(), self._status, slot)
+        out = torch.empty_like(u_in)
+        reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
+        hip.env_step_u8(u_in, act, out, reward, self.rule_mask(), self._status, slot, not cropped)
+        self._slot = slot ^ 1
+        self.universe = out
+        return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
 
 
 def _check_moore(module, incompatible_keys):

@@ -312,6 +312,110 @@ def env_step_b1(u_in, action, u_out, reward, rule, status, slot, publish_flags=T
 
 
 # ---------------------------------------------------------------------------------------------
+# uint8 format (CARLE_FMT_U8): tensors are uint8 (N,1,H,W), non-zero = alive; the action may be
+# fp32 (what the reference's agents emit) or uint8
+# ---------------------------------------------------------------------------------------------
+FMT_F32, FMT_U8, FMT_B1 = 0, 1, 2
+
+
+def _action_fmt(action):
+    if action.dtype == torch.float32:
+        return FMT_F32
+    if action.dtype == torch.uint8:
+        return FMT_U8
+    raise ValueError(f"action must be float32 or uint8 for uint8 grids, got {action.dtype}")
+
+
+def ca_step_u8(u_in, action, u_out, rule, status=None, slot=0):
+    """One generation on uint8 grids; action fp32 / uint8 (N,1,AH,AW) or None."""
+    lib = _lib.load()
+    _chk_grid(u_in, "u_in", torch.uint8)
+    _chk_grid(u_out, "u_out", torch.uint8)
+    n, _, h, w = u_in.shape
+    if u_out.shape != u_in.shape:
+        raise ValueError("u_out shape differs from u_in")
+    ap, fmt, ah, aw = None, FMT_F32, 0, 0
+    if action is not None:
+        fmt = _action_fmt(action)
+        _chk_grid(action, "action", action.dtype)
+        if action.shape[0] != n:
+            raise ValueError("action batch differs from universe batch")
+        ah, aw = action.shape[2], action.shape[3]
+        ap = action.data_ptr()
+    with _on_device(u_in.device):
+        rc = lib.carle_ca_step_u8(u_in.data_ptr(), ap, fmt, u_out.data_ptr(), n, h, w, ah, aw, rule,
+                                  _ptr(status), slot, _stream(u_in))
+    _lib.check(rc, "carle_ca_step_u8")
+
+
+def env_step_u8(u_in, action, u_out, reward, rule, status, slot, publish_flags=True):
+    """CARLE.step hot path on uint8 state: step kernel + epilogue, one library call."""
+    lib = _lib.load()
+    n, _, h, w = u_in.shape
+    if action is None:
+        ap, fmt, ah, aw = None, FMT_F32, 0, 0
+    else:
+        ap, fmt, ah, aw = action.data_ptr(), _action_fmt(action), action.shape[2], action.shape[3]
+    with _on_device(u_in.device):
+        rc = lib.carle_env_step_u8(u_in.data_ptr(), ap, fmt, u_out.data_ptr(), reward.data_ptr(), n, h,
+                                   w, ah, aw, rule, status.data_ptr(), slot,
+                                   1 if publish_flags else 0, _stream(u_in))
+    if rc != 0:
+        _lib.check(rc, "carle_env_step_u8")
+
+
+def ca_toggle_u8(u_in, action, u_out):
+    """u_out <- (u_in != 0) XOR centred (action != 0) on uint8 grids."""
+    lib = _lib.load()
+    _chk_grid(u_in, "u_in", torch.uint8)
+    _chk_grid(u_out, "u_out", torch.uint8)
+    _chk_grid(action, "action", action.dtype)
+    n, _, h, w = u_in.shape
+    with _on_device(u_in.device):
+        rc = lib.carle_ca_toggle_u8(u_in.data_ptr(), action.data_ptr(), _action_fmt(action),
+                                    u_out.data_ptr(), n, h, w, action.shape[2], action.shape[3],
+                                    _stream(u_in))
+    _lib.check(rc, "carle_ca_toggle_u8")
+
+
+def pack_u8_b1(src, status=None, slot=0, out=None):
+    """uint8 (N,1,H,W) -> int64 (N,1,H,W/64); optionally publishes the action predicates."""
+    lib = _lib.load()
+    _chk_grid(src, "src", torch.uint8)
+    n, _, h, w = src.shape
+    if out is None:
+        out = torch.empty(n, 1, h, w // 64, dtype=torch.int64, device=src.device)
+    with _on_device(src.device):
+        rc = lib.carle_pack_u8_b1(src.data_ptr(), out.data_ptr(), n, h, w, _ptr(status), slot,
+                                  _stream(src))
+    _lib.check(rc, "carle_pack_u8_b1")
+    return out
+
+
+def unpack_b1_u8(src, out=None):
+    """int64 (N,1,H,W/64) -> uint8 (N,1,H,W) of 0 / 1."""
+    lib = _lib.load()
+    _chk_grid(src, "src", torch.int64)
+    n, _, h, ww = src.shape
+    if out is None:
+        out = torch.empty(n, 1, h, ww * 64, dtype=torch.uint8, device=src.device)
+    with _on_device(src.device):
+        rc = lib.carle_unpack_b1_u8(src.data_ptr(), out.data_ptr(), n, h, ww * 64, _stream(src))
+    _lib.check(rc, "carle_unpack_b1_u8")
+    return out
+
+
+def action_flags_f32(action, status, slot):
+    """Sets ANY_NONZERO / NOT_ALL_ONES of `slot` from every element of an fp32 tensor."""
+    lib = _lib.load()
+    _chk_grid(action, "action", torch.float32)
+    with _on_device(action.device):
+        rc = lib.carle_action_flags_f32(action.data_ptr(), action.numel(), status.data_ptr(), slot,
+                                        _stream(action))
+    _lib.check(rc, "carle_action_flags_f32")
+
+
+# ---------------------------------------------------------------------------------------------
 # device-side agents
 # ---------------------------------------------------------------------------------------------
 

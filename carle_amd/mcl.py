@@ -182,6 +182,12 @@ class RND2D(Motivator):
             if allow_packed and obs.shape[2] == 64 and obs.shape[3] == 1:
                 return obs, True
             return hip.unpack_b1_f32(obs), True
+        if obs.dtype == torch.uint8:                      # uint8 observation (storage="u8"): alive bits
+            if obs.device != dev or not obs.is_contiguous():
+                obs = obs.to(dev).contiguous()
+            if allow_packed and obs.dim() == 4 and obs.shape[2] == 64 and obs.shape[3] == 64:
+                return hip.pack_u8_b1(obs), True
+            return (obs != 0).to(torch.float32), True
         binary = self.assume_binary_obs or (getattr(env, "storage", "f32") == "f32" and
                                             obs is env.__dict__.get("universe"))
         if obs.device != dev or obs.dtype != torch.float32 or not obs.is_contiguous():
@@ -614,7 +620,7 @@ class SpeedDetector(Motivator):
         # sum(obs * w) over the whole grid with the action window masked out of the weights;
         # live cells are counted on the inner universe (= obs) as in the reference (mcl.py:769)
         sums = hip.instance_sums_f32(_as_device_f32(obs, dev), self.mass_weight_h, self.mass_weight_w)
-        live_cells = sums[:, 0] if universe is obs else hip.instance_sums_f32(universe)[:, 0]
+        live_cells = sums[:, 0] if universe is obs else hip.instance_sums_f32(_as_device_f32(universe, dev))[:, 0]
         center_of_mass_h = sums[:, 1] / (live_cells + 1e-7)
         center_of_mass_w = sums[:, 2] / (live_cells + 1e-7)
         center_of_mass = torch.cat([center_of_mass_h.unsqueeze(0), center_of_mass_w.unsqueeze(0)])
@@ -647,7 +653,8 @@ class PufferDetector(Motivator):
 
     def step(self, action):
         obs, reward, done, info = self.env.step(action)
-        self.live_cells = float(hip.instance_sums_f32(self.inner_env.universe)[:, 0].sum().item())
+        self.live_cells = float(hip.instance_sums_f32(
+            _as_device_f32(self.inner_env.universe, self.inner_env.my_device))[:, 0].sum().item())
         a = _as_device_f32(action, self.inner_env.my_device)
         if not bool(torch.sum(a)):
             self.cells.append(self.live_cells)

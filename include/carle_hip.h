@@ -90,6 +90,35 @@ int carle_ca_step_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_o
                      int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                      int32_t *status, int slot, void *stream);
 
+/*
+ * One CA generation on uint8 grids (CARLE_FMT_U8): the fp32 layout at 1 B per cell, 2 B of traffic
+ * per cell update.  Same semantics as carle_ca_step_f32 (carle/env.py:150-182, 219-229).
+ *   u_in, u_out  N*H*W bytes; must not alias.  Any non-zero byte is alive; u_out holds 0 / 1.
+ *   action       NULL, or N*AH*AW elements of `action_fmt`: CARLE_FMT_F32 (the tensor a reference
+ *                agent emits; predicates as in carle_ca_step_f32) or CARLE_FMT_U8 (non-zero byte
+ *                toggles; NOT_ALL_ONES is set by any byte != 1).
+ * Same geometry domain and fast paths as carle_ca_step_f32 (64x64 with AW % 8 == 0; 256/512).
+ */
+int carle_ca_step_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out,
+                     int64_t n, int h, int w, int ah, int aw, uint32_t rule,
+                     int32_t *status, int slot, void *stream);
+/* stand-alone CARLE.apply_action on uint8 grids (carle/env.py:150-182); u_out may alias u_in */
+int carle_ca_toggle_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out,
+                       int64_t n, int h, int w, int ah, int aw, void *stream);
+/* uint8 <-> bit-packed (W % 64 == 0); status (nullable) receives the predicates of the uint8 source */
+int carle_pack_u8_b1(const uint8_t *src, uint64_t *dst, int64_t n, int h, int w,
+                     int32_t *status, int slot, void *stream);
+int carle_unpack_b1_u8(const uint64_t *src, uint8_t *dst, int64_t n, int h, int w, void *stream);
+/*
+ * The two whole-batch predicates CARLE.step evaluates on the action AS PASSED
+ * (`torch.sum(action)` truthiness, carle/env.py:191; `torch.mean(action) == 1.0`, env.py:208) for
+ * `count` fp32 elements: sets ANY_NONZERO(slot) / NOT_ALL_ONES(slot), never clears them.  The
+ * step kernels publish the same flags themselves; this entry point serves callers whose action
+ * does not reach a step kernel unchanged (oversize actions that are centre-cropped, env.py:164-169).
+ */
+int carle_action_flags_f32(const float *action, int64_t count, int32_t *status, int slot,
+                           void *stream);
+
 /* fp32 (N,1,H,W) -> bit-packed, bit = (value != 0) (the truthiness of env.py:182); W % 64 == 0.
  * status (nullable): publishes ANY_NONZERO / NOT_ALL_ONES of the fp32 source into `slot`. */
 int carle_pack_f32_b1(const float *src, uint64_t *dst, int64_t n, int h, int w,
@@ -132,6 +161,11 @@ int carle_env_step_f32(const float *u_in, const float *action, float *u_out, flo
 /* The same on bit-packed state: carle_ca_step_b1 + carle_ca_finish. */
 int carle_env_step_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out, float *reward,
                       int64_t n, int h, int w, int ah, int aw, uint32_t rule,
+                      int32_t *status, int slot, int publish_flags, void *stream);
+
+/* The same on uint8 state: carle_ca_step_u8 + carle_ca_finish. */
+int carle_env_step_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out,
+                      float *reward, int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                       int32_t *status, int slot, int publish_flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

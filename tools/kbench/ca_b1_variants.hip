@@ -2,7 +2,7 @@
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/kbench/ca_b1_variants tools/kbench/ca_b1_variants.hip
 #include "../../carle_amd/csrc/abi.hip"
 #include "../../carle_amd/csrc/ca_step_b1.hip"
-#include "../../carle_amd/csrc/ca_step_f32.hip"
+#include "../../carle_amd/csrc/ca_step_cells.hip"
 #include <algorithm>
 #include <vector>
 #include <cstdio>

@@ -2,7 +2,7 @@
 // step kernel timed interleaved in ONE process (cdna_hip_programming.md 5.4 rule 24).
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o /tmp/ca_f32_variants tools/kbench/ca_f32_variants.hip
 #include "../../carle_amd/csrc/abi.hip"
-#include "../../carle_amd/csrc/ca_step_f32.hip"
+#include "../../carle_amd/csrc/ca_step_cells.hip"
 #include <algorithm>
 #include <vector>
 #include <cstdio>
@@ -15,7 +15,7 @@ typedef void (*launch_fn)(const uint4 *, const float *, uint4 *, int64_t, uint32
 template <bool NL, bool NS, int BLOCK, int LDS = 0>
 void launch(const uint4 *in, const float *act, uint4 *out, int64_t n, uint32_t rule, int32_t *st, hipStream_t s) {
     const int wpb = BLOCK / 64;
-    hipLaunchKernelGGL((carle::ca_step_f32_64_kernel<true, NL, NS, BLOCK>), dim3((unsigned)((n + wpb - 1) / wpb)), dim3(BLOCK), LDS, s,
+    hipLaunchKernelGGL((carle::ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true, NL, NS, BLOCK>), dim3((unsigned)((n + wpb - 1) / wpb)), dim3(BLOCK), LDS, s,
                        in, act, out, n, 64, rule, st, 0);
 }
 

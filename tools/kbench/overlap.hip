@@ -1,7 +1,7 @@
 // Can the bandwidth-bound CA step of step t+1 overlap the compute-bound RND2D forward of step t
 // when they are enqueued on two HIP streams?  (development experiment)
 #include "../../carle_amd/csrc/abi.hip"
-#include "../../carle_amd/csrc/ca_step_f32.hip"
+#include "../../carle_amd/csrc/ca_step_cells.hip"
 #include "../../carle_amd/csrc/ca_step_b1.hip"
 #include "../../carle_amd/csrc/nets_staged.hip"
 #include "../../carle_amd/csrc/nets_fused.hip"
