@@ -166,18 +166,20 @@ def main():
     if args.rnd or args.ae:
         from carle_amd.mcl import RND2D, AE2D
         torch.manual_seed(0)                 # construction order predictor -> random (mcl.py:248)
-        kw = dict(async_reward=not args.sync_reward, train_predictor=False)   # forward passes only
+        # forward passes only.  RND2D alone is fused into the CA kernel (one stream); a stacked AE2D
+        # runs its kernels on the reward stream beside the next CA step unless --sync-reward
+        kw = dict(async_reward=args.ae and not args.sync_reward, train_predictor=False)
         wenv = RND2D(env, **kw)
         if args.ae:
             wenv = AE2D(wenv, **kw)
         wenv.eval()
         wenv.to(dev)
-    # reward consumers (reward nets of the wrappers, the per-step moments kernel) run on the reward
-    # stream unless --sync-reward: they overlap the CA kernel of the next step
-    # (measured: with no reward nets the cross-stream events cost more than the ~3 us moments
-    # kernel they would hide -- 45.6 vs 39.1 us/step -- so the plain CA config stays on one stream)
+    # with a stacked AE2D the reward consumers (its kernels, the per-step moments kernel) run on the
+    # reward stream unless --sync-reward: they overlap the CA kernel of the next step.  Measured:
+    # with no reward nets, or with RND2D alone (fused into the CA kernel), the cross-stream events
+    # cost more than they hide (45.6 vs 39.1 and 52.8 vs 46.5 us/step): those stay on one stream
     rs = None
-    if (args.rnd or args.ae) and not args.sync_reward:
+    if args.ae and not args.sync_reward:
         from carle_amd.streams import RewardStream
         rs = env.__dict__.get("reward_stream")
         if rs is None:

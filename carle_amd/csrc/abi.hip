@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
                                                         int tail_bytes, float *__restrict__ reward,
                                                         int64_t n, int32_t *__restrict__ st,
                                                         int slot, int has_action,
-                                                        uint4 *__restrict__ extra, int64_t extra16) {
+                                                        uint4 *__restrict__ extra, int64_t extra16,
+                                                        float *__restrict__ bonus, float reward_scale) {
     // the whole status block in one round trip (it is one 64-byte line)
     const uint4 *st4 = reinterpret_cast<const uint4 *>(st);
     const uint4 w0 = st4[0], w1 = st4[1], w2 = st4[2];
@@ -32,8 +33,18 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
         if (tid < tail_bytes) tail[tid] = 0;
         for (int64_t i = tid; i < extra16; i += nthreads) extra[i] = z;   // side copy of the state
     }
-    if (reward)
+    if (reward && bonus) {
+        // fused CA + RND2D step: reward = 0 + scale * bonus (mcl.py:403-405); after a master reset
+        // every observation is the all-dead grid, whose bonus the step kernel left in bonus[n]
+        const float dead = bonus[n];
+        for (int64_t i = tid; i < n; i += nthreads) {
+            const float b = reset ? dead : bonus[i];
+            if (reset) bonus[i] = dead;
+            reward[i] = reward_scale * b;
+        }
+    } else if (reward) {
         for (int64_t i = tid; i < n; i += nthreads) reward[i] = 0.0f;
+    }
     if (tid == 0) {
         int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z);       // int32 index 6..7
         int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x);             // index 8..9
@@ -75,17 +86,21 @@ extern "C" const char *carle_build_arch(void) {
 
 namespace carle {
 int ca_finish_impl(void *u_out, int64_t u_out_bytes, float *reward, int64_t n, int32_t *status, int slot,
-                   int has_action, void *extra, int64_t extra_bytes, void *stream);
+                   int has_action, void *extra, int64_t extra_bytes, float *bonus, float reward_scale,
+                   void *stream);
 }
 
 extern "C" int carle_ca_finish(void *u_out, int64_t u_out_bytes, float *reward, int64_t n,
                                int32_t *status, int slot, int has_action, void *stream) {
-    return ca_finish_impl(u_out, u_out_bytes, reward, n, status, slot, has_action, nullptr, 0, stream);
+    return ca_finish_impl(u_out, u_out_bytes, reward, n, status, slot, has_action, nullptr, 0, nullptr, 0.0f,
+                          stream);
 }
 
-// `extra` (16-byte multiple): a second buffer zeroed together with u_out on a master reset
+// `extra` (16-byte multiple): a second buffer zeroed together with u_out on a master reset.
+// `bonus` (n + 1 floats, nullable): reward := reward_scale * bonus instead of zero (fused RND2D step).
 int carle::ca_finish_impl(void *u_out, int64_t u_out_bytes, float *reward, int64_t n, int32_t *status,
-                          int slot, int has_action, void *extra, int64_t extra_bytes, void *stream) {
+                          int slot, int has_action, void *extra, int64_t extra_bytes, float *bonus,
+                          float reward_scale, void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_ca_finish: status is NULL");
     if (!u_out && u_out_bytes > 0) return fail_arg(CARLE_E_NULL, "carle_ca_finish: u_out is NULL");
     if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_ca_finish: slot must be 0 or 1");
@@ -99,7 +114,7 @@ int carle::ca_finish_impl(void *u_out, int64_t u_out_bytes, float *reward, int64
                        reinterpret_cast<uint4 *>(u_out), n16,
                        reinterpret_cast<unsigned char *>(u_out) + n16 * 16, tail, reward, n, status,
                        slot, (n > 0 && has_action) ? 1 : 0, reinterpret_cast<uint4 *>(extra),
-                       extra_bytes / 16);
+                       extra_bytes / 16, bonus, reward_scale);
     return check_launch("carle_ca_finish");
 }
 
@@ -190,6 +205,9 @@ int ca_step_f32_impl(const float *u_in, const float *action, float *u_out, int64
 int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp,
                   float *ws, float *bonus, float *pred_out, float *target_out, float *reward,
                   float reward_scale, bool tables_valid, hipStream_t s);
+int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
+                  int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
+                  bool tables_valid, hipStream_t s);
 }
 
 extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out,
@@ -202,26 +220,48 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: status is NULL");
     if (!pred_params || !rand_params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: NULL reward-net pointer");
-    // 64x64 grids with an aligned action window take the fast CA kernel, which can hand the
-    // fresh state to the reward net as 512-B "patch" words instead of the 16-KiB fp32 grid
-    const bool patch = patch_scratch && h == 64 && w == 64 && (!action || (aw % 8) == 0) && n > 0;
+    const bool tables_valid = (net_flags & CARLE_NET_TABLES_VALID) != 0;
+    const bool fork = stream_reward && stream_reward != stream_env;
+    if (fork && !event) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: event is NULL");
+
+    // 64x64 grids with an aligned action window: ONE kernel steps the automaton and evaluates the
+    // reward net on the state it still holds in registers (ca_rnd_fused.hip); the epilogue turns
+    // the bonus into the reward.  Everything runs on stream_env; stream_reward (if any) is ordered
+    // behind it so that reward consumers enqueued there see the result.
+    if (h == 64 && w == 64 && (!action || (aw % 8) == 0) && n > 0 && reward) {
+        if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: u_in/u_out is NULL");
+        if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
+        if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_env_step_f32_rnd: rule mask exceeds 18 bits");
+        if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_rnd: slot must be 0 or 1");
+        if (!aligned16(u_in) || !aligned16(u_out) || (action && !aligned16(action)) || !aligned16(workspace))
+            return fail_arg(CARLE_E_ALIGN, "carle_env_step_f32_rnd: pointers must be 16-byte aligned");
+        const size_t bytes = (size_t)n * h * w * sizeof(float);
+        if (overlap(u_in, bytes, u_out, bytes))
+            return fail_arg(CARLE_E_ALIAS, "carle_env_step_f32_rnd: u_in and u_out overlap");
+        if (int e = ca_step_rnd64(u_in, action, u_out, n, aw, rule, publish_flags ? status : nullptr, slot,
+                                  pred_params, rand_params, workspace, bonus, tables_valid,
+                                  static_cast<hipStream_t>(stream_env)))
+            return e;
+        if (int e = ca_finish_impl(u_out, (int64_t)bytes, reward, n, status, slot, action != nullptr, nullptr, 0,
+                                   bonus, reward_scale, stream_env))
+            return e;
+        return fork ? carle_stream_fork(event, stream_env, stream_reward) : 0;
+    }
+
+    // other geometries: step + epilogue on stream_env, then the bonus kernels (reward += scale *
+    // bonus fused into the last one) on stream_reward, ordered behind the step through `event`
+    (void)patch_scratch;
     if (int e = ca_step_f32_impl(u_in, action, u_out, n, h, w, ah, aw, rule,
-                                 publish_flags ? status : nullptr, slot, patch ? patch_scratch : nullptr,
-                                 stream_env))
+                                 publish_flags ? status : nullptr, slot, nullptr, stream_env))
         return e;
     if (int e = ca_finish_impl(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot,
-                               action != nullptr, patch ? patch_scratch : nullptr,
-                               patch ? n * 64 * 8 : 0, stream_env))
+                               action != nullptr, nullptr, 0, nullptr, 0.0f, stream_env))
         return e;
     void *rs = stream_env;
-    if (stream_reward && stream_reward != stream_env) {
+    if (fork) {
         if (int e = carle_stream_fork(event, stream_env, stream_reward)) return e;
         rs = stream_reward;
     }
-    if (patch)
-        return rnd2d_fused64(patch_scratch, 2, n, pred_params, rand_params, workspace, bonus, nullptr,
-                             nullptr, reward, reward_scale, (net_flags & CARLE_NET_TABLES_VALID) != 0,
-                             static_cast<hipStream_t>(rs));
     return carle_rnd2d_bonus_f32(u_out, n, h, w, pred_params, rand_params, workspace, bonus, nullptr,
                                  nullptr, reward, reward_scale, net_flags | CARLE_NET_OBS_BINARY, rs);
 }

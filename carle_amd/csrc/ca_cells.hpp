@@ -1,0 +1,157 @@
+// ca_cells.hpp -- device code shared by the cell-per-element CA kernels (ca_step_cells.hip) and the
+// kernel that fuses the RND2D bonus into the CA step (ca_rnd_fused.hip): cell traits (fp32 /
+// uint8), the whole-batch action predicates, and the "patch" generation of one 64x64 grid per
+// wavefront (see ca_step_cells.hip for the layout).
+#pragma once
+#include "ca_bits.hpp"
+#include "common.hpp"
+
+namespace carle {
+
+static constexpr uint32_t kOneBits = 0x3F800000u;   // 1.0f
+
+// 1 if the fp32 bit pattern is non-zero as a number (NaN counts, -0.0 does not): the
+// truthiness torch.logical_xor applies to its operands (carle/env.py:182).
+__device__ __forceinline__ uint32_t nonzero_bit(uint32_t bits) {
+    return min(bits & 0x7FFFFFFFu, 1u);
+}
+__device__ __forceinline__ uint32_t nibble_of(const uint4 &v) {
+    return nonzero_bit(v.x) | (nonzero_bit(v.y) << 1) | (nonzero_bit(v.z) << 2) |
+           (nonzero_bit(v.w) << 3);
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t x, int src_lane) {
+    uint32_t lo = __shfl((uint32_t)x, src_lane, 64);
+    uint32_t hi = __shfl((uint32_t)(x >> 32), src_lane, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int s) { return (x << s) | (x >> (64 - s)); }
+__device__ __forceinline__ uint64_t rotr64(uint64_t x, int s) { return (x >> s) | (x << (64 - s)); }
+
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const uint4 *p) {
+    if (NT) {
+        uint4 v;
+        v.x = __builtin_nontemporal_load(&p->x);
+        v.y = __builtin_nontemporal_load(&p->y);
+        v.z = __builtin_nontemporal_load(&p->z);
+        v.w = __builtin_nontemporal_load(&p->w);
+        return v;
+    }
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(uint4 *p, const uint4 &v) {
+    if (NT) {
+        __builtin_nontemporal_store(v.x, &p->x);
+        __builtin_nontemporal_store(v.y, &p->y);
+        __builtin_nontemporal_store(v.z, &p->z);
+        __builtin_nontemporal_store(v.w, &p->w);
+    } else {
+        *p = v;
+    }
+}
+
+// Per-lane summary of the action elements a lane has seen, for the two whole-batch predicates
+// of CARLE.step: any element non-zero (env.py:191), every element == 1 (env.py:208).  Raw bit
+// patterns are folded with AND / OR; the cell traits say what "non-zero" and "one" look like.
+struct ActionSeen {
+    uint32_t all_and = 0xFFFFFFFFu, all_or = 0u;
+    __device__ __forceinline__ void add(const uint4 &a) {
+        all_and &= a.x & a.y & a.z & a.w;
+        all_or |= a.x | a.y | a.z | a.w;
+    }
+    __device__ __forceinline__ void add(uint32_t a) { all_and &= a; all_or |= a; }
+    template <class A>
+    __device__ __forceinline__ bool any_nonzero() const { return (all_or & A::kNonzeroMask) != 0; }
+    template <class A>
+    __device__ __forceinline__ bool not_all_ones() const {
+        const bool seen = !(all_and == 0xFFFFFFFFu && all_or == 0u);
+        return seen && (all_and != A::kOnes || all_or != A::kOnes);
+    }
+};
+
+// Cell traits: how four horizontally adjacent cells travel between memory and a 4-bit nibble.
+struct F32Cells {
+    using T = float;
+    using Quad = uint4;
+    static constexpr uint32_t kOnes = kOneBits;             // raw pattern of an all-ones word
+    static constexpr uint32_t kNonzeroMask = 0x7FFFFFFFu;   // -0.0 is zero (env.py:182 truthiness)
+    template <bool NT>
+    static __device__ __forceinline__ Quad load(const T *p) { return ld16<NT>(reinterpret_cast<const uint4 *>(p)); }
+    static __device__ __forceinline__ uint32_t nibble(const Quad &v) { return nibble_of(v); }
+    template <bool NT>
+    static __device__ __forceinline__ void store(T *p, uint32_t nib) {
+        uint4 o4;
+        o4.x = (nib & 1u) ? kOneBits : 0u;
+        o4.y = (nib & 2u) ? kOneBits : 0u;
+        o4.z = (nib & 4u) ? kOneBits : 0u;
+        o4.w = (nib & 8u) ? kOneBits : 0u;
+        st16<NT>(reinterpret_cast<uint4 *>(p), o4);
+    }
+    static __device__ __forceinline__ uint32_t alive(T v) { return nonzero_bit(__float_as_uint(v)); }
+    static __device__ __forceinline__ uint32_t raw(T v) { return __float_as_uint(v); }
+    static __device__ __forceinline__ T make(uint32_t bit) { return bit ? 1.0f : 0.0f; }
+};
+
+struct U8Cells {
+    using T = uint8_t;
+    using Quad = uint32_t;
+    static constexpr uint32_t kOnes = 0x01010101u;
+    static constexpr uint32_t kNonzeroMask = 0xFFFFFFFFu;
+    template <bool NT>
+    static __device__ __forceinline__ Quad load(const T *p) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+        return NT ? __builtin_nontemporal_load(q) : *q;
+    }
+    // byte j non-zero -> bit j: high bit of every non-zero byte, then a multiply gathers them
+    static __device__ __forceinline__ uint32_t nibble(Quad x) {
+        const uint32_t t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+        return (((t >> 7) * 0x01020408u) >> 24) & 0xFu;
+    }
+    template <bool NT>
+    static __device__ __forceinline__ void store(T *p, uint32_t nib) {
+        const uint32_t v = ((nib & 0xFu) * 0x00204081u) & 0x01010101u;     // bit j -> byte j
+        uint32_t *q = reinterpret_cast<uint32_t *>(p);
+        if (NT) __builtin_nontemporal_store(v, q);
+        else *q = v;
+    }
+    static __device__ __forceinline__ uint32_t alive(T v) { return v != 0; }
+    static __device__ __forceinline__ uint32_t raw(T v) { return (uint32_t)v * 0x01010101u; }
+    static __device__ __forceinline__ T make(uint32_t bit) { return (T)bit; }
+};
+__device__ __forceinline__ void see(ActionSeen &s, const uint4 &a) { s.add(a); }
+__device__ __forceinline__ void see(ActionSeen &s, uint32_t a) { s.add(a); }
+
+template <class A>
+__device__ __forceinline__ void publish_flags(const ActionSeen &s, int32_t *status, int slot) {
+    if (status == nullptr) return;
+    const bool any = __ballot(s.any_nonzero<A>()) != 0ull;
+    const bool notone = __ballot(s.not_all_ones<A>()) != 0ull;
+    if ((threadIdx.x & 63) == 0) {      // every writer stores the same value: benign
+        if (any) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
+        if (notone) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
+    }
+}
+
+// One generation of a 64x64 torus held as one 64-bit "patch" word per lane: lane (q = L/16,
+// k = L%16), nibble i = row 4i+q, columns 4k..4k+3.
+__device__ __forceinline__ uint64_t patch_generation64(uint64_t c, int lane, uint32_t rule) {
+    const int q = lane >> 4, k = lane & 15;
+    // horizontal: west/east neighbour of every cell
+    const int grp = lane & 48;
+    const uint64_t cw = shfl64(c, grp | ((k + 15) & 15));
+    const uint64_t ce = shfl64(c, grp | ((k + 1) & 15));
+    const uint64_t wst = ((c << 1) & 0xEEEEEEEEEEEEEEEEull) | ((cw >> 3) & 0x1111111111111111ull);
+    const uint64_t est = ((c >> 1) & 0x7777777777777777ull) | ((ce << 3) & 0x8888888888888888ull);
+    uint64_t h0, h1, p0, p1;
+    row_sums(wst, c, est, h0, h1, p0, p1);
+    // vertical: triple sums of the rows above and below
+    const int lu = (lane + 48) & 63, ld = (lane + 16) & 63;
+    uint64_t a0 = shfl64(h0, lu), a1 = shfl64(h1, lu);
+    uint64_t b0 = shfl64(h0, ld), b1 = shfl64(h1, ld);
+    if (q == 0) { a0 = rotl64(a0, 4); a1 = rotl64(a1, 4); }
+    if (q == 3) { b0 = rotr64(b0, 4); b1 = rotr64(b1, 4); }
+    return apply_rule(neighbour_count(a0, a1, b0, b1, p0, p1), c, rule);
+}
+
+}  // namespace carle

@@ -12,16 +12,9 @@
 //   * HBM traffic per grid: 16 KiB in (fp32 obs) or 512 B (bit-packed obs), 4 B out.
 // Blocks are persistent-ish: 4 waves share one copy of the tables and each wave strides over
 // grids, so the 21 KiB table load is amortised.
-#include "common.hpp"
+#include "rnd_device.hpp"
 
 namespace carle {
-
-static constexpr int kLutFloats = 512 * 4 + 512 * 2;          // predictor float4 + random float2
-static constexpr int kLinStride = 68;                          // padded row of the 16x64 weights
-static constexpr int kLinFloats = 16 * kLinStride + 16;        // weights + bias, per net
-static constexpr int kFusedWsFloats = kLutFloats + 2 * kLinFloats;
-static constexpr int kPlaneStride = 24, kPlaneRows = 18;
-static constexpr int kPlaneFloats = kPlaneRows * kPlaneStride; // zero-bordered 16x16 map
 
 // ---------------------------------------------------------------------------------------------
 // per-call table build: conv1 LUTs (relu applied) + padded copy of the linear layers
@@ -60,23 +53,6 @@ __global__ __launch_bounds__(512) void rnd_prepare_kernel(const float *__restric
     if (p >= 40 && p < 59) c2[p] = rp[20 + (p - 40)];
 }
 
-__device__ __forceinline__ uint32_t nz_bit(uint32_t bits) { return min(bits & 0x7FFFFFFFu, 1u); }
-
-// 8 nibbles (32 bits) -> 8 bytes
-__device__ __forceinline__ uint64_t spread_nibbles(uint32_t x) {
-    uint64_t t = x;
-    t = (t | (t << 16)) & 0x0000FFFF0000FFFFull;
-    t = (t | (t << 8)) & 0x00FF00FF00FF00FFull;
-    t = (t | (t << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    return t;
-}
-
-// nibble j of a 16-bit field -> nibble 4j of a 64-bit word
-__device__ __forceinline__ uint64_t spread_field(uint32_t x) {
-    return (uint64_t)(x & 0xFu) | ((uint64_t)(x & 0xF0u) << 12) | ((uint64_t)(x & 0xF00u) << 24) |
-           ((uint64_t)(x & 0xF000u) << 36);
-}
-
 // OBS_MODE: 0 = fp32 grid, 1 = bit-packed rows (CARLE_FMT_B1), 2 = "patch" words written by the
 // 64x64 CA kernel (word g*64 + lane', nibble i = row 4i + lane'/16, cols 4*(lane'%16)..+3)
 template <int OBS_MODE>
@@ -87,23 +63,9 @@ __global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict
                                                           float *__restrict__ target_out,
                                                           float *__restrict__ reward, float reward_scale,
                                                           int64_t n) {
-    __shared__ float4 s_lut_p[512];
-    __shared__ float2 s_lut_r[512];
-    __shared__ float s_lin[2 * kLinFloats];
-    __shared__ float s_planes[4][6][kPlaneFloats];
-    __shared__ float s_feat[4][2][64];
-
+    __shared__ RndShared<4> s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // tables -> LDS (coalesced copies), zero the plane borders once
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(ws);
-        for (int i = tid; i < 512; i += 256) s_lut_p[i] = src[i];
-        const float2 *src2 = reinterpret_cast<const float2 *>(ws + 2048);
-        for (int i = tid; i < 512; i += 256) s_lut_r[i] = src2[i];
-        for (int i = tid; i < 2 * kLinFloats; i += 256) s_lin[i] = ws[kLutFloats + i];
-        float *pl = &s_planes[0][0][0];
-        for (int i = tid; i < 4 * 6 * kPlaneFloats; i += 256) pl[i] = 0.0f;
-    }
+    rnd_shared_init(s, ws, tid);
     __syncthreads();
 
     const int q = lane >> 4, k = lane & 15;
@@ -143,129 +105,12 @@ __global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict
                 for (int i = 0; i < 16; ++i) v[i] = gin[i * 16];
             }
         }
-        // ---- 2. 6-bit row segments [west | 4 cells | east], one byte per row; zero padding at
-        //         the grid border (conv1 uses zero padding, mcl.py:263)
-        uint64_t cw = ((uint64_t)__shfl((uint32_t)(c >> 32), lane - 1, 64) << 32) | __shfl((uint32_t)c, lane - 1, 64);
-        uint64_t ce = ((uint64_t)__shfl((uint32_t)(c >> 32), lane + 1, 64) << 32) | __shfl((uint32_t)c, lane + 1, 64);
-        if (k == 0) cw = 0;
-        if (k == 15) ce = 0;
-        const uint64_t wb = (cw >> 3) & 0x1111111111111111ull, eb = ce & 0x1111111111111111ull;
-        const uint64_t ea = (spread_nibbles((uint32_t)c) << 1) | spread_nibbles((uint32_t)wb) |
-                            (spread_nibbles((uint32_t)eb) << 5);                    // rows 0..7
-        const uint64_t ebb = (spread_nibbles((uint32_t)(c >> 32)) << 1) | spread_nibbles((uint32_t)(wb >> 32)) |
-                             (spread_nibbles((uint32_t)(eb >> 32)) << 5);           // rows 8..15
-        uint32_t top = __shfl((uint32_t)(ebb >> 56), lane - 16, 64);               // row 16q-1
-        uint32_t bot = __shfl((uint32_t)ea & 0xFFu, lane + 16, 64);                // row 16q+16
-        if (q == 0) top = 0;
-        if (q == 3) bot = 0;
-        uint32_t seg[18];
-        seg[0] = top;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            seg[1 + r] = (uint32_t)(ea >> (8 * r)) & 0xFFu;
-            seg[9 + r] = (uint32_t)(ebb >> (8 * r)) & 0xFFu;
+        // ---- 2..5: halo exchange, conv1 tables + pooling, conv2, linear layers, bonus
+        const float b = rnd_bonus_patch16(s, ws, c, lane, wv, g, pred_out, target_out);
+        if (lane == 0) {
+            bonus[g] = b;
+            if (reward) reward[g] += reward_scale * b;       // mcl.py:403-405
         }
-        seg[17] = bot;
-
-        // ---- 3. conv1 (table lookup) + relu + 4x4 max-pool -> zero-bordered planes in LDS
-        float *planes = &s_planes[wv][0][0];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
-#pragma unroll
-            for (int dy = 0; dy < 4; ++dy) {
-#pragma unroll
-                for (int dx = 0; dx < 4; ++dx) {
-                    const uint32_t p = ((seg[4 * j + dy] >> dx) & 7u) |
-                                       (((seg[4 * j + dy + 1] >> dx) & 7u) << 3) |
-                                       (((seg[4 * j + dy + 2] >> dx) & 7u) << 6);
-                    const float4 a = s_lut_p[p];
-                    const float2 b = s_lut_r[p];
-                    m0 = fmaxf(m0, a.x); m1 = fmaxf(m1, a.y); m2 = fmaxf(m2, a.z); m3 = fmaxf(m3, a.w);
-                    m4 = fmaxf(m4, b.x); m5 = fmaxf(m5, b.y);
-                }
-            }
-            const int off = (4 * q + j + 1) * kPlaneStride + k + 1;
-            planes[0 * kPlaneFloats + off] = m0;
-            planes[1 * kPlaneFloats + off] = m1;
-            planes[2 * kPlaneFloats + off] = m2;
-            planes[3 * kPlaneFloats + off] = m3;
-            planes[4 * kPlaneFloats + off] = m4;
-            planes[5 * kPlaneFloats + off] = m5;
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- 4. conv2 (C->1, 3x3, zero pad) + relu + 2x2 pool: lane = pooled output (fy, fx)
-        const int fy = lane >> 3, fx = lane & 7;
-#pragma unroll
-        for (int net = 0; net < 2; ++net) {
-            const int nch = net == 0 ? 4 : 2, chbase = net == 0 ? 0 : 4;
-            const float *cw2 = ws + kFusedWsFloats + (net == 0 ? 0 : 40);   // uniform -> SGPR loads
-            float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                if (cc < nch) {
-                    const float *pl = planes + (chbase + cc) * kPlaneFloats + (2 * fy) * kPlaneStride + 2 * fx;
-                    float patch[4][4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride);
-                        const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride + 2);
-                        patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
-                    }
-                    // same accumulation order as the staged kernel (channel, oy, ox, ky, kx)
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) o00 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][kx], o00);
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) o01 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][1 + kx], o01);
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) o10 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][kx], o10);
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) o11 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][1 + kx], o11);
-                }
-            }
-            const float mx = fmaxf(fmaxf(o00, o01), fmaxf(o10, o11)) + cw2[net == 0 ? 36 : 18];
-            s_feat[wv][net][fy * 8 + fx] = fmaxf(mx, 0.0f);
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- 5. linear(64->16) + tanh for both nets; lane = (net, k16, half)
-        {
-            const int half = lane & 1, kk = (lane >> 1) & 15, net = lane >> 5;
-            const float4 *f4 = reinterpret_cast<const float4 *>(&s_feat[wv][net][32 * half]);
-            const float4 *w4 = reinterpret_cast<const float4 *>(&s_lin[net * kLinFloats + kk * kLinStride + 32 * half]);
-            float acc = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 f = f4[i], w = w4[i];
-                acc = fmaf(w.x, f.x, acc); acc = fmaf(w.y, f.y, acc);
-                acc = fmaf(w.z, f.z, acc); acc = fmaf(w.w, f.w, acc);
-            }
-            acc += __shfl_xor(acc, 1, 64);
-            const float out = tanhf(acc + s_lin[net * kLinFloats + 16 * kLinStride + kk]);
-            if (half == 0) {
-                if (net == 0 && pred_out) pred_out[g * 16 + kk] = out;
-                if (net == 1 && target_out) target_out[g * 16 + kk] = out;
-            }
-            const float other = __shfl_xor(out, 32, 64);
-            float sq = (out - other) * (out - other);
-#pragma unroll
-            for (int s = 2; s < 32; s <<= 1) sq += __shfl_xor(sq, s, 64);
-            if (lane == 0) {
-                const float b = sq * (1.0f / 16.0f);
-                bonus[g] = b;
-                if (reward) reward[g] += reward_scale * b;       // mcl.py:403-405
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -278,10 +123,14 @@ namespace carle {
 // workspace: [tables + padded linear layers (kFusedWsFloats)] [conv2 parameters (64)]
 int64_t rnd2d_fused_workspace_floats() { return kFusedWsFloats + 64; }
 
+void rnd2d_prepare_tables(const float *pp, const float *rp, float *ws, hipStream_t s) {
+    hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
+}
+
 int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp,
                   float *ws, float *bonus, float *pred_out, float *target_out, float *reward,
                   float reward_scale, bool tables_valid, hipStream_t s) {
-    if (!tables_valid) hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
+    if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
     int64_t blocks = (n + 7) / 8;                     // two grids per wave when the batch allows
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;

@@ -113,8 +113,7 @@ class RND2D(Motivator):
         self.assume_binary_obs = False
         self.async_reward = bool(kwargs.get("async_reward", False))
         self._bonus_buf = None
-        self._patch = None                   # scratch ring: CA kernel -> reward net hand-off
-        self._patch_turn = 0
+        self._step_bonus = None              # bonus vector of the fused CA + RND2D step (n + 1)
         self._grad = None                    # flat gradient the fused training kernel accumulates
         self._grad_used = False
         self._partial = None                 # per-wave partial gradient rows (scratch)
@@ -410,14 +409,9 @@ class RND2D(Motivator):
             self._ws = torch.empty(need, dtype=torch.float32, device=dev)
             self._tables_key = None
         n = env.instances
-        if self._bonus_buf is None or self._bonus_buf.shape[0] != n or self._bonus_buf.device != dev:
-            self._bonus_buf = torch.empty(n, dtype=torch.float32, device=dev)
-        # hand-off scratch ring: the reward stream may lag the CA stream by up to join_every steps
-        # (streams.RewardStream), so step t must not reuse the words step t-1..t-8 handed over
-        if self._patch is None or self._patch[0].shape[0] != n or self._patch[0].device != dev:
-            self._patch = [torch.empty(n, 64, dtype=torch.int64, device=dev) for _ in range(10)]
-        patch = self._patch[self._patch_turn % len(self._patch)]
-        self._patch_turn += 1
+        # n + 1 slots: the fused kernel leaves the bonus of the all-dead grid behind the batch
+        if self._step_bonus is None or self._step_bonus.shape[0] != n + 1 or self._step_bonus.device != dev:
+            self._step_bonus = torch.empty(n + 1, dtype=torch.float32, device=dev)
         versions = (self._pred_blob.version, self._rand_blob.version)
         valid = self._tables_key == (id(self._ws), versions)
         rs = self._reward_stream()
@@ -430,7 +424,7 @@ class RND2D(Motivator):
                 rs_raw = rs.raw
                 ev = rs.event_for_fork(main_raw, out, reward)
             hip.env_step_f32_rnd(u_in, act, out, reward, rule, status, slot, publish, pb, rb, self._ws,
-                                 self._bonus_buf, self.reward_scale, valid, patch, ev, main_raw, rs_raw)
+                                 self._step_bonus, self.reward_scale, valid, None, ev, main_raw, rs_raw)
         result = env._step(action, launch)
         self._tables_key = (id(self._ws), versions)
         return result

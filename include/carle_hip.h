@@ -243,11 +243,17 @@ int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const floa
                         float *reward_accum, float reward_scale, int flags, void *stream);
 
 /* CARLE.step + the RND2D wrapper's bonus on the fresh observation (carle/env.py:188-242 +
- * carle/mcl.py:398-407) in one call: step and epilogue on stream_env; the bonus, with
- * reward += reward_scale * bonus fused in, on stream_reward behind `event` (or on stream_env when
- * stream_reward is NULL).  net_flags: CARLE_NET_TABLES_VALID as for carle_rnd2d_bonus_f32.
- * patch_scratch (nullable, N*64 uint64): caller-owned scratch through which the 64x64 CA kernel
- * hands the fresh state to the reward net as 512 B per grid instead of the 16-KiB fp32 grid. */
+ * carle/mcl.py:398-407) in one call.
+ *   64x64 grids with an aligned action window (AW % 8 == 0 or no action): ONE kernel steps the
+ *   automaton and evaluates the reward net on the state it still holds in registers; the epilogue
+ *   writes reward = reward_scale * bonus (all-dead-grid bonus for every instance after a master
+ *   reset).  Everything runs on stream_env; stream_reward (nullable) is ordered behind it through
+ *   `event`, so reward consumers enqueued there see the result.
+ *   other geometries: step and epilogue on stream_env, the bonus kernels (reward += reward_scale *
+ *   bonus fused in) on stream_reward behind `event` (or on stream_env when stream_reward is NULL).
+ * bonus: N + 1 floats (element N receives the bonus of the all-dead grid).
+ * net_flags: CARLE_NET_TABLES_VALID as for carle_rnd2d_bonus_f32.  patch_scratch: unused, may be NULL
+ * (kept for ABI stability). */
 int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out, float *reward,
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                            int32_t *status, int slot, int publish_flags,

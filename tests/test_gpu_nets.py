@@ -245,26 +245,31 @@ def test_fused_tables_follow_parameter_updates():
     check()
 
 
-@pytest.mark.parametrize("async_reward", [False, True])
-def test_one_call_step_plus_rnd_matches_generic_path(async_reward):
+@pytest.mark.parametrize("async_reward,n,asize", [(False, 9, 64), (True, 9, 64), (False, 1, 32),
+                                                   (True, 1030, 48), (False, 4099, 64), (True, 8192, 64)])
+def test_one_call_step_plus_rnd_matches_generic_path(async_reward, n, asize):
     """RND2D directly on a 64x64 CARLE, forward only: the single-library-call fast path
-    (carle_env_step_f32_rnd) returns exactly what env.step + get_bonus_only + reward add return."""
+    (carle_env_step_f32_rnd: ONE kernel for the CA step and the bonus, ca_rnd_fused.hip) returns
+    exactly what env.step + get_bonus_only + reward add return, master reset included."""
     from carle_amd.env import CARLE
     from carle_amd.mcl import RND2D
     torch.manual_seed(9)
-    env_a = CARLE(width=64, height=64, instances=9, device="cuda:0")
+    kw = dict(width=64, height=64, action_width=asize, action_height=asize, instances=n, device="cuda:0")
+    env_a = CARLE(**kw)
     fast = RND2D(env_a, async_reward=async_reward, train_predictor=False)
-    env_b = CARLE(width=64, height=64, instances=9, device="cuda:0")
+    env_b = CARLE(**kw)
     slow = RND2D(env_b, train_predictor=False)
     slow.load_state_dict(fast.state_dict())
     slow._can_fuse_step = lambda action: False          # force the generic path
     fast.eval(); slow.eval(); fast.reset(); slow.reset()
     assert fast._can_fuse_step(torch.zeros(1))
-    g = torch.Generator().manual_seed(1)
+    g = torch.Generator(device="cuda").manual_seed(1)
     for t in range(7):
-        a = (torch.rand(9, 1, 64, 64, generator=g) < 0.2).float()
+        a = (torch.rand(n, 1, asize, asize, generator=g, device="cuda") < 0.2).float()
         if t == 4:
             a.fill_(1.0)                                 # master reset goes through both paths
+        if t == 6:
+            a.zero_()
         of, rf, _, _ = fast.step(a)
         os_, rs_, _, _ = slow.step(a)
         fast.wait_rewards()
@@ -272,7 +277,11 @@ def test_one_call_step_plus_rnd_matches_generic_path(async_reward):
         assert torch.equal(of, os_)
         assert torch.equal(rf, rs_) and float(rf.abs().sum()) > 0
         assert of is env_a.universe
-    assert env_a.step_number == env_b.step_number
+        if t == 4:
+            assert float(of.sum()) == 0.0 and bool((rf == rf[0]).all())
+    assert env_a.step_number == env_b.step_number == 2
+    assert env_a.steps_since_action == env_b.steps_since_action == 1
+    assert env_a.master_resets == 1
 
 
 @pytest.mark.parametrize("n,packed", [(1, False), (5, False), (37, True), (1030, False)])
