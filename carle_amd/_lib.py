@@ -29,6 +29,7 @@ SIGNATURES = {
     "carle_pack_u8_b1": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_int, _c_vp]),
     "carle_unpack_b1_u8": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp]),
     "carle_action_flags_f32": (_c_int, [_c_vp, _c_i64, _c_vp, _c_int, _c_vp]),
+    "carle_ca_multistep_b1": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_u32, _c_int, _c_vp, _c_vp]),
     "carle_pack_f32_b1": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_int, _c_vp]),
     "carle_unpack_b1_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp]),
     "carle_ca_toggle_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int,

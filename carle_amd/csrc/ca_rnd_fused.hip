@@ -23,18 +23,14 @@
 
 namespace carle {
 
+// RndBlockShared (rnd_device.hpp) + the toggled input rows: 32,528 B.  The 2 x 64 pooled features
+// of phase E overlay rows[1..64] (dead by then: phase D is behind a barrier, phase B of the next grid
+// rewrites every row).  Four workgroups per CU: a fifth fits the LDS but needs <= 96 VGPRs, and the 16
+// spilled registers cost more than the extra occupancy gives (measured 72 vs 45 us per step at N=4096).
 struct CaRndShared {
-    float4 lut_p[512];
-    float2 lut_r[512];
-    float lin[2 * kLinFloats];
-    float planes[6][kPlaneFloats];
+    RndBlockShared net;
     uint32_t rows_in[64][2];     // toggled state, one 64-bit word per row (lo, hi)
-    uint64_t rows_out[66];       // new state at [1..64]; [0] and [65] stay zero (conv1 zero padding)
 };
-// 32,528 B.  The 2 x 64 pooled features of phase E overlay rows_out[1..64] (dead by then: phase D
-// is behind a barrier, phase B of the next grid rewrites every row).  Four workgroups per CU: a
-// fifth fits the LDS but needs <= 96 VGPRs, and the 16 spilled registers cost more than the
-// extra occupancy gives (measured 72 vs 45 us per step at N=4096).
 
 template <bool HAS_ACT>
 __global__ __launch_bounds__(256, 4) void ca_step_rnd64_kernel(
@@ -43,16 +39,7 @@ __global__ __launch_bounds__(256, 4) void ca_step_rnd64_kernel(
     float *__restrict__ bonus) {
     __shared__ CaRndShared s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(ws);
-        for (int i = tid; i < 512; i += 256) s.lut_p[i] = src[i];
-        const float2 *src2 = reinterpret_cast<const float2 *>(ws + 2048);
-        for (int i = tid; i < 512; i += 256) s.lut_r[i] = src2[i];
-        for (int i = tid; i < 2 * kLinFloats; i += 256) s.lin[i] = ws[kLutFloats + i];
-        float *pl = &s.planes[0][0];
-        for (int i = tid; i < 6 * kPlaneFloats; i += 256) pl[i] = 0.0f;
-        if (tid < 66) s.rows_out[tid] = 0ull;
-    }
+    rnd_block_init(s.net, ws, tid);
     __syncthreads();
 
     const int q = lane >> 4, k = lane & 15;
@@ -104,11 +91,7 @@ __global__ __launch_bounds__(256, 4) void ca_step_rnd64_kernel(
             if (g + stride < n) issue(g + stride);    // the next grid's quads travel during B..E
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // lanes k = 0..7 build the low dword, k = 8..15 the high dword of row 16w+4i+q
-                uint32_t x = nib[i] << (4 * (k & 7));
-                x |= __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xF, 0xF, true);   // row_shr:1
-                x |= __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xF, 0xF, true);   // row_shr:2
-                x |= __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+                const uint32_t x = row_nibbles_to_dword(nib[i], k);
                 if ((k & 7) == 7) s.rows_in[16 * wv + 4 * i + q][k >> 3] = x;
             }
         }
@@ -123,9 +106,9 @@ __global__ __launch_bounds__(256, 4) void ca_step_rnd64_kernel(
             const int lu = (lane + 63) & 63, ld = (lane + 1) & 63;      // torus seam in y
             const uint64_t a0 = shfl64(h0, lu), a1 = shfl64(h1, lu);
             const uint64_t b0 = shfl64(h0, ld), b1 = shfl64(h1, ld);
-            s.rows_out[1 + lane] = apply_rule(neighbour_count(a0, a1, b0, b1, p0, p1), c, rule);
+            s.net.rows[1 + lane] = apply_rule(neighbour_count(a0, a1, b0, b1, p0, p1), c, rule);
         } else if (wv == 0) {
-            s.rows_out[1 + lane] = 0ull;
+            s.net.rows[1 + lane] = 0ull;
         }
         __syncthreads();
 
@@ -134,47 +117,19 @@ __global__ __launch_bounds__(256, 4) void ca_step_rnd64_kernel(
             float *gout = u_out + g * 4096 + 1024 * wv + 4 * lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint64_t row = s.rows_out[1 + 16 * wv + 4 * i + q];
+                const uint64_t row = s.net.rows[1 + 16 * wv + 4 * i + q];
                 F32Cells::store<true>(gout + i * 256, (uint32_t)(row >> (4 * k)) & 0xFu);
             }
         }
 
-        // ---- D: conv1 (table lookup) + relu + 4x4 max-pool; thread = pooling window (py, px)
-        {
-            const int py = tid >> 4, px = tid & 15;
-            uint32_t seg[6];                          // [west | 4 cells | east] of rows 4py-1..4py+4
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const uint64_t row = s.rows_out[4 * py + r];            // rows_out[1 + (4py - 1 + r)]
-                seg[r] = (uint32_t)(px == 0 ? row << 1 : row >> (4 * px - 1)) & 0x3Fu;
-            }
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
-#pragma unroll
-            for (int dy = 0; dy < 4; ++dy) {
-#pragma unroll
-                for (int dx = 0; dx < 4; ++dx) {
-                    const uint32_t p = ((seg[dy] >> dx) & 7u) | (((seg[dy + 1] >> dx) & 7u) << 3) |
-                                       (((seg[dy + 2] >> dx) & 7u) << 6);
-                    const float4 pa = s.lut_p[p];
-                    const float2 pb = s.lut_r[p];
-                    m0 = fmaxf(m0, pa.x); m1 = fmaxf(m1, pa.y); m2 = fmaxf(m2, pa.z); m3 = fmaxf(m3, pa.w);
-                    m4 = fmaxf(m4, pb.x); m5 = fmaxf(m5, pb.y);
-                }
-            }
-            const int off = (py + 1) * kPlaneStride + px + 1;
-            s.planes[0][off] = m0;
-            s.planes[1][off] = m1;
-            s.planes[2][off] = m2;
-            s.planes[3][off] = m3;
-            s.planes[4][off] = m4;
-            s.planes[5][off] = m5;
-        }
+        // ---- D: conv1 (table lookup) + relu + 4x4 max-pool; thread = pooling window
+        rnd_block_conv1(s.net, tid);
         __syncthreads();
 
         // ---- E: conv2 + pool, linear layers, bonus (wave 0)
         if (wv == 0) {
-            float (*feat)[64] = reinterpret_cast<float (*)[64]>(&s.rows_out[1]);
-            const float b = rnd_tail(&s.planes[0][0], feat, s.lin, ws, lane, g, nullptr, nullptr);
+            float (*feat)[64] = reinterpret_cast<float (*)[64]>(&s.net.rows[1]);
+            const float b = rnd_tail(&s.net.planes[0][0], feat, s.net.lin, ws, lane, g, nullptr, nullptr);
             if (lane == 0) bonus[g] = b;
         }
         // the next iteration's first barrier orders E's plane reads before D's next plane writes;

@@ -220,6 +220,103 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// k generations without actions in ONE launch (= k calls of CARLE.step with an all-zero action,
+// carle/env.py:188-242): the grid stays in registers between generations.
+// ---------------------------------------------------------------------------------------------
+// One workgroup of WW waves per grid, lane = row as above.  Per generation the only traffic is, for
+// grids taller than 64 rows, the horizontal sums of each wave's first and last row through a
+// double-buffered LDS array (the rows bordering the next wave's strip; the wrap over the WW waves
+// is the y torus seam) and ONE workgroup barrier.  HBM traffic: 0.25 B per cell per k generations.
+template <int WW, int RULE_MODE>
+__global__ __launch_bounds__(64 * WW) void ca_multistep_b1_kernel(
+    const uint64_t *__restrict__ u_in, uint64_t *__restrict__ u_out, int64_t n, uint32_t rule, int k,
+    int32_t *__restrict__ status) {
+    constexpr int H = 64 * WW, NC = 2 * WW;
+    constexpr bool MULTI = WW > 1;
+    __shared__ uint32_t s_edge[2][MULTI ? WW : 1][2][NC][2];   // [buffer][wave][first/last row][chunk][h0/h1]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t g = blockIdx.x;
+    const int r = 64 * w + lane;
+
+    uint64_t c[WW];
+    load_row<WW>(u_in + (g * (int64_t)H + r) * WW, c);
+    uint32_t cc[NC];
+#pragma unroll
+    for (int j = 0; j < WW; ++j) { cc[2 * j] = (uint32_t)c[j]; cc[2 * j + 1] = (uint32_t)(c[j] >> 32); }
+
+    for (int t = 0; t < k; ++t) {
+        uint32_t h0[NC], h1[NC], p0[NC], p1[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const uint32_t prev = cc[(j + NC - 1) % NC], next = cc[(j + 1) % NC];
+            const uint32_t wst = __builtin_amdgcn_alignbit(cc[j], prev, 31);
+            const uint32_t est = __builtin_amdgcn_alignbit(next, cc[j], 1);
+            row_sums(wst, cc[j], est, h0[j], h1[j], p0[j], p1[j]);
+        }
+        uint32_t g0[NC], g1[NC];
+        if (MULTI) {
+            const int buf = t & 1;
+            if (lane == 0 || lane == 63) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    s_edge[buf][w][lane == 63][j][0] = h0[j];
+                    s_edge[buf][w][lane == 63][j][1] = h1[j];
+                }
+            }
+            __syncthreads();
+            // lane 0 needs the LAST row of the wave above, lane 63 the FIRST row of the wave below
+            const int src_w = lane == 0 ? (w + WW - 1) % WW : (w + 1) % WW;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                g0[j] = s_edge[buf][src_w][lane == 0][j][0];
+                g1[j] = s_edge[buf][src_w][lane == 0][j][1];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            uint32_t a0, a1, b0, b1;
+            if (MULTI) {
+                a0 = __builtin_amdgcn_update_dpp(g0[j], h0[j], 0x138, 0xF, 0xF, false);   // wave_shr:1
+                a1 = __builtin_amdgcn_update_dpp(g1[j], h1[j], 0x138, 0xF, 0xF, false);
+                b0 = __builtin_amdgcn_update_dpp(g0[j], h0[j], 0x130, 0xF, 0xF, false);   // wave_shl:1
+                b1 = __builtin_amdgcn_update_dpp(g1[j], h1[j], 0x130, 0xF, 0xF, false);
+            } else {
+                a0 = __builtin_amdgcn_update_dpp(0u, h0[j], 0x13C, 0xF, 0xF, false);      // wave_ror:1
+                a1 = __builtin_amdgcn_update_dpp(0u, h1[j], 0x13C, 0xF, 0xF, false);
+                b0 = __builtin_amdgcn_update_dpp(0u, h0[j], 0x134, 0xF, 0xF, false);      // wave_rol:1
+                b1 = __builtin_amdgcn_update_dpp(0u, h1[j], 0x134, 0xF, 0xF, false);
+            }
+            cc[j] = next_state<RULE_MODE>(neighbour_count(a0, a1, b0, b1, p0[j], p1[j]), cc[j], rule);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WW; ++j) c[j] = ((uint64_t)cc[2 * j + 1] << 32) | cc[2 * j];
+    store_row<WW>(u_out + (g * (int64_t)H + r) * WW, c);
+
+    // counters of k action-free steps (env.py:199-200, 230): step_number += k, steps_since_action += k
+    if (status != nullptr && g == 0 && threadIdx.x == 0) {
+        int64_t *cnt = reinterpret_cast<int64_t *>(status);
+        cnt[CARLE_ST_STEP_NUMBER / 2] += k;
+        cnt[CARLE_ST_STEPS_SINCE_ACTION / 2] += k;
+        if (k > 0) status[CARLE_ST_LAST_RESET] = 0;
+    }
+}
+
+template <int WW>
+static int launch_multistep(const uint64_t *u_in, uint64_t *u_out, int64_t n, uint32_t rule, int k,
+                            int32_t *status, hipStream_t s) {
+    if (n > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_multistep_b1: batch too large");
+    const dim3 grid((unsigned)n), block(64 * WW);
+    if (rule == kLifeMask)
+        hipLaunchKernelGGL((ca_multistep_b1_kernel<WW, kRuleLife>), grid, block, 0, s, u_in, u_out, n, rule, k, status);
+    else if (rule == kHighLifeMask)
+        hipLaunchKernelGGL((ca_multistep_b1_kernel<WW, kRuleHighLife>), grid, block, 0, s, u_in, u_out, n, rule, k, status);
+    else
+        hipLaunchKernelGGL((ca_multistep_b1_kernel<WW, kRuleGeneric>), grid, block, 0, s, u_in, u_out, n, rule, k, status);
+    return check_launch("carle_ca_multistep_b1");
+}
+
+// ---------------------------------------------------------------------------------------------
 // pack fp32 -> b1 (also publishes the action predicates of the fp32 source), unpack b1 -> fp32
 // ---------------------------------------------------------------------------------------------
 // one wave packs 64 words: iteration i loads 64 consecutive floats (one word), the ballot of
@@ -329,6 +426,29 @@ extern "C" int carle_ca_step_b1(const uint64_t *u_in, const uint64_t *action, ui
         case 128: return launch_b1<2>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
         case 256: return launch_b1<4>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
         default: return launch_b1<8>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
+    }
+}
+
+extern "C" int carle_ca_multistep_b1(const uint64_t *u_in, uint64_t *u_out, int64_t n, int h, int w,
+                                     uint32_t rule, int k, int32_t *status, void *stream) {
+    if (n == 0) return 0;
+    if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_multistep_b1: u_in/u_out is NULL");
+    if (int e = check_dims(n, h, w, false, 0, 0)) return e;
+    if (w != 64 && w != 128 && w != 256 && w != 512)
+        return fail_arg(CARLE_E_DIMS, "carle_ca_multistep_b1: W must be 64, 128, 256 or 512");
+    if (k < 0) return fail_arg(CARLE_E_DIMS, "carle_ca_multistep_b1: k must be >= 0");
+    if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_ca_multistep_b1: rule mask exceeds 18 bits");
+    if (!aligned16(u_in) || !aligned16(u_out) || (status && !aligned16(status)))
+        return fail_arg(CARLE_E_ALIGN, "carle_ca_multistep_b1: pointers must be 16-byte aligned");
+    const size_t bytes = (size_t)n * h * (w / 8);
+    if (u_in != u_out && overlap(u_in, bytes, u_out, bytes))
+        return fail_arg(CARLE_E_ALIAS, "carle_ca_multistep_b1: u_in and u_out overlap partially");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (w) {
+        case 64: return launch_multistep<1>(u_in, u_out, n, rule, k, status, s);
+        case 128: return launch_multistep<2>(u_in, u_out, n, rule, k, status, s);
+        case 256: return launch_multistep<4>(u_in, u_out, n, rule, k, status, s);
+        default: return launch_multistep<8>(u_in, u_out, n, rule, k, status, s);
     }
 }
 

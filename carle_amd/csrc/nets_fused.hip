@@ -5,13 +5,14 @@
 //   * the observation is binary, so conv1 (3x3, 1->4 and 1->2 channels) + bias + relu is a
 //     512-entry table per channel, indexed by the 9-bit neighbourhood pattern.  The tables are
 //     built once per call by rnd_prepare_kernel (1.5k patterns x 9 fma) and sit in LDS;
-//   * one wavefront per grid: lane (q,k) owns rows 16q..16q+15, cols 4k..4k+3 (a 16x4 patch =
-//     four 4x4 pooling windows), the 1-pixel halo comes from lanes k-1,k+1,q-1,q+1 by shuffles;
-//   * pooled conv1 maps (6 x 16x16) go to a wave-private, zero-bordered LDS image; conv2 + relu
-//     + 2x2 pool, the 64->16 linear layers + tanh and the bonus reduction run from LDS;
+//   * one workgroup per grid: the grid sits in LDS as 64 row words, thread = one 4x4 pooling
+//     window reads its 6x6 neighbourhood from them (zero padding = two zero rows + shifts);
+//   * pooled conv1 maps (6 x 16x16) go to a zero-bordered LDS image; conv2 + relu + 2x2 pool, the
+//     64->16 linear layers + tanh and the bonus reduction run from LDS on one wave;
 //   * HBM traffic per grid: 16 KiB in (fp32 obs) or 512 B (bit-packed obs), 4 B out.
-// Blocks are persistent-ish: 4 waves share one copy of the tables and each wave strides over
-// grids, so the 21 KiB table load is amortised.
+// Workgroups are persistent: they stride over grids, so the 21 KiB table load is amortised, and 4
+// of them per CU (33 KB of LDS each) are in different phases.  (The training kernels further down
+// keep the older wavefront-per-grid decomposition.)
 #include "rnd_device.hpp"
 
 namespace carle {
@@ -53,64 +54,67 @@ __global__ __launch_bounds__(512) void rnd_prepare_kernel(const float *__restric
     if (p >= 40 && p < 59) c2[p] = rp[20 + (p - 40)];
 }
 
-// OBS_MODE: 0 = fp32 grid, 1 = bit-packed rows (CARLE_FMT_B1), 2 = "patch" words written by the
-// 64x64 CA kernel (word g*64 + lane', nibble i = row 4i + lane'/16, cols 4*(lane'%16)..+3)
-template <int OBS_MODE>
-__global__ __launch_bounds__(256) void rnd_fused64_kernel(const void *__restrict__ obs_v,
-                                                          const float *__restrict__ ws,
-                                                          float *__restrict__ bonus,
-                                                          float *__restrict__ pred_out,
-                                                          float *__restrict__ target_out,
-                                                          float *__restrict__ reward, float reward_scale,
-                                                          int64_t n) {
-    __shared__ RndShared<4> s;
+// One workgroup (4 waves) per grid, persistent over grids; phases separated by barriers:
+//   load   fp32: every lane loads 4 quads (rows 16w+4i+q, columns 4k..4k+3; the quads of the
+//          workgroup's NEXT grid are requested before the conv1 phase), the 16 lanes of a row OR their
+//          nibbles into the row's 64-bit word in LDS.  bit-packed: the 64 row words are copied.
+//   conv1  thread = one 4x4 pooling window (rnd_block_conv1)
+//   tail   wave 0: conv2 + pooling, linear layers, tanh, bonus (rnd_tail)
+// 33 KB of LDS -> 4 workgroups (16 waves) per CU in different phases.
+template <bool PACKED_OBS>
+__global__ __launch_bounds__(256, 4) void rnd_block64_kernel(const void *__restrict__ obs_v,
+                                                             const float *__restrict__ ws,
+                                                             float *__restrict__ bonus,
+                                                             float *__restrict__ pred_out,
+                                                             float *__restrict__ target_out,
+                                                             float *__restrict__ reward, float reward_scale,
+                                                             int64_t n) {
+    __shared__ RndBlockShared s;
+    __shared__ float s_feat[2][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    rnd_shared_init(s, ws, tid);
+    rnd_block_init(s, ws, tid);
     __syncthreads();
 
     const int q = lane >> 4, k = lane & 15;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
-    // software prefetch: the fp32 loads of the NEXT grid are issued right after the current
-    // grid's words have been converted, so their latency hides under the compute phases
-    constexpr bool PACKED_OBS = OBS_MODE != 0;
-    uint4 v[16];
-    if (!PACKED_OBS && wave_id < n) {
-        const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + wave_id * 1024 + (16 * q) * 16 + k;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = gin[i * 16];
-    }
-    for (int64_t g = wave_id; g < n; g += nwaves) {
-        // ---- 1. the lane's 16x4 patch as one nibble per row
-        uint64_t c = 0;
-        if (OBS_MODE == 2) {
-            // rows 16q+i' of this lane are nibbles 4q..4q+3 of the CA lanes (q' = i' % 4, k)
-            const uint64_t *pw = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + k;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
-                c |= spread_field((uint32_t)(pw[16 * qq] >> (16 * q)) & 0xFFFFu) << (4 * qq);
-        } else if (OBS_MODE == 1) {
-            const uint64_t *rows = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + 16 * q;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) c |= ((rows[i] >> (4 * k)) & 0xFull) << (4 * i);
+    const int64_t first = blockIdx.x, stride = gridDim.x;
+    uint4 v[4];
+    uint64_t word = 0;
+    auto issue = [&](int64_t g) {
+        if (PACKED_OBS) {
+            if (tid < 64) word = reinterpret_cast<const uint64_t *>(obs_v)[g * 64 + tid];
         } else {
+            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + 256 * wv + lane;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 4; ++i) v[i] = gin[i * 64];
+        }
+    };
+    if (first < n) issue(first);
+    for (int64_t g = first; g < n; g += stride) {
+        if (PACKED_OBS) {
+            if (tid < 64) s.rows[1 + tid] = word;
+        } else {
+            uint32_t *rows32 = reinterpret_cast<uint32_t *>(&s.rows[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
                 const uint32_t nib = nz_bit(v[i].x) | (nz_bit(v[i].y) << 1) | (nz_bit(v[i].z) << 2) |
                                      (nz_bit(v[i].w) << 3);
-                c |= (uint64_t)nib << (4 * i);
-            }
-            if (g + nwaves < n) {
-                const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + (g + nwaves) * 1024 + (16 * q) * 16 + k;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = gin[i * 16];
+                const uint32_t x = row_nibbles_to_dword(nib, k);
+                if ((k & 7) == 7) rows32[2 * (16 * wv + 4 * i + q) + (k >> 3)] = x;
             }
         }
-        // ---- 2..5: halo exchange, conv1 tables + pooling, conv2, linear layers, bonus
-        const float b = rnd_bonus_patch16(s, ws, c, lane, wv, g, pred_out, target_out);
-        if (lane == 0) {
-            bonus[g] = b;
-            if (reward) reward[g] += reward_scale * b;       // mcl.py:403-405
+        if (g + stride < n) issue(g + stride);        // the next grid travels during conv1 + tail
+        __syncthreads();
+        rnd_block_conv1(s, tid);
+        __syncthreads();
+        if (wv == 0) {
+            const float b = rnd_tail(&s.planes[0][0], s_feat, s.lin, ws, lane, g, pred_out, target_out);
+            if (lane == 0) {
+                bonus[g] = b;
+                if (reward) reward[g] += reward_scale * b;       // mcl.py:403-405
+            }
         }
+        // rows are rewritten at the top of the next iteration: every wave has passed the barrier
+        // behind conv1 (their last reader); the planes only behind the next iteration's first barrier
     }
 }
 
@@ -131,17 +135,13 @@ int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, con
                   float *ws, float *bonus, float *pred_out, float *target_out, float *reward,
                   float reward_scale, bool tables_valid, hipStream_t s) {
     if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
-    int64_t blocks = (n + 7) / 8;                     // two grids per wave when the batch allows
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = n < 1024 ? n : 1024;             // persistent: 4 workgroups are resident per CU
     if (blocks < 1) blocks = 1;
-    if (obs_mode == 2)
-        hipLaunchKernelGGL(rnd_fused64_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
-                           bonus, pred_out, target_out, reward, reward_scale, n);
-    else if (obs_mode == 1)
-        hipLaunchKernelGGL(rnd_fused64_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
+    if (obs_mode == 1)
+        hipLaunchKernelGGL(rnd_block64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
                            bonus, pred_out, target_out, reward, reward_scale, n);
     else
-        hipLaunchKernelGGL(rnd_fused64_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
+        hipLaunchKernelGGL(rnd_block64_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
                            bonus, pred_out, target_out, reward, reward_scale, n);
     return check_launch("carle_rnd2d_bonus(fused 64x64)");
 }

@@ -1,7 +1,7 @@
 // rnd_device.hpp -- device side of the fused RND2D forward for 64x64 binary grids, shared by the
 // stand-alone bonus kernel (nets_fused.hip) and the kernel that fuses the bonus into the CA step
 // (ca_rnd_fused.hip).  See nets_fused.hip for the method (512-entry conv1 tables in LDS, one
-// wavefront per grid, zero-bordered wave-private planes).
+// workgroup per grid, zero-bordered LDS planes).
 #pragma once
 #include "common.hpp"
 
@@ -31,27 +31,69 @@ __device__ __forceinline__ uint64_t spread_field(uint32_t x) {
            ((uint64_t)(x & 0xF000u) << 36);
 }
 
-// LDS image of one workgroup of WAVES wavefronts
-template <int WAVES>
-struct RndShared {
-    float4 lut_p[512];
-    float2 lut_r[512];
+// LDS image of one workgroup (4 wavefronts) that owns one 64x64 grid at a time
+struct RndBlockShared {
+    float4 lut_p[512];                 // conv1 + relu of the predictor, per 9-bit neighbourhood pattern
+    float2 lut_r[512];                 // ... of the random network
     float lin[2 * kLinFloats];
-    float planes[WAVES][6][kPlaneFloats];
-    float feat[WAVES][2][64];
+    float planes[6][kPlaneFloats];     // pooled conv1 maps, zero-bordered 16x16
+    uint64_t rows[66];                 // the grid, one 64-bit word per row at [1..64]; [0], [65] stay zero
 };
 
-// tables -> LDS (coalesced copies), zero the plane borders once; the caller synchronises
-template <int WAVES>
-__device__ __forceinline__ void rnd_shared_init(RndShared<WAVES> &s, const float *__restrict__ ws, int tid) {
-    constexpr int T = 64 * WAVES;
+// tables -> LDS (coalesced copies), zero the plane borders and the two padding rows once; the
+// caller synchronises
+__device__ __forceinline__ void rnd_block_init(RndBlockShared &s, const float *__restrict__ ws, int tid) {
     const float4 *src = reinterpret_cast<const float4 *>(ws);
-    for (int i = tid; i < 512; i += T) s.lut_p[i] = src[i];
+    for (int i = tid; i < 512; i += 256) s.lut_p[i] = src[i];
     const float2 *src2 = reinterpret_cast<const float2 *>(ws + 2048);
-    for (int i = tid; i < 512; i += T) s.lut_r[i] = src2[i];
-    for (int i = tid; i < 2 * kLinFloats; i += T) s.lin[i] = ws[kLutFloats + i];
-    float *pl = &s.planes[0][0][0];
-    for (int i = tid; i < WAVES * 6 * kPlaneFloats; i += T) pl[i] = 0.0f;
+    for (int i = tid; i < 512; i += 256) s.lut_r[i] = src2[i];
+    for (int i = tid; i < 2 * kLinFloats; i += 256) s.lin[i] = ws[kLutFloats + i];
+    float *pl = &s.planes[0][0];
+    for (int i = tid; i < 6 * kPlaneFloats; i += 256) pl[i] = 0.0f;
+    if (tid < 66) s.rows[tid] = 0ull;
+}
+
+// The 16 lanes of a DPP row hold the nibbles (columns 4k..4k+3, k = lane % 16) of ONE grid row:
+// OR them into the row's 64-bit word.  Lanes k = 0..7 build the low dword, k = 8..15 the high one
+// (3 row_shr steps each); returns the dword in lanes k = 7 and k = 15.
+__device__ __forceinline__ uint32_t row_nibbles_to_dword(uint32_t nib, int k) {
+    uint32_t x = nib << (4 * (k & 7));
+    x |= __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xF, 0xF, true);   // row_shr:1
+    x |= __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x |= __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    return x;
+}
+
+// conv1 (table lookup) + relu + 4x4 max-pool of all six channels; thread = pooling window
+// (py = tid/16, px = tid%16), zero padding at the grid border (mcl.py:263)
+__device__ __forceinline__ void rnd_block_conv1(RndBlockShared &s, int tid) {
+    const int py = tid >> 4, px = tid & 15;
+    uint32_t seg[6];                                  // [west | 4 cells | east] of rows 4py-1..4py+4
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const uint64_t row = s.rows[4 * py + r];      // rows[1 + (4py - 1 + r)]
+        seg[r] = (uint32_t)(px == 0 ? row << 1 : row >> (4 * px - 1)) & 0x3Fu;
+    }
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const uint32_t p = ((seg[dy] >> dx) & 7u) | (((seg[dy + 1] >> dx) & 7u) << 3) |
+                               (((seg[dy + 2] >> dx) & 7u) << 6);
+            const float4 pa = s.lut_p[p];
+            const float2 pb = s.lut_r[p];
+            m0 = fmaxf(m0, pa.x); m1 = fmaxf(m1, pa.y); m2 = fmaxf(m2, pa.z); m3 = fmaxf(m3, pa.w);
+            m4 = fmaxf(m4, pb.x); m5 = fmaxf(m5, pb.y);
+        }
+    }
+    const int off = (py + 1) * kPlaneStride + px + 1;
+    s.planes[0][off] = m0;
+    s.planes[1][off] = m1;
+    s.planes[2][off] = m2;
+    s.planes[3][off] = m3;
+    s.planes[4][off] = m4;
+    s.planes[5][off] = m5;
 }
 
 // Stages 4-5 on ONE wavefront (all 64 lanes): conv2 + relu + 2x2 pool of both nets from the six
@@ -128,73 +170,6 @@ __device__ __forceinline__ float rnd_tail(const float *__restrict__ planes, floa
         for (int sh = 2; sh < 32; sh <<= 1) sq += __shfl_xor(sq, sh, 64);
         bonus_value = sq * (1.0f / 16.0f);               // complete in lane 0
     }
-    return bonus_value;
-}
-
-// RND2D bonus of one grid from the wave's 16x4 patches: lane (q = L/16, k = L%16) holds rows
-// 16q..16q+15, columns 4k..4k+3 as nibble r of `c`.  Returns mean_k (target - prediction)^2
-// (carle/mcl.py:343-352), complete in lane 0; optionally stores the two 16-vectors.
-template <int WAVES>
-__device__ __forceinline__ float rnd_bonus_patch16(RndShared<WAVES> &s, const float *__restrict__ ws,
-                                                   uint64_t c, int lane, int wv, int64_t g,
-                                                   float *__restrict__ pred_out,
-                                                   float *__restrict__ target_out) {
-    const int q = lane >> 4, k = lane & 15;
-    // ---- 2. 6-bit row segments [west | 4 cells | east], one byte per row; zero padding at
-    //         the grid border (conv1 uses zero padding, mcl.py:263)
-    uint64_t cw = ((uint64_t)__shfl((uint32_t)(c >> 32), lane - 1, 64) << 32) | __shfl((uint32_t)c, lane - 1, 64);
-    uint64_t ce = ((uint64_t)__shfl((uint32_t)(c >> 32), lane + 1, 64) << 32) | __shfl((uint32_t)c, lane + 1, 64);
-    if (k == 0) cw = 0;
-    if (k == 15) ce = 0;
-    const uint64_t wb = (cw >> 3) & 0x1111111111111111ull, eb = ce & 0x1111111111111111ull;
-    const uint64_t ea = (spread_nibbles((uint32_t)c) << 1) | spread_nibbles((uint32_t)wb) |
-                        (spread_nibbles((uint32_t)eb) << 5);                    // rows 0..7
-    const uint64_t ebb = (spread_nibbles((uint32_t)(c >> 32)) << 1) | spread_nibbles((uint32_t)(wb >> 32)) |
-                         (spread_nibbles((uint32_t)(eb >> 32)) << 5);           // rows 8..15
-    uint32_t top = __shfl((uint32_t)(ebb >> 56), lane - 16, 64);               // row 16q-1
-    uint32_t bot = __shfl((uint32_t)ea & 0xFFu, lane + 16, 64);                // row 16q+16
-    if (q == 0) top = 0;
-    if (q == 3) bot = 0;
-    uint32_t seg[18];
-    seg[0] = top;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        seg[1 + r] = (uint32_t)(ea >> (8 * r)) & 0xFFu;
-        seg[9 + r] = (uint32_t)(ebb >> (8 * r)) & 0xFFu;
-    }
-    seg[17] = bot;
-
-    // ---- 3. conv1 (table lookup) + relu + 4x4 max-pool -> zero-bordered planes in LDS
-    float *planes = &s.planes[wv][0][0];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
-#pragma unroll
-        for (int dy = 0; dy < 4; ++dy) {
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const uint32_t p = ((seg[4 * j + dy] >> dx) & 7u) |
-                                   (((seg[4 * j + dy + 1] >> dx) & 7u) << 3) |
-                                   (((seg[4 * j + dy + 2] >> dx) & 7u) << 6);
-                const float4 a = s.lut_p[p];
-                const float2 b = s.lut_r[p];
-                m0 = fmaxf(m0, a.x); m1 = fmaxf(m1, a.y); m2 = fmaxf(m2, a.z); m3 = fmaxf(m3, a.w);
-                m4 = fmaxf(m4, b.x); m5 = fmaxf(m5, b.y);
-            }
-        }
-        const int off = (4 * q + j + 1) * kPlaneStride + k + 1;
-        planes[0 * kPlaneFloats + off] = m0;
-        planes[1 * kPlaneFloats + off] = m1;
-        planes[2 * kPlaneFloats + off] = m2;
-        planes[3 * kPlaneFloats + off] = m3;
-        planes[4 * kPlaneFloats + off] = m4;
-        planes[5 * kPlaneFloats + off] = m5;
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    __builtin_amdgcn_wave_barrier();
-    const float bonus_value = rnd_tail(planes, s.feat[wv], s.lin, ws, lane, g, pred_out, target_out);
-    __builtin_amdgcn_wave_barrier();
     return bonus_value;
 }
 

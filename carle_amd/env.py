@@ -312,6 +312,30 @@ class CARLE(RLEMixin, nn.Module):
         info = [{}] * self.instances
         return self.universe, reward, done, info
 
+    def multistep(self, steps):
+        """``steps`` generations with no action in ONE kernel launch: the state, counters and return
+        value of ``steps`` consecutive ``step(zeros)`` calls (env.py:188-242; build-side extension).
+        The grid is bit-packed on the fly and stays in registers between generations
+        (``carle_ca_multistep_b1``); sizes the packed kernels do not cover fall back to a loop."""
+        hip.require_gpu()
+        self._check_domain()
+        self._ensure_status()
+        steps = int(steps)
+        if steps < 0:
+            raise ValueError("steps must be >= 0")
+        if self.width not in (64, 128, 256, 512) or self.logging:
+            zero = torch.zeros(self.instances, 1, self.action_width, self.action_height,
+                               device=self.my_device)
+            for _ in range(steps):
+                self.step(zero)
+        else:
+            bits = hip.pack_f32_b1(self._device_universe())
+            hip.ca_multistep_b1(bits, bits, self.rule_mask(), steps, self._status)
+            self.universe = hip.unpack_b1_f32(bits)
+        self.action = None
+        reward = torch.zeros(self.instances, 1, dtype=torch.float32, device=self.my_device)
+        return self.get_observation(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
+
     # ------------------------------------------------------------------ cold helpers
     def render(self):
         rows = self.universe[0, 0].cpu()
@@ -439,6 +463,23 @@ class CARLEPacked(CARLE):
         done = torch.zeros(self.instances, 1)
         info = [{}] * self.instances
         return self._obs(), reward, done, info
+
+
+    def multistep(self, steps):
+        hip.require_gpu()
+        self._check_domain()
+        self._ensure_status()
+        d = self.__dict__
+        if d["_bits"] is None:
+            raise RuntimeError("call reset() before multistep()")
+        if int(steps) < 0:
+            raise ValueError("steps must be >= 0")
+        out = torch.empty_like(d["_bits"])
+        hip.ca_multistep_b1(d["_bits"], out, self.rule_mask(), int(steps), self._status)
+        d["_bits"], d["_f32"] = out, None
+        self.action = None
+        reward = torch.zeros(self.instances, 1, dtype=torch.float32, device=self.my_device)
+        return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
 
 
 class CARLEBytes(CARLE):

@@ -295,6 +295,20 @@ def ca_step_b1(u_in, action, u_out, rule, status=None, slot=0):
     _lib.check(rc, "carle_ca_step_b1")
 
 
+def ca_multistep_b1(u_in, u_out, rule, k, status=None):
+    """k action-free generations on packed grids in one launch (u_out may be u_in)."""
+    lib = _lib.load()
+    _chk_grid(u_in, "u_in", torch.int64)
+    _chk_grid(u_out, "u_out", torch.int64)
+    n, _, h, ww = u_in.shape
+    if u_out.shape != u_in.shape:
+        raise ValueError("u_out shape differs from u_in")
+    with _on_device(u_in.device):
+        rc = lib.carle_ca_multistep_b1(u_in.data_ptr(), u_out.data_ptr(), n, h, ww * 64, rule, int(k),
+                                       _ptr(status), _stream(u_in))
+    _lib.check(rc, "carle_ca_multistep_b1")
+
+
 def env_step_b1(u_in, action, u_out, reward, rule, status, slot, publish_flags=True):
     """CARLE.step hot path on packed state: packed step kernel + epilogue, one library call."""
     lib = _lib.load()

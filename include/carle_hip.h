@@ -119,6 +119,17 @@ int carle_unpack_b1_u8(const uint64_t *src, uint8_t *dst, int64_t n, int h, int 
 int carle_action_flags_f32(const float *action, int64_t count, int32_t *status, int slot,
                            void *stream);
 
+/*
+ * k generations without actions on bit-packed grids in ONE launch: the result of k consecutive
+ * CARLE.step calls with an all-zero action (carle/env.py:188-242; the toggle is the identity and
+ * the master reset cannot fire).  One workgroup holds a grid in registers for all k generations:
+ * 0.25 B of HBM traffic per cell per k generations.  u_out may be u_in (in place).
+ *   status (nullable): step_number += k, steps_since_action += k (env.py:199-200, 230).
+ * H == W in {64, 128, 256, 512}; k >= 0 (k == 0 copies).
+ */
+int carle_ca_multistep_b1(const uint64_t *u_in, uint64_t *u_out, int64_t n, int h, int w,
+                          uint32_t rule, int k, int32_t *status, void *stream);
+
 /* fp32 (N,1,H,W) -> bit-packed, bit = (value != 0) (the truthiness of env.py:182); W % 64 == 0.
  * status (nullable): publishes ANY_NONZERO / NOT_ALL_ONES of the fp32 source into `slot`. */
 int carle_pack_f32_b1(const float *src, uint64_t *dst, int64_t n, int h, int w,

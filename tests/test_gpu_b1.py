@@ -161,3 +161,78 @@ def test_packed_env_packed_actions():
         of = ref.step(a)[0]
         assert torch.equal(hip.unpack_b1_f32(ob), of)
         assert env.step_number == ref.step_number
+
+
+@pytest.mark.parametrize("n,size,rule", [
+    (3, 64, ([3], [2, 3])), (2, 64, ([3, 6], [2, 3])), (2, 64, ([3, 6, 8], [2, 4, 5])),
+    (2, 128, ([3], [2, 3])), (2, 128, ([2], [0])), (2, 256, ([3, 6], [2, 3])),
+    (1, 256, ([0, 3, 5, 7], [2, 4, 6, 8])), (1, 512, ([3], [2, 3])), (2, 512, ([3, 6], [2, 3])),
+    (1, 512, ([3, 6, 7, 8], [3, 4, 6, 7, 8])),
+])
+def test_multistep_equals_single_steps(n, size, rule):
+    """carle_ca_multistep_b1(k) == k generations of the C oracle (and of the single-step kernel);
+    in place and out of place; counters advance by k."""
+    from carle_amd import hip
+    rng = np.random.default_rng(n + size)
+    mask = O.rule_mask(*rule)
+    u = (rng.random((n, 1, size, size)) < 0.35).astype(np.float32)
+    d_u = torch.from_numpy(np_pack(u)).cuda()
+    st = hip.new_status("cuda:0")
+    exp = u
+    done = 0
+    cur = d_u.clone()
+    for k in (0, 1, 2, 7, 33):
+        for _ in range(k):
+            exp, _, _ = O.c_env_step(exp, None, mask)
+        out = torch.empty_like(cur)
+        hip.ca_multistep_b1(cur, out, mask, k, st)
+        done += k
+        assert np.array_equal(out.cpu().numpy(), np_pack(exp)), f"after {done} generations"
+        cur = out
+    host = st.cpu()
+    assert int(host[6:8].view(torch.int64)) == done and int(host[8:10].view(torch.int64)) == done
+    # in place == out of place == repeated single steps
+    a = d_u.clone()
+    hip.ca_multistep_b1(a, a, mask, 5, None)
+    b = d_u
+    for _ in range(5):
+        nxt = torch.empty_like(b)
+        hip.ca_step_b1(b, None, nxt, mask, None, 0)
+        b = nxt
+    assert torch.equal(a, b)
+
+
+def test_multistep_through_the_env():
+    """CARLE.multistep(k) / CARLE(storage="b1").multistep(k): glider known answer (population 5
+    after 256 generations, ca_known.json) and equality with k step(zeros) calls."""
+    from carle_amd.env import CARLE
+    k = G.known()
+    for storage in ("f32", "b1"):
+        kw = dict(storage="b1", obs="f32") if storage == "b1" else {}
+        env = CARLE(width=64, height=64, instances=2, device="cuda:0", **kw)
+        env.reset()
+        a = torch.zeros(2, 1, 64, 64)
+        for r, c in k["glider_cells"]:
+            a[0, 0, r, c] = 1.0
+        a[1] = (torch.rand(64, 64, generator=torch.Generator().manual_seed(5)) < 0.3).float()
+        env.step(a)
+        ref = CARLE(width=64, height=64, instances=2, device="cuda:0")
+        ref.reset()
+        ref.universe = env.universe.clone()
+        obs, reward, done, info = env.multistep(255)
+        assert int(obs[0].sum().item()) == 5 and env.step_number == 256 and env.steps_since_action == 255
+        assert float(reward.abs().sum()) == 0.0 and tuple(reward.shape) == (2, 1) and len(info) == 2
+        z = torch.zeros(2, 1, 64, 64, device="cuda")
+        for _ in range(255):
+            ref.step(z)
+        assert torch.equal(obs, ref.universe)
+    env = CARLE(width=20, height=20, action_width=10, action_height=10, instances=1, device="cuda:0")
+    env.reset()
+    env.step(torch.ones(1, 1, 10, 10) * (torch.rand(1, 1, 10, 10) < 0.5))
+    before = env.universe.clone()
+    env.multistep(3)                                        # size without a packed kernel: loop
+    ref = CARLE(width=20, height=20, action_width=10, action_height=10, instances=1, device="cuda:0")
+    ref.reset(); ref.universe = before
+    for _ in range(3):
+        ref.step(torch.zeros(1, 1, 10, 10))
+    assert torch.equal(env.universe, ref.universe) and env.step_number == 4
