@@ -199,12 +199,6 @@ extern "C" int carle_rnd2d_bonus_f32(const float *, int64_t, int, int, const flo
 // NULL / equal.  The observation is the kernel's own 0/1 output, so the fused table-lookup path
 // of the reward net applies.  One call instead of four keeps the host below the GPU time.
 namespace carle {
-int ca_step_f32_impl(const float *u_in, const float *action, float *u_out, int64_t n, int h, int w,
-                     int ah, int aw, uint32_t rule, int32_t *status, int slot, uint64_t *patch_out,
-                     void *stream);
-int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp,
-                  float *ws, float *bonus, float *pred_out, float *target_out, float *reward,
-                  float reward_scale, bool tables_valid, hipStream_t s);
 int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
                   int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
                   bool tables_valid, hipStream_t s);
@@ -251,8 +245,8 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
     // other geometries: step + epilogue on stream_env, then the bonus kernels (reward += scale *
     // bonus fused into the last one) on stream_reward, ordered behind the step through `event`
     (void)patch_scratch;
-    if (int e = ca_step_f32_impl(u_in, action, u_out, n, h, w, ah, aw, rule,
-                                 publish_flags ? status : nullptr, slot, nullptr, stream_env))
+    if (int e = carle_ca_step_f32(u_in, action, u_out, n, h, w, ah, aw, rule,
+                                  publish_flags ? status : nullptr, slot, stream_env))
         return e;
     if (int e = ca_finish_impl(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot,
                                action != nullptr, nullptr, 0, nullptr, 0.0f, stream_env))

@@ -35,10 +35,6 @@ struct RandAct {
     float p = 0.0f;
     uint64_t seed = 0, offset = 0;
     float *action_out = nullptr;   // optional: also materialise the (N,1,AW,AW) action
-    // optional side output for the fused reward nets: the lane's 64-bit result word ("patch"
-    // layout: word g*64 + lane, nibble i = row 4i + lane/16, cols 4*(lane%16)..+3), 512 B per
-    // grid instead of the 16 KiB fp32 observation
-    uint64_t *patch_out = nullptr;
 };
 
 template <class C, class A, bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256,
@@ -101,7 +97,6 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
     typename C::T *gout = u_out + g * 4096 + 4 * lane;
 #pragma unroll
     for (int i = 0; i < 16; ++i) C::template store<NT_ST>(gout + i * 256, (uint32_t)(nxt >> (4 * i)) & 0xFu);
-    if (ra.patch_out) ra.patch_out[g * 64 + lane] = nxt;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -339,15 +334,11 @@ __global__ __launch_bounds__(256) void ca_toggle_kernel(
 using namespace carle;
 
 namespace carle {
-int ca_step_f32_impl(const float *u_in, const float *action, float *u_out, int64_t n, int h, int w,
-                     int ah, int aw, uint32_t rule, int32_t *status, int slot, uint64_t *patch_out,
-                     void *stream);
-
 // validation + dispatch shared by the fp32 and uint8 entry points (`who` prefixes error texts)
 template <class C, class A>
 static int ca_step_cells(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
                          int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status,
-                         int slot, uint64_t *patch_out, void *stream, const char *who) {
+                         int slot, void *stream, const char *who) {
     auto fail = [&](int code, const char *what) {
         char buf[200];
         snprintf(buf, sizeof buf, "%s: %s", who, what);
@@ -370,7 +361,6 @@ static int ca_step_cells(const typename C::T *u_in, const typename A::T *action,
         if (n > 0x7FFFFFFFll) return fail(CARLE_E_DIMS, "batch too large");
         const unsigned blocks = (unsigned)n;
         RandAct ra;
-        ra.patch_out = patch_out;
         if (action)
             hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, true, 64>), dim3(blocks), dim3(64), 0,
                                s, u_in, action, u_out, n, aw, rule, status, slot, ra);
@@ -411,15 +401,8 @@ static int ca_toggle_cells(const typename C::T *u_in, const typename A::T *actio
 extern "C" int carle_ca_step_f32(const float *u_in, const float *action, float *u_out, int64_t n,
                                  int h, int w, int ah, int aw, uint32_t rule, int32_t *status,
                                  int slot, void *stream) {
-    return ca_step_f32_impl(u_in, action, u_out, n, h, w, ah, aw, rule, status, slot, nullptr, stream);
-}
-
-// patch_out: only honoured by the 64x64 fast path (callers check can_patch first)
-int carle::ca_step_f32_impl(const float *u_in, const float *action, float *u_out, int64_t n, int h,
-                            int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
-                            uint64_t *patch_out, void *stream) {
     return ca_step_cells<F32Cells, F32Cells>(u_in, action, u_out, n, h, w, ah, aw, rule, status, slot,
-                                             patch_out, stream, "carle_ca_step_f32");
+                                             stream, "carle_ca_step_f32");
 }
 
 // uint8 state; the action is fp32 (what the reference's agents emit) or uint8
@@ -428,11 +411,11 @@ extern "C" int carle_ca_step_u8(const uint8_t *u_in, const void *action, int act
                                 int slot, void *stream) {
     if (action_fmt == CARLE_FMT_U8)
         return ca_step_cells<U8Cells, U8Cells>(u_in, static_cast<const uint8_t *>(action), u_out, n, h, w,
-                                               ah, aw, rule, status, slot, nullptr, stream,
+                                               ah, aw, rule, status, slot, stream,
                                                "carle_ca_step_u8");
     if (action_fmt == CARLE_FMT_F32)
         return ca_step_cells<U8Cells, F32Cells>(u_in, static_cast<const float *>(action), u_out, n, h, w,
-                                                ah, aw, rule, status, slot, nullptr, stream,
+                                                ah, aw, rule, status, slot, stream,
                                                 "carle_ca_step_u8");
     return fail_arg(CARLE_E_FORMAT, "carle_ca_step_u8: action_fmt must be CARLE_FMT_F32 or CARLE_FMT_U8");
 }

@@ -497,12 +497,7 @@ __global__ __launch_bounds__(64 * kTrainWaves) void rnd_train64_kernel(
     for (int64_t g = wave_id; g < n; g += nwaves) {
         // ---- observation -> 16x4 patch of this lane
         uint64_t c = 0;
-        if (OBS_MODE == 2) {
-            const uint64_t *pw = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + k;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
-                c |= spread_field((uint32_t)(pw[16 * qq] >> (16 * q)) & 0xFFFFu) << (4 * qq);
-        } else if (OBS_MODE == 1) {
+        if (OBS_MODE == 1) {
             const uint64_t *rows = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + 16 * q;
 #pragma unroll
             for (int i = 0; i < 16; ++i) c |= ((rows[i] >> (4 * k)) & 0xFull) << (4 * i);
@@ -762,10 +757,7 @@ int rnd2d_train64(const void *obs, int obs_mode, int64_t n, const float *pp, con
     if (!tables_valid) hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
     const int rows = rnd2d_train64_rows(n);
     const unsigned blocks = (unsigned)(rows / kTrainWaves);
-    if (obs_mode == 2)
-        hipLaunchKernelGGL(rnd_train64_kernel<2>, dim3(blocks), dim3(64 * kTrainWaves), 0, s, obs, ws, bonus,
-                           reward, reward_scale, grad_scale, partial, n);
-    else if (obs_mode == 1)
+    if (obs_mode == 1)
         hipLaunchKernelGGL(rnd_train64_kernel<1>, dim3(blocks), dim3(64 * kTrainWaves), 0, s, obs, ws, bonus,
                            reward, reward_scale, grad_scale, partial, n);
     else

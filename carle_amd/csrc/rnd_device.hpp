@@ -25,12 +25,6 @@ __device__ __forceinline__ uint64_t spread_nibbles(uint32_t x) {
     return t;
 }
 
-// nibble j of a 16-bit field -> nibble 4j of a 64-bit word
-__device__ __forceinline__ uint64_t spread_field(uint32_t x) {
-    return (uint64_t)(x & 0xFu) | ((uint64_t)(x & 0xF0u) << 12) | ((uint64_t)(x & 0xF00u) << 24) |
-           ((uint64_t)(x & 0xF000u) << 36);
-}
-
 // LDS image of one workgroup (4 wavefronts) that owns one 64x64 grid at a time
 struct RndBlockShared {
     float4 lut_p[512];                 // conv1 + relu of the predictor, per 9-bit neighbourhood pattern

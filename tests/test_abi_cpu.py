@@ -47,6 +47,28 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert lib.carle_ca_step_f32(p, None, q, 1, 64, 64, 0, 0, 1 << 18, None, 0, None) == 3
     assert lib.carle_ca_step_f32(p, None, p, 1, 64, 64, 0, 0, 0, None, 0, None) == 5     # alias
     assert lib.carle_ca_finish(None, 0, None, 0, None, 0, 0, None) == 1
+    # uint8 format, multi-generation kernel, stand-alone predicates, conversions
+    b8 = (ctypes.c_uint8 * 64)()
+    p8 = ctypes.cast(b8, ctypes.c_void_p)
+    q8 = ctypes.c_void_p(p8.value + 4096 * 16)
+    assert lib.carle_ca_step_u8(None, None, 0, None, 1, 64, 64, 0, 0, 0, None, 0, None) == 1
+    assert lib.carle_ca_step_u8(p8, p8, 7, q8, 1, 64, 64, 64, 64, 0, None, 0, None) == 6      # action_fmt
+    assert b"action_fmt" in lib.carle_last_error()
+    assert lib.carle_ca_step_u8(p8, None, 0, p8, 1, 64, 64, 0, 0, 0, None, 0, None) == 5      # alias
+    assert lib.carle_ca_step_u8(p8, None, 0, q8, 1, 64, 64, 0, 0, 0, None, 2, None) == 2      # slot
+    assert lib.carle_env_step_u8(p8, None, 0, q8, None, 1, 64, 64, 0, 0, 0, None, 0, 1, None) == 1
+    assert lib.carle_ca_toggle_u8(p8, None, 0, q8, 1, 64, 64, 64, 64, None) == 1
+    assert lib.carle_ca_multistep_b1(p8, q8, 1, 96, 96, 0, 3, None, None) == 2               # W not packed-able
+    assert lib.carle_ca_multistep_b1(p8, q8, 1, 64, 64, 0, -1, None, None) == 2              # k < 0
+    assert lib.carle_ca_multistep_b1(p8, q8, 1, 64, 64, 1 << 18, 1, None, None) == 3
+    assert lib.carle_ca_multistep_b1(p8, q8, 0, 64, 64, 0, 1, None, None) == 0               # empty batch
+    assert lib.carle_ca_multistep_b1(p8, ctypes.c_void_p(p8.value + 256), 1, 64, 64, 0, 1, None, None) == 5
+    assert lib.carle_action_flags_f32(p, 10, None, 0, None) == 1
+    assert lib.carle_action_flags_f32(None, 0, p, 0, None) == 0                              # nothing to scan
+    assert lib.carle_pack_u8_b1(p8, q8, 1, 64, 65, None, 0, None) == 2
+    assert lib.carle_unpack_b1_u8(p8, ctypes.c_void_p(q8.value + 4), 1, 64, 64, None) == 4    # alignment
+    assert lib.carle_env_step_f32_rnd(p, None, q, p, 1, 64, 64, 0, 0, 0, None, 0, 1, p, p, p, p, 1.0, 0,
+                                      None, None, None, None) == 1                           # status NULL
 
 
 def test_env_surface_without_gpu():
