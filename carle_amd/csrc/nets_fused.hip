@@ -152,13 +152,13 @@ int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, con
 // AE2D forward for 64x64 binary grids, fused (carle/mcl.py:452-467, 504-512; eval mode)
 // =============================================================================================
 // Same decomposition as the staged kernels (conv1+relu+pool2 -> conv2+relu+pool2 -> convT1+relu
-// -> convT2+sigmoid -> mean squared error) but per wavefront and LDS-resident:
-//   * lane (q,k) owns rows 16q..16q+15, cols 4k..4k+3 of the grid; conv1 is the 512-entry table
-//     (4 channels = one float4 per neighbourhood pattern);
-//   * A1 (4 x 32x32), A2 (2 x 16x16) and A3 (32x32) live in zero-bordered, wave-private LDS
-//     planes; A3 overlays A1.  Row strides (36 / 20 floats) put the 8-byte patch reads of the 32
-//     lanes of a half-wave on 32 distinct bank pairs;
-//   * every lane finally reconstructs its own 16x4 patch and accumulates (obs - sigmoid)^2.
+// -> convT2+sigmoid -> mean squared error) but per workgroup and LDS-resident:
+//   * the grid sits in LDS as 64 row words; conv1 is the 512-entry table (4 channels = one float4
+//     per neighbourhood pattern);
+//   * A1 (4 x 32x32), A2 (2 x 16x16) and A3 (32x32) live in zero-bordered LDS planes; A3 overlays
+//     A1.  Row strides of 36 / 20 floats spread the 8-byte patch reads over the banks;
+//   * every thread finally reconstructs its own 4x4 cells and accumulates (obs - sigmoid)^2.
+// (The forward+backward kernels further down keep the older wavefront-per-grid decomposition.)
 namespace carle {
 
 static constexpr int kAeLutFloats = 512 * 4;
@@ -166,8 +166,6 @@ static constexpr int kAeParamFloats = 128;                    // conv2, convT1, 
 static constexpr int kAeWsFloats = kAeLutFloats + kAeParamFloats;
 static constexpr int kA1Stride = 36, kA1Rows = 34, kA1Plane = kA1Rows * kA1Stride;   // also A3
 static constexpr int kA2Stride = 20, kA2Rows = 18, kA2Plane = kA2Rows * kA2Stride;
-static constexpr int kAeWaveFloats = 4 * kA1Plane + 2 * kA2Plane;
-static constexpr int kAeWavesPerBlock = 2;
 
 __global__ __launch_bounds__(512) void ae_prepare_kernel(const float *__restrict__ ap,
                                                          float *__restrict__ ws) {
@@ -189,118 +187,114 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return v;
 }
 
+// One workgroup (4 waves) per grid, persistent over grids; thread (py = tid/16, px = tid%16) owns the
+// 4x4 cell block rows 4py.., cols 4px.. in every layer (its 2x2 outputs of A1 / A3, its one output
+// of A2), phases separated by barriers.  31 KB of LDS -> 4-5 workgroups (16-20 waves) per CU.
+struct AeBlockShared {
+    float4 lut[512];
+    float a1[4 * kA1Plane];          // A1; A3 later overlays plane 0
+    float a2[2 * kA2Plane];
+    uint64_t rows[66];               // the grid, one 64-bit word per row at [1..64]; [0], [65] stay zero
+    float red[4];
+};
+
 template <bool PACKED_OBS>
-__global__ __launch_bounds__(64 * kAeWavesPerBlock) void ae_fused64_kernel(
+__global__ __launch_bounds__(256, 4) void ae_block64_kernel(
     const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
     float *__restrict__ recon, float *__restrict__ reward, float reward_scale, int64_t n) {
-    __shared__ float4 s_lut[512];
-    __shared__ float s_wave[kAeWavesPerBlock][kAeWaveFloats];
-
+    __shared__ AeBlockShared s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const float4 *src = reinterpret_cast<const float4 *>(ws);
-        for (int i = tid; i < 512; i += 64 * kAeWavesPerBlock) s_lut[i] = src[i];
-        float *z = &s_wave[0][0];
-        for (int i = tid; i < kAeWavesPerBlock * kAeWaveFloats; i += 64 * kAeWavesPerBlock) z[i] = 0.0f;
+        for (int i = tid; i < 512; i += 256) s.lut[i] = src[i];
+        for (int i = tid; i < 4 * kA1Plane; i += 256) s.a1[i] = 0.0f;
+        for (int i = tid; i < 2 * kA2Plane; i += 256) s.a2[i] = 0.0f;
+        if (tid < 66) s.rows[tid] = 0ull;
     }
     __syncthreads();
     const float *prm = ws + kAeLutFloats;            // uniform parameter block
     const float *w2 = prm, *b2 = prm + 72, *wt1 = prm + 74, *wt2 = prm + 107;
     const float bt1 = prm[106], bt2 = prm[123];
 
-    float *p1 = &s_wave[wv][0];                      // A1: 4 planes (A3 later overlays plane 0)
-    float *p2 = p1 + 4 * kA1Plane;                   // A2: 2 planes
-    const int q = lane >> 4, k = lane & 15;
-    const int64_t wave_id = (int64_t)blockIdx.x * kAeWavesPerBlock + wv;
-    const int64_t nwaves = (int64_t)gridDim.x * kAeWavesPerBlock;
-
-    for (int64_t g = wave_id; g < n; g += nwaves) {
-        // ---- the lane's 16x4 patch, one nibble per row
-        uint64_t c = 0;
+    const int q = lane >> 4, k = lane & 15;          // load mapping: rows 16w+4i+q, columns 4k..4k+3
+    const int py = tid >> 4, px = tid & 15;          // compute mapping
+    const int64_t first = blockIdx.x, stride = gridDim.x;
+    uint4 v[4];
+    uint64_t word = 0;
+    auto issue = [&](int64_t g) {
         if (PACKED_OBS) {
-            const uint64_t *rows = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + 16 * q;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) c |= ((rows[i] >> (4 * k)) & 0xFull) << (4 * i);
+            if (tid < 64) word = reinterpret_cast<const uint64_t *>(obs_v)[g * 64 + tid];
         } else {
-            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + (16 * q) * 16 + k;
-            uint4 v[16];
+            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + 256 * wv + lane;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = gin[i * 16];
+            for (int i = 0; i < 4; ++i) v[i] = gin[i * 64];
+        }
+    };
+    if (first < n) issue(first);
+    for (int64_t g = first; g < n; g += stride) {
+        // ---- the grid as 64 row words in LDS
+        if (PACKED_OBS) {
+            if (tid < 64) s.rows[1 + tid] = word;
+        } else {
+            uint32_t *rows32 = reinterpret_cast<uint32_t *>(&s.rows[1]);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 const uint32_t nib = nz_bit(v[i].x) | (nz_bit(v[i].y) << 1) | (nz_bit(v[i].z) << 2) |
                                      (nz_bit(v[i].w) << 3);
-                c |= (uint64_t)nib << (4 * i);
+                const uint32_t x = row_nibbles_to_dword(nib, k);
+                if ((k & 7) == 7) rows32[2 * (16 * wv + 4 * i + q) + (k >> 3)] = x;
             }
         }
-        // ---- 6-bit row segments [west | 4 cells | east] with zero padding at the grid border
-        uint64_t cw = ((uint64_t)__shfl((uint32_t)(c >> 32), lane - 1, 64) << 32) | __shfl((uint32_t)c, lane - 1, 64);
-        uint64_t ce = ((uint64_t)__shfl((uint32_t)(c >> 32), lane + 1, 64) << 32) | __shfl((uint32_t)c, lane + 1, 64);
-        if (k == 0) cw = 0;
-        if (k == 15) ce = 0;
-        const uint64_t wb = (cw >> 3) & 0x1111111111111111ull, eb = ce & 0x1111111111111111ull;
-        const uint64_t ea = (spread_nibbles((uint32_t)c) << 1) | spread_nibbles((uint32_t)wb) |
-                            (spread_nibbles((uint32_t)eb) << 5);
-        const uint64_t ebb = (spread_nibbles((uint32_t)(c >> 32)) << 1) | spread_nibbles((uint32_t)(wb >> 32)) |
-                             (spread_nibbles((uint32_t)(eb >> 32)) << 5);
-        uint32_t top = __shfl((uint32_t)(ebb >> 56), lane - 16, 64);
-        uint32_t bot = __shfl((uint32_t)ea & 0xFFu, lane + 16, 64);
-        if (q == 0) top = 0;
-        if (q == 3) bot = 0;
-        uint32_t seg[18];
-        seg[0] = top;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            seg[1 + r] = (uint32_t)(ea >> (8 * r)) & 0xFFu;
-            seg[9 + r] = (uint32_t)(ebb >> (8 * r)) & 0xFFu;
-        }
-        seg[17] = bot;
+        if (g + stride < n) issue(g + stride);        // the next grid travels during the layers
+        __syncthreads();
 
-        // ---- conv1 (table) + relu + 2x2 pool -> A1 planes: rows 8q+j, cols 2k+i
+        // ---- conv1 (table) + relu + 2x2 pool -> A1 (2py+a, 2px+b); zero padding at the border
+        uint32_t seg[6];                              // [west | 4 cells | east] of rows 4py-1..4py+4
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int r = 0; r < 6; ++r) {
+            const uint64_t row = s.rows[4 * py + r];
+            seg[r] = (uint32_t)(px == 0 ? row << 1 : row >> (4 * px - 1)) & 0x3Fu;
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
                 float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx) {
-                        const int r = 2 * j + dy, cx = 2 * i + dx;
+                        const int r = 2 * a + dy, cx = 2 * b + dx;
                         const uint32_t p = ((seg[r] >> cx) & 7u) | (((seg[r + 1] >> cx) & 7u) << 3) |
                                            (((seg[r + 2] >> cx) & 7u) << 6);
-                        const float4 a = s_lut[p];
-                        m0 = fmaxf(m0, a.x); m1 = fmaxf(m1, a.y); m2 = fmaxf(m2, a.z); m3 = fmaxf(m3, a.w);
+                        const float4 e = s.lut[p];
+                        m0 = fmaxf(m0, e.x); m1 = fmaxf(m1, e.y); m2 = fmaxf(m2, e.z); m3 = fmaxf(m3, e.w);
                     }
-                const int off = (8 * q + j + 1) * kA1Stride + 2 * k + i + 1;
-                p1[0 * kA1Plane + off] = m0;
-                p1[1 * kA1Plane + off] = m1;
-                p1[2 * kA1Plane + off] = m2;
-                p1[3 * kA1Plane + off] = m3;
+                const int off = (2 * py + a + 1) * kA1Stride + 2 * px + b + 1;
+                s.a1[0 * kA1Plane + off] = m0;
+                s.a1[1 * kA1Plane + off] = m1;
+                s.a1[2 * kA1Plane + off] = m2;
+                s.a1[3 * kA1Plane + off] = m3;
             }
-        }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
 
-        // ---- conv2 (4->2, 3x3, zero pad) + relu + 2x2 pool -> A2: rows 4q+t (t=0..3), col k
-        float acc2[2][4][2][2];
+        // ---- conv2 (4->2, 3x3, zero pad) + relu + 2x2 pool -> A2 (py, px)
+        {
+            float acc2[2][2][2];
 #pragma unroll
-        for (int oc = 0; oc < 2; ++oc)
+            for (int oc = 0; oc < 2; ++oc) { acc2[oc][0][0] = 0.f; acc2[oc][0][1] = 0.f; acc2[oc][1][0] = 0.f; acc2[oc][1][1] = 0.f; }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { acc2[oc][t][0][0] = 0.f; acc2[oc][t][0][1] = 0.f; acc2[oc][t][1][0] = 0.f; acc2[oc][t][1][1] = 0.f; }
+            for (int cc = 0; cc < 4; ++cc) {
+                const float *pl = s.a1 + cc * kA1Plane + (2 * py) * kA1Stride + 2 * px;   // padded rows 2py.., cols 2px..
+                float patch[4][4];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const float *pl = p1 + cc * kA1Plane + (8 * q) * kA1Stride + 2 * k;   // padded rows 8q.., cols 2k..
-            float patch[10][4];
+                for (int r = 0; r < 4; ++r) {
+                    const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
+                    const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
+                    patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+                }
 #pragma unroll
-            for (int r = 0; r < 10; ++r) {
-                const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
-                const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
-                patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
-            }
-#pragma unroll
-            for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -309,41 +303,37 @@ __global__ __launch_bounds__(64 * kAeWavesPerBlock) void ae_fused64_kernel(
                             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                                 for (int kx = 0; kx < 3; ++kx)
-                                    acc2[oc][t][dy][dx] = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx],
-                                                               patch[2 * t + dy + ky][dx + kx], acc2[oc][t][dy][dx]);
-        }
-        __builtin_amdgcn_wave_barrier();             // all A1 reads done before A3 overlays it
-#pragma unroll
-        for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float mx = fmaxf(fmaxf(acc2[oc][t][0][0], acc2[oc][t][0][1]),
-                                       fmaxf(acc2[oc][t][1][0], acc2[oc][t][1][1])) + b2[oc];
-                p2[oc * kA2Plane + (4 * q + t + 1) * kA2Stride + k + 1] = fmaxf(mx, 0.0f);
+                                    acc2[oc][dy][dx] = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx],
+                                                            patch[dy + ky][dx + kx], acc2[oc][dy][dx]);
             }
-        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int oc = 0; oc < 2; ++oc) {
+                const float mx = fmaxf(fmaxf(acc2[oc][0][0], acc2[oc][0][1]),
+                                       fmaxf(acc2[oc][1][0], acc2[oc][1][1])) + b2[oc];
+                s.a2[oc * kA2Plane + (py + 1) * kA2Stride + px + 1] = fmaxf(mx, 0.0f);
+            }
+        }
+        __syncthreads();                              // A1 reads done: A3 may overlay plane 0
 
-        // ---- convT1 (2->1, k4 s2 p1) + relu -> A3 rows 8q+j, cols 2k+i (overlaying A1 plane 0)
-        float a3[8][2];
+        // ---- convT1 (2->1, k4 s2 p1) + relu -> A3 (2py+j, 2px+i), overlaying A1 plane 0
         {
-            float r2[2][6][3];                       // A2 rows 4q-1..4q+4, cols k-1..k+1 (padded)
+            float r2[2][3][3];                        // A2 rows py-1..py+1, cols px-1..px+1 (padded)
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-                for (int r = 0; r < 6; ++r)
+                for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int x = 0; x < 3; ++x)
-                        r2[cc][r][x] = p2[cc * kA2Plane + (4 * q + r) * kA2Stride + k + x];
+                        r2[cc][r][x] = s.a2[cc * kA2Plane + (py + r) * kA2Stride + px + x];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    // output row y = 8q+j: y even (m = y/2): (iy=m, ky=1), (iy=m-1, ky=3);
-                    //                      y odd:           (iy=m, ky=2), (iy=m+1, ky=0)
-                    const int m = j >> 1;            // local A2 row of iy = m is index m + 1
-                    const int ry0 = m + 1, ky0 = (j & 1) ? 2 : 1;
-                    const int ry1 = (j & 1) ? m + 2 : m, ky1 = (j & 1) ? 0 : 3;
-                    const int cx0 = 1, kx0 = i ? 2 : 1;              // x = 2k+i: m = k
+                    // output row y = 2py+j: y even: (iy=py, ky=1), (iy=py-1, ky=3);
+                    //                       y odd:  (iy=py, ky=2), (iy=py+1, ky=0)
+                    const int ry0 = 1, ky0 = j ? 2 : 1;
+                    const int ry1 = j ? 2 : 0, ky1 = j ? 0 : 3;
+                    const int cx0 = 1, kx0 = i ? 2 : 1;
                     const int cx1 = i ? 2 : 0, kx1 = i ? 0 : 3;
                     float acc = 0.0f;
 #pragma unroll
@@ -353,57 +343,53 @@ __global__ __launch_bounds__(64 * kAeWavesPerBlock) void ae_fused64_kernel(
                         acc = fmaf(r2[cc][ry1][cx0], wt1[cc * 16 + ky1 * 4 + kx0], acc);
                         acc = fmaf(r2[cc][ry1][cx1], wt1[cc * 16 + ky1 * 4 + kx1], acc);
                     }
-                    a3[j][i] = fmaxf(acc + bt1, 0.0f);
+                    s.a1[(2 * py + j + 1) * kA1Stride + 2 * px + i + 1] = fmaxf(acc + bt1, 0.0f);
                 }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            p1[(8 * q + j + 1) * kA1Stride + 2 * k + 1] = a3[j][0];
-            p1[(8 * q + j + 1) * kA1Stride + 2 * k + 2] = a3[j][1];
-        }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
 
-        // ---- convT2 (1->1) + sigmoid + squared error on the lane's own 16x4 patch
-        float t3[10][4];                             // A3 rows 8q-1..8q+8, cols 2k-1..2k+2 (padded)
+        // ---- convT2 (1->1) + sigmoid + squared error on the thread's own 4x4 cells
+        float sq = 0.0f;
         {
-            const float *pl = p1 + (8 * q) * kA1Stride + 2 * k;
+            float t3[4][4];                           // A3 rows 2py-1..2py+2, cols 2px-1..2px+2 (padded)
+            const float *pl = s.a1 + (2 * py) * kA1Stride + 2 * px;
 #pragma unroll
-            for (int r = 0; r < 10; ++r) {
+            for (int r = 0; r < 4; ++r) {
                 const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
                 const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
                 t3[r][0] = lo.x; t3[r][1] = lo.y; t3[r][2] = hi.x; t3[r][3] = hi.y;
             }
-        }
-        __builtin_amdgcn_wave_barrier();             // A3 reads done before the next grid's A1 writes
-        float sq = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float out4[4];
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t bits = (uint32_t)(s.rows[1 + 4 * py + r] >> (4 * px)) & 0xFu;
+                float out4[4];
 #pragma unroll
-            for (int cx = 0; cx < 4; ++cx) {
-                const int my = r >> 1, mx = cx >> 1;                 // local A3 index of iy=m is m+1
-                const int ry0 = my + 1, ky0 = (r & 1) ? 2 : 1;
-                const int ry1 = (r & 1) ? my + 2 : my, ky1 = (r & 1) ? 0 : 3;
-                const int cx0 = mx + 1, kx0 = (cx & 1) ? 2 : 1;
-                const int cx1 = (cx & 1) ? mx + 2 : mx, kx1 = (cx & 1) ? 0 : 3;
-                float acc = 0.0f;
-                acc = fmaf(t3[ry0][cx0], wt2[ky0 * 4 + kx0], acc);
-                acc = fmaf(t3[ry0][cx1], wt2[ky0 * 4 + kx1], acc);
-                acc = fmaf(t3[ry1][cx0], wt2[ky1 * 4 + kx0], acc);
-                acc = fmaf(t3[ry1][cx1], wt2[ky1 * 4 + kx1], acc);
-                const float pr = 1.0f / (1.0f + expf(-(acc + bt2)));
-                out4[cx] = pr;
-                const float ob = (float)((c >> (4 * r + cx)) & 1ull);
-                const float df = ob - pr;
-                sq = fmaf(df, df, sq);
+                for (int cx = 0; cx < 4; ++cx) {
+                    const int my = r >> 1, mx = cx >> 1;              // local A3 index of iy=m is m+1
+                    const int ry0 = my + 1, ky0 = (r & 1) ? 2 : 1;
+                    const int ry1 = (r & 1) ? my + 2 : my, ky1 = (r & 1) ? 0 : 3;
+                    const int cx0 = mx + 1, kx0 = (cx & 1) ? 2 : 1;
+                    const int cx1 = (cx & 1) ? mx + 2 : mx, kx1 = (cx & 1) ? 0 : 3;
+                    float acc = 0.0f;
+                    acc = fmaf(t3[ry0][cx0], wt2[ky0 * 4 + kx0], acc);
+                    acc = fmaf(t3[ry0][cx1], wt2[ky0 * 4 + kx1], acc);
+                    acc = fmaf(t3[ry1][cx0], wt2[ky1 * 4 + kx0], acc);
+                    acc = fmaf(t3[ry1][cx1], wt2[ky1 * 4 + kx1], acc);
+                    const float pr = 1.0f / (1.0f + expf(-(acc + bt2)));
+                    out4[cx] = pr;
+                    const float df = (float)((bits >> cx) & 1u) - pr;
+                    sq = fmaf(df, df, sq);
+                }
+                if (recon)
+                    *reinterpret_cast<float4 *>(recon + g * 4096 + (4 * py + r) * 64 + 4 * px) =
+                        make_float4(out4[0], out4[1], out4[2], out4[3]);
             }
-            if (recon)
-                *reinterpret_cast<float4 *>(recon + g * 4096 + (16 * q + r) * 64 + 4 * k) =
-                    make_float4(out4[0], out4[1], out4[2], out4[3]);
         }
         sq = wave_sum_f32(sq);
-        if (lane == 0) {
-            const float b = sq * (1.0f / 4096.0f);
+        if (lane == 0) s.red[wv] = sq;
+        __syncthreads();                              // also: rows / A3 reads done before the next grid
+        if (tid == 0) {
+            const float b = ((s.red[0] + s.red[1]) + (s.red[2] + s.red[3])) * (1.0f / 4096.0f);
             bonus[g] = b;
             if (reward) reward[g] += reward_scale * b;
         }
@@ -415,15 +401,14 @@ int64_t ae2d_fused_workspace_floats() { return kAeWsFloats; }
 int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s) {
     if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
-    int64_t blocks = (n + kAeWavesPerBlock - 1) / kAeWavesPerBlock;
-    if (blocks > 256 * 3) blocks = 256 * 3;           // 3 blocks (6 waves) fit a CU's LDS
+    int64_t blocks = n < 1280 ? n : 1280;             // persistent: 5 workgroups are resident per CU
     if (blocks < 1) blocks = 1;
     if (packed)
-        hipLaunchKernelGGL(ae_fused64_kernel<true>, dim3((unsigned)blocks), dim3(64 * kAeWavesPerBlock), 0,
-                           s, obs, ws, bonus, recon, reward, reward_scale, n);
+        hipLaunchKernelGGL(ae_block64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,
+                           recon, reward, reward_scale, n);
     else
-        hipLaunchKernelGGL(ae_fused64_kernel<false>, dim3((unsigned)blocks), dim3(64 * kAeWavesPerBlock), 0,
-                           s, obs, ws, bonus, recon, reward, reward_scale, n);
+        hipLaunchKernelGGL(ae_block64_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,
+                           recon, reward, reward_scale, n);
     return check_launch("carle_ae2d_bonus(fused 64x64)");
 }
 
