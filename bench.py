@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1")
     ap.add_argument("--stats-every", type=int, default=16,
                     help="steps between reward-statistics all-gathers (reporting interval)")
+    ap.add_argument("--separate-stats-kernel", action="store_true",
+                    help="reduce the rewards with the stand-alone moments kernel every step instead of "
+                         "inside the step epilogue (A/B switch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -192,11 +195,16 @@ def main():
         agent = RandomAgent(action_width=asize, action_height=asize, fused=args.agent == "fused",
                             seed=4321 + rank)
 
+    # the step epilogue reduces the rewards itself where the reward is final at that point (bare
+    # CARLE, RND2D fused into the step): no third launch per step
+    if not args.separate_stats_kernel:
+        stats.attach(wenv)
+
     def one_step(i):
         action = ring[i % len(ring)] if agent is None else agent(env.universe)
         obs, reward, done, info = wenv.step(action)
         if rs is None:
-            stats.update(reward)
+            stats.after_step(wenv, reward)
         elif stats._pending_steps + 1 >= stats.sync_every:
             if wenv is env:
                 rs.fork(reward)

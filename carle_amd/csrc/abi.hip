@@ -17,10 +17,14 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
                                                         int64_t n, int32_t *__restrict__ st,
                                                         int slot, int has_action,
                                                         uint4 *__restrict__ extra, int64_t extra16,
-                                                        float *__restrict__ bonus, float reward_scale) {
+                                                        float *__restrict__ bonus, float reward_scale,
+                                                        int merge_moments) {
     // the whole status block in one round trip (it is one 64-byte line)
     const uint4 *st4 = reinterpret_cast<const uint4 *>(st);
-    const uint4 w0 = st4[0], w1 = st4[1], w2 = st4[2];
+    const uint4 w0 = st4[0], w1 = st4[1], w2 = st4[2], w3 = st4[3];
+    double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
+    double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
+    const bool moments = merge_moments && reward && mom_out && mom_acc;
     const int32_t any_flag = slot ? (int32_t)w0.y : (int32_t)w0.x;
     const int32_t notone_flag = slot ? (int32_t)w0.w : (int32_t)w0.z;
     const bool reset = has_action && notone_flag == 0;
@@ -33,7 +37,56 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
         if (tid < tail_bytes) tail[tid] = 0;
         for (int64_t i = tid; i < extra16; i += nthreads) extra[i] = z;   // side copy of the state
     }
-    if (reward && bonus) {
+    if (moments) {
+        // block 0 writes every reward itself and reduces what it writes: (count, mean, M2) of the
+        // step's final rewards, merged into the running triple (the arithmetic of
+        // batch_moments_kernel, stats.hip)
+        if (blockIdx.x == 0) {
+            __shared__ double part[2][16];
+            const float dead = bonus ? bonus[n] : 0.0f;
+            double s = 0.0, q = 0.0;
+            // eight independent loads in flight per thread and pass (latency-bound: one block)
+            for (int64_t base = 0; base < n; base += 8 * (int64_t)blockDim.x) {
+                float b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = base + u * (int64_t)blockDim.x + threadIdx.x;
+                    b[u] = (bonus && !reset && i < n) ? bonus[i] : dead;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = base + u * (int64_t)blockDim.x + threadIdx.x;
+                    if (i < n) {
+                        const float r = bonus ? reward_scale * b[u] : 0.0f;
+                        if (bonus && reset) bonus[i] = dead;
+                        reward[i] = r;
+                        s += (double)r;
+                        q = fma((double)r, (double)r, q);
+                    }
+                }
+            }
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
+            if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s; part[1][threadIdx.x >> 6] = q; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double sum = 0.0, sq = 0.0;
+                const int nw = (int)(blockDim.x >> 6);
+                for (int k = 0; k < nw; ++k) { sum += part[0][k]; sq += part[1][k]; }
+                const double nb = (double)n, mean = n > 0 ? sum / nb : 0.0;
+                double m2 = sq - sum * mean;
+                if (m2 < 0.0) m2 = 0.0;
+                mom_out[0] = nb; mom_out[1] = mean; mom_out[2] = m2;
+                const double na = mom_acc[0], ma = mom_acc[1], qa = mom_acc[2], tot = na + nb;
+                if (tot > 0.0) {
+                    const double delta = mean - ma;
+                    mom_acc[0] = tot;
+                    mom_acc[1] = ma + delta * nb / tot;
+                    mom_acc[2] = qa + m2 + delta * delta * na * nb / tot;
+                }
+            }
+        }
+    } else if (reward && bonus) {
         // fused CA + RND2D step: reward = 0 + scale * bonus (mcl.py:403-405); after a master reset
         // every observation is the all-dead grid, whose bonus the step kernel left in bonus[n]
         const float dead = bonus[n];
@@ -64,7 +117,7 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
         o2.x = (uint32_t)since; o2.y = (uint32_t)((uint64_t)since >> 32);
         o2.z = (uint32_t)resets; o2.w = (uint32_t)((uint64_t)resets >> 32);
         uint4 *so = reinterpret_cast<uint4 *>(st);
-        so[0] = o0; so[1] = o1; so[2] = o2;
+        so[0] = o0; so[1] = o1; so[2] = o2;              // words 12..15 (moment pointers) stay
     }
 }
 
@@ -87,20 +140,20 @@ extern "C" const char *carle_build_arch(void) {
 namespace carle {
 int ca_finish_impl(void *u_out, int64_t u_out_bytes, float *reward, int64_t n, int32_t *status, int slot,
                    int has_action, void *extra, int64_t extra_bytes, float *bonus, float reward_scale,
-                   void *stream);
+                   int merge_moments, void *stream);
 }
 
 extern "C" int carle_ca_finish(void *u_out, int64_t u_out_bytes, float *reward, int64_t n,
                                int32_t *status, int slot, int has_action, void *stream) {
     return ca_finish_impl(u_out, u_out_bytes, reward, n, status, slot, has_action, nullptr, 0, nullptr, 0.0f,
-                          stream);
+                          0, stream);
 }
 
 // `extra` (16-byte multiple): a second buffer zeroed together with u_out on a master reset.
 // `bonus` (n + 1 floats, nullable): reward := reward_scale * bonus instead of zero (fused RND2D step).
 int carle::ca_finish_impl(void *u_out, int64_t u_out_bytes, float *reward, int64_t n, int32_t *status,
                           int slot, int has_action, void *extra, int64_t extra_bytes, float *bonus,
-                          float reward_scale, void *stream) {
+                          float reward_scale, int merge_moments, void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_ca_finish: status is NULL");
     if (!u_out && u_out_bytes > 0) return fail_arg(CARLE_E_NULL, "carle_ca_finish: u_out is NULL");
     if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_ca_finish: slot must be 0 or 1");
@@ -114,7 +167,7 @@ int carle::ca_finish_impl(void *u_out, int64_t u_out_bytes, float *reward, int64
                        reinterpret_cast<uint4 *>(u_out), n16,
                        reinterpret_cast<unsigned char *>(u_out) + n16 * 16, tail, reward, n, status,
                        slot, (n > 0 && has_action) ? 1 : 0, reinterpret_cast<uint4 *>(extra),
-                       extra_bytes / 16, bonus, reward_scale);
+                       extra_bytes / 16, bonus, reward_scale, merge_moments);
     return check_launch("carle_ca_finish");
 }
 
@@ -126,10 +179,11 @@ extern "C" int carle_env_step_f32(const float *u_in, const float *action, float 
                                   void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32: status is NULL");
     if (int e = carle_ca_step_f32(u_in, action, u_out, n, h, w, ah, aw, rule,
-                                  publish_flags ? status : nullptr, slot, stream))
+                                  (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream))
         return e;
-    return carle_ca_finish(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status,
-                           slot, action != nullptr, stream);
+    return ca_finish_impl(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot,
+                          action != nullptr, nullptr, 0, nullptr, 0.0f,
+                          publish_flags & CARLE_STEP_MERGE_MOMENTS, stream);
 }
 
 extern "C" int carle_ca_step_b1(const uint64_t *, const uint64_t *, uint64_t *, int64_t, int, int, int,
@@ -142,10 +196,10 @@ extern "C" int carle_env_step_b1(const uint64_t *u_in, const uint64_t *action, u
                                  void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_b1: status is NULL");
     if (int e = carle_ca_step_b1(u_in, action, u_out, n, h, w, ah, aw, rule,
-                                 publish_flags ? status : nullptr, slot, stream))
+                                 (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream))
         return e;
-    return carle_ca_finish(u_out, (int64_t)n * h * (w / 8), reward, n, status, slot,
-                           action != nullptr, stream);
+    return ca_finish_impl(u_out, (int64_t)n * h * (w / 8), reward, n, status, slot, action != nullptr,
+                          nullptr, 0, nullptr, 0.0f, publish_flags & CARLE_STEP_MERGE_MOMENTS, stream);
 }
 
 extern "C" int carle_ca_step_u8(const uint8_t *, const void *, int, uint8_t *, int64_t, int, int, int, int,
@@ -157,9 +211,10 @@ extern "C" int carle_env_step_u8(const uint8_t *u_in, const void *action, int ac
                                  int32_t *status, int slot, int publish_flags, void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_u8: status is NULL");
     if (int e = carle_ca_step_u8(u_in, action, action_fmt, u_out, n, h, w, ah, aw, rule,
-                                 publish_flags ? status : nullptr, slot, stream))
+                                 (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream))
         return e;
-    return carle_ca_finish(u_out, (int64_t)n * h * w, reward, n, status, slot, action != nullptr, stream);
+    return ca_finish_impl(u_out, (int64_t)n * h * w, reward, n, status, slot, action != nullptr, nullptr, 0,
+                          nullptr, 0.0f, publish_flags & CARLE_STEP_MERGE_MOMENTS, stream);
 }
 
 extern "C" int carle_ca_step_f32_rand(const float *, float *, int64_t, int, int, int, int, uint32_t, float,
@@ -232,12 +287,13 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
         const size_t bytes = (size_t)n * h * w * sizeof(float);
         if (overlap(u_in, bytes, u_out, bytes))
             return fail_arg(CARLE_E_ALIAS, "carle_env_step_f32_rnd: u_in and u_out overlap");
-        if (int e = ca_step_rnd64(u_in, action, u_out, n, aw, rule, publish_flags ? status : nullptr, slot,
+        if (int e = ca_step_rnd64(u_in, action, u_out, n, aw, rule,
+                                  (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot,
                                   pred_params, rand_params, workspace, bonus, tables_valid,
                                   static_cast<hipStream_t>(stream_env)))
             return e;
         if (int e = ca_finish_impl(u_out, (int64_t)bytes, reward, n, status, slot, action != nullptr, nullptr, 0,
-                                   bonus, reward_scale, stream_env))
+                                   bonus, reward_scale, publish_flags & CARLE_STEP_MERGE_MOMENTS, stream_env))
             return e;
         return fork ? carle_stream_fork(event, stream_env, stream_reward) : 0;
     }
@@ -245,11 +301,12 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
     // other geometries: step + epilogue on stream_env, then the bonus kernels (reward += scale *
     // bonus fused into the last one) on stream_reward, ordered behind the step through `event`
     (void)patch_scratch;
+    // (the bonus is added after the epilogue here: CARLE_STEP_MERGE_MOMENTS does not apply)
     if (int e = carle_ca_step_f32(u_in, action, u_out, n, h, w, ah, aw, rule,
-                                  publish_flags ? status : nullptr, slot, stream_env))
+                                  (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream_env))
         return e;
     if (int e = ca_finish_impl(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot,
-                               action != nullptr, nullptr, 0, nullptr, 0.0f, stream_env))
+                               action != nullptr, nullptr, 0, nullptr, 0.0f, 0, stream_env))
         return e;
     void *rs = stream_env;
     if (fork) {

@@ -125,6 +125,35 @@ class RunningRewardStats:
             return self.flush()
         return None
 
+    def attach(self, env):
+        """Let the step epilogue of ``env`` feed these statistics: the kernel that finishes a step
+        (master reset, counters, reward vector) also reduces the step's rewards and merges them
+        into the pending triple, so ``after_step`` has nothing to launch.  ``env`` must be the
+        OUTERMOST environment the caller steps -- a bare ``CARLE`` (any storage), or an ``RND2D``
+        sitting directly on one (its bonus is part of the fused step) -- because the epilogue only
+        sees the rewards that exist when it runs.  Returns False (and changes nothing) otherwise;
+        ``after_step`` then falls back to the stand-alone moments kernel."""
+        inner = getattr(env, "inner_env", None) or env
+        if not hasattr(inner, "_install_reward_stats") or self.device.type != "cuda":
+            return False
+        if env is not inner:
+            from .mcl import RND2D
+            if type(env) is not RND2D or env.env is not inner or env.train_predictor:
+                return False
+        inner._install_reward_stats(self)
+        env.__dict__["_final_reward_stats"] = self
+        return True
+
+    def after_step(self, env, reward, stream=None):
+        """Account for one finished step of ``env``: nothing to launch when its epilogue already
+        merged the rewards (see ``attach``), else ``update(reward, stream)``."""
+        if getattr(env, "_moments_merged", False):
+            self._pending_steps += 1
+            if self._pending_steps >= self.sync_every:
+                return self.flush()
+            return None
+        return self.update(reward, stream)
+
     def flush(self):
         """Exchange whatever has accumulated since the last all-gather."""
         if self._pending_steps == 0:

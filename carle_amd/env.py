@@ -46,7 +46,7 @@ def _resolve_device(kwargs):
 
 # attributes rewritten every step: bypass nn.Module.__setattr__ (parameter/buffer/module
 # bookkeeping, ~3 us each) -- they are plain Python / tensor attributes
-_PLAIN_ATTRS = frozenset(("universe", "action", "_slot", "log"))
+_PLAIN_ATTRS = frozenset(("universe", "action", "_slot", "log", "_moments_merged"))
 
 
 class CARLE(RLEMixin, nn.Module):
@@ -96,6 +96,8 @@ class CARLE(RLEMixin, nn.Module):
 
         self._status = None          # device int32[16]: flags + counters (include/carle_hip.h)
         self._slot = 0
+        self._reward_stats = None    # dist.RunningRewardStats whose triples the step epilogue feeds
+        self._moments_merged = False
         self.universe = None
         self.action = None
         self.log = []
@@ -156,6 +158,22 @@ class CARLE(RLEMixin, nn.Module):
         if self._status is None or self._status.device != self.my_device:
             self._status = hip.new_status(self.my_device)
             self._slot = 0
+            self._write_stats_pointers()
+
+    def _install_reward_stats(self, stats):
+        """Called by ``dist.RunningRewardStats.attach``: the step epilogue reduces the rewards of a
+        step into ``stats`` when asked to (CARLE_STEP_MERGE_MOMENTS), through two device pointers
+        kept in the status block (rewritten after every ``reset``)."""
+        self._reward_stats = stats
+        self._write_stats_pointers()
+
+    def _write_stats_pointers(self):
+        stats = self.__dict__.get("_reward_stats")
+        if stats is None or self._status is None:
+            return
+        ptrs = torch.tensor([stats._batch.data_ptr(), stats._pending.data_ptr()], dtype=torch.int64)
+        self._status[hip.ST_MOMENTS_OUT:hip.ST_MOMENTS_OUT + 4] = \
+            ptrs.view(torch.int32).to(self._status.device, non_blocking=True)
 
     def _read_counter(self, idx):
         if self._status is None:
@@ -199,6 +217,7 @@ class CARLE(RLEMixin, nn.Module):
                                     dtype=torch.float32, device=self.my_device)
         self._ensure_status()
         self._status.zero_()
+        self._write_stats_pointers()
         self._slot = 0
         self.instance_id = str(int(time.time()))
         self.log = []
@@ -286,6 +305,10 @@ class CARLE(RLEMixin, nn.Module):
         slot = self._slot
         out = torch.empty_like(u_in)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
+        # the step's reward is final (this env is the outermost one a RunningRewardStats is attached
+        # to): the epilogue kernel reduces it, no separate moments launch
+        merge = launch is None and self.__dict__.get("_final_reward_stats") is not None
+        self._moments_merged = False
         if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
             if tuple(action.shape) != (self.instances, 1, self.action_width, self.action_height):
                 raise AssertionError(f"action shape {action.shape} does not match the environment")
@@ -303,7 +326,8 @@ class CARLE(RLEMixin, nn.Module):
             # for an oversize action evaluate them on the uncropped tensor (cold path, no sync)
             hip.action_flags_f32(full.contiguous(), self._status, slot)
         if launch is None:
-            hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, not cropped)
+            hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, not cropped, merge)
+            self._moments_merged = merge
         else:
             launch(u_in, act, out, reward, rule, self._status, slot, not cropped)
         self._slot = slot ^ 1
@@ -412,6 +436,7 @@ class CARLEPacked(CARLE):
         self.__dict__["_f32"] = None
         self._ensure_status()
         self._status.zero_()
+        self._write_stats_pointers()
         self._slot = 0
         self.instance_id = str(int(time.time()))
         self.log = []
@@ -456,7 +481,9 @@ class CARLEPacked(CARLE):
             publish = False
         out = torch.empty_like(bits)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
-        hip.env_step_b1(bits, act, out, reward, self.rule_mask(), self._status, slot, publish)
+        merge = self.__dict__.get("_final_reward_stats") is not None
+        hip.env_step_b1(bits, act, out, reward, self.rule_mask(), self._status, slot, publish, merge)
+        self._moments_merged = merge
         self._slot = slot ^ 1
         d["_bits"] = out
         d["_f32"] = None
@@ -508,6 +535,7 @@ class CARLEBytes(CARLE):
                                     device=self.my_device)
         self._ensure_status()
         self._status.zero_()
+        self._write_stats_pointers()
         self._slot = 0
         self.instance_id = str(int(time.time()))
         self.log = []
@@ -560,7 +588,9 @@ class CARLEBytes(CARLE):
                 hip.action_flags_f32(full.contiguous(), self._status, slot)
         out = torch.empty_like(u_in)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
-        hip.env_step_u8(u_in, act, out, reward, self.rule_mask(), self._status, slot, not cropped)
+        merge = self.__dict__.get("_final_reward_stats") is not None
+        hip.env_step_u8(u_in, act, out, reward, self.rule_mask(), self._status, slot, not cropped, merge)
+        self._moments_merged = merge
         self._slot = slot ^ 1
         self.universe = out
         return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances

@@ -9,6 +9,7 @@ from . import _lib
 
 STATUS_WORDS = 16
 ST_LAST_RESET, ST_STEP_NUMBER, ST_STEPS_SINCE_ACTION, ST_RESETS = 4, 6, 8, 10
+ST_MOMENTS_OUT, ST_MOMENTS_ACC = 12, 14      # two 64-bit device pointers (see carle_hip.h)
 
 
 _gpu_ok = False
@@ -221,7 +222,12 @@ def normalize_f32(x, moments, eps=1e-8):
     return y
 
 
-def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=True):
+def _step_flags(publish_flags, merge_moments):
+    """`publish_flags` argument of the carle_env_step_* entry points (CARLE_STEP_* bits)."""
+    return (1 if publish_flags else 0) | (2 if merge_moments else 0)
+
+
+def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False):
     """CARLE.step hot path: fused CA kernel + epilogue, one library call (shapes are validated by
     the caller; pointers by the library)."""
     lib = _lib.load()
@@ -233,7 +239,7 @@ def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=
     with _on_device(u_in.device):
         rc = lib.carle_env_step_f32(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h,
                                     w, ah, aw, rule, status.data_ptr(), slot,
-                                    1 if publish_flags else 0, _stream(u_in))
+                                    _step_flags(publish_flags, merge_moments), _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_step_f32")
 
@@ -309,7 +315,7 @@ def ca_multistep_b1(u_in, u_out, rule, k, status=None):
     _lib.check(rc, "carle_ca_multistep_b1")
 
 
-def env_step_b1(u_in, action, u_out, reward, rule, status, slot, publish_flags=True):
+def env_step_b1(u_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False):
     """CARLE.step hot path on packed state: packed step kernel + epilogue, one library call."""
     lib = _lib.load()
     n, _, h, ww = u_in.shape
@@ -320,7 +326,7 @@ def env_step_b1(u_in, action, u_out, reward, rule, status, slot, publish_flags=T
     with _on_device(u_in.device):
         rc = lib.carle_env_step_b1(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h,
                                    ww * 64, ah, aw, rule, status.data_ptr(), slot,
-                                   1 if publish_flags else 0, _stream(u_in))
+                                   _step_flags(publish_flags, merge_moments), _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_step_b1")
 
@@ -362,7 +368,7 @@ def ca_step_u8(u_in, action, u_out, rule, status=None, slot=0):
     _lib.check(rc, "carle_ca_step_u8")
 
 
-def env_step_u8(u_in, action, u_out, reward, rule, status, slot, publish_flags=True):
+def env_step_u8(u_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False):
     """CARLE.step hot path on uint8 state: step kernel + epilogue, one library call."""
     lib = _lib.load()
     n, _, h, w = u_in.shape
@@ -373,7 +379,7 @@ def env_step_u8(u_in, action, u_out, reward, rule, status, slot, publish_flags=T
     with _on_device(u_in.device):
         rc = lib.carle_env_step_u8(u_in.data_ptr(), ap, fmt, u_out.data_ptr(), reward.data_ptr(), n, h,
                                    w, ah, aw, rule, status.data_ptr(), slot,
-                                   1 if publish_flags else 0, _stream(u_in))
+                                   _step_flags(publish_flags, merge_moments), _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_step_u8")
 
@@ -482,15 +488,15 @@ def instance_sums_f32(x, w0=None, w1=None, w2=None):
 
 def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_flags, pred_params,
                      rand_params, workspace, bonus, reward_scale, tables_valid, patch_scratch,
-                     event_handle, stream_env, stream_reward):
+                     event_handle, stream_env, stream_reward, merge_moments=False):
     """CARLE.step + RND2D bonus of the fresh observation in one library call (see carle_hip.h)."""
     lib = _lib.load()
     n, _, h, w = u_in.shape
     with _on_device(u_in.device):
         rc = lib.carle_env_step_f32_rnd(u_in.data_ptr(), action.data_ptr(), u_out.data_ptr(),
                                         reward.data_ptr(), n, h, w, action.shape[2], action.shape[3],
-                                        rule, status.data_ptr(), slot, 1 if publish_flags else 0,
-                                        pred_params.data_ptr(), rand_params.data_ptr(),
+                                        rule, status.data_ptr(), slot,
+                                        _step_flags(publish_flags, merge_moments), pred_params.data_ptr(), rand_params.data_ptr(),
                                         workspace.data_ptr(), bonus.data_ptr(), float(reward_scale),
                                         2 if tables_valid else 0, _ptr(patch_scratch), event_handle,
                                         stream_env, stream_reward)

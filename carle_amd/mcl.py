@@ -377,6 +377,7 @@ class RND2D(Motivator):
         """
         if isinstance(action, torch.Tensor):
             action = action.to(self.inner_env.my_device)
+        self.__dict__["_moments_merged"] = False
         if self._can_fuse_step(action):
             return self._fused_step(action)
         obs, reward, done, info = self.env.step(action)
@@ -416,6 +417,8 @@ class RND2D(Motivator):
         valid = self._tables_key == (id(self._ws), versions)
         rs = self._reward_stream()
 
+        merge = self.__dict__.get("_final_reward_stats") is not None     # this wrapper is outermost
+
         def launch(u_in, act, out, reward, rule, status, slot, publish):
             main_raw = hip._stream(u_in)
             if rs is None:
@@ -424,7 +427,11 @@ class RND2D(Motivator):
                 rs_raw = rs.raw
                 ev = rs.event_for_fork(main_raw, out, reward)
             hip.env_step_f32_rnd(u_in, act, out, reward, rule, status, slot, publish, pb, rb, self._ws,
-                                 self._step_bonus, self.reward_scale, valid, None, ev, main_raw, rs_raw)
+                                 self._step_bonus, self.reward_scale, valid, None, ev, main_raw, rs_raw,
+                                 merge and act.shape[3] % 8 == 0)
+            # (the library fuses -- and can merge the moments -- only with an 8-aligned window)
+            self.__dict__["_moments_merged"] = merge and act.shape[3] % 8 == 0
+        self.__dict__["_moments_merged"] = False
         result = env._step(action, launch)
         self._tables_key = (id(self._ws), versions)
         return result

@@ -52,7 +52,17 @@ extern "C" {
 #define CARLE_ST_STEP_NUMBER         6              /* int64 at int32 index 6..7  (env.py:142,230) */
 #define CARLE_ST_STEPS_SINCE_ACTION  8              /* int64 at int32 index 8..9  (env.py:145,200) */
 #define CARLE_ST_RESETS              10             /* int64 at int32 index 10..11: number of master resets */
+#define CARLE_ST_MOMENTS_OUT         12             /* device pointer (64 bit) at index 12..13: double[3], see below */
+#define CARLE_ST_MOMENTS_ACC         14             /* device pointer (64 bit) at index 14..15: double[3], see below */
 #define CARLE_ST_WORDS               16
+
+/* `publish_flags` argument of the carle_env_step_* entry points (bit set) */
+#define CARLE_STEP_PUBLISH_FLAGS     1   /* the step kernel writes the action predicates into the status block */
+#define CARLE_STEP_MERGE_MOMENTS     2   /* the reward of this step is final: the epilogue also reduces it to the
+                                            moment triple (count, mean, M2; fp64) at MOMENTS_OUT and Chan-merges it
+                                            into the running triple at MOMENTS_ACC -- the per-step reward statistics
+                                            of carle_batch_moments_f32 without a third launch.  Ignored while the
+                                            two pointer slots of the status block are zero. */
 
 int         carle_abi_version(void);
 const char *carle_last_error(void);
