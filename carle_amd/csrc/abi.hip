@@ -40,44 +40,52 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
     if (moments) {
         // block 0 writes every reward itself and reduces what it writes: (count, mean, M2) of the
         // step's final rewards, merged into the running triple (the arithmetic of
-        // batch_moments_kernel, stats.hip)
+        // batch_moments_kernel, stats.hip).  The running triple is requested first: its round trip
+        // hides under the reward pass.
         if (blockIdx.x == 0) {
-            __shared__ double part[2][16];
-            const float dead = bonus ? bonus[n] : 0.0f;
-            double s = 0.0, q = 0.0;
-            // eight independent loads in flight per thread and pass (latency-bound: one block)
-            for (int64_t base = 0; base < n; base += 8 * (int64_t)blockDim.x) {
-                float b[8];
+            __shared__ double part[2][4];
+            double na = 0.0, ma = 0.0, qa = 0.0;
+            if (threadIdx.x == 0) { na = mom_acc[0]; ma = mom_acc[1]; qa = mom_acc[2]; }
+            double sum = 0.0, sq = 0.0;
+            if (bonus == nullptr) {
+                // bare CARLE.step: the reward is all zero (env.py:238), nothing to reduce
+                for (int64_t i = threadIdx.x; i < n; i += blockDim.x) reward[i] = 0.0f;
+            } else {
+                const float dead = bonus[n];
+                double s = 0.0, q = 0.0;
+                // eight independent loads in flight per thread and pass (latency-bound: one block)
+                for (int64_t base = 0; base < n; base += 8 * (int64_t)blockDim.x) {
+                    float b[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int64_t i = base + u * (int64_t)blockDim.x + threadIdx.x;
-                    b[u] = (bonus && !reset && i < n) ? bonus[i] : dead;
-                }
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t i = base + u * (int64_t)blockDim.x + threadIdx.x;
+                        b[u] = (!reset && i < n) ? bonus[i] : dead;
+                    }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int64_t i = base + u * (int64_t)blockDim.x + threadIdx.x;
-                    if (i < n) {
-                        const float r = bonus ? reward_scale * b[u] : 0.0f;
-                        if (bonus && reset) bonus[i] = dead;
-                        reward[i] = r;
-                        s += (double)r;
-                        q = fma((double)r, (double)r, q);
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t i = base + u * (int64_t)blockDim.x + threadIdx.x;
+                        if (i < n) {
+                            const float r = reward_scale * b[u];
+                            if (reset) bonus[i] = dead;
+                            reward[i] = r;
+                            s += (double)r;
+                            q = fma((double)r, (double)r, q);
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int sh = 32; sh > 0; sh >>= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
-            if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s; part[1][threadIdx.x >> 6] = q; }
-            __syncthreads();
+                for (int sh = 32; sh > 0; sh >>= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
+                if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s; part[1][threadIdx.x >> 6] = q; }
+                __syncthreads();
+                sum = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+                sq = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+            }
             if (threadIdx.x == 0) {
-                double sum = 0.0, sq = 0.0;
-                const int nw = (int)(blockDim.x >> 6);
-                for (int k = 0; k < nw; ++k) { sum += part[0][k]; sq += part[1][k]; }
                 const double nb = (double)n, mean = n > 0 ? sum / nb : 0.0;
                 double m2 = sq - sum * mean;
                 if (m2 < 0.0) m2 = 0.0;
                 mom_out[0] = nb; mom_out[1] = mean; mom_out[2] = m2;
-                const double na = mom_acc[0], ma = mom_acc[1], qa = mom_acc[2], tot = na + nb;
+                const double tot = na + nb;
                 if (tot > 0.0) {
                     const double delta = mean - ma;
                     mom_acc[0] = tot;
