@@ -56,7 +56,7 @@ def parse():
                     help="run the reward consumers (reward nets, reward statistics) on the CA "
                          "stream instead of the reward stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1")
-    ap.add_argument("--stats-every", type=int, default=16,
+    ap.add_argument("--stats-every", type=int, default=64,
                     help="steps between reward-statistics all-gathers (reporting interval)")
     ap.add_argument("--separate-stats-kernel", action="store_true",
                     help="reduce the rewards with the stand-alone moments kernel every step instead of "
@@ -267,7 +267,7 @@ def main():
     cells = "carle::U8Cells" if bytes_fmt else "carle::F32Cells"
     if rank == 0:
         out = {
-            "metric": "env-steps/sec at N=4096x64x64 (B3/S23, fp32 drop-in grids, action every step)"
+            "metric": f"env-steps/sec at N={n}x64x64 ({args.rule}, fp32 drop-in grids, action every step)"
                       if args.format == "f32" and size == 64 else
                       f"env-steps/sec at N={n}x{size}x{size} ({args.rule}, {args.format} grids, action every step)",
             "value": world * n * args.steps / dt,

@@ -357,6 +357,7 @@ class CARLE(RLEMixin, nn.Module):
             hip.ca_multistep_b1(bits, bits, self.rule_mask(), steps, self._status)
             self.universe = hip.unpack_b1_f32(bits)
         self.action = None
+        self._moments_merged = False
         reward = torch.zeros(self.instances, 1, dtype=torch.float32, device=self.my_device)
         return self.get_observation(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
 
@@ -505,6 +506,7 @@ class CARLEPacked(CARLE):
         hip.ca_multistep_b1(d["_bits"], out, self.rule_mask(), int(steps), self._status)
         d["_bits"], d["_f32"] = out, None
         self.action = None
+        self._moments_merged = False
         reward = torch.zeros(self.instances, 1, dtype=torch.float32, device=self.my_device)
         return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
 
@@ -567,6 +569,27 @@ class CARLEBytes(CARLE):
         out = torch.empty_like(u)
         hip.ca_toggle_u8(u, a, out)
         self.universe = out
+
+    def multistep(self, steps):
+        hip.require_gpu()
+        self._check_domain()
+        self._ensure_status()
+        steps = int(steps)
+        if steps < 0:
+            raise ValueError("steps must be >= 0")
+        if self.width not in (64, 128, 256, 512) or self.logging:
+            zero = torch.zeros(self.instances, 1, self.action_width, self.action_height,
+                               dtype=torch.uint8, device=self.my_device)
+            for _ in range(steps):
+                self.step(zero)
+        else:
+            bits = hip.pack_u8_b1(self._device_universe())
+            hip.ca_multistep_b1(bits, bits, self.rule_mask(), steps, self._status)
+            self.universe = hip.unpack_b1_u8(bits)
+        self.action = None
+        self._moments_merged = False
+        reward = torch.zeros(self.instances, 1, dtype=torch.float32, device=self.my_device)
+        return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
 
     def step(self, action):
         hip.require_gpu()

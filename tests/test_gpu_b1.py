@@ -207,8 +207,8 @@ def test_multistep_through_the_env():
     after 256 generations, ca_known.json) and equality with k step(zeros) calls."""
     from carle_amd.env import CARLE
     k = G.known()
-    for storage in ("f32", "b1"):
-        kw = dict(storage="b1", obs="f32") if storage == "b1" else {}
+    for storage in ("f32", "b1", "u8"):
+        kw = dict(storage=storage, obs="f32") if storage != "f32" else {}
         env = CARLE(width=64, height=64, instances=2, device="cuda:0", **kw)
         env.reset()
         a = torch.zeros(2, 1, 64, 64)
