@@ -263,3 +263,39 @@ def test_zero_instances_and_tiny_batches():
     obs, reward, done, info = env.step(torch.zeros(0, 1, 64, 64))
     assert tuple(obs.shape) == (0, 1, 64, 64) and tuple(reward.shape) == (0, 1) and info == []
     assert env.step_number == 1
+
+
+@pytest.mark.parametrize("storage", ["f32", "u8", "b1"])
+def test_long_run_against_oracle(storage):
+    """Soak: 600 steps with a fresh random action every step (every 97th all-zero, every 211th
+    all-ones = master reset), three rules changed on the fly as train_mcl.py does; grids and counters
+    equal the C oracle at every checkpoint."""
+    n, steps = 6, 600
+    rng = np.random.default_rng(11)
+    kw = dict(storage=storage, obs="f32") if storage != "f32" else {}
+    env = _env(width=64, height=64, instances=n, **kw)
+    env.reset()
+    cur = np.zeros((n, 1, 64, 64), np.float32)
+    rules = [([3], [2, 3]), ([3, 6], [2, 3]), ([3, 6, 8], [2, 4, 5])]
+    step_number = since = 0
+    for t in range(steps):
+        if t % 150 == 0:
+            b, s = rules[(t // 150) % 3]
+            env.birth, env.survive = list(b), list(s)
+            mask = O.rule_mask(b, s)
+        a = (rng.random((n, 1, 64, 64)) < 0.05).astype(np.float32)
+        if t % 97 == 96:
+            a[:] = 0.0
+        if t % 211 == 210:
+            a[:] = 1.0
+        obs = env.step(torch.from_numpy(a).cuda())[0]
+        nxt, reset, flags = O.c_env_step(cur, a, mask)
+        since = since + (0 if a.any() else 1)
+        if reset:
+            cur, step_number, since = np.zeros_like(cur), 0, 0
+        else:
+            cur, step_number = nxt, step_number + 1
+        if t % 50 == 49 or reset or t == steps - 1:
+            assert np.array_equal(obs.float().cpu().numpy(), cur), f"step {t}"
+            assert env.step_number == step_number and env.steps_since_action == since
+    assert env.master_resets == 2
