@@ -99,6 +99,25 @@ __device__ __forceinline__ void toggle_row(uint64_t (&c)[WW], const uint64_t *__
     if (ok) seen_and &= (n == 0xFFFFFFFFu) ? ~0ull : 0ull;
 }
 
+// The same for the usual 64-column window (AW == 64: one action word per row, at bit offset
+// 32*(WW-1) = the high half of grid word (WW-1)/2 and the low half of the next one): two dwords
+// instead of 2*WW, light enough to live inside the full-occupancy instantiation.
+template <int WW>
+__device__ __forceinline__ void toggle_row64(uint64_t (&c)[WW], const uint64_t *__restrict__ arow, bool ok,
+                                             uint32_t &seen_or, uint32_t &seen_and) {
+    const uint32_t *a32 = reinterpret_cast<const uint32_t *>(arow);
+    const uint32_t lo = a32[0], hi = a32[1];                 // arow is clamped to a valid row by the caller
+    const uint32_t l = ok ? lo : 0u, h = ok ? hi : 0u;
+    if constexpr (WW == 1) {
+        c[0] ^= ((uint64_t)h << 32) | l;
+    } else {
+        c[(WW - 1) / 2] ^= (uint64_t)l << 32;
+        c[(WW - 1) / 2 + 1] ^= (uint64_t)h;
+    }
+    seen_or |= l | h;
+    if (ok) seen_and &= lo & hi;
+}
+
 // RULE_MODE: the two rules of the BASELINE configs get a 2-instruction closed form; everything
 // else goes through the rule-independent 17-instruction multiplexer tree (no per-rule branches,
 // no extra live registers -- the branchy sparse form measured slower here: 142 VGPRs).
@@ -120,14 +139,15 @@ __device__ __forceinline__ uint32_t next_state(const Count4<uint32_t> &n, uint32
     }
 }
 
-template <int WW, bool HAS_ACT, int RULE_MODE>
+// ACT: 0 = no action, 1 = 64-column window (toggle_row64), 2 = any packed window (toggle_row)
+template <int WW, int ACT, int RULE_MODE>
 __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     const uint64_t *__restrict__ u_in, const uint64_t *__restrict__ act, uint64_t *__restrict__ u_out,
     int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot,
     int strip_first, int strip_count) {
     // the launch covers strips [strip_first, strip_first + strip_count) (mod WW) of every grid:
-    // the host launches the strips that can meet the action window with HAS_ACT = true and the
-    // others with the leaner HAS_ACT = false instantiation (half the registers)
+    // wide windows: the host launches the strips that can meet the action window with ACT = 2 and
+    // the others with the leaner ACT = 0 instantiation (half the registers)
     constexpr int H = 64 * WW;
     constexpr bool MULTI = WW > 1;                          // more than one 64-row strip per grid
     const int lane = threadIdx.x;
@@ -146,7 +166,30 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     for (int j = 0; j < WW; ++j) hal[j] = 0ull;
     if (MULTI && hr >= 0) load_row<WW>(gin + (int64_t)hr * WW, hal);
 
-    if (HAS_ACT) {
+    if (ACT == 1) {
+        const int oy = (H - ah) >> 1;
+        const bool touches = (r0 < oy + ah && r0 + 64 > oy) ||
+                             (MULTI && ((rt >= oy && rt < oy + ah) || (rb >= oy && rb < oy + ah)));
+        if (touches) {                          // wave-uniform
+            const uint64_t *ga = act + g * (int64_t)ah;
+            uint32_t s_or = 0u, s_and = 0xFFFFFFFFu, d0 = 0u, d1 = 0xFFFFFFFFu;
+            const bool in = r >= oy && r < oy + ah;
+            toggle_row64<WW>(c, ga + (in ? r - oy : 0), in, s_or, s_and);
+            if (MULTI) {
+                const bool hin = hr >= oy && hr < oy + ah;
+                toggle_row64<WW>(hal, ga + (hin ? hr - oy : 0), hin, d0, d1);
+            }
+            if (status != nullptr) {
+                const bool any = __ballot(s_or != 0u) != 0ull;
+                const bool notone = __ballot(in && s_and != 0xFFFFFFFFu) != 0ull;
+                if (lane == 0) {
+                    if (any) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
+                    if (notone) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
+                }
+            }
+        }
+    }
+    if (ACT == 2) {
         __builtin_amdgcn_sched_barrier(0);      // keep the toggle phase's registers out of the
         const int oy = (H - ah) >> 1, aww = aw >> 6;    // compute phase (occupancy: <= 64 VGPRs)
         // wave-uniform: does the strip or one of its halo rows meet the action window at all?
@@ -173,7 +216,7 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
         }
     }
 
-    if (HAS_ACT) __builtin_amdgcn_sched_barrier(0);
+    if (ACT == 2) __builtin_amdgcn_sched_barrier(0);
 
     // ---- compute phase on 32-bit chunks (NC = 2*WW per row): every operation below is a single
     // full-rate VALU instruction -- v_alignbit_b32 for the 1-bit funnel shifts across chunk
@@ -367,11 +410,18 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
                           int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
     if (n * WW > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1: batch too large");
     if (!act) {
-        hipLaunchKernelGGL((ca_step_b1_kernel<WW, false, RULE_MODE>), dim3((unsigned)(n * WW)), dim3(64), 0,
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE>), dim3((unsigned)(n * WW)), dim3(64), 0,
                            s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW);
         return check_launch("carle_ca_step_b1");
     }
-    // strips whose rows, or whose two bordering rows, intersect the window rows [oy, oy+ah)
+    if (aw == 64) {
+        // the usual 64x64 window: its toggle fits the full-occupancy instantiation -> one launch
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE>), dim3((unsigned)(n * WW)), dim3(64), 0,
+                           s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW);
+        return check_launch("carle_ca_step_b1");
+    }
+    // wider windows: the strips whose rows, or whose two bordering rows, intersect the window rows
+    // [oy, oy+ah) run the register-heavier instantiation, the others the lean one
     constexpr int H = 64 * WW;
     const int oy = (H - ah) / 2;
     int first = (oy > 0 ? oy - 1 : H - 1) / 64;              // strip of the row just above the window
@@ -379,10 +429,10 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     if (ah == H) { first = 0; last = WW - 1; }
     int count = ((last - first + WW) % WW) + 1;
     if (count > WW) count = WW;
-    hipLaunchKernelGGL((ca_step_b1_kernel<WW, true, RULE_MODE>), dim3((unsigned)(n * count)), dim3(64), 0, s,
+    hipLaunchKernelGGL((ca_step_b1_kernel<WW, 2, RULE_MODE>), dim3((unsigned)(n * count)), dim3(64), 0, s,
                        u_in, act, u_out, n, ah, aw, rule, status, slot, first, count);
     if (count < WW)
-        hipLaunchKernelGGL((ca_step_b1_kernel<WW, false, RULE_MODE>), dim3((unsigned)(n * (WW - count))),
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE>), dim3((unsigned)(n * (WW - count))),
                            dim3(64), 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot,
                            (first + count) % WW, WW - count);
     return check_launch("carle_ca_step_b1");

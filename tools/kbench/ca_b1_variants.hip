@@ -1,8 +1,8 @@
 // A/B microbenchmark for the bit-packed 512x512 step kernel (development tool).
-// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/kbench/ca_b1_variants tools/kbench/ca_b1_variants.hip
-#include "../../carle_amd/csrc/abi.hip"
+// build (after make -C carle_amd/csrc; the rest of the library is linked, this kernel file is compiled in):
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/kbench/ca_b1_variants tools/kbench/ca_b1_variants.hip \
+//         -Lcarle_amd/lib -lcarle_hip -Wl,-rpath,'$ORIGIN/../../carle_amd/lib'
 #include "../../carle_amd/csrc/ca_step_b1.hip"
-#include "../../carle_amd/csrc/ca_step_cells.hip"
 #include <algorithm>
 #include <vector>
 #include <cstdio>
@@ -47,7 +47,8 @@ int main(int argc, char **argv) {
     CK(hipMemset(act, 0x11, (size_t)n * 64 * 8));
     const uint32_t high = (1u << 12) | (1u << 15) | 0xC, life = (1u << 12) | 0xC;
     struct V { const char *name; int id; } vs[] = {{"flat_copy", 0}, {"strip_copy_direct", 1}, {"strip_copy_rowlane", 2},
-        {"step_noact_highlife", 3}, {"step_act_highlife", 4}, {"step_act_nostatus", 7}, {"step_noact_life", 5}, {"step_noact_dense", 6}};
+        {"step_noact_highlife", 3}, {"step_act_highlife", 4}, {"step_act_nostatus", 7}, {"step_noact_life", 5}, {"step_noact_dense", 6},
+        {"part_noact_5of8_from5", 8}, {"part_noact_5of8_from0", 10}, {"part_noact_4of8_from0", 11}, {"part_act_3of8_from2", 9}};
     const int nv = sizeof(vs) / sizeof(vs[0]);
     std::vector<std::vector<float>> t(nv);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -64,6 +65,14 @@ int main(int argc, char **argv) {
                     case 7: carle_ca_step_b1(a, act, b, n, 512, 512, 64, 64, high, nullptr, 0, nullptr); break;
                     case 5: carle_ca_step_b1(a, nullptr, b, n, 512, 512, 0, 0, life, st, 0, nullptr); break;
                     case 6: carle_ca_step_b1(a, nullptr, b, n, 512, 512, 0, 0, 0x3FFFF, st, 0, nullptr); break;
+                    case 8: hipLaunchKernelGGL((ca_step_b1_kernel<8, 0, kRuleHighLife>), dim3((unsigned)(n * 5)), dim3(64), 0, 0,
+                                               a, (const uint64_t *)nullptr, b, n, 0, 0, high, st, 0, 5, 5); break;
+                    case 10: hipLaunchKernelGGL((ca_step_b1_kernel<8, 0, kRuleHighLife>), dim3((unsigned)(n * 5)), dim3(64), 0, 0,
+                                                a, (const uint64_t *)nullptr, b, n, 0, 0, high, st, 0, 0, 5); break;
+                    case 11: hipLaunchKernelGGL((ca_step_b1_kernel<8, 0, kRuleHighLife>), dim3((unsigned)(n * 4)), dim3(64), 0, 0,
+                                                a, (const uint64_t *)nullptr, b, n, 0, 0, high, st, 0, 0, 4); break;
+                    case 9: hipLaunchKernelGGL((ca_step_b1_kernel<8, 2, kRuleHighLife>), dim3((unsigned)(n * 3)), dim3(64), 0, 0,
+                                               a, act, b, n, 64, 64, high, st, 0, 2, 3); break;
                 }
                 std::swap(a, b);
             }
