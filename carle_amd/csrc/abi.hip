@@ -232,13 +232,13 @@ extern "C" int carle_ca_step_f32_rand(const float *, float *, int64_t, int, int,
 extern "C" int carle_env_step_f32_rand(const float *u_in, float *u_out, float *reward, int64_t n, int h,
                                        int w, int ah, int aw, uint32_t rule, float p, uint64_t seed,
                                        uint64_t offset, float *action_out, int32_t *status, int slot,
-                                       void *stream) {
+                                       int step_flags, void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rand: status is NULL");
     if (int e = carle_ca_step_f32_rand(u_in, u_out, n, h, w, ah, aw, rule, p, seed, offset, action_out,
                                        status, slot, stream))
         return e;
-    return carle_ca_finish(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot, 1,
-                           stream);
+    return ca_finish_impl(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot, 1,
+                          nullptr, 0, nullptr, 0.0f, step_flags & CARLE_STEP_MERGE_MOMENTS, stream);
 }
 
 // Orders `to_stream` after everything enqueued so far on `from_stream` (event record + wait):

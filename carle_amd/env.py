@@ -315,7 +315,8 @@ class CARLE(RLEMixin, nn.Module):
             if self.height == 64 and self.action_width % 8 == 0:
                 # the toggles are drawn inside the step kernel: no action tensor exists
                 hip.env_step_f32_rand(u_in, out, reward, rule, self._status, slot, self.action_height,
-                                      self.action_width, action.p, action.seed, action.offset)
+                                      self.action_width, action.p, action.seed, action.offset, None, merge)
+                self._moments_merged = merge
                 self._slot = slot ^ 1
                 self.universe = out
                 return self.universe, reward, torch.zeros(self.instances, 1), [{}] * self.instances

@@ -451,14 +451,16 @@ def bernoulli_f32(shape, p, seed, offset, device, out=None):
     return out
 
 
-def env_step_f32_rand(u_in, u_out, reward, rule, status, slot, ah, aw, p, seed, offset, action_out=None):
+def env_step_f32_rand(u_in, u_out, reward, rule, status, slot, ah, aw, p, seed, offset, action_out=None,
+                      merge_moments=False):
     """CARLE.step with Bernoulli(p) toggles drawn inside the step kernel (64x64 grids)."""
     lib = _lib.load()
     n, _, h, w = u_in.shape
     with _on_device(u_in.device):
         rc = lib.carle_env_step_f32_rand(u_in.data_ptr(), u_out.data_ptr(), reward.data_ptr(), n, h, w,
                                          ah, aw, rule, float(p), int(seed), int(offset),
-                                         _ptr(action_out), status.data_ptr(), slot, _stream(u_in))
+                                         _ptr(action_out), status.data_ptr(), slot,
+                                         _step_flags(False, merge_moments), _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_step_f32_rand")
 

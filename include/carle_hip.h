@@ -303,10 +303,11 @@ int carle_bernoulli_f32(float *out, int64_t count, float p, uint64_t seed, uint6
 int carle_ca_step_f32_rand(const float *u_in, float *u_out, int64_t n, int h, int w, int ah, int aw,
                            uint32_t rule, float p, uint64_t seed, uint64_t offset, float *action_out,
                            int32_t *status, int slot, void *stream);
-/* ... followed by carle_ca_finish: the whole CARLE.step for a RandomAgent-driven environment */
+/* ... followed by carle_ca_finish: the whole CARLE.step for a RandomAgent-driven environment.
+ * step_flags: CARLE_STEP_MERGE_MOMENTS or 0 (the action predicates are always published). */
 int carle_env_step_f32_rand(const float *u_in, float *u_out, float *reward, int64_t n, int h, int w,
                             int ah, int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset,
-                            float *action_out, int32_t *status, int slot, void *stream);
+                            float *action_out, int32_t *status, int slot, int step_flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-instance sums for the hand-coded reward wrappers: for every instance i

@@ -89,9 +89,9 @@ def test_step_epilogue_merges_reward_moments(kind):
     np.testing.assert_allclose(other.mean, float(reward.double().mean()), rtol=1e-9)
 
 
-def test_attached_stats_with_fused_random_agent_fall_back():
-    """Paths whose epilogue cannot merge (in-kernel random toggles) report it: after_step launches
-    the stand-alone kernel, nothing is counted twice."""
+def test_attached_stats_with_fused_random_agent():
+    """The in-kernel random-toggle step merges the moments too; a wrapper the epilogue cannot cover
+    (here: logging, which falls back to the materialised action) still counts every step once."""
     from carle_amd import dist as cd
     from carle_amd.env import CARLE
     from carle_amd.agents import RandomAgent
@@ -102,7 +102,7 @@ def test_attached_stats_with_fused_random_agent_fall_back():
     agent = RandomAgent(action_width=64, action_height=64, fused=True, seed=3)
     for t in range(4):
         obs, reward, done, info = env.step(agent(env.universe))
-        assert not env._moments_merged
+        assert env._moments_merged
         stats.after_step(env, reward)
     stats.flush()
     assert stats.count == 20.0 and stats.mean == 0.0
