@@ -418,191 +418,176 @@ int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float
 // RND2D forward + BACKWARD for 64x64 binary grids: the predictor's gradient
 // of  sum_t mean_n mean_k (target - prediction)^2 / batch_size  (carle/mcl.py:343-386), computed
 // in the same kernel that evaluates the bonus -- no observation window to retain, no autograd
-// replay.  Eval-mode semantics (Dropout = identity).  Per grid and wavefront:
-//   forward as rnd_fused64_kernel, additionally remembering, per 4x4 pooling window and predictor
+// replay.  Eval-mode semantics (Dropout = identity).  Per grid:
+//   forward as rnd_block64_kernel, additionally remembering, per 4x4 pooling window and predictor
 //   channel, the 9-bit input pattern of the arg-max pixel (ties only occur between equal
 //   patterns or at the relu floor, where the routing does not matter);
-//   backward: dtanh -> linear (dW = dy p2^T in registers of lane (k, half)) -> dp2 -> arg-max of
-//   the 2x2 pool and relu gate -> conv2 weight gradients + scatter of dp1 into LDS planes
-//   (ds_add_f32) -> relu gate at the arg-max pixel of each 4x4 window -> conv1 weight gradients
-//   as gated sums of the remembered pattern bits.
-// Every lane accumulates its share of the 1117 gradient entries in registers over all grids of
-// the wave; one reduction + one partial-row store per wave at the end; rnd_grad_reduce_kernel adds
-// the partial rows in fixed order into the running gradient (deterministic).
+//   backward: dtanh -> linear -> arg-max of the 2x2 pool and relu gate -> conv2 -> relu gate at
+//   the arg-max pixel of each 4x4 window -> conv1 weight gradients as gated sums of the
+//   remembered pattern bits.
 // =============================================================================================
 namespace carle {
 
 static constexpr int kRndPredParams = 36 + 4 + 36 + 1 + 16 * 64 + 16;   // 1117
-static constexpr int kTrainWaves = 2;
 
-template <int OBS_MODE>
-__global__ __launch_bounds__(64 * kTrainWaves) void rnd_train64_kernel(
+// One WORKGROUP per grid (the decomposition of rnd_block64_kernel): thread (py,px) owns
+// pooling window (py,px) in the forward conv1 AND in the backward pass through it, so the arg-max
+// patterns stay in its registers; the gradient w.r.t. the conv2 outputs goes through a sparse
+// 16x16 map in LDS (one entry per 2x2 pooling block) and is GATHERED (no LDS atomics):
+//   d plane[c](P)      = sum_k  w2[c][k] * map(P - k + 1)
+//   d w2[c][k]        += plane[c](P) * map(P - k + 1)        (the same nine map reads)
+// Gradient accumulators per thread: conv1 36+4, conv2 36, its 4 entries of the 16x64 linear layer.
+// One partial row per workgroup at the end; rnd_grad_reduce_kernel adds the rows in a fixed order
+// (deterministic).  2 workgroups (8 waves) per CU; the first version (one WAVE per grid, all 1117
+// accumulators spread over 64 lanes, ds_add_f32 scatters, 4 waves per CU) took twice as long.
+template <bool PACKED_OBS>
+__global__ __launch_bounds__(256, 2) void rnd_train_block64_kernel(
     const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
     float *__restrict__ reward, float reward_scale, float grad_scale, float *__restrict__ partial,
     int64_t n) {
-    __shared__ float4 s_lut_p[512];
-    __shared__ float2 s_lut_r[512];
-    __shared__ float s_lin[2 * kLinFloats];
-    __shared__ float s_planes[kTrainWaves][6][kPlaneFloats];
-    __shared__ float s_dplanes[kTrainWaves][4][kPlaneFloats];
-    __shared__ float s_feat[kTrainWaves][2][64];
-    __shared__ float s_dy[kTrainWaves][16];
-
+    __shared__ RndBlockShared s;
+    __shared__ float s_map[kPlaneFloats];            // d loss / d conv2 output, zero-bordered 16x16
+    __shared__ float s_feat[2][64];
+    __shared__ float s_dy[16];
+    __shared__ float s_red[4][40];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int NT = 64 * kTrainWaves;
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(ws);
-        for (int i = tid; i < 512; i += NT) s_lut_p[i] = src[i];
-        const float2 *src2 = reinterpret_cast<const float2 *>(ws + 2048);
-        for (int i = tid; i < 512; i += NT) s_lut_r[i] = src2[i];
-        for (int i = tid; i < 2 * kLinFloats; i += NT) s_lin[i] = ws[kLutFloats + i];
-        float *pl = &s_planes[0][0][0];
-        for (int i = tid; i < kTrainWaves * 6 * kPlaneFloats; i += NT) pl[i] = 0.0f;
-    }
+    rnd_block_init(s, ws, tid);
+    for (int i = tid; i < kPlaneFloats; i += 256) s_map[i] = 0.0f;
     __syncthreads();
     const float *cw2p = ws + kFusedWsFloats;          // predictor conv2.w[36], b at [36]
     const float *cw2r = ws + kFusedWsFloats + 40;     // random conv2.w[18], b at [18]
 
-    const int q = lane >> 4, k = lane & 15;
-    const int fy = lane >> 3, fx = lane & 7;
+    const int q = lane >> 4, k = lane & 15;           // load mapping
+    const int py = tid >> 4, px = tid & 15;           // window mapping
+    const int fy = lane >> 3, fx = lane & 7;          // wave 0: pooled conv2 output
     const int half = lane & 1, kk = (lane >> 1) & 15, net = lane >> 5;
-    float *planes = &s_planes[wv][0][0];
-    float *dpl = &s_dplanes[wv][0][0];
+    const int wk = tid >> 4, wj = 4 * (tid & 15);     // this thread's entries W[wk][wj..wj+3] of lin.w
 
-    // gradient accumulators of this lane (over all grids of the wave)
-    float gW[32], gB = 0.0f, gw2[36], gb2 = 0.0f, gw1[36], gb1[4];
+    float gw1[36], gb1[4], gw2[36], gW[4], gB = 0.0f, gb2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) gW[i] = 0.0f;
+    for (int i = 0; i < 36; ++i) { gw1[i] = 0.0f; gw2[i] = 0.0f; }
 #pragma unroll
-    for (int i = 0; i < 36; ++i) { gw2[i] = 0.0f; gw1[i] = 0.0f; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gb1[i] = 0.0f;
+    for (int i = 0; i < 4; ++i) { gb1[i] = 0.0f; gW[i] = 0.0f; }
 
-    const int64_t wave_id = (int64_t)blockIdx.x * kTrainWaves + wv, nwaves = (int64_t)gridDim.x * kTrainWaves;
-    for (int64_t g = wave_id; g < n; g += nwaves) {
-        // ---- observation -> 16x4 patch of this lane
-        uint64_t c = 0;
-        if (OBS_MODE == 1) {
-            const uint64_t *rows = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + 16 * q;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) c |= ((rows[i] >> (4 * k)) & 0xFull) << (4 * i);
+    const int64_t first = blockIdx.x, stride = gridDim.x;
+    uint4 v[4];
+    uint64_t word = 0;
+    auto issue = [&](int64_t g) {
+        if (PACKED_OBS) {
+            if (tid < 64) word = reinterpret_cast<const uint64_t *>(obs_v)[g * 64 + tid];
         } else {
-            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + (16 * q) * 16 + k;
+            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + 256 * wv + lane;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint4 v = gin[i * 16];
-                const uint32_t nib = nz_bit(v.x) | (nz_bit(v.y) << 1) | (nz_bit(v.z) << 2) | (nz_bit(v.w) << 3);
-                c |= (uint64_t)nib << (4 * i);
+            for (int i = 0; i < 4; ++i) v[i] = gin[i * 64];
+        }
+    };
+    if (first < n) issue(first);
+    for (int64_t g = first; g < n; g += stride) {
+        // ---- the grid as 64 row words in LDS
+        if (PACKED_OBS) {
+            if (tid < 64) s.rows[1 + tid] = word;
+        } else {
+            uint32_t *rows32 = reinterpret_cast<uint32_t *>(&s.rows[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t nib = nz_bit(v[i].x) | (nz_bit(v[i].y) << 1) | (nz_bit(v[i].z) << 2) |
+                                     (nz_bit(v[i].w) << 3);
+                const uint32_t x = row_nibbles_to_dword(nib, k);
+                if ((k & 7) == 7) rows32[2 * (16 * wv + 4 * i + q) + (k >> 3)] = x;
             }
         }
-        uint64_t cw = ((uint64_t)__shfl((uint32_t)(c >> 32), lane - 1, 64) << 32) | __shfl((uint32_t)c, lane - 1, 64);
-        uint64_t ce = ((uint64_t)__shfl((uint32_t)(c >> 32), lane + 1, 64) << 32) | __shfl((uint32_t)c, lane + 1, 64);
-        if (k == 0) cw = 0;
-        if (k == 15) ce = 0;
-        const uint64_t wb = (cw >> 3) & 0x1111111111111111ull, eb = ce & 0x1111111111111111ull;
-        const uint64_t ea = (spread_nibbles((uint32_t)c) << 1) | spread_nibbles((uint32_t)wb) |
-                            (spread_nibbles((uint32_t)eb) << 5);
-        const uint64_t ebb = (spread_nibbles((uint32_t)(c >> 32)) << 1) | spread_nibbles((uint32_t)(wb >> 32)) |
-                             (spread_nibbles((uint32_t)(eb >> 32)) << 5);
-        uint32_t top = __shfl((uint32_t)(ebb >> 56), lane - 16, 64);
-        uint32_t bot = __shfl((uint32_t)ea & 0xFFu, lane + 16, 64);
-        if (q == 0) top = 0;
-        if (q == 3) bot = 0;
-        uint32_t seg[18];
-        seg[0] = top;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            seg[1 + r] = (uint32_t)(ea >> (8 * r)) & 0xFFu;
-            seg[9 + r] = (uint32_t)(ebb >> (8 * r)) & 0xFFu;
-        }
-        seg[17] = bot;
+        if (g + stride < n) issue(g + stride);
+        __syncthreads();
 
-        // ---- conv1 + relu + 4x4 pool, remembering the arg-max pattern per predictor channel
-        float pm[4][4];                               // [window][channel] pooled value
-        uint32_t pat[4][4];                           // [window][channel] arg-max pattern
+        // ---- conv1 + relu + 4x4 pool of window (py,px), remembering the arg-max pattern per
+        //      predictor channel
+        float pm[4];
+        uint32_t pat[4];
+        {
+            uint32_t seg[6];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+            for (int r = 0; r < 6; ++r) {
+                const uint64_t row = s.rows[4 * py + r];
+                seg[r] = (uint32_t)(px == 0 ? row << 1 : row >> (4 * px - 1)) & 0x3Fu;
+            }
             float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
             uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
             for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 4; ++dx) {
-                    const uint32_t p = ((seg[4 * j + dy] >> dx) & 7u) | (((seg[4 * j + dy + 1] >> dx) & 7u) << 3) |
-                                       (((seg[4 * j + dy + 2] >> dx) & 7u) << 6);
-                    const float4 a = s_lut_p[p];
-                    const float2 b = s_lut_r[p];
+                    const uint32_t p = ((seg[dy] >> dx) & 7u) | (((seg[dy + 1] >> dx) & 7u) << 3) |
+                                       (((seg[dy + 2] >> dx) & 7u) << 6);
+                    const float4 a = s.lut_p[p];
+                    const float2 b = s.lut_r[p];
                     if (a.x > m0) { m0 = a.x; a0 = p; }
                     if (a.y > m1) { m1 = a.y; a1 = p; }
                     if (a.z > m2) { m2 = a.z; a2 = p; }
                     if (a.w > m3) { m3 = a.w; a3 = p; }
                     m4 = fmaxf(m4, b.x); m5 = fmaxf(m5, b.y);
                 }
-            pm[j][0] = m0; pm[j][1] = m1; pm[j][2] = m2; pm[j][3] = m3;
-            pat[j][0] = a0; pat[j][1] = a1; pat[j][2] = a2; pat[j][3] = a3;
-            const int off = (4 * q + j + 1) * kPlaneStride + k + 1;
-            planes[0 * kPlaneFloats + off] = m0;
-            planes[1 * kPlaneFloats + off] = m1;
-            planes[2 * kPlaneFloats + off] = m2;
-            planes[3 * kPlaneFloats + off] = m3;
-            planes[4 * kPlaneFloats + off] = m4;
-            planes[5 * kPlaneFloats + off] = m5;
+            pm[0] = m0; pm[1] = m1; pm[2] = m2; pm[3] = m3;
+            pat[0] = a0; pat[1] = a1; pat[2] = a2; pat[3] = a3;
+            const int off = (py + 1) * kPlaneStride + px + 1;
+            s.planes[0][off] = m0;
+            s.planes[1][off] = m1;
+            s.planes[2][off] = m2;
+            s.planes[3][off] = m3;
+            s.planes[4][off] = m4;
+            s.planes[5][off] = m5;
         }
-        for (int i = lane; i < 4 * kPlaneFloats; i += 64) dpl[i] = 0.0f;     // gradient planes
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
 
-        // ---- conv2 + relu + 2x2 pool (both nets); predictor: arg-max position and relu gate
+        // ---- wave 0: conv2 + relu + 2x2 pool (both nets), linear + tanh, bonus, dL/dy
         int amax = 0;
         bool active = false;
+        if (wv == 0) {
+            const float *planes = &s.planes[0][0];
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
-            const int nch = nn == 0 ? 4 : 2, chbase = nn == 0 ? 0 : 4;
-            const float *cw2 = nn == 0 ? cw2p : cw2r;
-            float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+            for (int nn = 0; nn < 2; ++nn) {
+                const int nch = nn == 0 ? 4 : 2, chbase = nn == 0 ? 0 : 4;
+                const float *cw2 = nn == 0 ? cw2p : cw2r;
+                float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                if (cc < nch) {
-                    const float *pl = planes + (chbase + cc) * kPlaneFloats + (2 * fy) * kPlaneStride + 2 * fx;
-                    float patch[4][4];
+                for (int cc = 0; cc < 4; ++cc) {
+                    if (cc < nch) {
+                        const float *pl = planes + (chbase + cc) * kPlaneFloats + (2 * fy) * kPlaneStride + 2 * fx;
+                        float patch[4][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride);
-                        const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride + 2);
-                        patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+                        for (int r = 0; r < 4; ++r) {
+                            const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride);
+                            const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride + 2);
+                            patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+                        }
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) o00 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][kx], o00);
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) o01 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][1 + kx], o01);
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) o10 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][kx], o10);
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) o11 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][1 + kx], o11);
                     }
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) o00 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][kx], o00);
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) o01 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][1 + kx], o01);
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) o10 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][kx], o10);
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) o11 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][1 + kx], o11);
                 }
+                float mx = o00; int am = 0;
+                if (o01 > mx) { mx = o01; am = 1; }
+                if (o10 > mx) { mx = o10; am = 2; }
+                if (o11 > mx) { mx = o11; am = 3; }
+                mx += cw2[nn == 0 ? 36 : 18];
+                s_feat[nn][fy * 8 + fx] = fmaxf(mx, 0.0f);
+                if (nn == 0) { amax = am; active = mx > 0.0f; }
             }
-            float mx = o00; int am = 0;
-            if (o01 > mx) { mx = o01; am = 1; }
-            if (o10 > mx) { mx = o10; am = 2; }
-            if (o11 > mx) { mx = o11; am = 3; }
-            mx += cw2[nn == 0 ? 36 : 18];
-            s_feat[wv][nn][fy * 8 + fx] = fmaxf(mx, 0.0f);
-            if (nn == 0) { amax = am; active = mx > 0.0f; }
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- linear + tanh, bonus, dL/dy of the predictor
-        float dyk = 0.0f;
-        {
-            const float4 *f4 = reinterpret_cast<const float4 *>(&s_feat[wv][net][32 * half]);
-            const float4 *w4 = reinterpret_cast<const float4 *>(&s_lin[net * kLinFloats + kk * kLinStride + 32 * half]);
+            __builtin_amdgcn_wave_barrier();
+            const float4 *f4 = reinterpret_cast<const float4 *>(&s_feat[net][32 * half]);
+            const float4 *w4 = reinterpret_cast<const float4 *>(&s.lin[net * kLinFloats + kk * kLinStride + 32 * half]);
             float acc = 0.0f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -611,96 +596,89 @@ __global__ __launch_bounds__(64 * kTrainWaves) void rnd_train64_kernel(
                 acc = fmaf(w.z, f.z, acc); acc = fmaf(w.w, f.w, acc);
             }
             acc += __shfl_xor(acc, 1, 64);
-            const float out = tanhf(acc + s_lin[net * kLinFloats + 16 * kLinStride + kk]);
+            const float out = tanhf(acc + s.lin[net * kLinFloats + 16 * kLinStride + kk]);
             const float other = __shfl_xor(out, 32, 64);
             const float diff = out - other;                      // net 0 lanes: prediction - target
             float sq = diff * diff;
 #pragma unroll
-            for (int s = 2; s < 32; s <<= 1) sq += __shfl_xor(sq, s, 64);
+            for (int sh = 2; sh < 32; sh <<= 1) sq += __shfl_xor(sq, sh, 64);
             if (lane == 0) {
                 const float b = sq * (1.0f / 16.0f);
                 bonus[g] = b;
                 if (reward) reward[g] += reward_scale * b;
             }
-            if (net == 0) {
-                dyk = grad_scale * diff * (1.0f - out * out);    // d loss / d y_k
-                // linear layer gradients: this lane owns W[kk][32*half .. +32)
-                const float *fp = &s_feat[wv][0][32 * half];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) gW[i] = fmaf(dyk, fp[i], gW[i]);
-                if (half == 0) { gB += dyk; s_dy[wv][kk] = dyk; }
-            }
+            if (net == 0 && half == 0) s_dy[kk] = grad_scale * diff * (1.0f - out * out);   // d loss / d y_k
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
 
-        // ---- back through linear, 2x2 pool, relu and conv2 (lane = pooled position fy, fx)
+        // ---- linear layer gradients (every thread owns 4 weights); wave 0: back through the
+        //      linear layer, the 2x2 pool and relu -> the conv2-output gradient map
         {
+            const float dyk = s_dy[wk];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gW[i] = fmaf(dyk, s_feat[0][wj + i], gW[i]);
+            if (tid < 16) gB += s_dy[tid];
+        }
+        if (wv == 0) {
             float dp2 = 0.0f;
 #pragma unroll
-            for (int o = 0; o < 16; ++o) dp2 = fmaf(s_lin[o * kLinStride + lane], s_dy[wv][o], dp2);
+            for (int o = 0; o < 16; ++o) dp2 = fmaf(s.lin[o * kLinStride + lane], s_dy[o], dp2);
             const float dz2 = active ? dp2 : 0.0f;
             gb2 += dz2;
-            const int Y = 2 * fy + (amax >> 1), X = 2 * fx + (amax & 1);   // conv2 output position
+            // the four conv2 outputs of this pooling block: gradient at the arg-max, zero elsewhere
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                s_map[(2 * fy + (e >> 1) + 1) * kPlaneStride + 2 * fx + (e & 1) + 1] = e == amax ? dz2 : 0.0f;
+        }
+        __syncthreads();
+
+        // ---- back through conv2 (gather), the 4x4 pool, relu and conv1: thread = window (py,px)
+        {
+            float m[3][3];                            // map rows py..py+2, cols px..px+2 (padded coords)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) m[r][c] = s_map[(py + r) * kPlaneStride + px + c];
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                const float *pl = planes + cc * kPlaneFloats + Y * kPlaneStride + X;   // padded: +ky, +kx
-                float *dp = dpl + cc * kPlaneFloats + Y * kPlaneStride + X;
+                float d = 0.0f;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        gw2[cc * 9 + ky * 3 + kx] = fmaf(dz2, pl[ky * kPlaneStride + kx], gw2[cc * 9 + ky * 3 + kx]);
-                        atomicAdd(dp + ky * kPlaneStride + kx, cw2p[cc * 9 + ky * 3 + kx] * dz2);
+                        d = fmaf(cw2p[cc * 9 + ky * 3 + kx], m[2 - ky][2 - kx], d);
+                        gw2[cc * 9 + ky * 3 + kx] = fmaf(pm[cc], m[2 - ky][2 - kx], gw2[cc * 9 + ky * 3 + kx]);
                     }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- back through the 4x4 pool, relu and conv1 (lane = owner of 4 windows)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int off = (4 * q + j + 1) * kPlaneStride + k + 1;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const float gz = pm[j][cc] > 0.0f ? dpl[cc * kPlaneFloats + off] : 0.0f;
+                const float gz = pm[cc] > 0.0f ? d : 0.0f;
                 gb1[cc] += gz;
 #pragma unroll
                 for (int t = 0; t < 9; ++t)
-                    gw1[cc * 9 + t] = fmaf(gz, (float)((pat[j][cc] >> t) & 1u), gw1[cc * 9 + t]);
+                    gw1[cc * 9 + t] = fmaf(gz, (float)((pat[cc] >> t) & 1u), gw1[cc * 9 + t]);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        // the next iteration's barriers order its writes to rows / planes / the map behind these reads
     }
 
-    // ---- one partial gradient row per wave, parameter order of the predictor blob
-    if (wave_id < nwaves) {
-        float *row = partial + wave_id * kRndPredParams;
+    // ---- one partial gradient row per workgroup, parameter order of the predictor blob
+    float *row = partial + (int64_t)blockIdx.x * kRndPredParams;
 #pragma unroll
-        for (int i = 0; i < 36; ++i) {
-            float a = gw1[i], b = gw2[i];
+    for (int pass = 0; pass < 2; ++pass) {
+        // pass 0: conv1 (36 + 4) -> row[0..40); pass 1: conv2 (36) + its bias -> row[40..77)
 #pragma unroll
-            for (int s = 32; s > 0; s >>= 1) { a += __shfl_xor(a, s, 64); b += __shfl_xor(b, s, 64); }
-            if (lane == 0) { row[i] = a; row[40 + i] = b; }
+        for (int i = 0; i < 40; ++i) {
+            float a = pass == 0 ? (i < 36 ? gw1[i] : gb1[i - 36]) : (i < 36 ? gw2[i] : (i == 36 ? gb2 : 0.0f));
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) a += __shfl_xor(a, sh, 64);
+            if (lane == 0) s_red[wv][i] = a;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float a = gb1[i];
-#pragma unroll
-            for (int s = 32; s > 0; s >>= 1) a += __shfl_xor(a, s, 64);
-            if (lane == 0) row[36 + i] = a;
-        }
-        {
-            float a = gb2;
-#pragma unroll
-            for (int s = 32; s > 0; s >>= 1) a += __shfl_xor(a, s, 64);
-            if (lane == 0) row[76] = a;
-        }
-        if (net == 0) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) row[77 + kk * 64 + 32 * half + i] = gW[i];
-            if (half == 0) row[77 + 1024 + kk] = gB;
-        }
+        __syncthreads();
+        if (tid < (pass == 0 ? 40 : 37))
+            row[40 * pass + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+        __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row[77 + wk * 64 + wj + i] = gW[i];
+    if (tid < 16) row[77 + 1024 + tid] = gB;
 }
 
 // grad[p] += sum over wave rows, fixed order: 32 parameters x 8 row groups per block (128-byte
@@ -729,11 +707,10 @@ __global__ __launch_bounds__(256) void rnd_grad_reduce_kernel(const float *__res
     }
 }
 
-int rnd2d_train64_rows(int64_t n) {
-    int64_t blocks = (n + kTrainWaves - 1) / kTrainWaves;
-    if (blocks > 512) blocks = 512;
+int rnd2d_train64_rows(int64_t n) {                // = workgroups of rnd_train_block64_kernel
+    int64_t blocks = n < 512 ? n : 512;              // persistent: 2 workgroups are resident per CU
     if (blocks < 1) blocks = 1;
-    return (int)(blocks * kTrainWaves);
+    return (int)blocks;
 }
 
 int rnd2d_train64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp, float *ws,
@@ -741,12 +718,11 @@ int rnd2d_train64(const void *obs, int obs_mode, int64_t n, const float *pp, con
                   float *grad, bool tables_valid, hipStream_t s) {
     if (!tables_valid) hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
     const int rows = rnd2d_train64_rows(n);
-    const unsigned blocks = (unsigned)(rows / kTrainWaves);
     if (obs_mode == 1)
-        hipLaunchKernelGGL(rnd_train64_kernel<1>, dim3(blocks), dim3(64 * kTrainWaves), 0, s, obs, ws, bonus,
+        hipLaunchKernelGGL(rnd_train_block64_kernel<true>, dim3((unsigned)rows), dim3(256), 0, s, obs, ws, bonus,
                            reward, reward_scale, grad_scale, partial, n);
     else
-        hipLaunchKernelGGL(rnd_train64_kernel<0>, dim3(blocks), dim3(64 * kTrainWaves), 0, s, obs, ws, bonus,
+        hipLaunchKernelGGL(rnd_train_block64_kernel<false>, dim3((unsigned)rows), dim3(256), 0, s, obs, ws, bonus,
                            reward, reward_scale, grad_scale, partial, n);
     hipLaunchKernelGGL(rnd_grad_reduce_kernel, dim3((kRndPredParams + 31) / 32), dim3(256), 0, s, partial,
                        rows, grad, kRndPredParams);
