@@ -735,154 +735,168 @@ int rnd2d_train64(const void *obs, int obs_mode, int64_t n, const float *pp, con
 // AE2D forward + BACKWARD for 64x64 binary grids: gradient of
 //   sum_t mean_n mean_hw (obs - decoder(obs))^2 / batch_size   (carle/mcl.py:504-547)
 // with respect to the 164 predictor parameters, in the pass that evaluates the bonus.
-// One wavefront per workgroup (the LDS holds A1, A2, A3 and their gradient planes: 54 KiB):
-//   convT2/sigmoid backward on the lane's own 16x4 pixels -> scatter into dA3 (ds_add_f32)
-//   -> relu gate, convT1 backward -> scatter into dA2 -> 2x2 pool arg-max + relu gate, conv2
-//   backward (weight gradients from the A1 planes, scatter into dA1) -> 2x2 pool arg-max pattern +
-//   relu gate, conv1 weight gradients as gated sums of pattern bits.
 // =============================================================================================
 namespace carle {
 
 static constexpr int kAeParams = 164;
 
+// ONE WORKGROUP per grid.  Forward as ae_block64_kernel (thread (py,px) owns the 4x4
+// cell block at (4py,4px) in every layer), A3 in its own plane (A1 is needed again on the way
+// back).  Backward:
+//   convT2 / convT1: each thread accumulates the contributions of its own outputs to the 4x4
+//     (3x3) input neighbourhood in registers, then ds_add_f32's them into the d3 / d2 planes;
+//   conv2: the gradient w.r.t. its outputs goes to a sparse map (one entry per 2x2 pooling block);
+//   conv2 + conv1 weights: CHANNEL-SPLIT -- wave c walks all 32x32 positions of A1 plane c (16 per
+//     lane), gathers  d A1[c](P) = sum_{o,k} w2[o][c][k] map[o](P-k+1),  accumulates
+//     d w2[o][c][k] += A1[c](P) map[o](P-k+1)  and, through the relu gate and the arg-max pattern
+//     of P, the conv1 gradients of channel c: 18 + 9 + 1 accumulators per lane instead of 72 + 36 + 4.
+// 80 accumulators per thread in all (the first version, one wave per grid: 164 per lane, 512
+// registers, 1.6 KB of scratch, 3 waves per CU, twice the time); 62 KB of LDS -> 2 workgroups
+// (8 waves) per CU.
+struct AeTrainShared {
+    float4 lut[512];
+    float a1[4 * kA1Plane];
+    float a2[2 * kA2Plane];
+    float a3[kA1Plane];
+    float d3[kA1Plane];              // d loss / d A3 (before its relu gate)
+    float d2[2 * kA2Plane];          // d loss / d A2 (after the pool)
+    float map2[2 * kA1Plane];        // d loss / d conv2 output: one non-zero per 2x2 pooling block
+    uint16_t pat[4][1024];           // arg-max input pattern of every A1 position (32x32, row-major)
+    uint64_t rows[66];
+    float red[4][52];
+};
+
 template <bool PACKED_OBS>
-__global__ __launch_bounds__(64) void ae_train64_kernel(
+__global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
     const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
     float *__restrict__ reward, float reward_scale, float grad_scale, float *__restrict__ partial,
     int64_t n) {
-    __shared__ float4 s_lut[512];
-    __shared__ float s_a1[4 * kA1Plane], s_dz2[2 * kA1Plane];   // s_dz2: conv2-output gradient map
-    __shared__ float s_a2[2 * kA2Plane], s_d2[2 * kA2Plane];
-    __shared__ float s_a3[kA1Plane], s_d3[kA1Plane];
-
-    const int lane = threadIdx.x;
+    __shared__ AeTrainShared s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const float4 *src = reinterpret_cast<const float4 *>(ws);
-        for (int i = lane; i < 512; i += 64) s_lut[i] = src[i];
-        for (int i = lane; i < 4 * kA1Plane; i += 64) s_a1[i] = 0.0f;
-        for (int i = lane; i < 2 * kA2Plane; i += 64) s_a2[i] = 0.0f;
-        for (int i = lane; i < kA1Plane; i += 64) s_a3[i] = 0.0f;
+        for (int i = tid; i < 512; i += 256) s.lut[i] = src[i];
+        for (int i = tid; i < 4 * kA1Plane; i += 256) s.a1[i] = 0.0f;
+        for (int i = tid; i < 2 * kA2Plane; i += 256) { s.a2[i] = 0.0f; s.d2[i] = 0.0f; }
+        for (int i = tid; i < kA1Plane; i += 256) { s.a3[i] = 0.0f; s.d3[i] = 0.0f; }
+        for (int i = tid; i < 2 * kA1Plane; i += 256) s.map2[i] = 0.0f;
+        if (tid < 66) s.rows[tid] = 0ull;
     }
     __syncthreads();
-    const float *prm = ws + kAeLutFloats;
+    const float *prm = ws + kAeLutFloats;            // uniform parameter block
     const float *w2 = prm, *b2 = prm + 72, *wt1 = prm + 74, *wt2 = prm + 107;
     const float bt1 = prm[106], bt2 = prm[123];
-    const int q = lane >> 4, k = lane & 15;
 
-    float gw1[36], gb1[4], gw2[72], gb2[2], gwt1[32], gbt1 = 0.0f, gwt2[16], gbt2 = 0.0f;
+    const int q = lane >> 4, k = lane & 15;          // load mapping
+    const int py = tid >> 4, px = tid & 15;          // cell-block mapping
+
+    float gwt2[16], gbt2 = 0.0f, gwt1[32], gbt1 = 0.0f, gb2[2] = {0.0f, 0.0f};
+    float gw2c[18], gw1c[9], gb1c = 0.0f;            // conv2 / conv1 gradients of input channel wv
 #pragma unroll
-    for (int i = 0; i < 36; ++i) gw1[i] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gb1[i] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 72; ++i) gw2[i] = 0.0f;
-    gb2[0] = gb2[1] = 0.0f;
+    for (int i = 0; i < 16; ++i) gwt2[i] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) gwt1[i] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) gwt2[i] = 0.0f;
+    for (int i = 0; i < 18; ++i) gw2c[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gw1c[i] = 0.0f;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);   // provably wave-uniform: scalar loads below
+    float wc[18];                                    // w2[oc][wv][k], oc-major (SGPRs)
+#pragma unroll
+    for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+        for (int kq = 0; kq < 9; ++kq) wc[oc * 9 + kq] = w2[(oc * 4 + wvs) * 9 + kq];
 
-    const int64_t wave_id = blockIdx.x, nwaves = gridDim.x;
-    for (int64_t g = wave_id; g < n; g += nwaves) {
-        // ---- observation patch and row segments (as in ae_fused64_kernel)
-        uint64_t c = 0;
+    const int64_t first = blockIdx.x, stride = gridDim.x;
+    uint4 v[4];
+    uint64_t word = 0;
+    auto issue = [&](int64_t g) {
         if (PACKED_OBS) {
-            const uint64_t *rows = reinterpret_cast<const uint64_t *>(obs_v) + g * 64 + 16 * q;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) c |= ((rows[i] >> (4 * k)) & 0xFull) << (4 * i);
+            if (tid < 64) word = reinterpret_cast<const uint64_t *>(obs_v)[g * 64 + tid];
         } else {
-            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + (16 * q) * 16 + k;
+            const uint4 *gin = reinterpret_cast<const uint4 *>(obs_v) + g * 1024 + 256 * wv + lane;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint4 v = gin[i * 16];
-                const uint32_t nib = nz_bit(v.x) | (nz_bit(v.y) << 1) | (nz_bit(v.z) << 2) | (nz_bit(v.w) << 3);
-                c |= (uint64_t)nib << (4 * i);
+            for (int i = 0; i < 4; ++i) v[i] = gin[i * 64];
+        }
+    };
+    if (first < n) issue(first);
+    for (int64_t g = first; g < n; g += stride) {
+        // ---- the grid as 64 row words in LDS
+        if (PACKED_OBS) {
+            if (tid < 64) s.rows[1 + tid] = word;
+        } else {
+            uint32_t *rows32 = reinterpret_cast<uint32_t *>(&s.rows[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t nib = nz_bit(v[i].x) | (nz_bit(v[i].y) << 1) | (nz_bit(v[i].z) << 2) |
+                                     (nz_bit(v[i].w) << 3);
+                const uint32_t x = row_nibbles_to_dword(nib, k);
+                if ((k & 7) == 7) rows32[2 * (16 * wv + 4 * i + q) + (k >> 3)] = x;
             }
         }
-        uint64_t cw = ((uint64_t)__shfl((uint32_t)(c >> 32), lane - 1, 64) << 32) | __shfl((uint32_t)c, lane - 1, 64);
-        uint64_t ce = ((uint64_t)__shfl((uint32_t)(c >> 32), lane + 1, 64) << 32) | __shfl((uint32_t)c, lane + 1, 64);
-        if (k == 0) cw = 0;
-        if (k == 15) ce = 0;
-        const uint64_t wb = (cw >> 3) & 0x1111111111111111ull, eb = ce & 0x1111111111111111ull;
-        const uint64_t ea = (spread_nibbles((uint32_t)c) << 1) | spread_nibbles((uint32_t)wb) |
-                            (spread_nibbles((uint32_t)eb) << 5);
-        const uint64_t ebb = (spread_nibbles((uint32_t)(c >> 32)) << 1) | spread_nibbles((uint32_t)(wb >> 32)) |
-                             (spread_nibbles((uint32_t)(eb >> 32)) << 5);
-        uint32_t top = __shfl((uint32_t)(ebb >> 56), lane - 16, 64);
-        uint32_t bot = __shfl((uint32_t)ea & 0xFFu, lane + 16, 64);
-        if (q == 0) top = 0;
-        if (q == 3) bot = 0;
-        uint32_t seg[18];
-        seg[0] = top;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            seg[1 + r] = (uint32_t)(ea >> (8 * r)) & 0xFFu;
-            seg[9 + r] = (uint32_t)(ebb >> (8 * r)) & 0xFFu;
-        }
-        seg[17] = bot;
+        if (g + stride < n) issue(g + stride);
+        __syncthreads();
 
-        // ---- zero the gradient planes of this grid
+        // ---- conv1 (table) + relu + 2x2 pool -> A1 (2py+a, 2px+b) with arg-max patterns
         {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 *d1 = reinterpret_cast<float4 *>(s_dz2);
-            for (int i = lane; i < kA1Plane / 2; i += 64) d1[i] = z;            // 2 planes = kA1Plane/2 float4
-            float4 *d2 = reinterpret_cast<float4 *>(s_d2);
-            for (int i = lane; i < kA2Plane / 2; i += 64) d2[i] = z;           // 2 planes
-            float4 *d3 = reinterpret_cast<float4 *>(s_d3);
-            for (int i = lane; i < kA1Plane / 4; i += 64) d3[i] = z;
+            uint32_t seg[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const uint64_t row = s.rows[4 * py + r];
+                seg[r] = (uint32_t)(px == 0 ? row << 1 : row >> (4 * px - 1)) & 0x3Fu;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+                    uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int r = 2 * a + dy, cx = 2 * b + dx;
+                            const uint32_t p = ((seg[r] >> cx) & 7u) | (((seg[r + 1] >> cx) & 7u) << 3) |
+                                               (((seg[r + 2] >> cx) & 7u) << 6);
+                            const float4 e = s.lut[p];
+                            if (e.x > m0) { m0 = e.x; p0 = p; }
+                            if (e.y > m1) { m1 = e.y; p1 = p; }
+                            if (e.z > m2) { m2 = e.z; p2 = p; }
+                            if (e.w > m3) { m3 = e.w; p3 = p; }
+                        }
+                    const int off = (2 * py + a + 1) * kA1Stride + 2 * px + b + 1;
+                    s.a1[0 * kA1Plane + off] = m0;
+                    s.a1[1 * kA1Plane + off] = m1;
+                    s.a1[2 * kA1Plane + off] = m2;
+                    s.a1[3 * kA1Plane + off] = m3;
+                    const int pos = (2 * py + a) * 32 + 2 * px + b;
+                    s.pat[0][pos] = (uint16_t)p0;
+                    s.pat[1][pos] = (uint16_t)p1;
+                    s.pat[2][pos] = (uint16_t)p2;
+                    s.pat[3][pos] = (uint16_t)p3;
+                }
         }
+        __syncthreads();
 
-        // ---- conv1 (table) + relu + 2x2 pool -> A1 (rows 8q+j, cols 2k+i); arg-max patterns
-        uint32_t patlo[8][2], pathi[8][2];            // ch0 | ch1<<9 | ch2<<18 ; ch3
+        // ---- conv2 (4->2) + relu + 2x2 pool -> A2 (py, px); arg-max position + gate
+        int am2[2];
+        bool on2[2];
+        {
+            float acc2[2][2][2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+            for (int oc = 0; oc < 2; ++oc) { acc2[oc][0][0] = 0.f; acc2[oc][0][1] = 0.f; acc2[oc][1][0] = 0.f; acc2[oc][1][1] = 0.f; }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
-                uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            for (int cc = 0; cc < 4; ++cc) {
+                const float *pl = s.a1 + cc * kA1Plane + (2 * py) * kA1Stride + 2 * px;
+                float patch[4][4];
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
+                for (int r = 0; r < 4; ++r) {
+                    const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
+                    const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
+                    patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+                }
 #pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int r = 2 * j + dy, cx = 2 * i + dx;
-                        const uint32_t p = ((seg[r] >> cx) & 7u) | (((seg[r + 1] >> cx) & 7u) << 3) |
-                                           (((seg[r + 2] >> cx) & 7u) << 6);
-                        const float4 a = s_lut[p];
-                        if (a.x > m0) { m0 = a.x; p0 = p; }
-                        if (a.y > m1) { m1 = a.y; p1 = p; }
-                        if (a.z > m2) { m2 = a.z; p2 = p; }
-                        if (a.w > m3) { m3 = a.w; p3 = p; }
-                    }
-                patlo[j][i] = p0 | (p1 << 9) | (p2 << 18);
-                pathi[j][i] = p3;
-                const int off = (8 * q + j + 1) * kA1Stride + 2 * k + i + 1;
-                s_a1[0 * kA1Plane + off] = m0;
-                s_a1[1 * kA1Plane + off] = m1;
-                s_a1[2 * kA1Plane + off] = m2;
-                s_a1[3 * kA1Plane + off] = m3;
-            }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- conv2 (4->2) + relu + 2x2 pool -> A2 (rows 4q+t, col k); arg-max + gate
-        float acc2[2][4][2][2];
-#pragma unroll
-        for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { acc2[oc][t][0][0] = 0.f; acc2[oc][t][0][1] = 0.f; acc2[oc][t][1][0] = 0.f; acc2[oc][t][1][1] = 0.f; }
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const float *pl = s_a1 + cc * kA1Plane + (8 * q) * kA1Stride + 2 * k;
-            float patch[10][4];
-#pragma unroll
-            for (int r = 0; r < 10; ++r) {
-                const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
-                const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
-                patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
-            }
-#pragma unroll
-            for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -891,43 +905,40 @@ __global__ __launch_bounds__(64) void ae_train64_kernel(
                             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                                 for (int kx = 0; kx < 3; ++kx)
-                                    acc2[oc][t][dy][dx] = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx],
-                                                               patch[2 * t + dy + ky][dx + kx], acc2[oc][t][dy][dx]);
-        }
-        int am2[2][4];
-        bool on2[2][4];
-#pragma unroll
-        for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float mx = acc2[oc][t][0][0]; int am = 0;
-                if (acc2[oc][t][0][1] > mx) { mx = acc2[oc][t][0][1]; am = 1; }
-                if (acc2[oc][t][1][0] > mx) { mx = acc2[oc][t][1][0]; am = 2; }
-                if (acc2[oc][t][1][1] > mx) { mx = acc2[oc][t][1][1]; am = 3; }
-                mx += b2[oc];
-                am2[oc][t] = am;
-                on2[oc][t] = mx > 0.0f;
-                s_a2[oc * kA2Plane + (4 * q + t + 1) * kA2Stride + k + 1] = fmaxf(mx, 0.0f);
+                                    acc2[oc][dy][dx] = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx],
+                                                            patch[dy + ky][dx + kx], acc2[oc][dy][dx]);
             }
-        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int oc = 0; oc < 2; ++oc) {
+                float mx = acc2[oc][0][0]; int am = 0;
+                if (acc2[oc][0][1] > mx) { mx = acc2[oc][0][1]; am = 1; }
+                if (acc2[oc][1][0] > mx) { mx = acc2[oc][1][0]; am = 2; }
+                if (acc2[oc][1][1] > mx) { mx = acc2[oc][1][1]; am = 3; }
+                mx += b2[oc];
+                am2[oc] = am;
+                on2[oc] = mx > 0.0f;
+                s.a2[oc * kA2Plane + (py + 1) * kA2Stride + px + 1] = fmaxf(mx, 0.0f);
+            }
+        }
+        __syncthreads();
 
-        // ---- convT1 (2->1) + relu -> A3 (rows 8q+j, cols 2k+i)
-        float r2[2][6][3];
+        // ---- convT1 (2->1, k4 s2 p1) + relu -> A3 (2py+j, 2px+i)
+        bool on3[2][2];
+        {
+        float r2[2][3][3];                            // A2 rows py-1..py+1, cols px-1..px+1 (padded)
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int x = 0; x < 3; ++x)
-                    r2[cc][r][x] = s_a2[cc * kA2Plane + (4 * q + r) * kA2Stride + k + x];
-        float a3[8][2];
+                    r2[cc][r][x] = s.a2[cc * kA2Plane + (py + r) * kA2Stride + px + x];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int m = j >> 1;
-                const int ry0 = m + 1, ky0 = (j & 1) ? 2 : 1;
-                const int ry1 = (j & 1) ? m + 2 : m, ky1 = (j & 1) ? 0 : 3;
+                const int ry0 = 1, ky0 = j ? 2 : 1;
+                const int ry1 = j ? 2 : 0, ky1 = j ? 0 : 3;
                 const int cx0 = 1, kx0 = i ? 2 : 1;
                 const int cx1 = i ? 2 : 0, kx1 = i ? 0 : 3;
                 float acc = 0.0f;
@@ -938,84 +949,99 @@ __global__ __launch_bounds__(64) void ae_train64_kernel(
                     acc = fmaf(r2[cc][ry1][cx0], wt1[cc * 16 + ky1 * 4 + kx0], acc);
                     acc = fmaf(r2[cc][ry1][cx1], wt1[cc * 16 + ky1 * 4 + kx1], acc);
                 }
-                a3[j][i] = fmaxf(acc + bt1, 0.0f);
-                s_a3[(8 * q + j + 1) * kA1Stride + 2 * k + i + 1] = a3[j][i];
+                const float a3 = fmaxf(acc + bt1, 0.0f);
+                on3[j][i] = a3 > 0.0f;
+                s.a3[(2 * py + j + 1) * kA1Stride + 2 * px + i + 1] = a3;
             }
-        __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
 
-        // ---- convT2 + sigmoid + loss; backward of convT2 on the lane's own pixels
-        float t3[10][4], dt3[10][4];
+        // ---- convT2 + sigmoid + loss on the thread's own 4x4 cells; backward of convT2
+        float sq = 0.0f;
         {
-            const float *pl = s_a3 + (8 * q) * kA1Stride + 2 * k;
+            float t3[4][4], dt3[4][4];                // A3 rows 2py-1..2py+2, cols 2px-1..2px+2 (padded)
+            const float *pl = s.a3 + (2 * py) * kA1Stride + 2 * px;
 #pragma unroll
-            for (int r = 0; r < 10; ++r) {
+            for (int r = 0; r < 4; ++r) {
                 const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
                 const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
                 t3[r][0] = lo.x; t3[r][1] = lo.y; t3[r][2] = hi.x; t3[r][3] = hi.y;
                 dt3[r][0] = 0.f; dt3[r][1] = 0.f; dt3[r][2] = 0.f; dt3[r][3] = 0.f;
             }
-        }
-        float sq = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t bits = (uint32_t)(s.rows[1 + 4 * py + r] >> (4 * px)) & 0xFu;
 #pragma unroll
-            for (int cx = 0; cx < 4; ++cx) {
-                const int my = r >> 1, mx = cx >> 1;
-                const int ry0 = my + 1, ky0 = (r & 1) ? 2 : 1;
-                const int ry1 = (r & 1) ? my + 2 : my, ky1 = (r & 1) ? 0 : 3;
-                const int cx0 = mx + 1, kx0 = (cx & 1) ? 2 : 1;
-                const int cx1 = (cx & 1) ? mx + 2 : mx, kx1 = (cx & 1) ? 0 : 3;
-                float acc = 0.0f;
-                acc = fmaf(t3[ry0][cx0], wt2[ky0 * 4 + kx0], acc);
-                acc = fmaf(t3[ry0][cx1], wt2[ky0 * 4 + kx1], acc);
-                acc = fmaf(t3[ry1][cx0], wt2[ky1 * 4 + kx0], acc);
-                acc = fmaf(t3[ry1][cx1], wt2[ky1 * 4 + kx1], acc);
-                const float pr = 1.0f / (1.0f + expf(-(acc + bt2)));
-                const float ob = (float)((c >> (4 * r + cx)) & 1ull);
-                const float df = ob - pr;
-                sq = fmaf(df, df, sq);
-                const float dz = grad_scale * (pr - ob) * pr * (1.0f - pr);     // d loss / d (pre-sigmoid)
-                gbt2 += dz;
-                gwt2[ky0 * 4 + kx0] = fmaf(dz, t3[ry0][cx0], gwt2[ky0 * 4 + kx0]);
-                gwt2[ky0 * 4 + kx1] = fmaf(dz, t3[ry0][cx1], gwt2[ky0 * 4 + kx1]);
-                gwt2[ky1 * 4 + kx0] = fmaf(dz, t3[ry1][cx0], gwt2[ky1 * 4 + kx0]);
-                gwt2[ky1 * 4 + kx1] = fmaf(dz, t3[ry1][cx1], gwt2[ky1 * 4 + kx1]);
-                dt3[ry0][cx0] = fmaf(dz, wt2[ky0 * 4 + kx0], dt3[ry0][cx0]);
-                dt3[ry0][cx1] = fmaf(dz, wt2[ky0 * 4 + kx1], dt3[ry0][cx1]);
-                dt3[ry1][cx0] = fmaf(dz, wt2[ky1 * 4 + kx0], dt3[ry1][cx0]);
-                dt3[ry1][cx1] = fmaf(dz, wt2[ky1 * 4 + kx1], dt3[ry1][cx1]);
+                for (int cx = 0; cx < 4; ++cx) {
+                    const int my = r >> 1, mx = cx >> 1;
+                    const int ry0 = my + 1, ky0 = (r & 1) ? 2 : 1;
+                    const int ry1 = (r & 1) ? my + 2 : my, ky1 = (r & 1) ? 0 : 3;
+                    const int cx0 = mx + 1, kx0 = (cx & 1) ? 2 : 1;
+                    const int cx1 = (cx & 1) ? mx + 2 : mx, kx1 = (cx & 1) ? 0 : 3;
+                    float acc = 0.0f;
+                    acc = fmaf(t3[ry0][cx0], wt2[ky0 * 4 + kx0], acc);
+                    acc = fmaf(t3[ry0][cx1], wt2[ky0 * 4 + kx1], acc);
+                    acc = fmaf(t3[ry1][cx0], wt2[ky1 * 4 + kx0], acc);
+                    acc = fmaf(t3[ry1][cx1], wt2[ky1 * 4 + kx1], acc);
+                    const float pr = 1.0f / (1.0f + expf(-(acc + bt2)));
+                    const float ob = (float)((bits >> cx) & 1u);
+                    const float df = ob - pr;
+                    sq = fmaf(df, df, sq);
+                    const float dz = grad_scale * (pr - ob) * pr * (1.0f - pr);     // d loss / d (pre-sigmoid)
+                    gbt2 += dz;
+                    gwt2[ky0 * 4 + kx0] = fmaf(dz, t3[ry0][cx0], gwt2[ky0 * 4 + kx0]);
+                    gwt2[ky0 * 4 + kx1] = fmaf(dz, t3[ry0][cx1], gwt2[ky0 * 4 + kx1]);
+                    gwt2[ky1 * 4 + kx0] = fmaf(dz, t3[ry1][cx0], gwt2[ky1 * 4 + kx0]);
+                    gwt2[ky1 * 4 + kx1] = fmaf(dz, t3[ry1][cx1], gwt2[ky1 * 4 + kx1]);
+                    dt3[ry0][cx0] = fmaf(dz, wt2[ky0 * 4 + kx0], dt3[ry0][cx0]);
+                    dt3[ry0][cx1] = fmaf(dz, wt2[ky0 * 4 + kx1], dt3[ry0][cx1]);
+                    dt3[ry1][cx0] = fmaf(dz, wt2[ky1 * 4 + kx0], dt3[ry1][cx0]);
+                    dt3[ry1][cx1] = fmaf(dz, wt2[ky1 * 4 + kx1], dt3[ry1][cx1]);
+                }
             }
+            // scatter into d3 (interior positions only: the border is never read)
+            float *dp = s.d3 + (2 * py) * kA1Stride + 2 * px;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int Y = 2 * py + r, X = 2 * px + x;                 // padded coordinates
+                    if (Y >= 1 && Y <= 32 && X >= 1 && X <= 32) atomicAdd(dp + r * kA1Stride + x, dt3[r][x]);
+                }
+        }
         sq = wave_sum_f32(sq);
-        if (lane == 0) {
-            const float b = sq * (1.0f / 4096.0f);
+        if (lane == 0) s.red[wv][0] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            const float b = ((s.red[0][0] + s.red[1][0]) + (s.red[2][0] + s.red[3][0])) * (1.0f / 4096.0f);
             bonus[g] = b;
             if (reward) reward[g] += reward_scale * b;
         }
-        {
-            float *dp = s_d3 + (8 * q) * kA1Stride + 2 * k;
-#pragma unroll
-            for (int r = 0; r < 10; ++r)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) atomicAdd(dp + r * kA1Stride + x, dt3[r][x]);
-        }
-        __builtin_amdgcn_wave_barrier();
 
-        // ---- relu gate of A3, convT1 backward
+        // ---- relu gate of A3, convT1 backward (thread's own 2x2 outputs)
         {
-            float dr2[2][6][3];
+            float r2[2][3][3], dr2[2][3][3];          // A2 neighbourhood re-read: cheaper than 18 live registers
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { dr2[cc][r][0] = 0.f; dr2[cc][r][1] = 0.f; dr2[cc][r][2] = 0.f; }
+                for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+                    for (int x = 0; x < 3; ++x)
+                        r2[cc][r][x] = s.a2[cc * kA2Plane + (py + r) * kA2Stride + px + x];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { dr2[cc][r][0] = 0.f; dr2[cc][r][1] = 0.f; dr2[cc][r][2] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const float gz = a3[j][i] > 0.0f ? s_d3[(8 * q + j + 1) * kA1Stride + 2 * k + i + 1] : 0.0f;
+                    float *own = s.d3 + (2 * py + j + 1) * kA1Stride + 2 * px + i + 1;
+                    const float gz = on3[j][i] ? *own : 0.0f;
+                    *own = 0.0f;                                   // ready for the next grid
                     gbt1 += gz;
-                    const int m = j >> 1;
-                    const int ry0 = m + 1, ky0 = (j & 1) ? 2 : 1;
-                    const int ry1 = (j & 1) ? m + 2 : m, ky1 = (j & 1) ? 0 : 3;
+                    const int ry0 = 1, ky0 = j ? 2 : 1;
+                    const int ry1 = j ? 2 : 0, ky1 = j ? 0 : 3;
                     const int cx0 = 1, kx0 = i ? 2 : 1;
                     const int cx1 = i ? 2 : 0, kx1 = i ? 0 : 3;
 #pragma unroll
@@ -1033,103 +1059,113 @@ __global__ __launch_bounds__(64) void ae_train64_kernel(
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-                for (int r = 0; r < 6; ++r)
+                for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int x = 0; x < 3; ++x)
-                        atomicAdd(&s_d2[cc * kA2Plane + (4 * q + r) * kA2Stride + k + x], dr2[cc][r][x]);
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- 2x2 pool arg-max + relu gate of A2, conv2 weight gradients (A1 planes in LDS); the
-        //      gradient w.r.t. the conv2 outputs goes to a sparse 32x32 map (one entry per 2x2 block)
-#pragma unroll
-        for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float gz = on2[oc][t] ? s_d2[oc * kA2Plane + (4 * q + t + 1) * kA2Stride + k + 1] : 0.0f;
-                gb2[oc] += gz;
-                // conv2 output (Y, X) = (2a+dy, 2k+dx), a = 4q+t: padded A1 origin row 8q+2t+dy, col 2k+dx
-                const int base = (8 * q + 2 * t + (am2[oc][t] >> 1)) * kA1Stride + 2 * k + (am2[oc][t] & 1);
-                s_dz2[oc * kA1Plane + base + kA1Stride + 1] = gz;          // padded (Y+1, X+1)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int o = cc * kA1Plane + base + ky * kA1Stride + kx;
-                            gw2[(oc * 4 + cc) * 9 + ky * 3 + kx] = fmaf(gz, s_a1[o], gw2[(oc * 4 + cc) * 9 + ky * 3 + kx]);
-                        }
-            }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- dA1 by gathering the conv2-output gradients (transposed convolution), then the
-        //      2x2 pool arg-max pattern + relu gate of A1 and the conv1 weight gradients
-        {
-            float dzp[2][10][4];                      // map rows 8q-1..8q+8, cols 2k-1..2k+2 (padded)
-#pragma unroll
-            for (int oc = 0; oc < 2; ++oc) {
-                const float *pl = s_dz2 + oc * kA1Plane + (8 * q) * kA1Stride + 2 * k;
-#pragma unroll
-                for (int r = 0; r < 10; ++r) {
-                    const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
-                    const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
-                    dzp[oc][r][0] = lo.x; dzp[oc][r][1] = lo.y; dzp[oc][r][2] = hi.x; dzp[oc][r][3] = hi.y;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int off = (8 * q + j + 1) * kA1Stride + 2 * k + i + 1;
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        // A1 position P receives w2[oc][cc][ky][kx] * dz2[oc][P - k + 1]; local map
-                        // index of output row (8q+j) - ky + 1 is j + 2 - ky, column i + 2 - kx
-                        float d = 0.0f;
-#pragma unroll
-                        for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-                            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                                for (int kx = 0; kx < 3; ++kx)
-                                    d = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx], dzp[oc][j + 2 - ky][i + 2 - kx], d);
-                        const float gz = s_a1[cc * kA1Plane + off] > 0.0f ? d : 0.0f;
-                        const uint32_t pt = cc < 3 ? (patlo[j][i] >> (9 * cc)) & 0x1FFu : pathi[j][i];
-                        gb1[cc] += gz;
-#pragma unroll
-                        for (int t = 0; t < 9; ++t)
-                            gw1[cc * 9 + t] = fmaf(gz, (float)((pt >> t) & 1u), gw1[cc * 9 + t]);
+                    for (int x = 0; x < 3; ++x) {
+                        const int Y = py + r, X = px + x;                    // padded coordinates
+                        if (Y >= 1 && Y <= 16 && X >= 1 && X <= 16)
+                            atomicAdd(&s.d2[cc * kA2Plane + Y * kA2Stride + X], dr2[cc][r][x]);
                     }
-                }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+
+        // ---- 2x2 pool arg-max + relu gate of A2 -> the conv2-output gradient map
+#pragma unroll
+        for (int oc = 0; oc < 2; ++oc) {
+            float *own = &s.d2[oc * kA2Plane + (py + 1) * kA2Stride + px + 1];
+            const float gz = on2[oc] ? *own : 0.0f;
+            *own = 0.0f;
+            gb2[oc] += gz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                s.map2[oc * kA1Plane + (2 * py + (e >> 1) + 1) * kA1Stride + 2 * px + (e & 1) + 1] =
+                    e == am2[oc] ? gz : 0.0f;
+        }
+        __syncthreads();
+
+        // ---- conv2 and conv1 weight gradients of input channel wv: lane = 16 positions of A1
+        //      row Y = lane / 2, columns 16 * (lane & 1) ..
+        {
+            const int Y = lane >> 1, X0 = 16 * (lane & 1);
+            const float *ap = s.a1 + wvs * kA1Plane + (Y + 1) * kA1Stride + X0 + 1;
+            const uint16_t *pp = &s.pat[wvs][Y * 32 + X0];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                float mp[2][3][6];                    // map rows Y..Y+2, cols X0+4ch .. +5 (padded)
+#pragma unroll
+                for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float *mr = s.map2 + oc * kA1Plane + (Y + r) * kA1Stride + X0 + 4 * ch;
+                        const float2 m01 = *reinterpret_cast<const float2 *>(mr);
+                        const float2 m23 = *reinterpret_cast<const float2 *>(mr + 2);
+                        const float2 m45 = *reinterpret_cast<const float2 *>(mr + 4);
+                        mp[oc][r][0] = m01.x; mp[oc][r][1] = m01.y; mp[oc][r][2] = m23.x;
+                        mp[oc][r][3] = m23.y; mp[oc][r][4] = m45.x; mp[oc][r][5] = m45.y;
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float av = ap[4 * ch + i];
+                    const uint32_t pt = pp[4 * ch + i];
+                    float d = 0.0f;
+#pragma unroll
+                    for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const float mv = mp[oc][2 - ky][i + 2 - kx];
+                                gw2c[oc * 9 + ky * 3 + kx] = fmaf(av, mv, gw2c[oc * 9 + ky * 3 + kx]);
+                                d = fmaf(wc[oc * 9 + ky * 3 + kx], mv, d);
+                            }
+                    const float gz = av > 0.0f ? d : 0.0f;
+                    gb1c += gz;
+#pragma unroll
+                    for (int tt = 0; tt < 9; ++tt)
+                        gw1c[tt] = fmaf(gz, (float)((pt >> tt) & 1u), gw1c[tt]);
+                }
+            }
+        }
+        // the next iteration's barriers order its writes to rows / A1 / pat / map2 behind these reads
     }
 
-    // ---- one partial gradient row per wave, parameter order of the AE blob
-    float *row = partial + wave_id * kAeParams;
-    auto put = [&](int idx, float v) {
-        v = wave_sum_f32(v);
-        if (lane == 0) row[idx] = v;
-    };
+    // ---- one partial gradient row per workgroup, parameter order of the AE blob
+    float *row = partial + (int64_t)blockIdx.x * kAeParams;
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 36; ++i) put(i, gw1[i]);
+    for (int i = 0; i < 52; ++i) {
+        // 0..15 convT2.w, 16 convT2.b, 17..48 convT1.w, 49 convT1.b, 50..51 conv2.b
+        float a = i < 16 ? gwt2[i] : i == 16 ? gbt2 : i < 49 ? gwt1[i - 17] : i == 49 ? gbt1 : gb2[i - 50];
+        a = wave_sum_f32(a);
+        if (lane == 0) s.red[wv][i] = a;
+    }
+    __syncthreads();
+    if (tid < 52) {
+        const float a = (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
+        const int dst = tid < 16 ? 147 + tid : tid == 16 ? 163 : tid < 49 ? 114 + (tid - 17) : tid == 49 ? 146 : 112 + (tid - 50);
+        row[dst] = a;
+    }
+    // channel-split parts: wave wv owns conv1 channel wv and conv2 input channel wv
 #pragma unroll
-    for (int i = 0; i < 4; ++i) put(36 + i, gb1[i]);
+    for (int i = 0; i < 9; ++i) {
+        const float a = wave_sum_f32(gw1c[i]);
+        if (lane == 0) row[wv * 9 + i] = a;
+    }
+    {
+        const float a = wave_sum_f32(gb1c);
+        if (lane == 0) row[36 + wv] = a;
+    }
 #pragma unroll
-    for (int i = 0; i < 72; ++i) put(40 + i, gw2[i]);
-    put(112, gb2[0]);
-    put(113, gb2[1]);
+    for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
-    for (int i = 0; i < 32; ++i) put(114 + i, gwt1[i]);
-    put(146, gbt1);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) put(147 + i, gwt2[i]);
-    put(163, gbt2);
+        for (int kq = 0; kq < 9; ++kq) {
+            const float a = wave_sum_f32(gw2c[oc * 9 + kq]);
+            if (lane == 0) row[40 + (oc * 4 + wv) * 9 + kq] = a;
+        }
 }
 
-int ae2d_train64_rows(int64_t n) {
-    int64_t rows = n < 768 ? n : 768;                  // 3 one-wave workgroups (53 KiB LDS) per CU
+int ae2d_train64_rows(int64_t n) {                 // = workgroups of ae_train_block64_kernel
+    int64_t rows = n < 512 ? n : 512;                  // persistent: 2 workgroups are resident per CU
     return (int)(rows < 1 ? 1 : rows);
 }
 
@@ -1139,11 +1175,11 @@ int ae2d_train64(const void *obs, bool packed, int64_t n, const float *ap, float
     if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
     const int rows = ae2d_train64_rows(n);
     if (packed)
-        hipLaunchKernelGGL(ae_train64_kernel<true>, dim3((unsigned)rows), dim3(64), 0, s, obs, ws, bonus, reward,
-                           reward_scale, grad_scale, partial, n);
+        hipLaunchKernelGGL(ae_train_block64_kernel<true>, dim3((unsigned)rows), dim3(256), 0, s, obs, ws, bonus,
+                           reward, reward_scale, grad_scale, partial, n);
     else
-        hipLaunchKernelGGL(ae_train64_kernel<false>, dim3((unsigned)rows), dim3(64), 0, s, obs, ws, bonus, reward,
-                           reward_scale, grad_scale, partial, n);
+        hipLaunchKernelGGL(ae_train_block64_kernel<false>, dim3((unsigned)rows), dim3(256), 0, s, obs, ws, bonus,
+                           reward, reward_scale, grad_scale, partial, n);
     hipLaunchKernelGGL(rnd_grad_reduce_kernel, dim3((kAeParams + 31) / 32), dim3(256), 0, s, partial, rows, grad,
                        kAeParams);
     return check_launch("carle_ae2d_train(fused 64x64)");
