@@ -52,6 +52,10 @@ def parse():
                     help="configs[3]: also run the RND2D intrinsic-reward forward (eval mode) on "
                          "every observation and feed ITS reward to the running statistics")
     ap.add_argument("--ae", action="store_true", help="additionally the AE2D forward")
+    ap.add_argument("--train", action="store_true",
+                    help="reward nets in training mode: every step also accumulates the predictor "
+                         "gradient (fused forward+backward kernels), Adam update every 64 steps "
+                         "(carle/train_mcl.py's per-step work)")
     ap.add_argument("--sync-reward", action="store_true",
                     help="run the reward consumers (reward nets, reward statistics) on the CA "
                          "stream instead of the reward stream")
@@ -171,7 +175,7 @@ def main():
         torch.manual_seed(0)                 # construction order predictor -> random (mcl.py:248)
         # forward passes only.  RND2D alone is fused into the CA kernel (one stream); a stacked AE2D
         # runs its kernels on the reward stream beside the next CA step unless --sync-reward
-        kw = dict(async_reward=args.ae and not args.sync_reward, train_predictor=False)
+        kw = dict(async_reward=args.ae and not args.sync_reward, train_predictor=args.train)
         wenv = RND2D(env, **kw)
         if args.ae:
             wenv = AE2D(wenv, **kw)
@@ -288,7 +292,8 @@ def main():
                        "action": asize, "rule": args.rule, "sharding": f"batch x{world}",
                        "action_source": args.agent,
                        "reward_nets": ("RND2D" if args.rnd else "") + ("+AE2D" if args.ae else "") +
-                                      (" forward" if (args.rnd or args.ae) else ""),
+                                      ((" forward+backward, Adam every 64 steps" if args.train else " forward")
+                                       if (args.rnd or args.ae) else ""),
                        "reward_consumers": "reward stream" if rs is not None else "same stream",
                        "collective": f"all-gather of 24 B/rank reward moments every {args.stats_every} steps"},
             "cell_updates_per_s": world * n * args.steps * size * size / dt,
