@@ -1,7 +1,8 @@
 // Kernel A/B microbenchmark (development tool, not shipped): variants of the 64x64 fp32 CA
 // step kernel timed interleaved in ONE process (cdna_hip_programming.md 5.4 rule 24).
-// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o /tmp/ca_f32_variants tools/kbench/ca_f32_variants.hip
-#include "../../carle_amd/csrc/abi.hip"
+// build (after make -C carle_amd/csrc; the rest of the library is linked, this kernel file is compiled in):
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/kbench/ca_f32_variants tools/kbench/ca_f32_variants.hip \
+//         -Lcarle_amd/lib -lcarle_hip -Wl,-rpath,'$ORIGIN/../../carle_amd/lib'
 #include "../../carle_amd/csrc/ca_step_cells.hip"
 #include <algorithm>
 #include <vector>
@@ -10,10 +11,10 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
-typedef void (*launch_fn)(const uint4 *, const float *, uint4 *, int64_t, uint32_t, int32_t *, hipStream_t);
+typedef void (*launch_fn)(const float *, const float *, float *, int64_t, uint32_t, int32_t *, hipStream_t);
 
 template <bool NL, bool NS, int BLOCK, int LDS = 0>
-void launch(const uint4 *in, const float *act, uint4 *out, int64_t n, uint32_t rule, int32_t *st, hipStream_t s) {
+void launch(const float *in, const float *act, float *out, int64_t n, uint32_t rule, int32_t *st, hipStream_t s) {
     const int wpb = BLOCK / 64;
     hipLaunchKernelGGL((carle::ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true, NL, NS, BLOCK>), dim3((unsigned)((n + wpb - 1) / wpb)), dim3(BLOCK), LDS, s,
                        in, act, out, n, 64, rule, st, 0);
@@ -49,7 +50,7 @@ int main(int argc, char **argv) {
     for (int r = 0; r < rounds; ++r)
         for (int v = 0; v < nv; ++v) {
             CK(hipEventRecord(e0, 0));
-            for (int i = 0; i < reps; ++i) { vs[v].f((const uint4 *)a, act[i % ring], (uint4 *)b, n, life, st, 0); std::swap(a, b); }
+            for (int i = 0; i < reps; ++i) { vs[v].f(a, act[i % ring], b, n, life, st, 0); std::swap(a, b); }
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (r >= 2) t[v].push_back(ms * 1000.f / reps);
