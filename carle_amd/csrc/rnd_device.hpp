@@ -41,9 +41,12 @@ __device__ __forceinline__ void rnd_block_init(RndBlockShared &s, const float *_
     for (int i = tid; i < 512; i += 256) s.lut_p[i] = src[i];
     const float2 *src2 = reinterpret_cast<const float2 *>(ws + 2048);
     for (int i = tid; i < 512; i += 256) s.lut_r[i] = src2[i];
-    for (int i = tid; i < 2 * kLinFloats; i += 256) s.lin[i] = ws[kLutFloats + i];
-    float *pl = &s.planes[0][0];
-    for (int i = tid; i < 6 * kPlaneFloats; i += 256) pl[i] = 0.0f;
+    static_assert((2 * kLinFloats) % 4 == 0 && (6 * kPlaneFloats) % 4 == 0 && kLutFloats % 4 == 0, "float4 copies");
+    const float4 *lsrc = reinterpret_cast<const float4 *>(ws + kLutFloats);
+    float4 *ldst = reinterpret_cast<float4 *>(s.lin);
+    for (int i = tid; i < 2 * kLinFloats / 4; i += 256) ldst[i] = lsrc[i];
+    float4 *pl = reinterpret_cast<float4 *>(&s.planes[0][0]);
+    for (int i = tid; i < 6 * kPlaneFloats / 4; i += 256) pl[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 66) s.rows[tid] = 0ull;
 }
 
