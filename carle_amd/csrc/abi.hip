@@ -272,8 +272,8 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
                                       uint32_t rule, int32_t *status, int slot, int publish_flags,
                                       const float *pred_params, const float *rand_params,
                                       float *workspace, float *bonus, float reward_scale,
-                                      int net_flags, uint64_t *patch_scratch, void *event,
-                                      void *stream_env, void *stream_reward) {
+                                      int net_flags, void *event, void *stream_env,
+                                      void *stream_reward) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: status is NULL");
     if (!pred_params || !rand_params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: NULL reward-net pointer");
@@ -308,7 +308,6 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
 
     // other geometries: step + epilogue on stream_env, then the bonus kernels (reward += scale *
     // bonus fused into the last one) on stream_reward, ordered behind the step through `event`
-    (void)patch_scratch;
     // (the bonus is added after the epilogue here: CARLE_STEP_MERGE_MOMENTS does not apply)
     if (int e = carle_ca_step_f32(u_in, action, u_out, n, h, w, ah, aw, rule,
                                   (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream_env))

@@ -489,7 +489,7 @@ def instance_sums_f32(x, w0=None, w1=None, w2=None):
 
 
 def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_flags, pred_params,
-                     rand_params, workspace, bonus, reward_scale, tables_valid, patch_scratch,
+                     rand_params, workspace, bonus, reward_scale, tables_valid,
                      event_handle, stream_env, stream_reward, merge_moments=False):
     """CARLE.step + RND2D bonus of the fresh observation in one library call (see carle_hip.h)."""
     lib = _lib.load()
@@ -500,7 +500,7 @@ def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_fl
                                         rule, status.data_ptr(), slot,
                                         _step_flags(publish_flags, merge_moments), pred_params.data_ptr(), rand_params.data_ptr(),
                                         workspace.data_ptr(), bonus.data_ptr(), float(reward_scale),
-                                        2 if tables_valid else 0, _ptr(patch_scratch), event_handle,
+                                        2 if tables_valid else 0, event_handle,
                                         stream_env, stream_reward)
     if rc != 0:
         _lib.check(rc, "carle_env_step_f32_rnd")

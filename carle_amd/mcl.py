@@ -427,7 +427,7 @@ class RND2D(Motivator):
                 rs_raw = rs.raw
                 ev = rs.event_for_fork(main_raw, out, reward)
             hip.env_step_f32_rnd(u_in, act, out, reward, rule, status, slot, publish, pb, rb, self._ws,
-                                 self._step_bonus, self.reward_scale, valid, None, ev, main_raw, rs_raw,
+                                 self._step_bonus, self.reward_scale, valid, ev, main_raw, rs_raw,
                                  merge and act.shape[3] % 8 == 0)
             # (the library fuses -- and can merge the moments -- only with an 8-aligned window)
             self.__dict__["_moments_merged"] = merge and act.shape[3] % 8 == 0

@@ -273,15 +273,13 @@ int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const floa
  *   other geometries: step and epilogue on stream_env, the bonus kernels (reward += reward_scale *
  *   bonus fused in) on stream_reward behind `event` (or on stream_env when stream_reward is NULL).
  * bonus: N + 1 floats (element N receives the bonus of the all-dead grid).
- * net_flags: CARLE_NET_TABLES_VALID as for carle_rnd2d_bonus_f32.  patch_scratch: unused, may be NULL
- * (kept for ABI stability). */
+ * net_flags: CARLE_NET_TABLES_VALID as for carle_rnd2d_bonus_f32. */
 int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out, float *reward,
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                            int32_t *status, int slot, int publish_flags,
                            const float *pred_params, const float *rand_params, float *workspace,
                            float *bonus, float reward_scale, int net_flags,
-                           uint64_t *patch_scratch, void *event, void *stream_env,
-                           void *stream_reward);
+                           void *event, void *stream_env, void *stream_reward);
 
 /* Orders `to_stream` after everything enqueued so far on `from_stream` (hipEventRecord on
  * from_stream + hipStreamWaitEvent on to_stream; `event` is a caller-owned hipEvent_t).  Used to
