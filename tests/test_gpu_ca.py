@@ -299,3 +299,40 @@ def test_long_run_against_oracle(storage):
             assert np.array_equal(obs.float().cpu().numpy(), cur), f"step {t}"
             assert env.step_number == step_number and env.steps_since_action == since
     assert env.master_resets == 2
+
+
+def test_random_geometries_and_rules_hypothesis():
+    """Property test: for arbitrary even sizes, centred windows, 18-bit rule masks, densities and
+    batch sizes the fp32 and uint8 step kernels (fast and generic paths) equal the C oracle."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from carle_amd import hip
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(st.data())
+    def run(data):
+        half = data.draw(st.integers(1, 40))
+        size = 2 * half if data.draw(st.booleans()) else data.draw(st.sampled_from([64, 64, 128, 256]))
+        ahalf = data.draw(st.integers(1, size // 2))
+        asize = 2 * ahalf if (size - 2 * ahalf) % 2 == 0 else size
+        n = data.draw(st.integers(1, 5))
+        rule = data.draw(st.integers(0, (1 << 18) - 1))
+        dens = data.draw(st.sampled_from([0.0, 0.05, 0.3, 0.5, 0.9, 1.0]))
+        seed = data.draw(st.integers(0, 2 ** 31 - 1))
+        rng = np.random.default_rng(seed)
+        u = (rng.random((n, 1, size, size)) < dens).astype(np.float32)
+        a = (rng.random((n, 1, asize, asize)) < 0.2).astype(np.float32)
+        exp, _, _ = O.c_env_step(u, a, rule)
+        d_u, d_a = torch.from_numpy(u).cuda(), torch.from_numpy(a).cuda()
+        out = torch.empty_like(d_u)
+        hip.ca_step_f32(d_u, d_a, out, rule, None, 0)
+        assert np.array_equal(out.cpu().numpy(), exp), (size, asize, n, hex(rule))
+        out8 = torch.empty(n, 1, size, size, dtype=torch.uint8, device="cuda")
+        hip.ca_step_u8(d_u.to(torch.uint8), d_a.to(torch.uint8), out8, rule, None, 0)
+        assert np.array_equal(out8.cpu().numpy(), exp.astype(np.uint8)), (size, asize, n, hex(rule))
+        if size in (64, 128, 256) and asize % 64 == 0:
+            bits, abits = hip.pack_f32_b1(d_u), hip.pack_f32_b1(d_a)
+            outb = torch.empty_like(bits)
+            hip.ca_step_b1(bits, abits, outb, rule, None, 0)
+            assert np.array_equal(hip.unpack_b1_f32(outb).cpu().numpy(), exp), (size, asize, n, hex(rule))
+
+    run()
