@@ -115,31 +115,52 @@ __global__ __launch_bounds__(256) void rnd_conv2_pool2_kernel(
 }
 
 // RND2D stage 3: linear(D->16) + tanh for both nets, bonus = mean_k (t_k - p_k)^2
-// one wavefront per grid: lane = (net, k, quarter of D); quarters reduced by shuffles
-__global__ __launch_bounds__(64) void rnd_linear_bonus_kernel(
+// one 256-thread workgroup per grid: thread = (net, k, eighth of D); every thread streams its own
+// contiguous slice of the weight row (float4 loads), the eight partial sums of an output are
+// combined in a fixed order by shuffles.  (One wavefront per grid with strided weight reads took
+// 63 us at N=16, 256x256: the reference's default geometry.)
+__global__ __launch_bounds__(256) void rnd_linear_bonus_kernel(
     const float *__restrict__ ws2, const float *__restrict__ pp, const float *__restrict__ rp,
     float *__restrict__ bonus, float *__restrict__ pred_out, float *__restrict__ target_out,
     float *__restrict__ reward, float reward_scale, int64_t n, int d) {
+    __shared__ float s_out[2][kRndDim];
     const int64_t g = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int quarter = lane & 1, k = (lane >> 1) & 15, net = lane >> 5;   // 2 partials per output
+    const int t = threadIdx.x;
+    const int seg = t & 7, k = (t >> 3) & 15, net = t >> 7;
     const float *f = ws2 + (g * 2 + net) * (int64_t)d;
     const float *lw = (net == 0 ? pp + 77 : rp + 39) + (int64_t)k * d;
     const float *lb = (net == 0 ? pp + 77 : rp + 39) + (int64_t)kRndDim * d;
+    const int len = d >> 3, i0 = seg * len;               // d is a multiple of 64 (H = W multiple of 64) or 8
     float acc = 0.0f;
-    for (int i = quarter; i < d; i += 2) acc = fmaf(lw[i], f[i], acc);
+    if (len > 0 && (len & 3) == 0 && (((uintptr_t)(lw + i0) | (uintptr_t)(f + i0)) & 15u) == 0) {
+        const float4 *w4 = reinterpret_cast<const float4 *>(lw + i0);
+        const float4 *f4 = reinterpret_cast<const float4 *>(f + i0);
+        for (int i = 0; i < (len >> 2); ++i) {
+            const float4 a = w4[i], b = f4[i];
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
+            acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        }
+    } else {
+        const int i1 = seg == 7 ? d : i0 + len;           // the last slice takes the remainder
+        for (int i = i0; i < i1; ++i) acc = fmaf(lw[i], f[i], acc);
+    }
     acc += __shfl_xor(acc, 1, 64);
-    const float out = tanhf(acc + lb[k]);
-    if (quarter == 0) {
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (seg == 0) {
+        const float out = tanhf(acc + lb[k]);
+        s_out[net][k] = out;
         if (net == 0 && pred_out) pred_out[g * kRndDim + k] = out;
         if (net == 1 && target_out) target_out[g * kRndDim + k] = out;
     }
-    const float other = __shfl_xor(out, 32, 64);          // same k, other net
-    float sq = (out - other) * (out - other);             // identical on both nets' lanes
-    // sum over k within lanes 0..31 (each k appears on two lanes: quarter 0/1 -> halve)
+    __syncthreads();
+    if (t == 0) {
+        float sq = 0.0f;
 #pragma unroll
-    for (int s = 2; s < 32; s <<= 1) sq += __shfl_xor(sq, s, 64);
-    if (lane == 0) {
+        for (int i = 0; i < kRndDim; ++i) {
+            const float df = s_out[1][i] - s_out[0][i];
+            sq = fmaf(df, df, sq);
+        }
         const float b = sq * (1.0f / kRndDim);
         bonus[g] = b;
         if (reward) reward[g] += reward_scale * b;        // mcl.py:403-405
@@ -270,20 +291,25 @@ __global__ __launch_bounds__(256) void ae_convt1_kernel(
 }
 
 // AE2D stage 4: convT2 (1->1) + sigmoid, squared error against obs, mean over the grid.
-// one 256-thread block per grid, deterministic tree reduction.
+// Workgroup (g, c) covers pixels [c*chunk, (c+1)*chunk) of grid g and leaves one partial sum; the
+// finish kernel adds the partials of a grid in a fixed order (deterministic).  (One workgroup per
+// whole grid took 223 us at N=16, 256x256: the reference's default geometry.)
+static constexpr int kMseChunk = 4096;
+
 __global__ __launch_bounds__(256) void ae_convt2_mse_kernel(
     const float *__restrict__ obs, const float *__restrict__ a3, const float *__restrict__ ap,
-    float *__restrict__ bonus, float *__restrict__ recon, float *__restrict__ reward,
-    float reward_scale, int64_t n, int h, int w) {
-    __shared__ float red[256];
+    float *__restrict__ partial, float *__restrict__ recon, int chunks, int h, int w) {
+    __shared__ float red[4];
     const int h2 = h >> 1, w2 = w >> 1;
-    const int64_t g = blockIdx.x;
+    const int64_t g = blockIdx.x / chunks;
+    const int c = (int)(blockIdx.x % chunks);
     const float *wt = ap + 147;                           // convT2.w[1][1][4][4]
     const float bias = ap[163];
     const float *pl = a3 + g * (int64_t)h2 * w2;
     const float *go = obs + g * (int64_t)h * w;
+    const int p_end = min((c + 1) * kMseChunk, h * w);
     float sum = 0.0f;
-    for (int p = threadIdx.x; p < h * w; p += 256) {
+    for (int p = c * kMseChunk + threadIdx.x; p < p_end; p += 256) {
         const int x = p % w, y = p / w;
         int iy[2], ky[2], ix[2], kx[2];
         convt_taps(y, iy[0], ky[0], iy[1], ky[1]);
@@ -300,18 +326,24 @@ __global__ __launch_bounds__(256) void ae_convt2_mse_kernel(
         const float df = go[p] - pr;
         sum = fmaf(df, df, sum);
     }
-    red[threadIdx.x] = sum;
-    __syncthreads();
 #pragma unroll
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const float b = red[0] / (float)(h * w);
-        bonus[g] = b;
-        if (reward) reward[g] += reward_scale * b;
-    }
+    for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void ae_mse_finish_kernel(const float *__restrict__ partial,
+                                                            float *__restrict__ bonus,
+                                                            float *__restrict__ reward, float reward_scale,
+                                                            int64_t n, int chunks, float inv_pixels) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    float s = 0.0f;
+    for (int c = 0; c < chunks; ++c) s += partial[g * chunks + c];
+    const float b = s * inv_pixels;
+    bonus[g] = b;
+    if (reward) reward[g] += reward_scale * b;
 }
 
 static inline int check_net_dims(int64_t n, int h, int w, const char *who) {
@@ -392,7 +424,7 @@ extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
                        pred_params, rand_params, ws1, n, h, w);
     hipLaunchKernelGGL(rnd_conv2_pool2_kernel, dim3(blocks_for(n * 2 * (int64_t)d)), dim3(256), 0, s,
                        ws1, pred_params, rand_params, ws2, n, h, w);
-    hipLaunchKernelGGL(rnd_linear_bonus_kernel, dim3((unsigned)n), dim3(64), 0, s, ws2, pred_params,
+    hipLaunchKernelGGL(rnd_linear_bonus_kernel, dim3((unsigned)n), dim3(256), 0, s, ws2, pred_params,
                        rand_params, bonus, pred_out, target_out, reward_accum, reward_scale, n, d);
     return check_launch("carle_rnd2d_bonus_f32");
 }
@@ -400,7 +432,8 @@ extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
 extern "C" int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w) {
     if (n < 0 || h < 8 || w < 8) return 0;
     const int64_t q = (int64_t)(h / 2) * (w / 2);
-    const int64_t staged = n * (4 * q + 2 * (q / 4) + q);    // A1 (4ch) + A2 (2ch) + A3
+    const int64_t chunks = ((int64_t)h * w + 4095) / 4096;
+    const int64_t staged = n * (4 * q + 2 * (q / 4) + q + chunks);   // A1 (4ch) + A2 (2ch) + A3 + MSE partials
     const int64_t fused = ae2d_fused_workspace_floats();
     return staged > fused ? staged : fused;
 }
@@ -440,8 +473,13 @@ extern "C" int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, c
                        params, a2, n, h, w);
     hipLaunchKernelGGL(ae_convt1_kernel, dim3(blocks_for(n * q)), dim3(256), 0, s, a2, params, a3, n,
                        h, w);
-    hipLaunchKernelGGL(ae_convt2_mse_kernel, dim3((unsigned)n), dim3(256), 0, s, obs, a3, params,
-                       bonus, recon_out, reward_accum, reward_scale, n, h, w);
+    const int chunks = (h * w + kMseChunk - 1) / kMseChunk;
+    float *part = a3 + n * q;
+    if (n * chunks > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ae2d_bonus_f32: batch too large");
+    hipLaunchKernelGGL(ae_convt2_mse_kernel, dim3((unsigned)(n * chunks)), dim3(256), 0, s, obs, a3, params,
+                       part, recon_out, chunks, h, w);
+    hipLaunchKernelGGL(ae_mse_finish_kernel, dim3(blocks_for(n)), dim3(256), 0, s, part, bonus, reward_accum,
+                       reward_scale, n, chunks, 1.0f / (float)(h * w));
     return check_launch("carle_ae2d_bonus_f32");
 }
 
