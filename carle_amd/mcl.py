@@ -248,15 +248,35 @@ class RND2D(Motivator):
         self.optimizer.zero_grad()
         self.updates += 1
 
+    # cells per autograd pass of the window replay (64 MiB of fp32 input; bounds the activation
+    # memory -- AE2D keeps 4 x (H/2) x (W/2) floats per grid -- and keeps the convolution shapes in
+    # the range MIOpen handles without minutes of first-use tuning)
+    replay_cells = 1 << 24
+
     def _replay_window(self, scale):
-        """backward of sum_t mean(loss_t) * scale over the retained window, one step at a time
-        (gradients accumulate in .grad exactly as one backward through the summed graph)."""
+        """backward of sum_t mean_n(loss_t) * scale over the retained window.  Every step holds
+        the same number of grids, so sum_t mean_n = T * mean_{t,n}: the window is replayed in a few
+        LARGE batches (torch.cat of up to ``replay_cells`` cells) instead of one small pass per step
+        -- at the reference's default geometry (16 instances of 256x256) the per-step passes are pure
+        launch overhead.  Gradients accumulate in .grad exactly as one backward through the summed
+        graph (same sum, different association)."""
         total = 0.0
-        for o in self._window:
-            loss = torch.mean(self._torch_loss(o)) * scale
+        window, self._window = self._window, []
+        i = 0
+        while i < len(window):
+            cells = max(int(window[i].numel()), 1)
+            k = max(1, min(len(window) - i, self.replay_cells // cells))
+            chunk = window[i:i + k]
+            same = all(o.shape == chunk[0].shape for o in chunk)
+            if k > 1 and same:
+                batch = torch.cat(chunk, dim=0)
+                loss = torch.mean(self._torch_loss(batch)) * (k * scale)
+            else:
+                k = 1
+                loss = torch.mean(self._torch_loss(chunk[0])) * scale
             loss.backward()
             total = total + loss.detach()
-        self._window = []
+            i += k
         return total
 
     def get_bonus_update(self, obs):

@@ -10,7 +10,7 @@ from carle_amd.mcl import RND2D, AE2D
 from carle_amd.env import CARLE
 
 for mcl, label in (() if os.environ.get("SKIP_TRAIN") else (((RND2D,), "RND2D"), ((RND2D, AE2D), "RND2D+AE2D"))):
-    for instances in (16, 256):
+    for instances in (16, 64):
         kw = dict(instances=instances, out_dir=None, verbose=False, width=256, height=256, mcl=mcl)
         train(RandomAgent, steps=[1, 130], **kw)
         torch.cuda.synchronize()
