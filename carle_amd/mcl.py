@@ -19,8 +19,22 @@ import torch.nn as nn
 from . import hip
 
 
+# bookkeeping attributes rewritten every step: plain Python / tensor values that need none of
+# nn.Module.__setattr__'s parameter / buffer / sub-module handling (~1 us each)
+_PLAIN_WRAPPER_ATTRS = frozenset((
+    "_ws", "_tables_key", "_tables_key_next", "_bonus_buf", "_step_bonus", "buffer_length",
+    "accumulate_loss", "_window", "_grad_used", "live_cells", "speed", "velocity", "center_of_mass",
+    "growing_steps", "cells"))
+
+
 class Motivator(nn.Module):
     """Wrapper base (mcl.py:29-84): holds ``env``, resolves ``inner_env``, forwards rules."""
+
+    def __setattr__(self, name, value):
+        if name in _PLAIN_WRAPPER_ATTRS:
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
 
     def __init__(self, env, **kwargs):
         super().__init__()
