@@ -71,6 +71,26 @@ def test_argument_errors_do_not_touch_the_gpu():
                                       None, None, None) == 1                                 # status NULL
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/carle_hip.h compiled by a C compiler (gcc -std=c99) and linked against the library:
+    the boundary really is a C ABI."""
+    import shutil
+    import subprocess
+    from carle_amd import _lib
+    _lib.load()
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "abi_errors"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi", "abi_errors.c"), "-o", str(exe),
+                    "-L", libdir, "-lcarle_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "abi ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_env_surface_without_gpu():
     from carle_amd.env import CARLE
     k = G.known()
