@@ -124,11 +124,11 @@ __device__ __forceinline__ void horiz_neighbours(uint64_t c, uint64_t cw, uint64
     est = ((c >> 1) & 0x7777777777777777ull) | ((ce << 3) & 0x8888888888888888ull);
 }
 
-template <class C, class A, bool HAS_ACT, int NS, int RW>
+template <class C, class A, bool HAS_ACT, int NS, int RW, bool RAND_ACT = false>
 __global__ __launch_bounds__(64) void ca_step_wide_kernel(
     const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
     typename C::T *__restrict__ u_out, int64_t n, int ah, int aw, uint32_t rule,
-    int32_t *__restrict__ status, int slot) {
+    int32_t *__restrict__ status, int slot, RandAct ra = RandAct()) {
     constexpr int W = WideGeom<NS, RW>::kW, H = W, R = WideGeom<NS, RW>::kR;
     constexpr int kStrips = H / R;
     const int k = threadIdx.x;                       // lane = column quad
@@ -169,7 +169,13 @@ __global__ __launch_bounds__(64) void ca_step_wide_kernel(
         const bool touches = (r0 + R > oy && r0 < oy + ah) || (rt >= oy && rt < oy + ah) ||
                              (rb >= oy && rb < oy + ah);
         if (touches) {
-            const typename A::T *ga = act + g * (int64_t)ah * aw;
+            const typename A::T *ga = RAND_ACT ? nullptr : act + g * (int64_t)ah * aw;
+            // in-kernel random agent: the nibble of action quad (ay, ax) is a pure function of its
+            // index, so halo rows draw the same toggles as the strip that owns the row
+            auto drawn = [&](int ay, int ax) -> uint32_t {
+                const uint64_t quad = (uint64_t)((g * ah + ay) * (int64_t)aw + ax) >> 2;
+                return bernoulli_nibble(quad, ra.seed, ra.offset, ra.p);
+            };
             ActionSeen seen;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -182,18 +188,31 @@ __global__ __launch_bounds__(64) void ca_step_wide_kernel(
                     for (int i = 0; i < 16; ++i) {
                         const int ay = r0 + 16 * m + i - oy;
                         if (col_in && ay >= 0 && ay < ah) {
-                            const typename A::Quad a = A::template load<true>(ga + (int64_t)ay * aw + ax);
-                            see(seen, a);
-                            tog |= (uint64_t)A::nibble(a) << (4 * i);
+                            if (RAND_ACT) {
+                                const uint32_t nib = drawn(ay, ax);
+                                uint4 a;
+                                a.x = (nib & 1u) ? kOneBits : 0u;
+                                a.y = (nib & 2u) ? kOneBits : 0u;
+                                a.z = (nib & 4u) ? kOneBits : 0u;
+                                a.w = (nib & 8u) ? kOneBits : 0u;
+                                seen.add(a);
+                                tog |= (uint64_t)nib << (4 * i);
+                                if (ra.action_out)
+                                    *reinterpret_cast<uint4 *>(ra.action_out + (g * ah + ay) * (int64_t)aw + ax) = a;
+                            } else {
+                                const typename A::Quad a = A::template load<true>(ga + (int64_t)ay * aw + ax);
+                                see(seen, a);
+                                tog |= (uint64_t)A::nibble(a) << (4 * i);
+                            }
                         }
                     }
                     c[s][m] ^= tog;
                 }
                 const int ayt = rt - oy, ayb = rb - oy;
                 if (col_in && ayt >= 0 && ayt < ah)
-                    halo[s] ^= A::nibble(A::template load<false>(ga + (int64_t)ayt * aw + ax));
+                    halo[s] ^= RAND_ACT ? drawn(ayt, ax) : A::nibble(A::template load<false>(ga + (int64_t)ayt * aw + ax));
                 if (col_in && ayb >= 0 && ayb < ah)
-                    halo[s] ^= A::nibble(A::template load<false>(ga + (int64_t)ayb * aw + ax)) << 4;
+                    halo[s] ^= (RAND_ACT ? drawn(ayb, ax) : A::nibble(A::template load<false>(ga + (int64_t)ayb * aw + ax))) << 4;
             }
             publish_flags<A>(seen, status, slot);
         } else if (status != nullptr && k == 0) {
@@ -446,9 +465,12 @@ extern "C" int carle_ca_step_f32_rand(const float *u_in, float *u_out, int64_t n
     if (n == 0) return 0;
     if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_step_f32_rand: u_in/u_out is NULL");
     if (int e = check_dims(n, h, w, true, ah, aw)) return e;
-    if (h != 64 || (aw % 8) != 0)
-        return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: fused random toggles need 64x64 grids "
-                                      "and AW % 8 == 0 (generate the action with carle_bernoulli_f32 otherwise)");
+    const bool fast64 = h == 64 && (aw % 8) == 0;
+    const bool wide = (h == 256 || h == 512) && (aw % 4) == 0 && ((w - aw) % 8) == 0;
+    if (!fast64 && !wide)
+        return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: fused random toggles need 64x64 grids with "
+                                      "AW % 8 == 0, or 256 / 512 grids with AW % 4 == 0 and (W-AW) % 8 == 0 "
+                                      "(generate the action with carle_bernoulli_f32 otherwise)");
     if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_ca_step_f32_rand: rule mask exceeds 18 bits");
     if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: slot must be 0 or 1");
     if (!aligned16(u_in) || !aligned16(u_out) || (action_out && !aligned16(action_out)))
@@ -460,6 +482,19 @@ extern "C" int carle_ca_step_f32_rand(const float *u_in, float *u_out, int64_t n
     if (n > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: batch too large");
     RandAct ra;
     ra.p = p; ra.seed = seed; ra.offset = offset; ra.action_out = action_out;
+    if (wide) {
+        const int64_t wgs = n * (h / (16 * kWideRW));
+        if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: batch too large");
+        if (h == 256)
+            hipLaunchKernelGGL((ca_step_wide_kernel<F32Cells, F32Cells, true, 1, kWideRW, true>), dim3((unsigned)wgs),
+                               dim3(64), 0, static_cast<hipStream_t>(stream), u_in, (const float *)nullptr, u_out, n,
+                               ah, aw, rule, status, slot, ra);
+        else
+            hipLaunchKernelGGL((ca_step_wide_kernel<F32Cells, F32Cells, true, 2, kWideRW, true>), dim3((unsigned)wgs),
+                               dim3(64), 0, static_cast<hipStream_t>(stream), u_in, (const float *)nullptr, u_out, n,
+                               ah, aw, rule, status, slot, ra);
+        return check_launch("carle_ca_step_f32_rand");
+    }
     hipLaunchKernelGGL((ca_step_64_kernel<F32Cells, F32Cells, true, true, true, 64, true>),
                        dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), u_in,
                        (const float *)nullptr, u_out, n, aw, rule, status, slot, ra);

@@ -312,7 +312,9 @@ class CARLE(RLEMixin, nn.Module):
         if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
             if tuple(action.shape) != (self.instances, 1, self.action_width, self.action_height):
                 raise AssertionError(f"action shape {action.shape} does not match the environment")
-            if self.height == 64 and self.action_width % 8 == 0:
+            if (self.height == 64 and self.action_width % 8 == 0) or \
+                    (self.height in (256, 512) and self.action_width % 4 == 0 and
+                     (self.width - self.action_width) % 8 == 0):
                 # the toggles are drawn inside the step kernel: no action tensor exists
                 hip.env_step_f32_rand(u_in, out, reward, rule, self._status, slot, self.action_height,
                                       self.action_width, action.p, action.seed, action.offset, None, merge)

@@ -296,8 +296,9 @@ int carle_stream_fork(void *event, void *from_stream, void *to_stream);
 int carle_bernoulli_f32(float *out, int64_t count, float p, uint64_t seed, uint64_t offset,
                         void *stream);
 /* carle_ca_step_f32 with the action drawn IN the kernel (identical to generating the action with
- * carle_bernoulli_f32(seed, offset) and passing it in): no action tensor is read; 64x64 grids,
- * AW % 8 == 0.  action_out (nullable): also write the drawn (N,1,AW,AW) action. */
+ * carle_bernoulli_f32(seed, offset) and passing it in): no action tensor is read.  64x64 grids
+ * with AW % 8 == 0, or 256 / 512 grids with AW % 4 == 0 and (W-AW) % 8 == 0.  action_out (nullable):
+ * also write the drawn (N,1,AW,AW) action. */
 int carle_ca_step_f32_rand(const float *u_in, float *u_out, int64_t n, int h, int w, int ah, int aw,
                            uint32_t rule, float p, uint64_t seed, uint64_t offset, float *action_out,
                            int32_t *status, int slot, void *stream);

@@ -61,16 +61,24 @@ def test_fused_random_step_equals_materialised(n, asize):
     assert envs[0].steps_since_action == envs[1].steps_since_action
 
 
-def test_fused_token_on_other_geometries_falls_back_to_materialise():
+@pytest.mark.parametrize("size,asize", [(256, 64), (512, 64), (256, 128), (128, 64), (66, 64)])
+def test_fused_token_on_other_geometries(size, asize):
+    """256 / 512 grids draw the toggles inside the wide step kernel, every other geometry falls back
+    to the materialised action: either way the step equals the oracle on the Philox stream of
+    oracle/philox.py, for several steps (the call counter advances the offset)."""
     from carle_amd.agents import RandomAgent
     from carle_amd.env import CARLE
-    env = CARLE(width=256, height=256, instances=2, device="cuda:0")
+    n = 3
+    env = CARLE(width=size, height=size, action_width=asize, action_height=asize, instances=n, device="cuda:0")
     env.reset()
-    agent = RandomAgent(fused=True, seed=1)
-    obs = env.step(agent(env.universe))[0]
-    exp, _, _ = O.c_env_step(np.zeros((2, 1, 256, 256), np.float32),
-                             np_bernoulli(2 * 64 * 64, 0.1, 1, 0).reshape(2, 1, 64, 64), O.rule_mask([3], [2, 3]))
-    assert np.array_equal(obs.cpu().numpy(), exp)
+    agent = RandomAgent(action_width=asize, action_height=asize, fused=True, seed=1)
+    cur = np.zeros((n, 1, size, size), np.float32)
+    mask = O.rule_mask([3], [2, 3])
+    for t in range(4):
+        obs = env.step(agent(env.universe))[0]
+        cur, _, _ = O.c_env_step(cur, np_bernoulli(n * asize * asize, 0.1, 1, t).reshape(n, 1, asize, asize), mask)
+        assert np.array_equal(obs.cpu().numpy(), cur), f"step {t}"
+    assert env.step_number == 4
 
 
 def test_random_network_agent():
