@@ -170,8 +170,11 @@ int carle::ca_finish_impl(void *u_out, int64_t u_out_bytes, float *reward, int64
         return fail_arg(CARLE_E_ALIGN, "carle_ca_finish: pointers must be 16-byte aligned");
     const int64_t n16 = u_out_bytes / 16;
     const int tail = (int)(u_out_bytes % 16);
-    // small fixed grid: in the common (no reset) case every block exits after one flag load
-    hipLaunchKernelGGL(ca_finish_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream),
+    // fixed grid: in the common (no reset) case every block but the first exits after one flag
+    // load; on a master reset the blocks zero the output together (8 blocks: 870 us for the 1 GiB of
+    // N=4096 256x256 grids; 128 blocks: see profiles/r01_bench_matrix.txt)
+    constexpr int kFinishBlocks = 128;
+    hipLaunchKernelGGL(ca_finish_kernel, dim3(kFinishBlocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<uint4 *>(u_out), n16,
                        reinterpret_cast<unsigned char *>(u_out) + n16 * 16, tail, reward, n, status,
                        slot, (n > 0 && has_action) ? 1 : 0, reinterpret_cast<uint4 *>(extra),
