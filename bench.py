@@ -175,7 +175,7 @@ def main():
         torch.manual_seed(0)                 # construction order predictor -> random (mcl.py:248)
         # forward passes only.  RND2D alone is fused into the CA kernel (one stream); a stacked AE2D
         # runs its kernels on the reward stream beside the next CA step unless --sync-reward
-        kw = dict(async_reward=args.ae and not args.sync_reward, train_predictor=args.train)
+        kw = dict(async_reward=(args.ae or args.train) and not args.sync_reward, train_predictor=args.train)
         wenv = RND2D(env, **kw)
         if args.ae:
             wenv = AE2D(wenv, **kw)
@@ -186,7 +186,7 @@ def main():
     # with no reward nets, or with RND2D alone (fused into the CA kernel), the cross-stream events
     # cost more than they hide (45.6 vs 39.1 and 52.8 vs 46.5 us/step): those stay on one stream
     rs = None
-    if args.ae and not args.sync_reward:
+    if (args.ae or args.train) and not args.sync_reward:
         from carle_amd.streams import RewardStream
         rs = env.__dict__.get("reward_stream")
         if rs is None:
