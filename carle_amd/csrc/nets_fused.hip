@@ -436,12 +436,13 @@ static constexpr int kRndPredParams = 36 + 4 + 36 + 1 + 16 * 64 + 16;   // 1117
 // 16x16 map in LDS (one entry per 2x2 pooling block) and is GATHERED (no LDS atomics):
 //   d plane[c](P)      = sum_k  w2[c][k] * map(P - k + 1)
 //   d w2[c][k]        += plane[c](P) * map(P - k + 1)        (the same nine map reads)
-// Gradient accumulators per thread: conv1 36+4, conv2 36, its 4 entries of the 16x64 linear layer.
+// conv1 / conv2 weight gradients are channel-split (wave c walks the 256 windows of channel c, 4 per
+// lane): accumulators per thread 9+1 (conv1) + 9 (conv2) + its 4 entries of the 16x64 linear layer.
 // One partial row per workgroup at the end; rnd_grad_reduce_kernel adds the rows in a fixed order
 // (deterministic).  2 workgroups (8 waves) per CU; the first version (one WAVE per grid, all 1117
 // accumulators spread over 64 lanes, ds_add_f32 scatters, 4 waves per CU) took twice as long.
 template <bool PACKED_OBS>
-__global__ __launch_bounds__(256, 2) void rnd_train_block64_kernel(
+__global__ __launch_bounds__(256, 3) void rnd_train_block64_kernel(
     const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
     float *__restrict__ reward, float reward_scale, float grad_scale, float *__restrict__ partial,
     int64_t n) {
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void rnd_train_block64_kernel(
     __shared__ float s_map[kPlaneFloats];            // d loss / d conv2 output, zero-bordered 16x16
     __shared__ float s_feat[2][64];
     __shared__ float s_dy[16];
-    __shared__ float s_red[4][40];
+    __shared__ uint16_t s_pat[4][256];               // arg-max input pattern per predictor channel and window
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     rnd_block_init(s, ws, tid);
     for (int i = tid; i < kPlaneFloats; i += 256) s_map[i] = 0.0f;
@@ -463,11 +464,16 @@ __global__ __launch_bounds__(256, 2) void rnd_train_block64_kernel(
     const int half = lane & 1, kk = (lane >> 1) & 15, net = lane >> 5;
     const int wk = tid >> 4, wj = 4 * (tid & 15);     // this thread's entries W[wk][wj..wj+3] of lin.w
 
-    float gw1[36], gb1[4], gw2[36], gW[4], gB = 0.0f, gb2 = 0.0f;
+    // conv1 / conv2 gradients are CHANNEL-SPLIT: wave c accumulates those of predictor channel c
+    float gw1c[9], gb1c = 0.0f, gw2c[9], gW[4], gB = 0.0f, gb2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 36; ++i) { gw1[i] = 0.0f; gw2[i] = 0.0f; }
+    for (int i = 0; i < 9; ++i) { gw1c[i] = 0.0f; gw2c[i] = 0.0f; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { gb1[i] = 0.0f; gW[i] = 0.0f; }
+    for (int i = 0; i < 4; ++i) gW[i] = 0.0f;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    float wc[9];                                      // conv2.w of input channel wv (scalar registers)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wc[i] = cw2p[wvs * 9 + i];
 
     const int64_t first = blockIdx.x, stride = gridDim.x;
     uint4 v[4];
@@ -501,8 +507,6 @@ __global__ __launch_bounds__(256, 2) void rnd_train_block64_kernel(
 
         // ---- conv1 + relu + 4x4 pool of window (py,px), remembering the arg-max pattern per
         //      predictor channel
-        float pm[4];
-        uint32_t pat[4];
         {
             uint32_t seg[6];
 #pragma unroll
@@ -526,8 +530,10 @@ __global__ __launch_bounds__(256, 2) void rnd_train_block64_kernel(
                     if (a.w > m3) { m3 = a.w; a3 = p; }
                     m4 = fmaxf(m4, b.x); m5 = fmaxf(m5, b.y);
                 }
-            pm[0] = m0; pm[1] = m1; pm[2] = m2; pm[3] = m3;
-            pat[0] = a0; pat[1] = a1; pat[2] = a2; pat[3] = a3;
+            s_pat[0][tid] = (uint16_t)a0;
+            s_pat[1][tid] = (uint16_t)a1;
+            s_pat[2][tid] = (uint16_t)a2;
+            s_pat[3][tid] = (uint16_t)a3;
             const int off = (py + 1) * kPlaneStride + px + 1;
             s.planes[0][off] = m0;
             s.planes[1][off] = m1;
@@ -632,49 +638,51 @@ __global__ __launch_bounds__(256, 2) void rnd_train_block64_kernel(
         }
         __syncthreads();
 
-        // ---- back through conv2 (gather), the 4x4 pool, relu and conv1: thread = window (py,px)
-        {
-            float m[3][3];                            // map rows py..py+2, cols px..px+2 (padded coords)
+        // ---- back through conv2 (gather), the 4x4 pool, relu and conv1 of channel wv: lane = 4 windows
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int wdx = lane + 64 * j, wy = wdx >> 4, wx = wdx & 15;
+            float m[3][3];                            // map rows wy..wy+2, cols wx..wx+2 (padded coords)
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) m[r][c] = s_map[(py + r) * kPlaneStride + px + c];
+                for (int c = 0; c < 3; ++c) m[r][c] = s_map[(wy + r) * kPlaneStride + wx + c];
+            const float pmv = s.planes[wvs][(wy + 1) * kPlaneStride + wx + 1];
+            const uint32_t pt = s_pat[wvs][wdx];
+            float d = 0.0f;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                float d = 0.0f;
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    d = fmaf(wc[ky * 3 + kx], m[2 - ky][2 - kx], d);
+                    gw2c[ky * 3 + kx] = fmaf(pmv, m[2 - ky][2 - kx], gw2c[ky * 3 + kx]);
+                }
+            const float gz = pmv > 0.0f ? d : 0.0f;
+            gb1c += gz;
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        d = fmaf(cw2p[cc * 9 + ky * 3 + kx], m[2 - ky][2 - kx], d);
-                        gw2[cc * 9 + ky * 3 + kx] = fmaf(pm[cc], m[2 - ky][2 - kx], gw2[cc * 9 + ky * 3 + kx]);
-                    }
-                const float gz = pm[cc] > 0.0f ? d : 0.0f;
-                gb1[cc] += gz;
-#pragma unroll
-                for (int t = 0; t < 9; ++t)
-                    gw1[cc * 9 + t] = fmaf(gz, (float)((pat[cc] >> t) & 1u), gw1[cc * 9 + t]);
-            }
+            for (int tt = 0; tt < 9; ++tt) gw1c[tt] = fmaf(gz, (float)((pt >> tt) & 1u), gw1c[tt]);
         }
-        // the next iteration's barriers order its writes to rows / planes / the map behind these reads
+        // the next iteration's barriers order its writes to rows / planes / patterns / the map behind
+        // these reads
     }
 
     // ---- one partial gradient row per workgroup, parameter order of the predictor blob
     float *row = partial + (int64_t)blockIdx.x * kRndPredParams;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        // pass 0: conv1 (36 + 4) -> row[0..40); pass 1: conv2 (36) + its bias -> row[40..77)
+    for (int i = 0; i < 9; ++i) {
+        float a = gw1c[i], b = gw2c[i];
 #pragma unroll
-        for (int i = 0; i < 40; ++i) {
-            float a = pass == 0 ? (i < 36 ? gw1[i] : gb1[i - 36]) : (i < 36 ? gw2[i] : (i == 36 ? gb2 : 0.0f));
+        for (int sh = 32; sh > 0; sh >>= 1) { a += __shfl_xor(a, sh, 64); b += __shfl_xor(b, sh, 64); }
+        if (lane == 0) { row[wvs * 9 + i] = a; row[40 + wvs * 9 + i] = b; }
+    }
+    {
+        float a = gb1c, b = gb2;                      // gb2 is non-zero on wave 0 only
 #pragma unroll
-            for (int sh = 32; sh > 0; sh >>= 1) a += __shfl_xor(a, sh, 64);
-            if (lane == 0) s_red[wv][i] = a;
+        for (int sh = 32; sh > 0; sh >>= 1) { a += __shfl_xor(a, sh, 64); b += __shfl_xor(b, sh, 64); }
+        if (lane == 0) {
+            row[36 + wvs] = a;
+            if (wvs == 0) row[76] = b;
         }
-        __syncthreads();
-        if (tid < (pass == 0 ? 40 : 37))
-            row[40 * pass + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
-        __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) row[77 + wk * 64 + wj + i] = gW[i];
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(256) void rnd_grad_reduce_kernel(const float *__res
 }
 
 int rnd2d_train64_rows(int64_t n) {                // = workgroups of rnd_train_block64_kernel
-    int64_t blocks = n < 512 ? n : 512;              // persistent: 2 workgroups are resident per CU
+    int64_t blocks = n < 768 ? n : 768;              // persistent: 3 workgroups are resident per CU (a fourth needs <= 128 VGPRs: spills, slower)
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
