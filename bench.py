@@ -6,18 +6,30 @@ A "step" is one CARLE.step(action) over the whole batch: the fused HIP CA kernel
 Python surface (carle_amd.env.CARLE).  Workload at N=1: BASELINE.json configs[1] -- B3/S23,
 N=4096, 64x64 grids, fp32 drop-in format, a fresh device-resident Bernoulli(0.1) 64x64 action
 every step (ring of action buffers larger than the 256 MiB Infinity Cache, so state and action
-really stream from HBM).  For --gpus N > 1 the batch is sharded: every rank owns 4096 instances
-(weak scaling, no data-path collective: universes are independent).
+really stream from HBM).
+
+Multi-GPU (--gpus N > 1): one process per GPU, every rank owns --instances universes (weak
+scaling, no data-path collective: universes are independent); the only exchange is
+the 24-byte all-gather of the reward moments every --stats-every steps (RCCL).  Two launch forms:
+  * under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment):
+    this process IS one rank;
+  * plain `python bench.py --gpus N`: this process is only a launcher -- it spawns N fresh rank
+    processes (before anything here has touched the GPU), waits for them and exits with the first
+    non-zero code.  Rank 0 prints the JSON line.
+--gpus must equal WORLD_SIZE, and the node must expose N devices: anything else exits non-zero
+instead of silently measuring fewer GPUs.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with two extra objects:
-  roofline      algorithmic bytes of the dominant kernel (ca_step_f32_64) / its average launch
-                duration measured here with HIP events on the launch stream, against 8 TB/s
+  roofline      algorithmic bytes of the config's dominant kernel / its average launch duration
+                measured here with HIP events on the launch stream, against 8 TB/s
   cpu_baseline  oracle/torch_port.py (a port of the reference's per-step ATen op sequence; the
                 reference itself cannot travel) timed on this host's cores, bounded sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,9 +40,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+FP32_PEAK = 157.3e12       # FLOP/s, same guide, "Peak FP32 (vector)"
+MIN_TIMED_MS = 5.0         # below this the timed region is too short to quote (warned in the JSON)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
@@ -60,6 +74,12 @@ def parse():
                     help="run the reward consumers (reward nets, reward statistics) on the CA "
                          "stream instead of the reward stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="rehearsal only: let several ranks share a device when the node has fewer "
+                         "than --gpus (needs --backend gloo; RCCL refuses two ranks on one device)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="ranks only join the process group, all-gather (rank, local_rank, device) "
+                         "and rank 0 prints it as JSON: tests the launcher without a GPU")
     ap.add_argument("--stats-every", type=int, default=64,
                     help="steps between reward-statistics all-gathers (reporting interval)")
     ap.add_argument("--separate-stats-kernel", action="store_true",
@@ -67,12 +87,66 @@ def parse():
                          "inside the step epilogue (A/B switch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(size, rule, seconds):
-    """Port of the reference step (oracle/torch_port.py) on the host cores, bounded sample."""
-    from oracle.torch_port import TorchPortEnv
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` outside torch.distributed.run
+# ------------------------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Spawns one fresh process per GPU and waits for them.  Runs BEFORE any HIP call in this
+    process (torch.cuda.device_count() does not initialise the GPU) and never exec()s: the ranks
+    are ordinary children, rank 0 inherits stdout for the JSON line."""
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if not args.launch_check and have < n and not args.share_gpus:
+        print(f"bench.py: --gpus {n} but this node exposes {have} HIP device(s); refusing to run "
+              f"fewer GPUs than asked (use --share-gpus --backend gloo for a rehearsal)", file=sys.stderr)
+        return 2
+    if args.share_gpus and args.backend == "nccl" and have < n:
+        print("bench.py: --share-gpus needs --backend gloo (RCCL refuses two ranks on one device)",
+              file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending.values():
+                    q.terminate()               # exactly the children started above
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------
+
+def _host_threads():
     # the threads this process may actually run on (a 1-GPU box exposes a CPU share, not all cores)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:        # cgroup v2 CPU quota ("1600000 100000" = 16 CPUs): more threads only thrash
@@ -81,33 +155,57 @@ def cpu_baseline(size, rule, seconds):
             cores = min(cores, max(1, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
-    cores = max(1, min(cores, int(os.environ.get("CARLE_CPU_THREADS", cores))))
-    torch.set_num_threads(cores)
-    n = 256
+    return max(1, min(cores, int(os.environ.get("CARLE_CPU_THREADS", cores))))
+
+
+def _time_port(n, size, rule, seconds, min_steps):
+    from oracle.torch_port import TorchPortEnv
     b, s = rule
-    env = TorchPortEnv(n, size, min(64, size), b, s)
+    asize = min(64, size)
+    env = TorchPortEnv(n, size, asize, b, s)
     g = torch.Generator().manual_seed(1234)
     env.universe = (torch.rand(n, 1, size, size, generator=g) < 0.5).float()
-    acts = [(torch.rand(n, 1, min(64, size), min(64, size), generator=g) <= 0.1).float()
-            for _ in range(4)]
-    for i in range(2):
-        env.step(acts[i % 4])
+    acts = [(torch.rand(n, 1, asize, asize, generator=g) <= 0.1).float() for _ in range(2)]
+    env.step(acts[0])                                   # warm-up (allocator, thread pool)
     t0 = time.perf_counter()
     k = 0
     while True:
-        env.step(acts[k % 4])
+        env.step(acts[k % 2])
         k += 1
-        if time.perf_counter() - t0 >= seconds and k >= 3:
+        if k >= min_steps and time.perf_counter() - t0 >= seconds:
             break
     dt = time.perf_counter() - t0
-    return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/torch_port.py (reference ATen op sequence), N={n} {size}x{size} "
-                      f"{k} steps in {dt:.1f} s, torch {torch.__version__} {cores} threads"}
+    return n * k / dt, k, dt
 
+
+def cpu_baseline(n, size, rule, seconds):
+    """Port of the reference step (oracle/torch_port.py) on the host cores, bounded sample: the
+    SAME batch as the GPU leg (N per GPU, capped at 4096: the CPU rate falls with N), at
+    least 3 steps; the N=256 rate (the CPU's cache-friendlier batch) is printed beside it."""
+    cores = _host_threads()
+    torch.set_num_threads(cores)
+    n_big = min(n, 4096)
+    v_big, k_big, dt_big = _time_port(n_big, size, rule, seconds, 3)
+    out = {"value": v_big, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"oracle/torch_port.py (reference ATen op sequence), N={n_big} {size}x{size} "
+                     f"{k_big} steps in {dt_big:.1f} s, torch {torch.__version__} {cores} threads"}
+    if n_big > 256:
+        v_small, k_small, dt_small = _time_port(256, size, rule, min(3.0, seconds), 3)
+        out["value_n256"] = v_small
+        out["sample_n256"] = f"N=256: {k_small} steps in {dt_small:.1f} s"
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# workload naming / PMC traffic
+# ------------------------------------------------------------------------------------------------
 
 def cfg_name(args, n, size):
     if args.format == "f32" and size == 64 and n == 4096:
         return "BASELINE configs[3] (CA + RND2D forward)" if args.rnd else "BASELINE configs[1]"
+    if args.format == "f32" and size == 64 and not (args.rnd or args.ae):
+        return f"BASELINE configs[1] shape at N={n} (state arrays beyond the Infinity Cache)" \
+            if n * size * size * 4 > (256 << 20) else "BASELINE configs[1] shape"
     if args.format == "b1" and size == 512 and n == 4096:
         return "BASELINE configs[4] (bit-packed)"
     if size == 256:
@@ -115,26 +213,157 @@ def cfg_name(args, n, size):
     return "custom"
 
 
-def pmc_traffic(size, n):
+def pmc_traffic(kernel, fmt, size, n):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_summary.py).  The
-    counters cannot be collected from inside this process, so the value is read from
-    profiles/pmc_latest.json when it describes the same workload, else null."""
+    counters cannot be collected from inside this process, so the value comes from
+    profiles/pmc_latest.json -- and only when that record names THIS kernel, THIS workload and
+    was taken from the kernel sources this library was built from (sha256 of carle_amd/csrc +
+    include/); otherwise traffic is null."""
+    from carle_amd import _lib
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
-        rec = json.load(open(path))
-        if rec.get("size") == size and rec.get("instances") == n:
-            return {"traffic": rec["traffic_bytes_per_launch"],
-                    "traffic_source": rec.get("source", "profiles/pmc_latest.json")}
-    except (OSError, ValueError, KeyError):
-        pass
-    return {"traffic": None}
+        recs = json.load(open(path))
+    except (OSError, ValueError):
+        return {"traffic": None, "traffic_note": "no profiles/pmc_latest.json"}
+    if isinstance(recs, dict):
+        recs = [recs]
+    sha = _lib.source_hash()
+    stale = False
+    for rec in recs:
+        if (rec.get("size") == size and rec.get("instances") == n and rec.get("format", "f32") == fmt
+                and rec.get("kernel") and kernel.startswith(rec["kernel"].split("<")[0])):
+            if rec.get("csrc_sha256") == sha:
+                return {"traffic": rec["traffic_bytes_per_launch"],
+                        "traffic_source": rec.get("source", "profiles/pmc_latest.json")}
+            stale = True
+    return {"traffic": None,
+            "traffic_note": "PMC record predates the current kernel sources" if stale
+            else "no PMC record for this kernel / workload"}
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+
+def launch_check(rank, world, dev, backend):
+    import torch.distributed as dist
+    mine = [rank, int(os.environ.get("LOCAL_RANK", "-1")), int(os.environ.get("WORLD_SIZE", "-1")),
+            dev.index if dev.type == "cuda" else -1]
+    if world > 1:
+        t = torch.tensor(mine, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        rows = [o.tolist() for o in out]
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        rows = [mine]
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "backend": backend,
+                          "ranks": [{"rank": r[0], "local_rank": r[1], "world_size": r[2], "device": r[3]}
+                                    for r in rows],
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}),
+              flush=True)
+
+
+def time_kernel(launch, reps, dev):
+    """Average duration (ms) of `reps` back-to-back launches, HIP events on the launch stream
+    (torch's current stream is the stream the ABI is given)."""
+    for i in range(4):
+        launch(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for i in range(reps):
+        launch(i)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / reps
+
+
+def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
+    """Candidates for the config's dominant kernel: (name, launch(i), algorithmic bytes per launch,
+    FLOP per launch or None).  Each `launch` enqueues that ONE kernel on the current stream."""
+    packed, bytes_fmt = args.format == "b1", args.format == "u8"
+    state = env.universe_bits if packed else env.universe
+    rule = env.rule_mask()
+    bufs = [state, torch.empty_like(state)]
+    cand = []
+    if packed:
+        alg = n * (size * size * 2 + asize * asize) // 8
+        name = "ca_step_b1_kernel"
+        step_fn = hip.ca_step_b1
+    elif bytes_fmt:
+        alg = n * (size * size * 2 + asize * asize)
+        name = ("ca_step_64_kernel" if size == 64 else "ca_step_wide_kernel") + "<carle::U8Cells, carle::U8Cells, true, ...>"
+        step_fn = hip.ca_step_u8
+    else:
+        alg = n * (size * size * 8 + asize * asize * 4)
+        name = ("ca_step_64_kernel" if size == 64 else "ca_step_wide_kernel") + "<carle::F32Cells, carle::F32Cells, true, ...>"
+        step_fn = hip.ca_step_f32
+
+    def ca(i):
+        step_fn(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], rule, env._status, 0)
+
+    nets = args.rnd or args.ae
+    fused_rnd = args.rnd and not args.train and args.format == "f32" and size == 64
+    if fused_rnd:
+        # BASELINE configs[3]: the CA step and the RND2D forward are ONE kernel
+        rnd = wenv if not args.ae else wenv.env
+        pb, rb = rnd._pred_blob.get(state.device), rnd._rand_blob.get(state.device)
+        ws, bonus = rnd._ws, rnd._step_bonus
+
+        def ca_rnd(i):
+            hip.ca_step_f32_rnd(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], rule, env._status, 0,
+                                pb, rb, ws, bonus, True)
+        rnd_flop = 2 * 9 * size * size * 6 + 2 * 9 * (size // 4) ** 2 * 6 + 2 * (size // 8) ** 2 * 16 * 2
+        cand.append(("ca_step_rnd64_kernel<true>", ca_rnd, alg + 4 * n, n * rnd_flop))
+    else:
+        cand.append((name, ca, alg, None))
+    if nets and size == 64 and args.format == "f32":
+        obs = state
+        grid_bytes = n * (size * size * 4 + 4)
+        # AE2D forward per grid: conv1 1->4 @64^2, conv2 4->2 @32^2, convT 2->1 (4 taps/output) @32^2,
+        # convT 1->1 @64^2
+        ae_flop = 2 * 9 * 4096 * 4 + 2 * 9 * 4 * 2 * 1024 + 2 * 4 * 2 * 1024 + 2 * 4 * 4096
+        rnd_flop = 474112
+        for w in ([wenv, wenv.env] if args.ae and args.rnd else [wenv]):
+            is_ae = w.my_name == "AE2D"
+            if args.train:
+                bonus = torch.empty(n, dtype=torch.float32, device=obs.device)
+
+                def tr(i, w=w, bonus=bonus):
+                    w._fused_train(obs, None, bonus, None)
+                cand.append(("ae_train_block64_kernel" if is_ae else "rnd_train_block64_kernel", tr,
+                             grid_bytes, 3 * n * (ae_flop if is_ae else rnd_flop)))
+            elif is_ae or not fused_rnd:
+                bonus = torch.empty(n, dtype=torch.float32, device=obs.device)
+
+                def fw(i, w=w, bonus=bonus):
+                    w._hip_forward(obs, False, None, bonus, None)
+                cand.append(("ae_block64_kernel" if is_ae else "rnd_block64_kernel", fw, grid_bytes,
+                             n * (ae_flop if is_ae else rnd_flop)))
+    return cand
+
+
+def run_rank(args):
     from carle_amd import dist as cdist
-    rank, world, dev = cdist.init_from_env(args.backend)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:               # checked BEFORE the rendezvous: a mismatch must not hang
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a "
+              f"{env_world}-GPU number as a {args.gpus}-GPU one", file=sys.stderr)
+        sys.exit(2)
+    rank, world, dev = cdist.init_from_env(args.backend, share_devices=args.share_gpus)
+    if args.launch_check:
+        launch_check(rank, world, dev, args.backend)
+        return
+    if dev.type != "cuda":
+        print("bench.py: no HIP device visible (carle_amd has no CPU path)", file=sys.stderr)
+        sys.exit(2)
+    if world > 1 and not args.share_gpus and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s)", file=sys.stderr)
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -176,7 +405,8 @@ def main():
         # forward passes only.  RND2D alone is fused into the CA kernel (one stream); a stacked AE2D
         # runs its kernels on the reward stream beside the next CA step unless --sync-reward
         kw = dict(async_reward=(args.ae or args.train) and not args.sync_reward, train_predictor=args.train)
-        wenv = RND2D(env, **kw)
+        if args.rnd:
+            wenv = RND2D(env, **kw)
         if args.ae:
             wenv = AE2D(wenv, **kw)
         wenv.eval()
@@ -240,36 +470,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     pop = float(env.universe.sum().item())      # keeps the result live / sanity
-    state = env.universe_bits if packed else env.universe
-    step_fn = hip.ca_step_b1 if packed else hip.ca_step_u8 if bytes_fmt else hip.ca_step_f32
+    reward_count = stats.count                  # rewards seen by ALL ranks (the collective's result)
 
-    # ---- roofline of the dominant kernel: back-to-back launches of the step kernel alone,
-    # HIP events on the launch stream (torch's current stream is the stream the ABI is given)
-    rule = env.rule_mask()
-    a_buf, b_buf = state, torch.empty_like(state)
-    reps = max(32, min(args.steps, 256))
-    for i in range(4):
-        step_fn(a_buf, ring[i % len(ring)], b_buf, rule, env._status, 0)
-        a_buf, b_buf = b_buf, a_buf
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    e0.record()
-    for i in range(reps):
-        step_fn(a_buf, ring[i % len(ring)], b_buf, rule, env._status, 0)
-        a_buf, b_buf = b_buf, a_buf
-    e1.record()
-    torch.cuda.synchronize(dev)
-    k_ms = e0.elapsed_time(e1) / reps
-    if packed:
-        alg_bytes = n * (size * size * 2 + asize * asize) // 8
-    elif bytes_fmt:
-        alg_bytes = n * (size * size * 2 + asize * asize)
-    else:
-        alg_bytes = n * (size * size * 8 + asize * asize * 4)
+    # ---- roofline of the config's dominant kernel: back-to-back launches of that kernel alone
+    warnings = []
+    cands = dominant_kernels(args, env, wenv, ring, hip, n, size, asize)
+    timed = []
+    for name, launch, alg, flop in cands:
+        reps = 256
+        k_ms = time_kernel(launch, reps, dev)
+        while k_ms * reps < 2 * MIN_TIMED_MS and reps < 8192:     # >= 10 ms of launches per estimate
+            reps *= 4
+            k_ms = time_kernel(launch, reps, dev)
+        timed.append((k_ms, name, alg, flop, reps))
+    k_ms, kname, alg_bytes, flop, reps = max(timed)
     achieved = alg_bytes / (k_ms * 1e-3)
+    if dt * 1e3 < MIN_TIMED_MS:
+        warnings.append(f"timed region is {dt * 1e3:.2f} ms (< {MIN_TIMED_MS} ms): value is launch-jitter "
+                        f"sensitive; use --steps >= {int(args.steps * MIN_TIMED_MS / (dt * 1e3)) + 1}")
 
-    cells = "carle::U8Cells" if bytes_fmt else "carle::F32Cells"
     if rank == 0:
+        roof = {"bound": "hbm", "kernel": kname,
+                "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK,
+                **pmc_traffic(kname, args.format, size, n),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_us": k_ms * 1e3, "launches_timed": reps,
+                "frac_of_measured_copy_ceiling": achieved / 6.29e12}
+        if flop:
+            roof["flop_per_launch"] = flop
+            roof["flop_frac_fp32_valu"] = flop / (k_ms * 1e-3) / FP32_PEAK
+        if len(timed) > 1:
+            roof["other_kernels_us"] = {nm: ms * 1e3 for ms, nm, _, _, _ in timed if nm != kname}
         out = {
             "metric": f"env-steps/sec at N={n}x64x64 ({args.rule}, fp32 drop-in grids, action every step)"
                       if args.format == "f32" and size == 64 else
@@ -295,25 +527,35 @@ def main():
                                       ((" forward+backward, Adam every 64 steps" if args.train else " forward")
                                        if (args.rnd or args.ae) else ""),
                        "reward_consumers": "reward stream" if rs is not None else "same stream",
-                       "collective": f"all-gather of 24 B/rank reward moments every {args.stats_every} steps"},
+                       "collective": f"all-gather of 24 B/rank reward moments every {args.stats_every} steps"
+                                     f" ({args.backend if world > 1 else 'single rank'})",
+                       "state_bytes_per_array": int(env.universe_bits.numel() * 8 if packed else
+                                                    env.universe.numel() * env.universe.element_size())},
             "cell_updates_per_s": world * n * args.steps * size * size / dt,
             "final_population_rank0": pop,
-            "roofline": {"bound": "hbm", "kernel": ("ca_step_b1_kernel" if packed else
-                                    f"ca_step_64_kernel<{cells}, {cells}, true, ...>" if size == 64 else
-                                    f"ca_step_wide_kernel<{cells}, {cells}, true, ...>"),
-                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK,
-                         **(pmc_traffic(size, n) if args.format == "f32" else {"traffic": None}),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_us": k_ms * 1e3, "launches_timed": reps},
+            "rewards_counted_all_ranks": reward_count,
+            "roofline": roof,
         }
+        if warnings:
+            out["warnings"] = warnings
         if world == 1 and not args.no_cpu_baseline:
             b, s = env.birth, env.survive
-            out["cpu_baseline"] = cpu_baseline(size, (b, s), args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(n, size, (b, s), args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -43,6 +43,8 @@ SIGNATURES = {
     "carle_env_step_f32_rnd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
                                         _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
                                         _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp]),
+    "carle_ca_step_f32_rnd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
+                                       _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
     "carle_rnd2d_train_partial_floats": (_c_i64, [_c_i64]),
     "carle_rnd2d_train_f32": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                        _c_vp, _c_vp, ctypes.c_float, ctypes.c_float, _c_int, _c_vp]),
@@ -80,6 +82,21 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def source_hash():
+    """sha256 over the kernel sources the library is built from (carle_amd/csrc/*.hip, *.hpp and
+    include/carle_hip.h, in name order).  Profiles record it so that a PMC figure is only quoted
+    for the kernels it was measured on (bench.py, tools/pmc_summary.py)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.hpp")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "carle_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 class CarleHipError(RuntimeError):

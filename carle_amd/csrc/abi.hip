@@ -270,6 +270,36 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
                   bool tables_valid, hipStream_t s);
 }
 
+// argument checks of the fused 64x64 CA + RND2D kernel (shared by the two entry points below)
+static int rnd_step_checks(const char *who, const float *u_in, const float *action, float *u_out, int64_t n,
+                           int h, int w, int ah, int aw, uint32_t rule, int slot, const float *workspace) {
+    std::string p(who);
+    if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, (p + ": u_in/u_out is NULL").c_str());
+    if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
+    if (rule >> 18) return fail_arg(CARLE_E_RULE, (p + ": rule mask exceeds 18 bits").c_str());
+    if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, (p + ": slot must be 0 or 1").c_str());
+    if (!aligned16(u_in) || !aligned16(u_out) || (action && !aligned16(action)) || !aligned16(workspace))
+        return fail_arg(CARLE_E_ALIGN, (p + ": pointers must be 16-byte aligned").c_str());
+    const size_t bytes = (size_t)n * h * w * sizeof(float);
+    if (overlap(u_in, bytes, u_out, bytes)) return fail_arg(CARLE_E_ALIAS, (p + ": u_in and u_out overlap").c_str());
+    return 0;
+}
+
+// The fused kernel alone (no epilogue): one generation + the RND2D bonus of the new state.
+extern "C" int carle_ca_step_f32_rnd(const float *u_in, const float *action, float *u_out, int64_t n, int h,
+                                     int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
+                                     const float *pred_params, const float *rand_params, float *workspace,
+                                     float *bonus, int net_flags, void *stream) {
+    if (!pred_params || !rand_params || !workspace || !bonus)
+        return fail_arg(CARLE_E_NULL, "carle_ca_step_f32_rnd: NULL reward-net pointer");
+    if (h != 64 || w != 64 || (action && (aw % 8) != 0) || n <= 0)
+        return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rnd: 64x64 grids with AW % 8 == 0 only");
+    if (int e = rnd_step_checks("carle_ca_step_f32_rnd", u_in, action, u_out, n, h, w, ah, aw, rule, slot, workspace))
+        return e;
+    return ca_step_rnd64(u_in, action, u_out, n, aw, rule, status, slot, pred_params, rand_params, workspace,
+                         bonus, (net_flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out,
                                       float *reward, int64_t n, int h, int w, int ah, int aw,
                                       uint32_t rule, int32_t *status, int slot, int publish_flags,
@@ -289,15 +319,10 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
     // the bonus into the reward.  Everything runs on stream_env; stream_reward (if any) is ordered
     // behind it so that reward consumers enqueued there see the result.
     if (h == 64 && w == 64 && (!action || (aw % 8) == 0) && n > 0 && reward) {
-        if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: u_in/u_out is NULL");
-        if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
-        if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_env_step_f32_rnd: rule mask exceeds 18 bits");
-        if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_rnd: slot must be 0 or 1");
-        if (!aligned16(u_in) || !aligned16(u_out) || (action && !aligned16(action)) || !aligned16(workspace))
-            return fail_arg(CARLE_E_ALIGN, "carle_env_step_f32_rnd: pointers must be 16-byte aligned");
+        if (int e = rnd_step_checks("carle_env_step_f32_rnd", u_in, action, u_out, n, h, w, ah, aw, rule, slot,
+                                    workspace))
+            return e;
         const size_t bytes = (size_t)n * h * w * sizeof(float);
-        if (overlap(u_in, bytes, u_out, bytes))
-            return fail_arg(CARLE_E_ALIAS, "carle_env_step_f32_rnd: u_in and u_out overlap");
         if (int e = ca_step_rnd64(u_in, action, u_out, n, aw, rule,
                                   (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot,
                                   pred_params, rand_params, workspace, bonus, tables_valid,

@@ -31,14 +31,22 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-def init_from_env(backend="nccl"):
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)
-    and bind this process to its GPU.  Returns (rank, world, device)."""
+def init_from_env(backend="nccl", share_devices=False):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run,
+    or bench.py's own launcher) and bind this process to its GPU.  Returns (rank, world, device).
+
+    One process per GPU: LOCAL_RANK must name an existing device.  ``share_devices=True`` (gloo
+    rehearsals of the multi-rank path on a node with fewer GPUs) wraps LOCAL_RANK around the
+    device count instead of failing."""
     w = int(os.environ.get("WORLD_SIZE", "1"))
     r = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
-    use_cuda = torch.cuda.is_available()
-    dev = torch.device("cuda", lr % max(torch.cuda.device_count(), 1)) if use_cuda else torch.device("cpu")
+    count = torch.cuda.device_count()            # does not initialise the GPU
+    if count > 0 and lr >= count and not share_devices:
+        raise RuntimeError(f"LOCAL_RANK={lr} but only {count} HIP device(s) are visible: one process "
+                           f"per GPU (pass share_devices=True for a gloo rehearsal)")
+    use_cuda = count > 0 and torch.cuda.is_available()
+    dev = torch.device("cuda", lr % count) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(dev)
     if w > 1 and not dist.is_initialized():

@@ -83,6 +83,14 @@ class CARLE(RLEMixin, nn.Module):
         # reference behaviour for an empty birth/survive list is a TypeError (env.py:221-224);
         # by default this build treats an empty list as "never" (a superset); strict mirrors it
         self.strict_reference_errors = kwargs.get("strict_reference_errors", False)
+        # the two whole-batch action predicates of step() (env.py:191 `if torch.sum(action)`,
+        # env.py:208 `torch.mean(action) == 1.0`).  Default: evaluated inside the step kernel as
+        # "some element is non-zero" / "every element equals 1.0" -- identical for {0,1}-valued
+        # actions (what every agent of the reference emits).  True: evaluated exactly as the
+        # reference does, with torch.sum / torch.mean over the action as passed (two extra device
+        # reductions per step, still no host synchronisation): actions whose values cancel, or
+        # average to exactly 1.0 without all being 1, then behave as in the reference.
+        self.exact_action_predicates = bool(kwargs.get("exact_action_predicates", False))
         self.storage = kwargs.get("storage", "f32")
         if self.storage not in ("f32", "u8", "b1"):
             raise ValueError("storage must be 'f32' (reference format), 'u8' or 'b1' (bit-packed)")
@@ -255,6 +263,13 @@ class CARLE(RLEMixin, nn.Module):
             action = action.expand(self.instances, -1, -1, -1)   # broadcast like logical_xor
         return action.contiguous(), cropped, full
 
+    def _exact_predicates(self, action, slot):
+        """env.py:191 / env.py:208 with the reference's own reductions, written into the flag slot
+        of the status block on the device (ANY_NONZERO = sum != 0, NOT_ALL_ONES = mean != 1.0)."""
+        a = action if action.dtype == torch.float32 else action.float()
+        flags = torch.stack([torch.sum(a) != 0, torch.mean(a) != 1.0]).to(torch.int32)
+        self._status[slot::2][:2] = flags                # words slot and 2 + slot
+
     def _device_universe(self):
         u = self.universe
         if u is None:
@@ -324,15 +339,19 @@ class CARLE(RLEMixin, nn.Module):
                 return self.universe, reward, torch.zeros(self.instances, 1), [{}] * self.instances
             action = action.materialize()
         act, cropped, full = self._device_action(action)
-        if cropped:
+        publish = not cropped
+        if self.exact_action_predicates:
+            self._exact_predicates(full, slot)
+            publish = False
+        elif cropped:
             # the two whole-batch predicates are defined on the action AS PASSED (env.py:191,208);
             # for an oversize action evaluate them on the uncropped tensor (cold path, no sync)
             hip.action_flags_f32(full.contiguous(), self._status, slot)
         if launch is None:
-            hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, not cropped, merge)
+            hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, publish, merge)
             self._moments_merged = merge
         else:
-            launch(u_in, act, out, reward, rule, self._status, slot, not cropped)
+            launch(u_in, act, out, reward, rule, self._status, slot, publish)
         self._slot = slot ^ 1
         self.universe = out
         done = torch.zeros(self.instances, 1)
@@ -477,11 +496,14 @@ class CARLEPacked(CARLE):
             if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
                 action = action.materialize()
             a32, cropped, full = self._device_action(action)
-            if cropped:
+            if self.exact_action_predicates:
+                self._exact_predicates(full, slot)
+                act = hip.pack_f32_b1(a32)
+            elif cropped:
                 hip.action_flags_f32(full.contiguous(), self._status, slot)
                 act = hip.pack_f32_b1(a32)
             else:
-                act = hip.pack_f32_b1(a32, self._status, slot)   # exact fp32 predicates
+                act = hip.pack_f32_b1(a32, self._status, slot)   # predicates of the fp32 values
             publish = False
         out = torch.empty_like(bits)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
@@ -608,9 +630,15 @@ class CARLEBytes(CARLE):
         if (isinstance(action, torch.Tensor) and action.dtype == torch.uint8 and action.is_cuda
                 and tuple(action.shape) == (self.instances, 1, self.action_width, self.action_height)):
             act, cropped = action.contiguous(), False              # hot path: uint8 on the device
+            if self.exact_action_predicates:
+                self._exact_predicates(act, slot)
+                cropped = True                                     # = do not publish from the kernel
         else:
             act, cropped, full = self._device_action(action)
-            if cropped:
+            if self.exact_action_predicates:
+                self._exact_predicates(full, slot)
+                cropped = True
+            elif cropped:
                 hip.action_flags_f32(full.contiguous(), self._status, slot)
         out = torch.empty_like(u_in)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)

@@ -506,6 +506,21 @@ def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_fl
         _lib.check(rc, "carle_env_step_f32_rnd")
 
 
+def ca_step_f32_rnd(u_in, action, u_out, rule, status, slot, pred_params, rand_params, workspace, bonus,
+                    tables_valid):
+    """The fused 64x64 CA + RND2D kernel alone (no epilogue); bonus has N + 1 elements."""
+    lib = _lib.load()
+    n, _, h, w = u_in.shape
+    ap, ah, aw = (None, 0, 0) if action is None else (action.data_ptr(), action.shape[2], action.shape[3])
+    with _on_device(u_in.device):
+        rc = lib.carle_ca_step_f32_rnd(u_in.data_ptr(), ap, u_out.data_ptr(), n, h, w, ah, aw, rule,
+                                       _ptr(status), slot, pred_params.data_ptr(), rand_params.data_ptr(),
+                                       workspace.data_ptr(), bonus.data_ptr(), 2 if tables_valid else 0,
+                                       _stream(u_in))
+    if rc != 0:
+        _lib.check(rc, "carle_ca_step_f32_rnd")
+
+
 def rnd2d_train(obs, pred_params, rand_params, workspace, partial, grad, bonus, reward, reward_scale,
                 grad_scale, tables_valid, stream=None):
     """RND2D bonus + accumulated predictor gradient in one pass (64x64 binary obs, fp32 or packed)."""

@@ -88,6 +88,9 @@ class _ParamBlob:
         self.blob = None
         self.params = None
         self.version = 0            # bumped whenever the blob is rebuilt (= the values changed)
+        self._previous = None       # the blob of the last generation: kernels enqueued on another
+        # stream may still read it when it is replaced, so it is released one rebuild later (an
+        # update window = many cross-stream joins later), never straight into the allocator
 
     def get(self, device):
         # the Parameter objects of an nn.Sequential are stable (.to()/load_state_dict/optimisers
@@ -97,6 +100,7 @@ class _ParamBlob:
             ps = self.params = list(self.module.parameters())
         key = (device,) + tuple([(p.data_ptr(), p._version) for p in ps])
         if key != self.key:
+            self._previous = self.blob
             with torch.no_grad():
                 self.blob = torch.cat([p.detach().reshape(-1).to(device, torch.float32) for p in ps])
             self.key = key
@@ -256,6 +260,25 @@ class RND2D(Motivator):
         prediction = self.predictor(obs)
         return torch.mean(torch.abs((target - prediction) ** 2), dim=[1])
 
+    # -- observation window of the autograd replay (sizes without a fused gradient kernel) --------
+    # retained bytes above which the window is replayed early (gradients keep accumulating in .grad:
+    # parameters are constant inside a window, so the sum is the same)
+    window_bytes_cap = 256 << 20
+
+    def _retain(self, obs):
+        """Keeps ``obs`` for the replay.  Binary observations (anything CARLE.step returned) are kept
+        bit-packed (carle_pack_f32_b1: 1/32 of the fp32 bytes) and unpacked per replay chunk; nothing
+        is kept while no predictor parameter requires a gradient (``set_no_grad``)."""
+        if not any(p.requires_grad for p in self._pred_blob.params or self.predictor.parameters()):
+            return
+        o, binary = self._obs(obs)
+        if binary and o.dtype == torch.float32 and o.shape[3] % 64 == 0:
+            o = hip.pack_f32_b1(o)
+        self._window.append(o)
+        self.__dict__["_window_bytes"] = self.__dict__.get("_window_bytes", 0) + o.numel() * o.element_size()
+        if self.__dict__["_window_bytes"] > self.window_bytes_cap:
+            self.accumulate_loss = self.accumulate_loss + self._replay_window(1.0 / self.batch_size)
+
     def update_predictor(self, loss):
         loss.backward()
         self.optimizer.step()
@@ -276,28 +299,39 @@ class RND2D(Motivator):
         graph (same sum, different association)."""
         total = 0.0
         window, self._window = self._window, []
-        i = 0
-        while i < len(window):
-            cells = max(int(window[i].numel()), 1)
-            k = max(1, min(len(window) - i, self.replay_cells // cells))
-            chunk = window[i:i + k]
-            same = all(o.shape == chunk[0].shape for o in chunk)
-            if k > 1 and same:
-                batch = torch.cat(chunk, dim=0)
+        self.__dict__["_window_bytes"] = 0
+        # eval-mode semantics everywhere (Dropout = identity), like the HIP bonus and gradient
+        # kernels: the replay must differentiate the SAME function the reward was computed with,
+        # whatever mode the caller left the wrapper in (the reference's train-mode dropout noise is
+        # a documented deviation, DESIGN.md section 7)
+        was_training = self.predictor.training
+        self.predictor.eval()
+        try:
+            i = 0
+            while i < len(window):
+                cells = max(int(window[i].numel()) * (64 if window[i].dtype == torch.int64 else 1), 1)
+                k = max(1, min(len(window) - i, self.replay_cells // cells))
+                chunk = window[i:i + k]
+                same = all(o.shape == chunk[0].shape and o.dtype == chunk[0].dtype for o in chunk)
+                if not (k > 1 and same):
+                    k, chunk = 1, chunk[:1]
+                batch = torch.cat(chunk, dim=0) if k > 1 else chunk[0]
+                if batch.dtype == torch.int64:
+                    batch = hip.unpack_b1_f32(batch)
                 loss = torch.mean(self._torch_loss(batch)) * (k * scale)
-            else:
-                k = 1
-                loss = torch.mean(self._torch_loss(chunk[0])) * scale
-            loss.backward()
-            total = total + loss.detach()
-            i += k
+                loss.backward()
+                total = total + loss.detach()
+                i += k
+        finally:
+            self.predictor.train(was_training)
         return total
 
     def get_bonus_update(self, obs):
         """Bonus + immediate predictor update on this observation (mcl.py:354-366)."""
         self.predictor.zero_grad()
         bonus = self.get_bonus(obs)
-        self._window = [self._obs(obs)[0]]
+        self._window = []
+        self._retain(obs)
         self._replay_window(1.0)
         self.optimizer.step()
         self._after_update()
@@ -312,8 +346,9 @@ class RND2D(Motivator):
             self.predictor.zero_grad()
             self.accumulate_loss = 0.0
             self._window = []
+            self.__dict__["_window_bytes"] = 0
         if not self._fused_train(obs, None, bonus, None):
-            self._window.append(self._obs(obs)[0])
+            self._retain(obs)
             bonus = self.get_bonus(obs)
         self.buffer_length += 1
         if self.buffer_length >= self.batch_size:
@@ -339,8 +374,9 @@ class RND2D(Motivator):
             self.predictor.zero_grad()
             self.accumulate_loss = 0.0
             self._window = []
+            self.__dict__["_window_bytes"] = 0
         if not self._fused_train(obs, reward, self._bonus_buf, stream):
-            self._window.append(self._obs(obs)[0])
+            self._retain(obs)
             self._hip_forward(obs, False, reward, self._bonus_buf, stream)
         self.buffer_length += 1
         if self.buffer_length >= self.batch_size:
@@ -350,7 +386,7 @@ class RND2D(Motivator):
         """End of an update window: replay retained observations (if any), add the gradient the
         fused kernel accumulated, Adam step (mcl.py:380-384, 333-341)."""
         if self._window:
-            self.accumulate_loss = self._replay_window(1.0 / self.batch_size)
+            self.accumulate_loss = self.accumulate_loss + self._replay_window(1.0 / self.batch_size)
         if self._grad_used:
             off = 0
             for p in self._pred_blob.params:
@@ -420,10 +456,11 @@ class RND2D(Motivator):
             self._bonus_into(obs, reward)
             return obs, reward, done, info
         rs_raw = rs.fork(obs, reward)                    # reward stream ordered after CA step t
-        if self.train_predictor and self.buffer_length + 1 >= self.batch_size:
-            with rs.context():                           # the Adam replay uses torch ops: rare path
-                self._bonus_into(obs, reward, rs_raw)
-        else:
+        # EVERYTHING of the bonus runs with the reward stream current: the kernels (explicit stream
+        # argument) and every torch-side preparation they consume -- parameter-blob rebuild after an
+        # Adam step, gradient / workspace allocation and zero fill, observation format conversion,
+        # the window replay and the optimiser -- so producer and consumer are always on one stream
+        with rs.context():
             self._bonus_into(obs, reward, rs_raw)
         return obs, reward, done, info
 

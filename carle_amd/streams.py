@@ -54,5 +54,23 @@ class RewardStream:
         self._held = []
 
     def context(self):
-        """torch stream context for the rare torch-op work that must run on the reward stream."""
-        return torch.cuda.stream(self.stream)
+        """Makes the reward stream torch's current stream for a ``with`` block (entered every step
+        by the asynchronous wrappers: a plain set_stream pair, cheaper than torch.cuda.stream())."""
+        return _Current(self)
+
+
+class _Current:
+    __slots__ = ("rs", "prev")
+
+    def __init__(self, rs):
+        self.rs = rs
+        self.prev = None
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_stream(self.rs.device)
+        torch.cuda.set_stream(self.rs.stream)
+        return self.rs
+
+    def __exit__(self, *exc):
+        torch.cuda.set_stream(self.prev)
+        return False

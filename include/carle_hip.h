@@ -281,6 +281,15 @@ int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out,
                            float *bonus, float reward_scale, int net_flags,
                            void *event, void *stream_env, void *stream_reward);
 
+/* The fused kernel of the 64x64 case alone, without the epilogue (as carle_ca_step_f32 is to
+ * carle_env_step_f32): u_out = one generation of (u_in XOR action) (carle/env.py:150-182, 219-229),
+ * bonus[i] = RND2D.get_bonus(u_out_i) (carle/mcl.py:343-352), bonus[N] = bonus of the all-dead grid.
+ * 64x64 grids, AW % 8 == 0 (or action == NULL); status nullable. */
+int carle_ca_step_f32_rnd(const float *u_in, const float *action, float *u_out, int64_t n, int h, int w,
+                          int ah, int aw, uint32_t rule, int32_t *status, int slot,
+                          const float *pred_params, const float *rand_params, float *workspace,
+                          float *bonus, int net_flags, void *stream);
+
 /* Orders `to_stream` after everything enqueued so far on `from_stream` (hipEventRecord on
  * from_stream + hipStreamWaitEvent on to_stream; `event` is a caller-owned hipEvent_t).  Used to
  * run the reward networks of step t on a second stream beside the CA kernel of step t+1. */

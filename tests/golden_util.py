@@ -56,6 +56,19 @@ def ca_case(name):
     raise KeyError(name)
 
 
+def predicate_case_names():
+    z = np.load(os.path.join(GOLDEN, "ca_predicates.npz"))
+    return sorted(k[:-5] for k in z.files if k.endswith("/meta"))
+
+
+def predicate_case(name):
+    """Cases of ca_predicates.npz: actions whose values cancel / average to exactly 1.0."""
+    if "pred" not in _CACHE:
+        z = np.load(os.path.join(GOLDEN, "ca_predicates.npz"))
+        _CACHE["pred"] = {nm: CACase(z, nm) for nm in predicate_case_names()}
+    return _CACHE["pred"][name]
+
+
 def known():
     with open(os.path.join(GOLDEN, "ca_known.json")) as f:
         return json.load(f)

@@ -91,3 +91,52 @@ def test_chan_merge_matches_numpy():
     allx = np.concatenate(parts)
     np.testing.assert_allclose(merged.numpy(), [allx.size, allx.mean(), ((allx - allx.mean()) ** 2).sum()],
                                rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py's own launcher (python bench.py --gpus N outside torch.distributed.run)
+# ---------------------------------------------------------------------------------------------
+import json
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags, env=None, timeout=240):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True,
+                          text=True, timeout=timeout, cwd=ROOT, env=e)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launcher_spawns_one_rank_per_gpu(world):
+    """`bench.py --gpus N` starts N fresh rank processes with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, they rendezvous (gloo here), and rank 0 prints ONE JSON line with n_gpus == N."""
+    out = _bench("--gpus", str(world), "--backend", "gloo", "--launch-check")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["master"].startswith("127.0.0.1:")
+    assert [(r["rank"], r["local_rank"], r["world_size"]) for r in d["ranks"]] == \
+        [(r, r, world) for r in range(world)]
+
+
+def test_bench_refuses_mismatched_world():
+    # --gpus disagrees with WORLD_SIZE: fail loudly before the rendezvous (no hang, no 1-GPU number)
+    out = _bench("--gpus", "4", "--launch-check", env={"WORLD_SIZE": "2", "RANK": "0"}, timeout=60)
+    assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr
+    # more GPUs asked for than the node has (none here): refuse instead of measuring fewer
+    if torch.cuda.device_count() < 2:
+        out = _bench("--gpus", "2", timeout=60)
+        assert out.returncode == 2 and "refusing" in out.stderr
+
+
+def test_bench_launcher_propagates_rank_failure():
+    # one rank dies (bad backend name): the launcher stops the others and exits non-zero
+    out = _bench("--gpus", "2", "--backend", "no_such_backend", "--launch-check", timeout=120)
+    assert out.returncode != 0

@@ -236,3 +236,31 @@ def test_multistep_through_the_env():
     for _ in range(3):
         ref.step(torch.zeros(1, 1, 10, 10))
     assert torch.equal(env.universe, ref.universe) and env.step_number == 4
+
+
+def test_cfg5_full_size_with_action_against_the_oracle():
+    """BASELINE configs[4] at its full size (B36/S23, N=4096, 512x512 bit-packed) WITH the 64x64
+    action window, against oracle/ca_oracle.c on sampled instances (incl. the first / last instance
+    and a workgroup boundary), three consecutive steps through CARLE(storage='b1')."""
+    from carle_amd import hip
+    from carle_amd.env import CARLE
+    n, size = 4096, 512
+    env = CARLE(width=size, height=size, instances=n, device="cuda:0", storage="b1")
+    env.rules_from_string("B36/S23")
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(99)
+    bits = torch.randint(-2 ** 63, 2 ** 63 - 1, (n, 1, size, size // 64), device="cuda", generator=g,
+                         dtype=torch.int64)
+    env.universe_bits = bits.clone()
+    idx = [0, 1, 7, 8, 2047, 2048, 4094, 4095]
+    u_ref = hip.unpack_b1_f32(bits[idx].contiguous()).cpu().numpy()
+    high = O.rule_mask([3, 6], [2, 3])
+    for t in range(3):
+        a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) <= 0.1).float()
+        ap = hip.pack_f32_b1(a)
+        obs = env.step(ap if t % 2 else a)[0]            # packed and fp32 actions
+        u_ref, reset, _ = O.c_env_step(u_ref, a[idx].cpu().numpy(), high)
+        assert not reset
+        got = hip.unpack_b1_f32(obs[idx].contiguous()).cpu().numpy()
+        assert np.array_equal(got, u_ref), f"grids differ at step {t}"
+    assert env.step_number == 3 and env.steps_since_action == 0

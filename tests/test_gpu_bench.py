@@ -32,3 +32,26 @@ def test_bench_contract_short_run():
     assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"] * 0.99
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py --gpus 2 through its own launcher: two rank processes (sharing the one device of the
+    test box, gloo), n_gpus == 2 in the JSON, the reward statistics counted on both ranks."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpus",
+                          "--backend", "gloo", "--instances", "512", "--steps", "130", "--warmup", "4",
+                          "--stats-every", "64"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["sharding"] == "batch x2"
+    assert d["rewards_counted_all_ranks"] == 2 * 512 * (130 + 4)
+    assert "cpu_baseline" not in d
+
+
+def test_bench_refuses_more_gpus_than_present():
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 2 and "refusing" in out.stderr

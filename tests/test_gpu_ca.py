@@ -46,6 +46,65 @@ def test_env_replays_golden_case(name):
     assert rec == len(c.record)
 
 
+def _replay(c, env, to_device):
+    """-> list of (obs, step_number, steps_since_action) at the recorded steps."""
+    env.birth, env.survive = list(c.birth), list(c.survive)
+    env.reset()
+    env.universe = torch.from_numpy(c.init.copy()).cuda()
+    out = []
+    for t in range(c.steps):
+        a = torch.from_numpy(c.actions[t].copy())
+        obs = env.step(a.cuda() if to_device else a)[0]
+        if (t + 1) in c.record:
+            o = env.universe.float() if obs.dtype != torch.float32 or obs.shape[-1] != c.size else obs
+            out.append((o.cpu().numpy(), env.step_number, env.steps_since_action))
+    return out
+
+
+@pytest.mark.parametrize("storage", ["f32", "u8", "b1"])
+@pytest.mark.parametrize("name", G.predicate_case_names())
+def test_exact_action_predicates_follow_the_reference(name, storage):
+    """Actions outside {0,1}: values that cancel (torch.sum(action) == 0 although cells toggle,
+    env.py:191) and a mean of exactly 1.0 without all ones (env.py:208 -> master reset).
+    CARLE(exact_action_predicates=True) reproduces the reference's grids AND counters."""
+    c = G.predicate_case(name)
+    env = _env(width=c.size, height=c.size, action_width=c.asize, action_height=c.asize, instances=c.n,
+               storage=storage, exact_action_predicates=True)
+    got = _replay(c, env, to_device=True)
+    for i, (o, sn, ssa) in enumerate(got):
+        t = c.record[i] - 1
+        assert np.array_equal(o, c.obs[i]), f"grid mismatch at step {t + 1}"
+        assert sn == c.step_number[t] and ssa == c.steps_since_action[t], (t, sn, ssa)
+
+
+@pytest.mark.parametrize("name", G.predicate_case_names())
+def test_default_action_predicates_documented_deviation(name):
+    """The default (in-kernel) predicates are 'some element non-zero' / 'every element == 1.0'
+    (DESIGN.md 4.4).  On the cancelling actions the grids still equal the reference's (the toggle
+    is the same) and only steps_since_action differs; an action of mean 1.0 that is not all ones
+    does NOT reset.  Pinned against the oracle driven with those two predicates."""
+    c = G.predicate_case(name)
+    env = _env(width=c.size, height=c.size, action_width=c.asize, action_height=c.asize, instances=c.n)
+    got = _replay(c, env, to_device=False)
+    rule = O.rule_mask(c.birth, c.survive)
+    u, sn, ssa = c.init.copy(), 0, 0
+    for t in range(c.steps):
+        a = c.actions[t]
+        if not (a != 0).any():
+            ssa += 1
+        if (a == 1.0).all():
+            u, sn, ssa = np.zeros_like(u), 0, 0
+        else:
+            u = O.np_ca_update(O.np_apply_action(u, a), rule).astype(np.float32)
+            sn += 1
+        o, gsn, gssa = got[t]
+        assert np.array_equal(o, u) and (gsn, gssa) == (sn, ssa), t
+        if "cancel" in name:
+            assert np.array_equal(o, c.obs[t])           # same grids as the reference
+    if "cancel" in name:
+        assert got[-1][2] < c.steps_since_action[-1]     # the counter is where they differ
+
+
 def _pops(cells, birth, survive, at):
     env = _env(width=64, height=64)
     env.birth, env.survive = birth, survive

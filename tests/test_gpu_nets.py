@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import golden_util as G
+from oracle import ca as O_ca
 from oracle import nets as ON
 
 pytestmark = pytest.mark.gpu
@@ -366,3 +367,131 @@ def test_fused_ae_gradient_matches_autograd(n, packed):
     scale = np.abs(ref).max()
     assert scale > 0
     np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+
+
+@pytest.mark.parametrize("size,n,steps", [(64, 64, 20), (32, 8, 20)])
+def test_async_training_matches_sync_training(size, n, steps):
+    """async_reward=True WITH train_predictor=True (the path bench.py --train measures): over more
+    than two update windows the rewards and the updated parameters equal the same-stream run's.
+    Exercises the parameter-blob rebuild after an Adam step, gradient zero fill and the window
+    replay with the reward stream current (64x64: fused gradient kernels; 32x32: autograd replay)."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D
+    outs = []
+    for async_reward in (False, True):
+        torch.manual_seed(11)
+        env = CARLE(width=size, height=size, action_width=size, action_height=size, instances=n, device="cuda:0")
+        w = AE2D(RND2D(env, async_reward=async_reward), async_reward=async_reward)
+        w.batch_size = w.env.batch_size = 8
+        w.eval()
+        w.reset()
+        g = torch.Generator().manual_seed(6)
+        rews = []
+        for t in range(steps):
+            a = (torch.rand(n, 1, size, size, generator=g) < 0.2).float()
+            obs, reward, done, info = w.step(a)
+            rews.append(reward)
+        w.wait_rewards()
+        torch.cuda.synchronize()
+        assert w.env.updates == steps // 8
+        outs.append((torch.stack(rews).cpu().numpy(),
+                     {k: v.detach().cpu().numpy() for k, v in w.state_dict().items()}))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][0].max() > 0
+    changed = 0
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+    torch.manual_seed(11)
+    fresh = AE2D(RND2D(CARLE(width=size, height=size, instances=n, device="cuda:0")))
+    for k, v in fresh.state_dict().items():
+        changed += int(not np.array_equal(v.cpu().numpy(), outs[0][1][k]))
+    assert changed >= 8                                  # the predictors really were updated
+
+
+@pytest.mark.parametrize("size", [32, 64])
+def test_training_mode_flag_does_not_change_the_numbers(size):
+    """A wrapper left in nn.Module's default train mode (carle/train_mcl.py never calls .eval())
+    gives the same rewards AND the same parameter updates as one in eval mode: bonus kernels,
+    fused gradient kernels and the autograd replay all use eval-mode semantics (Dropout = identity;
+    documented deviation from the reference's train-mode dropout noise)."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D
+    outs = []
+    for mode in ("train", "eval"):
+        torch.manual_seed(17)
+        env = CARLE(width=size, height=size, action_width=size, action_height=size, instances=6, device="cuda:0")
+        w = AE2D(RND2D(env))
+        w.batch_size = w.env.batch_size = 3
+        if mode == "eval":
+            w.eval()
+        w.reset()
+        g = torch.Generator().manual_seed(2)
+        rews = []
+        for t in range(7):
+            obs, reward, done, info = w.step((torch.rand(6, 1, size, size, generator=g) < 0.3).float())
+            rews.append(reward.clone())
+        assert w.predictor.training == (mode == "train")      # the replay restores the caller's mode
+        outs.append((torch.stack(rews).cpu().numpy(),
+                     {k: v.detach().cpu().numpy() for k, v in w.state_dict().items()}))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_replay_window_is_bounded_and_packed():
+    """Sizes without a fused gradient kernel retain the window bit-packed (1/32 of the fp32 bytes)
+    and replay early above window_bytes_cap; the update equals the uncapped one."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D
+    sds = []
+    for cap in (256 << 20, 3 * 8 * 128 * 128 // 8):          # second: room for 3 packed steps
+        torch.manual_seed(23)
+        env = CARLE(width=128, height=128, instances=8, device="cuda:0")
+        w = RND2D(env)
+        w.window_bytes_cap = cap
+        w.batch_size = 10
+        w.eval(); w.reset()
+        g = torch.Generator().manual_seed(1)
+        for t in range(10):
+            w.step((torch.rand(8, 1, 64, 64, generator=g) < 0.3).float())
+            if t < 9:
+                assert all(o.dtype == torch.int64 for o in w._window)
+                assert sum(o.numel() * 8 for o in w._window) <= max(cap, 8 * 128 * 128 // 8)
+        assert w.updates == 1 and not w._window
+        sds.append({k: v.detach().cpu().numpy() for k, v in w.state_dict().items()})
+    for k in sds[0]:
+        np.testing.assert_allclose(sds[0][k], sds[1][k], rtol=0, atol=2e-6, err_msg=k)
+    # no gradient wanted -> nothing retained
+    w.set_no_grad()
+    w.step(torch.zeros(8, 1, 64, 64))
+    assert not w._window
+
+
+def test_cfg3_full_size_against_the_oracle():
+    """BASELINE configs[3] at its full size (N=4096, 64x64, B3/S23 + RND2D forward) through the ONE
+    fused CA + RND2D kernel, checked against the CPU ORACLE (not against another HIP path) on sampled
+    instances: grids bit-exact vs oracle/ca_oracle.c, bonuses within 1e-5 of oracle/nets.py."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D
+    n = 4096
+    torch.manual_seed(0)
+    env = CARLE(width=64, height=64, instances=n, device="cuda:0")
+    w = RND2D(env, train_predictor=False)
+    w.eval(); w.reset()
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    u0 = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.5).float()
+    env.universe = u0.clone()
+    idx = [0, 1, 2, 3, 4, 1023, 1024, 2047, 2048, 4093, 4094, 4095]
+    sd = {k: v.detach().cpu().numpy() for k, v in w.state_dict().items()}
+    life = O_ca.rule_mask([3], [2, 3])
+    u_ref = u0[idx].cpu().numpy()
+    for t in range(3):
+        a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) <= 0.1).float()
+        assert w._can_fuse_step(a)
+        obs, reward, done, info = w.step(a)
+        u_ref, reset, _ = O_ca.c_env_step(u_ref, a[idx].cpu().numpy(), life)
+        assert not reset
+        assert np.array_equal(obs[idx].cpu().numpy(), u_ref), f"grids differ at step {t}"
+        with torch.no_grad():
+            exp = ON.rnd_bonus(torch.from_numpy(u_ref), sd).numpy()
+        np.testing.assert_allclose(reward[idx, 0].cpu().numpy(), exp, rtol=0, atol=TOL)
+    assert float(reward.min()) > 0

@@ -106,3 +106,74 @@ def test_attached_stats_with_fused_random_agent():
         stats.after_step(env, reward)
     stats.flush()
     assert stats.count == 20.0 and stats.mean == 0.0
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_merge_moments_kernel_matches_numpy(world):
+    """carle_merge_moments on a fabricated all-gather result [world, 3] (what RCCL delivers at
+    N GPUs), including an empty rank: Chan merge in rank order vs numpy on the pooled samples."""
+    from carle_amd import hip
+    rng = np.random.default_rng(world)
+    parts = [rng.normal(2.0 * r, 1.0 + r, size=(0 if (world > 2 and r == 3) else 50 + 7 * r)) for r in range(world)]
+    rows = [[p.size, p.mean() if p.size else 0.0, ((p - p.mean()) ** 2).sum() if p.size else 0.0] for p in parts]
+    gathered = torch.tensor(rows, dtype=torch.float64, device="cuda")
+    prev = rng.normal(-1.0, 0.5, size=33)
+    state = torch.tensor([prev.size, prev.mean(), ((prev - prev.mean()) ** 2).sum()], dtype=torch.float64,
+                         device="cuda")
+    last = torch.zeros(3, dtype=torch.float64, device="cuda")
+    pending = torch.ones(3, dtype=torch.float64, device="cuda")
+    hip.merge_moments(gathered, world, state, last, pending)
+    pooled = np.concatenate(parts)
+    both = np.concatenate([prev, pooled])
+    np.testing.assert_allclose(last.cpu().numpy(), [pooled.size, pooled.mean(), ((pooled - pooled.mean()) ** 2).sum()],
+                               rtol=1e-12)
+    np.testing.assert_allclose(state.cpu().numpy(), [both.size, both.mean(), ((both - both.mean()) ** 2).sum()],
+                               rtol=1e-12)
+    assert pending.abs().sum().item() == 0.0
+
+
+def _flush_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from carle_amd import dist as cd
+    # two ranks on the ONE device of the test box: gloo moves the device tensors (RCCL refuses two
+    # ranks per device); flush() takes its device branch: all_gather_into_tensor + carle_merge_moments
+    r, w, dev = cd.init_from_env("gloo", share_devices=True)
+    try:
+        assert w == world and dev.type == "cuda"
+        stats = cd.RunningRewardStats(dev, sync_every=2)
+        g = torch.Generator().manual_seed(100 + rank)
+        seen = []
+        for t in range(5):
+            x = (torch.randn(64 + 3 * rank, 1, generator=g) * (t + 1) + rank).to(dev)
+            seen.append(x.cpu())
+            stats.update(x)
+        stats.flush()
+        torch.cuda.synchronize()
+        q.put((rank, stats.state.cpu().tolist(), stats.last_batch.cpu().tolist(),
+               torch.cat(seen).reshape(-1).tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_running_stats_flush_two_ranks_on_device():
+    """World-size-2 run of RunningRewardStats.flush()'s DEVICE branch (all-gather of the 24-byte
+    triples into a device tensor + carle_merge_moments with world = 2)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flush_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    allx = np.asarray(res[0][3] + res[1][3], np.float64)
+    for r in res:
+        np.testing.assert_allclose(r[1], [allx.size, allx.mean(), ((allx - allx.mean()) ** 2).sum()], rtol=1e-10)
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]      # bit-identical on both ranks

@@ -10,9 +10,9 @@ import golden_util as G
 from oracle import ca as O
 
 
-@pytest.mark.parametrize("name", G.ca_case_names())
+@pytest.mark.parametrize("name", G.ca_case_names() + G.predicate_case_names())
 def test_oracle_replays_golden_case(name):
-    c = G.ca_case(name)
+    c = G.predicate_case(name) if name in G.predicate_case_names() else G.ca_case(name)
     rule = O.rule_mask(c.birth, c.survive)
     u_c = c.init.copy()
     u_np = c.init.copy()
@@ -37,6 +37,8 @@ def test_oracle_replays_golden_case(name):
         else:
             u_c2, reset, flags = O.c_env_step(u_c, a, rule)
             assert not reset
+            if a is a_full:                  # C-side predicates (sum != 0, mean == 1) on this action
+                assert flags.tolist() == [int(any_nz), 0]
             u_np2, reset_np = O.np_env_step(u_np, a, rule)
             assert not reset_np
             u_c, u_np = u_c2, u_np2

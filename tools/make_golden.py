@@ -18,6 +18,7 @@ Run (from any cwd that is NOT /root/repo, so ``import carle`` resolves to the re
 
 Fixture files
   ca_cases.npz     CA-step cases: initial grids, per-step actions, expected grids (bit-packed)
+  ca_predicates.npz  CA-step cases whose action values cancel / average to exactly 1.0 (env.py:191,208)
   ca_known.json    RNG-free known answers (populations of glider / R-pentomino / puffer ...)
   nets_64.npz      RND2D + AE2D(RND2D) freshly constructed under torch.manual_seed(0) at 64x64:
                    state_dicts, 16 input grids, get_bonus_only outputs (eval mode), stacked
@@ -109,6 +110,26 @@ def run_case(torch, ref_env, name, rule, n, size, asize, steps, init_p, action_k
                 a[0] = 1.0
             else:
                 a = (rng.random((n, 1, aw, aw)) <= 0.1).astype(np.float32)
+        elif action_kind == "cancel":        # values cancel: sum == 0 although cells toggle (env.py:191)
+            if t % 2 == 0:
+                a = np.zeros((n, 1, aw, aw), np.float32)
+                a[:, 0, 5, 5] = 1.0
+                a[:, 0, 9, 9] = -1.0
+                a[0, 0, 20, 3:5] = (2.0, -2.0)
+            elif t == 3:
+                a = np.zeros((n, 1, aw, aw), np.float32)
+            else:
+                a = (rng.random((n, 1, aw, aw)) <= 0.1).astype(np.float32)
+        elif action_kind == "mean1":         # mean == 1.0 without being all ones (env.py:208): RESET
+            if t == 2:
+                a = np.ones((n, 1, aw, aw), np.float32)
+                a[0, 0, 3, 3] = 0.0
+                a[0, 0, 4, 4] = 2.0
+            elif t == 4:                      # all ones but one element 0.5: mean != 1, no reset
+                a = np.ones((n, 1, aw, aw), np.float32)
+                a[n - 1, 0, 7, 7] = 0.5
+            else:
+                a = (rng.random((n, 1, aw, aw)) <= 0.1).astype(np.float32)
         else:
             raise ValueError(action_kind)
         acts.append(a)
@@ -195,6 +216,25 @@ def make_ca(torch, ref_env, outdir):
                           {1, 64, 128, 256}, seed))
     np.savez_compressed(os.path.join(outdir, "ca_cases.npz"), **cases)
     print("ca_cases.npz:", len([k for k in cases if k.endswith("/meta")]), "cases")
+
+
+def make_predicates(torch, ref_env, outdir):
+    """The two whole-batch action predicates of CARLE.step on actions outside {0,1}: values that
+    cancel (torch.sum(action) == 0 although cells toggle, env.py:191) and a mean of exactly 1.0
+    without every element being 1 (env.py:208 -> master reset).  Separate file: the default build
+    evaluates 'any element non-zero' / 'every element == 1' (identical on {0,1} actions) and only
+    CARLE(exact_action_predicates=True) follows the reference on these inputs."""
+    cases = {}
+    cases.update(run_case(torch, ref_env, "cancel64_life", "life", 2, 64, 64, 6, 0.3, "cancel",
+                          set(range(1, 7)), 2001))
+    cases.update(run_case(torch, ref_env, "cancel256_highlife", "highlife", 2, 256, 64, 6, 0.3, "cancel",
+                          set(range(1, 7)), 2002))
+    cases.update(run_case(torch, ref_env, "mean1_64_life", "life", 2, 64, 64, 6, 0.4, "mean1",
+                          set(range(1, 7)), 2003))
+    cases.update(run_case(torch, ref_env, "mean1_128_life", "life", 3, 128, 64, 6, 0.4, "mean1",
+                          set(range(1, 7)), 2004))
+    np.savez_compressed(os.path.join(outdir, "ca_predicates.npz"), **cases)
+    print("ca_predicates.npz:", len([k for k in cases if k.endswith("/meta")]), "cases")
 
 
 def make_known(torch, ref_env, ref_mcl, outdir):
@@ -509,9 +549,11 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch, ref_env, ref_mcl = import_reference()
     torch.set_num_threads(8)
-    todo = args.only.split(",") if args.only else ["ca", "known", "nets", "wrappers", "rle"]
+    todo = args.only.split(",") if args.only else ["ca", "predicates", "known", "nets", "wrappers", "rle"]
     if "ca" in todo:
         make_ca(torch, ref_env, args.out)
+    if "predicates" in todo:
+        make_predicates(torch, ref_env, args.out)
     if "known" in todo:
         make_known(torch, ref_env, ref_mcl, args.out)
     if "nets" in todo:
