@@ -396,10 +396,13 @@ def test_async_training_matches_sync_training(size, n, steps):
         assert w.env.updates == steps // 8
         outs.append((torch.stack(rews).cpu().numpy(),
                      {k: v.detach().cpu().numpy() for k, v in w.state_dict().items()}))
-    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][0].max() > 0
+    # (the AE2D gradient kernel accumulates two of its gradients with LDS float atomics: run-to-run
+    # differences of an ulp are expected; a stale or half-written parameter blob would be far off)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
+    assert outs[0][0].max() > 0
     changed = 0
     for k in outs[0][1]:
-        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+        np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=1e-5, atol=1e-6, err_msg=k)
     torch.manual_seed(11)
     fresh = AE2D(RND2D(CARLE(width=size, height=size, instances=n, device="cuda:0")))
     for k, v in fresh.state_dict().items():
@@ -432,9 +435,11 @@ def test_training_mode_flag_does_not_change_the_numbers(size):
         assert w.predictor.training == (mode == "train")      # the replay restores the caller's mode
         outs.append((torch.stack(rews).cpu().numpy(),
                      {k: v.detach().cpu().numpy() for k, v in w.state_dict().items()}))
-    assert np.array_equal(outs[0][0], outs[1][0])
+    # dropout noise would move rewards and weights by ~10 %; run-to-run float-atomic noise of the
+    # gradient kernels / MIOpen backward is at the ulp level
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
     for k in outs[0][1]:
-        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+        np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=1e-4, atol=1e-5, err_msg=k)
 
 
 def test_replay_window_is_bounded_and_packed():
