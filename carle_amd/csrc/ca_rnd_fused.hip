@@ -15,33 +15,68 @@
 //   C  every lane expands its nibbles of the new rows into fp32 quads and stores them (nt);
 //   D  thread = one 4x4 pooling window: six row segments out of the LDS rows, 16 table lookups
 //      for the six conv1 channels (rnd_device.hpp), max -> the zero-bordered planes;
-//   E  wave 0: conv2 + pooling, the two 64->16 linear layers, tanh, the bonus (rnd_tail).
-// The bonus of the ALL-DEAD grid is written to bonus[n]: the epilogue (ca_finish_kernel) uses it
-// for every instance when the step turns out to be a whole-batch master reset (env.py:208-216).
+//   E  all threads: conv2 + pooling (rnd_block_conv2); the two 64->16 linear layers, tanh and the
+//      bonus (rnd_linear_bonus) run on wave 1 during the NEXT grid's phase B, beside wave 0.
+// Three barriers per grid.  Every LDS-reading phase issues all its reads before the first use:
+// with 16 waves on the CU a dependent LDS round trip costs 250-500 cycles (profiles/r02_rnd_stamps.txt).
+// The bonus of the ALL-DEAD grid is copied to bonus[n] (it is evaluated together with the tables,
+// nets_fused.hip: rnd2d_prepare_tables): the epilogue (ca_finish_kernel) uses it for every
+// instance when the step turns out to be a whole-batch master reset (env.py:208-216).
+#include <stdlib.h>
 #include "ca_cells.hpp"
 #include "rnd_device.hpp"
 
+// Diagnostic build only (tools/kbench/ca_rnd_variants.hip defines CARLE_RND_STAMPS): wave 0 of every
+// workgroup records s_memtime at the phase boundaries of each grid into a debug buffer that nothing
+// else reads.  The shipped library compiles these to nothing.
+#ifdef CARLE_RND_STAMPS
+__device__ unsigned long long *g_rnd_stamps = nullptr;      // [block][iteration < 8][16]
+#define RND_STAMP(i) do { if (tid == 0 && g_rnd_stamps && it_ < 8) \
+    g_rnd_stamps[((size_t)blockIdx.x * 8 + it_) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define RND_STAMP_NEXT() (++it_)
+#define RND_STAMP_DECL() int it_ = 0
+#else
+#define RND_STAMP(i) do {} while (0)
+#define RND_STAMP_NEXT() do {} while (0)
+#define RND_STAMP_DECL() do {} while (0)
+#endif
+
 namespace carle {
 
-// RndBlockShared (rnd_device.hpp) + the toggled input rows: 32,528 B.  The 2 x 64 pooled features
-// of phase E overlay rows[1..64] (dead by then: phase D is behind a barrier, phase B of the next grid
-// rewrites every row).  Four workgroups per CU: a fifth fits the LDS but needs <= 96 VGPRs, and the 16
-// spilled registers cost more than the extra occupancy gives (measured 72 vs 45 us per step at N=4096).
+// RndBlockShared (rnd_device.hpp) + the toggled input rows + the pooled conv2 features of the grid
+// whose linear layers are still pending: 37.6 KB, four workgroups per CU (128 VGPRs).
 struct CaRndShared {
     RndBlockShared net;
     uint32_t rows_in[64][2];     // toggled state, one 64-bit word per row (lo, hi)
+    float feat[2][64];           // conv2 + pool output of both nets (read one phase later, see E)
 };
 
+// 1 if the fp32 bit pattern is a non-zero NUMBER (NaN counts, -0.0 does not; the truthiness of
+// torch.logical_xor, env.py:182) in two VALU ops: the add drops the sign, v_min_u32 clamps to 1.
+// (Written as asm: hipcc rewrites umin(x, 1) into compare + select, three ops and a VCC hazard.)
+__device__ __forceinline__ uint32_t nz1(uint32_t bits) {
+    uint32_t r;
+    const uint32_t t = bits + bits;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(t));
+    return r;
+}
+__device__ __forceinline__ uint32_t nibble_fast(const uint4 &v) {
+    return nz1(v.x) | (nz1(v.y) << 1) | (nz1(v.z) << 2) | (nz1(v.w) << 3);
+}
+
+struct Quads { uint4 v[4], a[4]; };     // one grid's loads of a lane: 4 state + 4 action quads
+
+#ifndef CARLE_RND_WG_PER_CU
+#define CARLE_RND_WG_PER_CU 4
+#endif
+
 template <bool HAS_ACT>
-__global__ __launch_bounds__(256, 4) void ca_step_rnd64_kernel(
+__global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel(
     const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out, int64_t n,
     int aw, uint32_t rule, int32_t *__restrict__ status, int slot, const float *__restrict__ ws,
     float *__restrict__ bonus) {
     __shared__ CaRndShared s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    rnd_block_init(s.net, ws, tid);
-    __syncthreads();
-
     const int q = lane >> 4, k = lane & 15;
     // action window: offset o = (64-aw)/2 is a multiple of 4 (aw % 8 == 0): a lane's four columns
     // are all inside or all outside; bit i of `rows_in_win` = row 16w+4i+q is inside
@@ -56,84 +91,160 @@ __global__ __launch_bounds__(256, 4) void ca_step_rnd64_kernel(
         }
     }
 
-    uint4 v[4], a[4];
-    auto issue = [&](int64_t g) {
-        const uint4 *gin = reinterpret_cast<const uint4 *>(u_in) + g * 1024 + 256 * wv + lane;
+    // Loads go through buffer descriptors built per grid in SGPRs (base = the grid / its action,
+    // 16 KiB / aw*aw*4 bytes of range): a lane contributes one loop-invariant 32-bit byte offset per
+    // load, so no 64-bit pointer per row lives in vector registers, and rows outside the action
+    // window use an out-of-range offset -- the range check returns zeros, no branch.
+    const uint32_t voff = (uint32_t)(256 * wv + lane) * 16u;
+    // action rows: a lane's byte offset of load i is abase + arow[i] (one VGPR + four SGPRs; the sum is
+    // formed in 32-bit VALU arithmetic, so a negative row of abase wraps back correctly).  Columns
+    // outside the window (per lane) and rows outside it (per wave and i: o is a multiple of 4) add
+    // 0x40000000 each, which lands beyond the descriptor's range whatever the other term is.
+    const uint32_t abase = (HAS_ACT && ax >= 0 && ax < aw) ? (uint32_t)((16 * wv + q - o) * aw + ax) * 4u : 0x40000000u;
+    uint32_t arow[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = ld16<true>(gin + i * 64);
+    for (int i = 0; i < 4; ++i) {
+        const int ay0 = __builtin_amdgcn_readfirstlane(16 * wv) + 4 * i - o;     // row of q = 0; rows ay0..ay0+3 go together
+        arow[i] = (ay0 >= 0 && ay0 < aw) ? (uint32_t)(4 * i * aw) * 4u : 0x40000000u;
+    }
+    const uint32_t act_bytes = (uint32_t)(aw * aw) * 4u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // `valid` false (no such grid): the descriptors get a zero range, every lane reads zeros and no
+    // memory is touched -- the loads stay unconditional, so a register set is never live across a
+    // phase it is not needed in (a conditional load would keep its old contents alive)
+    auto issue = [&](int64_t g, Quads &r, bool valid) __attribute__((always_inline)) {
+        if (!valid) g = 0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(reinterpret_cast<const char *>(u_in) + g * 16384), 0, valid ? 16384 : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 1024u * i, 0, 2);   // aux 2 = nt
+            r.v[i] = make_uint4(t.x, t.y, t.z, t.w);
+        }
         if (HAS_ACT) {
-            const float *abase = act + g * (int64_t)aw * aw + ax;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(reinterpret_cast<const char *>(act) + g * (int64_t)act_bytes), 0,
+                valid ? act_bytes : 0u, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = make_uint4(0u, 0u, 0u, 0u);
-                if ((rows_in_win >> i) & 1u)
-                    a[i] = ld16<true>(reinterpret_cast<const uint4 *>(abase + (int64_t)(16 * wv + 4 * i + q - o) * aw));
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ra, abase + arow[i], 0, 2);
+                r.a[i] = make_uint4(t.x, t.y, t.z, t.w);
             }
         }
     };
 
     const int64_t first = blockIdx.x, stride = gridDim.x;
-    if (first < n) issue(first);
+    Quads r0, r1;
+    issue(first, r0, first < n);                      // the first grid travels while the tables are laid down
+    rnd_block_init(s.net, ws, tid);
+    __syncthreads();
     ActionSeen seen;
-    for (int64_t g = first; g <= n; g += stride) {
-        const bool live = g < n;                      // g == n: the all-dead grid
-        if (live) {
-            // ---- A: nibbles of this lane's four rows, toggled; row words by OR over the 16 lanes
-            uint32_t nib[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                nib[i] = nibble_of(v[i]);
-                if (HAS_ACT) {
-                    if ((rows_in_win >> i) & 1u) seen.add(a[i]);
-                    nib[i] ^= nibble_of(a[i]);        // toggle, env.py:182
-                }
-            }
-            if (g + stride < n) issue(g + stride);    // the next grid's quads travel during B..E
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t x = row_nibbles_to_dword(nib[i], k);
-                if ((k & 7) == 7) s.rows_in[16 * wv + 4 * i + q][k >> 3] = x;
-            }
-        }
-        __syncthreads();
+    RND_STAMP_DECL();
+    int64_t pending = -1;                             // grid whose features wait in s.feat for the linear layers
 
-        // ---- B: one generation, lane = row (wave 0)
-        if (live && wv == 0) {
+    // One grid: `cur` holds its loads, `nxt` receives the next grid's (issued as soon as cur is consumed).
+    auto step = [&](int64_t g, Quads &cur, Quads &nxt) __attribute__((always_inline)) {
+        RND_STAMP(0);
+        // the NEXT grid's loads go out first, into the register set the previous grid vacated a whole
+        // iteration ago: this workgroup then always has a grid in flight (issued after the conversion
+        // below, 13 % of every iteration had none, and the chip's load stream thinned out with it)
+        issue(g + stride, nxt, g + stride < n);
+        // ---- A: nibbles of this lane's four rows, toggled; row words by OR over the 16 lanes
+        uint32_t x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t nib = nibble_fast(cur.v[i]);
+            if (HAS_ACT) {
+                if ((rows_in_win >> i) & 1u) seen.add(cur.a[i]);
+                nib ^= nibble_fast(cur.a[i]);         // toggle, env.py:182
+            }
+            x[i] = nib << (4 * (k & 7));
+        }
+        RND_STAMP(1);
+        // the four rows' DPP chains are independent: interleaved, they fill each other's wait states
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] |= __builtin_amdgcn_update_dpp(0u, x[i], 0x111, 0xF, 0xF, true);   // row_shr:1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] |= __builtin_amdgcn_update_dpp(0u, x[i], 0x112, 0xF, 0xF, true);   // row_shr:2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] |= __builtin_amdgcn_update_dpp(0u, x[i], 0x114, 0xF, 0xF, true);   // row_shr:4
+        if ((k & 7) == 7) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.rows_in[16 * wv + 4 * i + q][k >> 3] = x[i];
+        }
+        RND_STAMP(2);
+        __syncthreads();
+        RND_STAMP(3);
+
+        // ---- B: one generation, lane = row (wave 0; rows above / below by DPP wave rotates = y seam)
+        //      E2 (wave 1, at the same time): linear layers + bonus of the PREVIOUS grid of this workgroup
+        if (wv == 0) {
             const uint64_t c = ((uint64_t)s.rows_in[lane][1] << 32) | s.rows_in[lane][0];
-            const uint64_t wst = rotl64(c, 1), est = rotr64(c, 1);      // torus seam in x
+            const uint64_t wst = rotl64(c, 1), est = rotr64(c, 1);          // torus seam in x
             uint64_t h0, h1, p0, p1;
             row_sums(wst, c, est, h0, h1, p0, p1);
-            const int lu = (lane + 63) & 63, ld = (lane + 1) & 63;      // torus seam in y
-            const uint64_t a0 = shfl64(h0, lu), a1 = shfl64(h1, lu);
-            const uint64_t b0 = shfl64(h0, ld), b1 = shfl64(h1, ld);
+            const uint64_t a0 = dpp64_ror1(h0), a1 = dpp64_ror1(h1);        // row above (lane - 1, wraps)
+            const uint64_t b0 = dpp64_rol1(h0), b1 = dpp64_rol1(h1);        // row below
             s.net.rows[1 + lane] = apply_rule(neighbour_count(a0, a1, b0, b1, p0, p1), c, rule);
-        } else if (wv == 0) {
-            s.net.rows[1 + lane] = 0ull;
+        } else if (wv == 1 && pending >= 0) {
+            const float b = rnd_linear_bonus(s.feat, s.net.lin, lane, pending, nullptr, nullptr);
+            if (lane == 0) bonus[pending] = b;
         }
+        RND_STAMP(4);
         __syncthreads();
+        RND_STAMP(5);
 
-        // ---- C: fp32 store of the new state (the lane's own four quads)
-        if (live) {
-            float *gout = u_out + g * 4096 + 1024 * wv + 4 * lane;
+        // ---- C: fp32 store of the new state (the lane's own four quads): the lane's dword of the row
+        // word, its nibble, bits -> bytes (one multiply), bytes -> 0.0f / 1.0f (hipcc selects v_cvt_f32_ubyteN)
+        {
+            const uint32_t *rows32 = reinterpret_cast<const uint32_t *>(&s.net.rows[1]);
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<char *>(u_out) + g * 16384, 0, 16384, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint64_t row = s.net.rows[1 + 16 * wv + 4 * i + q];
-                F32Cells::store<true>(gout + i * 256, (uint32_t)(row >> (4 * k)) & 0xFu);
+                const uint32_t w = rows32[2 * (16 * wv + 4 * i + q) + (k >> 3)];
+                const uint32_t by = (((w >> (4 * (k & 7))) & 0xFu) * 0x00204081u) & 0x01010101u;
+                u32x4 o4;
+                o4.x = __float_as_uint((float)((by >> 0) & 0xFFu));
+                o4.y = __float_as_uint((float)((by >> 8) & 0xFFu));
+                o4.z = __float_as_uint((float)((by >> 16) & 0xFFu));
+                o4.w = __float_as_uint((float)((by >> 24) & 0xFFu));
+                __builtin_amdgcn_raw_buffer_store_b128(o4, ro, voff + 1024u * i, 0, 2);      // aux 2 = nt
             }
         }
 
+        RND_STAMP(6);
         // ---- D: conv1 (table lookup) + relu + 4x4 max-pool; thread = pooling window
         rnd_block_conv1(s.net, tid);
+        RND_STAMP(7);
         __syncthreads();
+        RND_STAMP(8);
 
-        // ---- E: conv2 + pool, linear layers, bonus (wave 0)
-        if (wv == 0) {
-            float (*feat)[64] = reinterpret_cast<float (*)[64]>(&s.net.rows[1]);
-            const float b = rnd_tail(&s.net.planes[0][0], feat, s.net.lin, ws, lane, g, nullptr, nullptr);
-            if (lane == 0) bonus[g] = b;
+        // ---- E1: conv2 + pool on all threads -> s.feat.  No barrier behind it: the features are read
+        // by wave 1 during the NEXT grid's phase B, i.e. behind that grid's first barrier; the planes are
+        // rewritten by D two barriers from here, rows_in by A (last read in B, two barriers back).
+        rnd_block_conv2(s.net, s.feat, tid);
+        pending = g;
+        RND_STAMP(9);
+        RND_STAMP_NEXT();
+    };
+
+    for (int64_t g = first; g < n;) {                 // unrolled by two: the register sets swap roles
+        step(g, r0, r1);
+        g += stride;
+        if (g >= n) break;
+        step(g, r1, r0);
+        g += stride;
+    }
+    // the bonus of the all-dead grid (used by the epilogue for every instance after a master reset)
+    // was evaluated with the tables: rnd2d_prepare_tables
+    if (blockIdx.x == 0 && tid == 0) bonus[n] = ws[kWsDeadBonus];
+    if (pending >= 0) {                               // the last grid's linear layers
+        __syncthreads();
+        if (wv == 1) {
+            const float b = rnd_linear_bonus(s.feat, s.net.lin, lane, pending, nullptr, nullptr);
+            if (lane == 0) bonus[pending] = b;
         }
-        // the next iteration's first barrier orders E's plane reads before D's next plane writes;
-        // rows_in / rows_out are rewritten only after that barrier and the one behind B
     }
     if (HAS_ACT) publish_flags<F32Cells>(seen, status, slot);
 }
@@ -145,8 +256,12 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
                   int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
                   bool tables_valid, hipStream_t s) {
     if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
-    int64_t blocks = (n + 1 + 3) / 4;                 // persistent: 4 grids per workgroup when the
-    if (blocks > 1024) blocks = 1024;                 // batch allows; 4 workgroups are resident per CU
+    int64_t blocks = (n + 3) / 4;                     // persistent: 4 grids per workgroup when the
+    if (blocks > 256 * CARLE_RND_WG_PER_CU) blocks = 256 * CARLE_RND_WG_PER_CU;   // batch allows; all resident
+    if (const char *e = getenv("CARLE_RND_BLOCKS")) {  // experiment knob (tools/kbench_rnd.py)
+        const int64_t v = atoll(e);
+        if (v > 0) blocks = v < n ? v : n;
+    }
     if (action)
         hipLaunchKernelGGL(ca_step_rnd64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, u_in, action,
                            u_out, n, aw, rule, status, slot, ws, bonus);

@@ -16,29 +16,6 @@
 
 namespace carle {
 
-__device__ __forceinline__ uint64_t dpp64_ror1(uint64_t x) {      // lane i <- lane i-1 (0 <- 63)
-    const uint32_t lo = __builtin_amdgcn_update_dpp(0u, (uint32_t)x, 0x13C, 0xF, 0xF, false);
-    const uint32_t hi = __builtin_amdgcn_update_dpp(0u, (uint32_t)(x >> 32), 0x13C, 0xF, 0xF, false);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t dpp64_rol1(uint64_t x) {      // lane i <- lane i+1 (63 <- 0)
-    const uint32_t lo = __builtin_amdgcn_update_dpp(0u, (uint32_t)x, 0x134, 0xF, 0xF, false);
-    const uint32_t hi = __builtin_amdgcn_update_dpp(0u, (uint32_t)(x >> 32), 0x134, 0xF, 0xF, false);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// lane i <- lane i-1, lane 0 keeps `old` (wave_shr:1); lane i <- lane i+1, lane 63 keeps `old`
-__device__ __forceinline__ uint64_t dpp64_shr1(uint64_t x, uint64_t old) {
-    const uint32_t lo = __builtin_amdgcn_update_dpp((uint32_t)old, (uint32_t)x, 0x138, 0xF, 0xF, false);
-    const uint32_t hi = __builtin_amdgcn_update_dpp((uint32_t)(old >> 32), (uint32_t)(x >> 32), 0x138, 0xF, 0xF, false);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t dpp64_shl1(uint64_t x, uint64_t old) {
-    const uint32_t lo = __builtin_amdgcn_update_dpp((uint32_t)old, (uint32_t)x, 0x130, 0xF, 0xF, false);
-    const uint32_t hi = __builtin_amdgcn_update_dpp((uint32_t)(old >> 32), (uint32_t)(x >> 32), 0x130, 0xF, 0xF, false);
-    return ((uint64_t)hi << 32) | lo;
-}
-
 template <int WW>
 __device__ __forceinline__ void load_row(const uint64_t *__restrict__ p, uint64_t (&r)[WW]) {
     if constexpr (WW == 1) {

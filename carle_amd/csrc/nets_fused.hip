@@ -52,6 +52,7 @@ __global__ __launch_bounds__(512) void rnd_prepare_kernel(const float *__restric
     float *c2 = ws + kFusedWsFloats;
     if (p < 37) c2[p] = pp[40 + p];
     if (p >= 40 && p < 59) c2[p] = rp[20 + (p - 40)];
+    if (p < 128) ws[kWsZeroGrid + p] = 0.0f;                    // the all-dead grid, bit-packed
 }
 
 // One workgroup (4 waves) per grid, persistent over grids; phases separated by barriers:
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(512) void rnd_prepare_kernel(const float *__restric
 //          workgroup's NEXT grid are requested before the conv1 phase), the 16 lanes of a row OR their
 //          nibbles into the row's 64-bit word in LDS.  bit-packed: the 64 row words are copied.
 //   conv1  thread = one 4x4 pooling window (rnd_block_conv1)
-//   tail   wave 0: conv2 + pooling, linear layers, tanh, bonus (rnd_tail)
+//   tail   all threads: conv2 + pooling (rnd_block_conv2); wave 0: linear layers, tanh, bonus
 // 33 KB of LDS -> 4 workgroups (16 waves) per CU in different phases.
 template <bool PACKED_OBS>
 __global__ __launch_bounds__(256, 4) void rnd_block64_kernel(const void *__restrict__ obs_v,
@@ -106,8 +107,10 @@ __global__ __launch_bounds__(256, 4) void rnd_block64_kernel(const void *__restr
         __syncthreads();
         rnd_block_conv1(s, tid);
         __syncthreads();
+        rnd_block_conv2(s, s_feat, tid);
+        __syncthreads();
         if (wv == 0) {
-            const float b = rnd_tail(&s.planes[0][0], s_feat, s.lin, ws, lane, g, pred_out, target_out);
+            const float b = rnd_linear_bonus(s_feat, s.lin, lane, g, pred_out, target_out);
             if (lane == 0) {
                 bonus[g] = b;
                 if (reward) reward[g] += reward_scale * b;       // mcl.py:403-405
@@ -124,11 +127,18 @@ using namespace carle;
 
 namespace carle {
 
-// workspace: [tables + padded linear layers (kFusedWsFloats)] [conv2 parameters (64)]
-int64_t rnd2d_fused_workspace_floats() { return kFusedWsFloats + 64; }
+// workspace: [tables + padded linear layers (kFusedWsFloats)] [conv2 parameters (64)] [all-dead
+// packed grid (128)] [its bonus (4)]
+int64_t rnd2d_fused_workspace_floats() { return kFusedWsTotal; }
 
+// Tables, and the bonus of the all-dead grid (the observation of every instance after a master
+// reset, env.py:208-216): it depends on the parameters only, so it is evaluated here, once per
+// parameter change, by the ordinary kernel on a zero grid kept in the workspace.
 void rnd2d_prepare_tables(const float *pp, const float *rp, float *ws, hipStream_t s) {
     hipLaunchKernelGGL(rnd_prepare_kernel, dim3(1), dim3(512), 0, s, pp, rp, ws);
+    hipLaunchKernelGGL(rnd_block64_kernel<true>, dim3(1), dim3(256), 0, s, static_cast<const void *>(ws + kWsZeroGrid),
+                       static_cast<const float *>(ws), ws + kWsDeadBonus, static_cast<float *>(nullptr),
+                       static_cast<float *>(nullptr), static_cast<float *>(nullptr), 0.0f, (int64_t)1);
 }
 
 int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp,

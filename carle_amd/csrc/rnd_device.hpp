@@ -11,6 +11,11 @@ static constexpr int kLutFloats = 512 * 4 + 512 * 2;          // predictor float
 static constexpr int kLinStride = 68;                          // padded row of the 16x64 weights
 static constexpr int kLinFloats = 16 * kLinStride + 16;        // weights + bias, per net
 static constexpr int kFusedWsFloats = kLutFloats + 2 * kLinFloats;
+// behind the tables: conv2 parameters (64 floats), an all-dead bit-packed grid (64 row words) and
+// the bonus of that grid -- a function of the parameters alone, evaluated when the tables are built
+static constexpr int kWsZeroGrid = kFusedWsFloats + 64;
+static constexpr int kWsDeadBonus = kWsZeroGrid + 128;
+static constexpr int kFusedWsTotal = kWsDeadBonus + 4;
 static constexpr int kPlaneStride = 24, kPlaneRows = 18;
 static constexpr int kPlaneFloats = kPlaneRows * kPlaneStride; // zero-bordered 16x16 map
 
@@ -32,6 +37,9 @@ struct RndBlockShared {
     float lin[2 * kLinFloats];
     float planes[6][kPlaneFloats];     // pooled conv1 maps, zero-bordered 16x16
     uint64_t rows[66];                 // the grid, one 64-bit word per row at [1..64]; [0], [65] stay zero
+    float w2[2][4][12];                // conv2 weights per net and input channel: 9 taps + 3 zeros;
+                                       // rows [1][2], [1][3] are zero (the random net has two channels)
+    float b2[4];                       // conv2 biases: [0] predictor, [1] random net
 };
 
 // tables -> LDS (coalesced copies), zero the plane borders and the two padding rows once; the
@@ -48,6 +56,13 @@ __device__ __forceinline__ void rnd_block_init(RndBlockShared &s, const float *_
     float4 *pl = reinterpret_cast<float4 *>(&s.planes[0][0]);
     for (int i = tid; i < 6 * kPlaneFloats / 4; i += 256) pl[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 66) s.rows[tid] = 0ull;
+    // conv2 parameters (behind the tables in the workspace: pred w[36] b at +0, rand w[18] b at +40)
+    if (tid < 96) {
+        const int net = tid / 48, c = (tid % 48) / 12, t = tid % 12;
+        const float *c2 = ws + kFusedWsFloats + (net == 0 ? 0 : 40);
+        (&s.w2[0][0][0])[tid] = (t < 9 && (net == 0 || c < 2)) ? c2[c * 9 + t] : 0.0f;
+    }
+    if (tid >= 96 && tid < 100) s.b2[tid - 96] = tid == 96 ? ws[kFusedWsFloats + 36] : tid == 97 ? ws[kFusedWsFloats + 58] : 0.0f;
 }
 
 // The 16 lanes of a DPP row hold the nibbles (columns 4k..4k+3, k = lane % 16) of ONE grid row:
@@ -62,8 +77,16 @@ __device__ __forceinline__ uint32_t row_nibbles_to_dword(uint32_t nib, int k) {
 }
 
 // conv1 (table lookup) + relu + 4x4 max-pool of all six channels; thread = pooling window
-// (py = tid/16, px = tid%16), zero padding at the grid border (mcl.py:263)
+// (py = tid/16, px = tid%16), zero padding at the grid border (mcl.py:263).  The 16 lookups of a
+// window are issued in batches of BATCH (1.5 LDS reads and 6 registers each): a dependent LDS round
+// trip costs 250-500 cycles with 16 waves on the CU, so few round trips -- as many lookups in
+// flight as the kernel's register budget allows.
+#ifndef CARLE_RND_CONV1_BATCH
+#define CARLE_RND_CONV1_BATCH 4
+#endif
+template <int BATCH = CARLE_RND_CONV1_BATCH>
 __device__ __forceinline__ void rnd_block_conv1(RndBlockShared &s, int tid) {
+    static_assert(16 % BATCH == 0, "whole batches");
     const int py = tid >> 4, px = tid & 15;
     uint32_t seg[6];                                  // [west | 4 cells | east] of rows 4py-1..4py+4
 #pragma unroll
@@ -73,15 +96,22 @@ __device__ __forceinline__ void rnd_block_conv1(RndBlockShared &s, int tid) {
     }
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy) {
+    for (int b = 0; b < 16 / BATCH; ++b) {
+        float4 pa[BATCH];
+        float2 pb[BATCH];
 #pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {
+        for (int j = 0; j < BATCH; ++j) {
+            const int c = b * BATCH + j, dy = c >> 2, dx = c & 3;
             const uint32_t p = ((seg[dy] >> dx) & 7u) | (((seg[dy + 1] >> dx) & 7u) << 3) |
                                (((seg[dy + 2] >> dx) & 7u) << 6);
-            const float4 pa = s.lut_p[p];
-            const float2 pb = s.lut_r[p];
-            m0 = fmaxf(m0, pa.x); m1 = fmaxf(m1, pa.y); m2 = fmaxf(m2, pa.z); m3 = fmaxf(m3, pa.w);
-            m4 = fmaxf(m4, pb.x); m5 = fmaxf(m5, pb.y);
+            pa[j] = s.lut_p[p];
+            pb[j] = s.lut_r[p];
+        }
+        __builtin_amdgcn_sched_barrier(0);            // the whole batch is issued before its first max
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            m0 = fmaxf(m0, pa[j].x); m1 = fmaxf(m1, pa[j].y); m2 = fmaxf(m2, pa[j].z); m3 = fmaxf(m3, pa[j].w);
+            m4 = fmaxf(m4, pb[j].x); m5 = fmaxf(m5, pb[j].y);
         }
     }
     const int off = (py + 1) * kPlaneStride + px + 1;
@@ -93,81 +123,110 @@ __device__ __forceinline__ void rnd_block_conv1(RndBlockShared &s, int tid) {
     s.planes[5][off] = m5;
 }
 
-// Stages 4-5 on ONE wavefront (all 64 lanes): conv2 + relu + 2x2 pool of both nets from the six
-// zero-bordered 16x16 planes, the two 64->16 linear layers + tanh, and the bonus
-// mean_k (target - prediction)^2 (carle/mcl.py:343-352).  The result is complete in lane 0.
-__device__ __forceinline__ float rnd_tail(const float *__restrict__ planes, float (*__restrict__ feat)[64],
-                                          const float *__restrict__ lin, const float *__restrict__ ws,
-                                          int lane, int64_t g, float *__restrict__ pred_out,
-                                          float *__restrict__ target_out) {
-    float bonus_value;
-    // ---- 4. conv2 (C->1, 3x3, zero pad) + relu + 2x2 pool: lane = pooled output (fy, fx)
-    const int fy = lane >> 3, fx = lane & 7;
+__device__ __forceinline__ float dpp_quad_xor1(float x) {      // value of lane ^ 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_xor2(float x) {      // value of lane ^ 2
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_row_ror(float x, int ctrl) {   // 0x124 = row_ror:4, 0x128 = row_ror:8
+    return ctrl == 0x124
+        ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xF, 0xF, true))
+        : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));
+}
+
+// Stage 4 on ALL 256 threads: conv2 (C->1, 3x3, zero pad) + bias + relu + 2x2 max-pool of both nets
+// from the six zero-bordered 16x16 planes.  Thread = (pooling window f = tid / 4, input channel
+// c = tid % 4): it reads the 4x4 patch of ITS channel under the window (predictor plane c and, for
+// c < 2, random-net plane 4 + c; zero weights otherwise) plus its 9 + 9 weights -- every LDS read
+// is issued before the first use, ONE round trip -- computes the window's four conv outputs for
+// that channel, and the four channel lanes (a DPP quad) add up.  Summation order: taps (ky, kx)
+// inside a channel, then (c0 + c1) + (c2 + c3).
+__device__ __forceinline__ void rnd_block_conv2(const RndBlockShared &s, float (*__restrict__ feat)[64], int tid) {
+    const int f = tid >> 2, c = tid & 3;
+    const int fy = f >> 3, fx = f & 7;
+    float patch[2][4][4], w[2][12];
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
-        const int nch = net == 0 ? 4 : 2, chbase = net == 0 ? 0 : 4;
-        const float *cw2 = ws + kFusedWsFloats + (net == 0 ? 0 : 40);   // uniform -> SGPR loads
-        float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+        const float *pl = &s.planes[net == 0 ? c : 4 + (c & 1)][(2 * fy) * kPlaneStride + 2 * fx];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            if (cc < nch) {
-                const float *pl = planes + (chbase + cc) * kPlaneFloats + (2 * fy) * kPlaneStride + 2 * fx;
-                float patch[4][4];
+        for (int r = 0; r < 4; ++r) {
+            const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride);
+            const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride + 2);
+            patch[net][r][0] = lo.x; patch[net][r][1] = lo.y; patch[net][r][2] = hi.x; patch[net][r][3] = hi.y;
+        }
+        const float4 *wp = reinterpret_cast<const float4 *>(&s.w2[net][c][0]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride);
-                    const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride + 2);
-                    patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
-                }
-                // same accumulation order as the staged kernel (channel, oy, ox, ky, kx)
+        for (int i = 0; i < 3; ++i) {
+            const float4 t = wp[i];
+            w[net][4 * i] = t.x; w[net][4 * i + 1] = t.y; w[net][4 * i + 2] = t.z; w[net][4 * i + 3] = t.w;
+        }
+    }
+    const float bias0 = s.b2[0], bias1 = s.b2[1];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+    for (int net = 0; net < 2; ++net) {
+        float o[2][2];
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) o00 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][kx], o00);
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) o01 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[ky][1 + kx], o01);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) o10 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][kx], o10);
+            for (int dx = 0; dx < 2; ++dx) {
+                float acc = 0.f;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) o11 = fmaf(cw2[cc * 9 + ky * 3 + kx], patch[1 + ky][1 + kx], o11);
+                    for (int kx = 0; kx < 3; ++kx) acc = fmaf(w[net][ky * 3 + kx], patch[net][dy + ky][dx + kx], acc);
+                acc += dpp_quad_xor1(acc);            // channels (c0 + c1), (c2 + c3)
+                acc += dpp_quad_xor2(acc);            // all four
+                o[dy][dx] = acc;
             }
-        }
-        const float mx = fmaxf(fmaxf(o00, o01), fmaxf(o10, o11)) + cw2[net == 0 ? 36 : 18];
-        feat[net][fy * 8 + fx] = fmaxf(mx, 0.0f);
+        const float mx = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1])) + (net == 0 ? bias0 : bias1);
+        if (c == 0) feat[net][f] = fmaxf(mx, 0.0f);
     }
-    __builtin_amdgcn_wave_barrier();
+}
 
-    // ---- 5. linear(64->16) + tanh for both nets; lane = (net, k16, half)
-    {
-        const int half = lane & 1, kk = (lane >> 1) & 15, net = lane >> 5;
-        const float4 *f4 = reinterpret_cast<const float4 *>(&feat[net][32 * half]);
-        const float4 *w4 = reinterpret_cast<const float4 *>(&lin[net * kLinFloats + kk * kLinStride + 32 * half]);
-        float acc = 0.0f;
+// Stage 5 on ONE wavefront (all 64 lanes): the two 64->16 linear layers + tanh and the bonus
+// mean_k (target - prediction)^2 (carle/mcl.py:343-352).  lane = (net, k16, half): 32 inputs per
+// lane, eight LDS reads in flight at a time; the two halves, the 16 outputs and the two nets meet
+// through DPP / v_permlane32_swap / v_readlane (no LDS round trips).  Wave-uniform result.
+__device__ __forceinline__ float rnd_linear_bonus(const float (*__restrict__ feat)[64], const float *__restrict__ lin,
+                                                  int lane, int64_t g, float *__restrict__ pred_out,
+                                                  float *__restrict__ target_out) {
+    const int half = lane & 1, kk = (lane >> 1) & 15, net = lane >> 5;
+    const float4 *f4 = reinterpret_cast<const float4 *>(&feat[net][32 * half]);
+    const float4 *w4 = reinterpret_cast<const float4 *>(&lin[net * kLinFloats + kk * kLinStride + 32 * half]);
+    const float bias = lin[net * kLinFloats + 16 * kLinStride + kk];
+    float acc = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 f = f4[i], w = w4[i];
-            acc = fmaf(w.x, f.x, acc); acc = fmaf(w.y, f.y, acc);
-            acc = fmaf(w.z, f.z, acc); acc = fmaf(w.w, f.w, acc);
-        }
-        acc += __shfl_xor(acc, 1, 64);
-        const float out = tanhf(acc + lin[net * kLinFloats + 16 * kLinStride + kk]);
-        if (half == 0) {
-            if (net == 0 && pred_out) pred_out[g * 16 + kk] = out;
-            if (net == 1 && target_out) target_out[g * 16 + kk] = out;
-        }
-        const float other = __shfl_xor(out, 32, 64);
-        float sq = (out - other) * (out - other);
+    for (int b = 0; b < 2; ++b) {                         // two batches of 4 + 4 reads (32 registers)
+        float4 fv[4], wv[4];
 #pragma unroll
-        for (int sh = 2; sh < 32; sh <<= 1) sq += __shfl_xor(sq, sh, 64);
-        bonus_value = sq * (1.0f / 16.0f);               // complete in lane 0
+        for (int i = 0; i < 4; ++i) { fv[i] = f4[4 * b + i]; wv[i] = w4[4 * b + i]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc = fmaf(wv[i].x, fv[i].x, acc); acc = fmaf(wv[i].y, fv[i].y, acc);
+            acc = fmaf(wv[i].z, fv[i].z, acc); acc = fmaf(wv[i].w, fv[i].w, acc);
+        }
     }
-    return bonus_value;
+    acc += dpp_quad_xor1(acc);                            // the other half of the inputs
+    const float out = tanhf(acc + bias);
+    if (half == 0) {
+        if (net == 0 && pred_out) pred_out[g * 16 + kk] = out;
+        if (net == 1 && target_out) target_out[g * 16 + kk] = out;
+    }
+    // the other net's output for the same k sits 32 lanes away: v_permlane32_swap exchanges the
+    // upper half of its first operand with the lower half of its second
+    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, out),
+                                                     __builtin_bit_cast(unsigned, out), false, false);
+    const float other = __builtin_bit_cast(float, lane < 32 ? sw[1] : sw[0]);
+    float sq = (out - other) * (out - other);
+    sq += dpp_quad_xor2(sq);                              // k ^ 1
+    sq += dpp_row_ror(sq, 0x124);                         // + the other k's of this 16-lane row: eight per
+    sq += dpp_row_ror(sq, 0x128);                         //   row, each once (lane bits 1..3 are summed)
+    const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 0)) +
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 16));
+    return total * (1.0f / 16.0f);
 }
 
 }  // namespace carle
