@@ -14,6 +14,16 @@
 #include "common.hpp"
 #include <stdlib.h>
 
+// Diagnostic build only (tools/kbench/ca_b1_variants.hip defines CARLE_B1_STAMPS): every wave records
+// s_memtime per work item at its start, after its loads have arrived, after the compute and at its end.
+#ifdef CARLE_B1_STAMPS
+__device__ unsigned long long *g_b1_stamps = nullptr;       // [work item][4]
+#define B1_STAMP(i) do { if (threadIdx.x == 0 && g_b1_stamps) \
+    g_b1_stamps[(size_t)wid * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define B1_STAMP(i) do {} while (0)
+#endif
+
 namespace carle {
 
 template <int WW>
@@ -128,10 +138,20 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     constexpr int H = 64 * WW;
     constexpr bool MULTI = WW > 1;                          // more than one 64-row strip per grid
     const int lane = threadIdx.x;
-    const int64_t wid = blockIdx.x;
-    const int64_t g = wid / strip_count;
-    const int r0 = ((strip_first + (int)(wid % strip_count)) % WW) * 64;
-    if (g >= n) return;
+    // Persistent waves: the launch has just under 32 waves per CU and every wave walks the (grid,
+    // strip) list with stride gridDim.x.  One-shot waves spent more time being launched and retired
+    // than running (profiles/r02_b1_stamps.txt: 5 us of instructions per strip in 13 us of wave slot).
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD,
+    // and gridDim.x is a multiple of 8), so XCD x takes the grids g = x (mod 8) and walks their strips
+    // one after the other: the strips of a grid share an L2 (halo rows are L2 hits) and every XCD
+    // gets every strip.  (Placement is not guaranteed: any other dealing only changes the speed.)
+    const int64_t total = ((n + 7) / 8) * 8 * strip_count;
+  for (int64_t wid = blockIdx.x; wid < total; wid += gridDim.x) {
+    const int64_t j = wid >> 3;
+    const int64_t g = 8 * (j / strip_count) + (wid & 7);
+    const int r0 = ((strip_first + (int)(j % strip_count)) % WW) * 64;
+    if (g >= n) continue;
+    B1_STAMP(0);
     const int r = r0 + lane;
     const uint64_t *gin = u_in + g * (int64_t)H * WW;
     const int rt = (r0 + H - 1) % H, rb = (r0 + 64) % H;   // rows bordering the strip (y torus)
@@ -194,6 +214,10 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     }
 
     if (ACT == 2) __builtin_amdgcn_sched_barrier(0);
+#ifdef CARLE_B1_STAMPS
+    { uint64_t keep = c[0]; asm volatile("s_waitcnt vmcnt(0)" : "+v"(keep)); c[0] = keep; }
+#endif
+    B1_STAMP(1);
 
     // ---- compute phase on 32-bit chunks (NC = 2*WW per row): every operation below is a single
     // full-rate VALU instruction -- v_alignbit_b32 for the 1-bit funnel shifts across chunk
@@ -236,7 +260,10 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     uint64_t nx[WW];
 #pragma unroll
     for (int j = 0; j < WW; ++j) nx[j] = ((uint64_t)nx32[2 * j + 1] << 32) | nx32[2 * j];
+    B1_STAMP(2);
     store_row<WW>(u_out + (g * (int64_t)H + r) * WW, nx);
+    B1_STAMP(3);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,15 +412,22 @@ __global__ __launch_bounds__(256) void unpack_b1_f32_kernel(const uint64_t *__re
 template <int WW, int RULE_MODE>
 static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
                           int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
-    if (n * WW > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1: batch too large");
+    const int64_t n8 = (n + 7) / 8 * 8;         // the XCD-aware mapping walks the batch in groups of 8 grids
+    // persistent: just under 32 one-wave workgroups per CU (8 per SIMD).  8 x 1021: a multiple of 8 (a
+    // wave stays on "its" XCD's grids) whose per-XCD stride 1021 is prime, so a wave's successive work
+    // items rotate through the strips -- with a stride that is a multiple of the strip count every wave
+    // kept ONE strip index, and the waves of the two strips under the action window finished last
+    int64_t cap = 8 * 1021;
+    if (const char *e = getenv("CARLE_B1_BLOCKS")) { const int64_t v = atoll(e); if (v >= 8) cap = v / 8 * 8; }   // experiment knob
+    auto blocks = [&](int64_t wg) { return (unsigned)(wg < cap ? wg : cap); };
     if (!act) {
-        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE>), dim3((unsigned)(n * WW)), dim3(64), 0,
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE>), dim3(blocks(n8 * WW)), dim3(64), 0,
                            s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW);
         return check_launch("carle_ca_step_b1");
     }
     if (aw == 64) {
         // the usual 64x64 window: its toggle fits the full-occupancy instantiation -> one launch
-        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE>), dim3((unsigned)(n * WW)), dim3(64), 0,
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE>), dim3(blocks(n8 * WW)), dim3(64), 0,
                            s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW);
         return check_launch("carle_ca_step_b1");
     }
@@ -406,10 +440,10 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     if (ah == H) { first = 0; last = WW - 1; }
     int count = ((last - first + WW) % WW) + 1;
     if (count > WW) count = WW;
-    hipLaunchKernelGGL((ca_step_b1_kernel<WW, 2, RULE_MODE>), dim3((unsigned)(n * count)), dim3(64), 0, s,
+    hipLaunchKernelGGL((ca_step_b1_kernel<WW, 2, RULE_MODE>), dim3(blocks(n8 * count)), dim3(64), 0, s,
                        u_in, act, u_out, n, ah, aw, rule, status, slot, first, count);
     if (count < WW)
-        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE>), dim3((unsigned)(n * (WW - count))),
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE>), dim3(blocks(n8 * (WW - count))),
                            dim3(64), 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot,
                            (first + count) % WW, WW - count);
     return check_launch("carle_ca_step_b1");

@@ -2,6 +2,15 @@
 // build (after make -C carle_amd/csrc; the rest of the library is linked, this kernel file is compiled in):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/kbench/ca_b1_variants tools/kbench/ca_b1_variants.hip \
 //         -Lcarle_amd/lib -lcarle_hip -Wl,-rpath,'$ORIGIN/../../carle_amd/lib'
+// the library exports the same symbols: this build's copies get their own names
+#define ca_step_b1_kernel ca_step_b1_kernel_dbg
+#define carle_ca_step_b1 carle_ca_step_b1_dbg
+#define carle_ca_multistep_b1 carle_ca_multistep_b1_dbg
+#define ca_multistep_b1_kernel ca_multistep_b1_kernel_dbg
+#define carle_pack_f32_b1 carle_pack_f32_b1_dbg
+#define carle_unpack_b1_f32 carle_unpack_b1_f32_dbg
+#define pack_f32_b1_kernel pack_f32_b1_kernel_dbg
+#define unpack_b1_f32_kernel unpack_b1_f32_kernel_dbg
 #include "../../carle_amd/csrc/ca_step_b1.hip"
 #include <algorithm>
 #include <vector>
@@ -48,7 +57,7 @@ int main(int argc, char **argv) {
     const uint32_t high = (1u << 12) | (1u << 15) | 0xC, life = (1u << 12) | 0xC;
     struct V { const char *name; int id; } vs[] = {{"flat_copy", 0}, {"strip_copy_direct", 1}, {"strip_copy_rowlane", 2},
         {"step_noact_highlife", 3}, {"step_act_highlife", 4}, {"step_act_nostatus", 7}, {"step_noact_life", 5}, {"step_noact_dense", 6},
-        {"part_noact_5of8_from5", 8}, {"part_noact_5of8_from0", 10}, {"part_noact_4of8_from0", 11}, {"part_act_3of8_from2", 9}};
+        {"act1_kernel_window_h0", 12}, {"act1_kernel_h64_nostatus", 13}, {"act1_h64_win_rows_0_63", 14}};
     const int nv = sizeof(vs) / sizeof(vs[0]);
     std::vector<std::vector<float>> t(nv);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -65,6 +74,12 @@ int main(int argc, char **argv) {
                     case 7: carle_ca_step_b1(a, act, b, n, 512, 512, 64, 64, high, nullptr, 0, nullptr); break;
                     case 5: carle_ca_step_b1(a, nullptr, b, n, 512, 512, 0, 0, life, st, 0, nullptr); break;
                     case 6: carle_ca_step_b1(a, nullptr, b, n, 512, 512, 0, 0, 0x3FFFF, st, 0, nullptr); break;
+                    case 12: hipLaunchKernelGGL((ca_step_b1_kernel<8, 1, kRuleHighLife>), dim3(8168), dim3(64), 0, 0,
+                                                a, act, b, n, 0, 64, high, st, 0, 0, 8); break;      // ACT=1 code, no strip meets the window
+                    case 13: hipLaunchKernelGGL((ca_step_b1_kernel<8, 1, kRuleHighLife>), dim3(8168), dim3(64), 0, 0,
+                                                a, act, b, n, 64, 64, high, (int32_t *)nullptr, 0, 0, 8); break;
+                    case 14: hipLaunchKernelGGL((ca_step_b1_kernel<8, 1, kRuleHighLife>), dim3(8168), dim3(64), 0, 0,
+                                                a, act, b, n, 64, 64, high, (int32_t *)nullptr, 0, 5, 8); break;   // strips rotated by 5
                     case 8: hipLaunchKernelGGL((ca_step_b1_kernel<8, 0, kRuleHighLife>), dim3((unsigned)(n * 5)), dim3(64), 0, 0,
                                                a, (const uint64_t *)nullptr, b, n, 0, 0, high, st, 0, 5, 5); break;
                     case 10: hipLaunchKernelGGL((ca_step_b1_kernel<8, 0, kRuleHighLife>), dim3((unsigned)(n * 5)), dim3(64), 0, 0,
@@ -86,5 +101,35 @@ int main(int argc, char **argv) {
         float med = t[v][t[v].size() / 2];
         printf("%-22s median %7.2f us  %6.3f TB/s\n", vs[v].name, med, bytes / med * 1e-6);
     }
+#ifdef CARLE_B1_STAMPS
+    {   // per-strip wave timing of the action launch: median cycles start->loads, loads->computed, ->stored
+        const int64_t blocks = (n + 7) / 8 * 8 * 8;
+        unsigned long long *st4; CK(hipMalloc(&st4, blocks * 4 * 8)); CK(hipMemset(st4, 0, blocks * 4 * 8));
+        for (int mode = 0; mode < 2; ++mode) {
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_b1_stamps), &st4, sizeof(st4)));
+            if (mode == 0) carle_ca_step_b1(a, nullptr, b, n, 512, 512, 0, 0, high, st, 0, nullptr);
+            else carle_ca_step_b1(a, act, b, n, 512, 512, 64, 64, high, st, 0, nullptr);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> hs(blocks * 4);
+            CK(hipMemcpy(hs.data(), st4, blocks * 4 * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (auto v : hs) if (v) { t0 = std::min(t0, v); t1 = std::max(t1, v); }
+            printf("%s launch: span %llu cycles\n", mode ? "action" : "no-action", t1 - t0);
+            for (int sidx = 0; sidx < 8; ++sidx) {
+                std::vector<double> d[4];
+                for (int64_t blk = 0; blk < blocks; ++blk) {
+                    if ((int)((blk >> 3) % 8) != sidx) continue;
+                    const unsigned long long *p = &hs[blk * 4];
+                    if (!p[0] || !p[3]) continue;
+                    d[0].push_back((double)(p[1] - p[0])); d[1].push_back((double)(p[2] - p[1]));
+                    d[2].push_back((double)(p[3] - p[2])); d[3].push_back((double)(p[3] - p[0]));
+                }
+                auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+                printf("   strip %d: loads %7.0f  compute %7.0f  store-issue %6.0f  total %7.0f  (%zu waves)\n", sidx,
+                       med(d[0]), med(d[1]), med(d[2]), med(d[3]), d[0].size());
+            }
+        }
+    }
+#endif
     return 0;
 }
