@@ -1,5 +1,6 @@
 // abi.hip -- library-level C-ABI entry points: version, error text, and the step epilogue
 // (master reset + counters, carle/env.py:208-216,142-145,200,230).
+#include "ca_cells.hpp"
 #include "common.hpp"
 
 namespace carle {
@@ -106,27 +107,7 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
     } else if (reward) {
         for (int64_t i = tid; i < n; i += nthreads) reward[i] = 0.0f;
     }
-    if (tid == 0) {
-        int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z);       // int32 index 6..7
-        int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x);             // index 8..9
-        int64_t resets = (int64_t)(((uint64_t)w2.w << 32) | w2.z);            // index 10..11
-        if (!any) since += 1;                       // env.py:199-200
-        if (reset) {                                // env.py:216 -> reset(): env.py:142-145
-            step_number = 0;
-            since = 0;
-            resets += 1;
-        } else {
-            step_number += 1;                       // env.py:230
-        }
-        uint4 o0 = w0, o1 = w1, o2;
-        if (slot) { o0.x = 0u; o0.z = 0u; } else { o0.y = 0u; o0.w = 0u; }   // recycle slot^1
-        o1.x = reset ? 1u : 0u;                     // CARLE_ST_LAST_RESET (index 4)
-        o1.z = (uint32_t)step_number; o1.w = (uint32_t)((uint64_t)step_number >> 32);
-        o2.x = (uint32_t)since; o2.y = (uint32_t)((uint64_t)since >> 32);
-        o2.z = (uint32_t)resets; o2.w = (uint32_t)((uint64_t)resets >> 32);
-        uint4 *so = reinterpret_cast<uint4 *>(st);
-        so[0] = o0; so[1] = o1; so[2] = o2;              // words 12..15 (moment pointers) stay
-    }
+    if (tid == 0) finish_status(st, w0, w1, w2, slot, reset, any);
 }
 
 }  // namespace carle
@@ -182,13 +163,27 @@ int carle::ca_finish_impl(void *u_out, int64_t u_out_bytes, float *reward, int64
     return check_launch("carle_ca_finish");
 }
 
+namespace carle {
+struct RandAct;
+int env_step_small64(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h,
+                     int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
+                     const RandAct *rand, void *stream);
+int env_step_small64_rand(const float *u_in, float *u_out, float *reward, int64_t n, int h, int w, int ah, int aw,
+                          uint32_t rule, float p, uint64_t seed, uint64_t offset, float *action_out,
+                          int32_t *status, int slot, int step_flags, void *stream);
+}
+
 // step + epilogue in one call: the per-step host cost of the drop-in surface is dominated by
-// Python/ctypes overhead, so CARLE.step makes ONE library call per step.
+// Python/ctypes overhead, so CARLE.step makes ONE library call per step.  Batches of up to 16
+// 64x64 grids take ONE launch (step and epilogue in the same single-workgroup kernel).
 extern "C" int carle_env_step_f32(const float *u_in, const float *action, float *u_out,
                                   float *reward, int64_t n, int h, int w, int ah, int aw,
                                   uint32_t rule, int32_t *status, int slot, int publish_flags,
                                   void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32: status is NULL");
+    if (const int e = env_step_small64(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
+                                       publish_flags, nullptr, stream); e != -1000)
+        return e;
     if (int e = carle_ca_step_f32(u_in, action, u_out, n, h, w, ah, aw, rule,
                                   (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream))
         return e;
@@ -237,11 +232,43 @@ extern "C" int carle_env_step_f32_rand(const float *u_in, float *u_out, float *r
                                        uint64_t offset, float *action_out, int32_t *status, int slot,
                                        int step_flags, void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rand: status is NULL");
+    if (const int e = env_step_small64_rand(u_in, u_out, reward, n, h, w, ah, aw, rule, p, seed, offset, action_out,
+                                            status, slot, step_flags, stream); e != -1000)
+        return e;
     if (int e = carle_ca_step_f32_rand(u_in, u_out, n, h, w, ah, aw, rule, p, seed, offset, action_out,
                                        status, slot, stream))
         return e;
     return ca_finish_impl(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot, 1,
                           nullptr, 0, nullptr, 0.0f, step_flags & CARLE_STEP_MERGE_MOMENTS, stream);
+}
+
+// k consecutive CARLE.step calls in ONE library call: the loop of carle/train_mcl.py:64-69 with the
+// actions already on the device (a stack of k action tensors) or drawn in the step kernel (the
+// device-side RandomAgent).  The host pays one ctypes round trip for k steps instead of k.
+extern "C" int carle_env_run_f32(float *buf_a, float *buf_b, const float *actions, float *reward, int64_t n,
+                                 int h, int w, int ah, int aw, uint32_t rule, float p, uint64_t seed,
+                                 uint64_t offset, int k, int32_t *status, int slot0, int step_flags,
+                                 void *stream) {
+    if (!status) return fail_arg(CARLE_E_NULL, "carle_env_run_f32: status is NULL");
+    if (k < 0) return fail_arg(CARLE_E_DIMS, "carle_env_run_f32: k must be >= 0");
+    if (slot0 != 0 && slot0 != 1) return fail_arg(CARLE_E_DIMS, "carle_env_run_f32: slot0 must be 0 or 1");
+    if (k > 0 && (!buf_a || !buf_b)) return fail_arg(CARLE_E_NULL, "carle_env_run_f32: buf_a/buf_b is NULL");
+    const int64_t act_elems = n * (int64_t)ah * aw;
+    for (int t = 0; t < k; ++t) {
+        float *in = (t & 1) ? buf_b : buf_a, *out = (t & 1) ? buf_a : buf_b;
+        const int slot = (slot0 + t) & 1;
+        int e;
+        if (actions)
+            e = carle_env_step_f32(in, actions + t * act_elems, out, reward, n, h, w, ah, aw, rule, status, slot,
+                                   step_flags | CARLE_STEP_PUBLISH_FLAGS, stream);
+        else if (p >= 0.0f)
+            e = carle_env_step_f32_rand(in, out, reward, n, h, w, ah, aw, rule, p, seed, offset + (uint64_t)t, nullptr,
+                                        status, slot, step_flags, stream);
+        else
+            e = carle_env_step_f32(in, nullptr, out, reward, n, h, w, 0, 0, rule, status, slot, step_flags, stream);
+        if (e) return e;
+    }
+    return 0;
 }
 
 // Orders `to_stream` after everything enqueued so far on `from_stream` (event record + wait):

@@ -133,6 +133,31 @@ __device__ __forceinline__ void publish_flags(const ActionSeen &s, int32_t *stat
     }
 }
 
+// Counter / flag bookkeeping at the end of a step (env.py:142-145, 199-200, 216, 230), by ONE thread:
+// w0..w2 = the first three 16-byte words of the status block as read at the start of the epilogue.
+__device__ __forceinline__ void finish_status(int32_t *st, const uint4 &w0, const uint4 &w1, const uint4 &w2,
+                                              int slot, bool reset, bool any) {
+    int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z);       // int32 index 6..7
+    int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x);             // index 8..9
+    int64_t resets = (int64_t)(((uint64_t)w2.w << 32) | w2.z);            // index 10..11
+    if (!any) since += 1;                       // env.py:199-200
+    if (reset) {                                // env.py:216 -> reset(): env.py:142-145
+        step_number = 0;
+        since = 0;
+        resets += 1;
+    } else {
+        step_number += 1;                       // env.py:230
+    }
+    uint4 o0 = w0, o1 = w1, o2;
+    if (slot) { o0.x = 0u; o0.z = 0u; } else { o0.y = 0u; o0.w = 0u; }   // recycle slot^1
+    o1.x = reset ? 1u : 0u;                     // CARLE_ST_LAST_RESET (index 4)
+    o1.z = (uint32_t)step_number; o1.w = (uint32_t)((uint64_t)step_number >> 32);
+    o2.x = (uint32_t)since; o2.y = (uint32_t)((uint64_t)since >> 32);
+    o2.z = (uint32_t)resets; o2.w = (uint32_t)((uint64_t)resets >> 32);
+    uint4 *so = reinterpret_cast<uint4 *>(st);
+    so[0] = o0; so[1] = o1; so[2] = o2;              // words 12..15 (moment pointers) stay
+}
+
 // One generation of a 64x64 torus held as one 64-bit "patch" word per lane: lane (q = L/16,
 // k = L%16), nibble i = row 4i+q, columns 4k..4k+3.
 __device__ __forceinline__ uint64_t patch_generation64(uint64_t c, int lane, uint32_t rule) {

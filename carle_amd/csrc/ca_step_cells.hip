@@ -100,6 +100,106 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// small batches of 64x64 fp32 grids (N <= 16): the WHOLE CARLE.step in ONE launch
+// ---------------------------------------------------------------------------------------------
+// One workgroup, one wavefront per grid.  Every grid of the batch is inside the workgroup, so the
+// whole-batch master reset (env.py:208-216) needs no second kernel: the waves meet at a barrier,
+// combine their action predicates through LDS, and the epilogue of carle_ca_finish (reset, counters,
+// zero reward, optional reward moments; abi.hip) runs in place.  Halves the launches of the
+// configurations whose step is bound by the host (BASELINE configs[0]: N = 1).
+template <bool HAS_ACT, bool RAND_ACT>
+__global__ __launch_bounds__(1024) void ca_env_step_small64_kernel(
+    const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out,
+    float *__restrict__ reward, int64_t n, int aw, uint32_t rule, int32_t *__restrict__ st, int slot,
+    int publish, int merge_moments, RandAct ra) {
+    __shared__ uint32_t s_any[16], s_notone[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t g = wv;                                  // blockDim.x = 64 * n
+    const int q = lane >> 4, k = lane & 15;
+    const float *gin = u_in + g * 4096 + 4 * lane;
+    uint4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = ld16<false>(reinterpret_cast<const uint4 *>(gin + i * 256));
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c |= (uint64_t)nibble_of(v[i]) << (4 * i);
+    ActionSeen seen;
+    if (HAS_ACT) {
+        const int o = (64 - aw) >> 1;
+        const int ax = 4 * k - o;
+        const bool col_in = ax >= 0 && ax < aw;
+        const float *abase = act + g * (int64_t)aw * aw + ax;
+        uint64_t tog = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ay = 4 * i + q - o;
+            if (col_in && ay >= 0 && ay < aw) {
+                uint4 a;
+                if (RAND_ACT) {
+                    const uint64_t quad = (uint64_t)((g * aw + ay) * (int64_t)aw + ax) >> 2;
+                    const uint32_t nib = bernoulli_nibble(quad, ra.seed, ra.offset, ra.p);
+                    a.x = (nib & 1u) ? kOneBits : 0u;
+                    a.y = (nib & 2u) ? kOneBits : 0u;
+                    a.z = (nib & 4u) ? kOneBits : 0u;
+                    a.w = (nib & 8u) ? kOneBits : 0u;
+                    if (ra.action_out)
+                        *reinterpret_cast<uint4 *>(ra.action_out + (g * aw + ay) * (int64_t)aw + ax) = a;
+                } else {
+                    a = ld16<false>(reinterpret_cast<const uint4 *>(abase + (int64_t)ay * aw));
+                }
+                seen.add(a);
+                tog |= (uint64_t)nibble_of(a) << (4 * i);
+            }
+        }
+        c ^= tog;                                          // toggle, env.py:182
+    }
+    const uint64_t nxt = patch_generation64(c, lane, rule);
+
+    // ---- whole-batch predicates: through LDS; flags a caller stored beforehand (publish == 0:
+    // oversize / exact predicates) are read from the status block instead
+    const bool w_any = HAS_ACT && __ballot(seen.any_nonzero<F32Cells>()) != 0ull;       // wave-wide: every lane votes
+    const bool w_notone = HAS_ACT && __ballot(seen.not_all_ones<F32Cells>()) != 0ull;
+    if (lane == 0) {
+        s_any[wv] = w_any;
+        s_notone[wv] = w_notone;
+    }
+    __syncthreads();
+    const uint4 *st4 = reinterpret_cast<const uint4 *>(st);
+    const uint4 w0 = st4[0], w1 = st4[1], w2 = st4[2], w3 = st4[3];
+    bool any = false, notone = false;
+    if (publish) {
+        for (int i = 0; i < (int)n; ++i) { any |= s_any[i] != 0u; notone |= s_notone[i] != 0u; }
+    } else {
+        any = (slot ? w0.y : w0.x) != 0u;
+        notone = (slot ? w0.w : w0.z) != 0u;
+    }
+    const bool reset = HAS_ACT && !notone;                 // env.py:208: every element of the batch is 1.0
+    any = HAS_ACT && any;
+
+    float *gout = u_out + g * 4096 + 4 * lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        F32Cells::store<false>(gout + i * 256, reset ? 0u : (uint32_t)(nxt >> (4 * i)) & 0xFu);
+    if (reward && threadIdx.x < n) reward[threadIdx.x] = 0.0f;          // env.py:238
+    if (threadIdx.x == 0) {
+        if (merge_moments && reward) {                     // moments of an all-zero reward vector
+            double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
+            double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
+            if (mom_out && mom_acc) {
+                const double nb = (double)n, na = mom_acc[0], ma = mom_acc[1], qa = mom_acc[2], tot = na + nb;
+                mom_out[0] = nb; mom_out[1] = 0.0; mom_out[2] = 0.0;
+                if (tot > 0.0) {
+                    mom_acc[0] = tot;
+                    mom_acc[1] = ma - ma * nb / tot;
+                    mom_acc[2] = qa + ma * ma * na * nb / tot;
+                }
+            }
+        }
+        finish_status(st, w0, w1, w2, slot, reset, any);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // wide fast path: W = 256 * NS (NS = 1, 2), one wavefront per strip of R = 16 * RW rows
 // ---------------------------------------------------------------------------------------------
 // One load instruction covers 256 consecutive floats = (a 256-column block of) one row, so lane k
@@ -414,6 +514,49 @@ static int ca_toggle_cells(const typename C::T *u_in, const typename A::T *actio
     hipLaunchKernelGGL((ca_toggle_kernel<C, A>), dim3((unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), u_in, action, u_out, n, h, w, ah, aw);
     return check_launch(who);
+}
+}  // namespace carle
+
+namespace carle {
+// Whole CARLE.step of a small 64x64 fp32 batch in one launch (see ca_env_step_small64_kernel);
+// returns -1000 when the geometry does not qualify (the caller then takes the two-launch path).
+// rand != nullptr: in-kernel Bernoulli toggles instead of an action tensor.
+int env_step_small64(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h,
+                     int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
+                     const RandAct *rand, void *stream) {
+    const bool has_act = action != nullptr || rand != nullptr;
+    if (h != 64 || w != 64 || n < 1 || n > 16 || !status || (has_act && (aw % 8) != 0)) return -1000;
+    if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_env_step_f32: u_in/u_out is NULL");
+    if (int e = check_dims(n, h, w, has_act, ah, aw)) return e;
+    if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_env_step_f32: rule mask exceeds 18 bits");
+    if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32: slot must be 0 or 1");
+    if (!aligned16(u_in) || !aligned16(u_out) || (action && !aligned16(action)) || !aligned16(status))
+        return fail_arg(CARLE_E_ALIGN, "carle_env_step_f32: pointers must be 16-byte aligned");
+    const size_t bytes = (size_t)n * h * w * sizeof(float);
+    if (overlap(u_in, bytes, u_out, bytes)) return fail_arg(CARLE_E_ALIAS, "carle_env_step_f32: u_in and u_out overlap");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(1), block((unsigned)(64 * n));
+    const int publish = rand ? 1 : (step_flags & CARLE_STEP_PUBLISH_FLAGS) ? 1 : 0;
+    const int merge = (step_flags & CARLE_STEP_MERGE_MOMENTS) ? 1 : 0;
+    if (rand)
+        hipLaunchKernelGGL((ca_env_step_small64_kernel<true, true>), grid, block, 0, s, u_in, action, u_out, reward, n,
+                           aw, rule, status, slot, publish, merge, *rand);
+    else if (action)
+        hipLaunchKernelGGL((ca_env_step_small64_kernel<true, false>), grid, block, 0, s, u_in, action, u_out, reward,
+                           n, aw, rule, status, slot, publish, merge, RandAct());
+    else
+        hipLaunchKernelGGL((ca_env_step_small64_kernel<false, false>), grid, block, 0, s, u_in, action, u_out, reward,
+                           n, 0, rule, status, slot, publish, merge, RandAct());
+    return check_launch("carle_env_step_f32(small batch)");
+}
+
+int env_step_small64_rand(const float *u_in, float *u_out, float *reward, int64_t n, int h, int w, int ah, int aw,
+                          uint32_t rule, float p, uint64_t seed, uint64_t offset, float *action_out,
+                          int32_t *status, int slot, int step_flags, void *stream) {
+    RandAct ra;
+    ra.p = p; ra.seed = seed; ra.offset = offset; ra.action_out = action_out;
+    if (action_out && !aligned16(action_out)) return -1000;
+    return env_step_small64(u_in, nullptr, u_out, reward, n, h, w, ah, aw, rule, status, slot, step_flags, &ra, stream);
 }
 }  // namespace carle
 

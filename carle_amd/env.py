@@ -358,6 +358,71 @@ class CARLE(RLEMixin, nn.Module):
         info = [{}] * self.instances
         return self.universe, reward, done, info
 
+    def run(self, actions=None, steps=None, agent=None):
+        """Several consecutive ``step`` calls in ONE library call (``carle_env_run_f32``; build-side
+        extension).  The state, counters, flags and return value are those of the loop
+
+            for t in range(k): obs, reward, done, info = env.step(action_t)
+
+        (carle/train_mcl.py:64-69) for action sources that do not look at the observations:
+          * ``actions``: a (k, N, 1, AH, AW) tensor, one action per step;
+          * ``agent``: a ``carle_amd.agents.RandomAgent`` -- its next ``steps`` draws, made inside the
+            step kernel (the agent's call counter advances by ``steps``);
+          * neither: ``steps`` steps without an action.
+        One ctypes round trip instead of k: for small batches the per-step cost is the kernel launch
+        (N <= 16 at 64x64: one launch per step), not Python.  fp32 storage only."""
+        hip.require_gpu()
+        self._check_domain()
+        self._ensure_status()
+        if self.storage != "f32" or self.logging or self.exact_action_predicates:
+            raise NotImplementedError("run() covers storage='f32' without logging / exact predicates")
+        u = self._device_universe()
+        ah = aw = 0
+        p, seed, offset = -1.0, 0, 0
+        if actions is not None:
+            if not isinstance(actions, torch.Tensor):
+                actions = torch.as_tensor(actions, dtype=torch.float32)
+            actions = actions.to(self.my_device, torch.float32).contiguous()
+            if actions.dim() != 5 or tuple(actions.shape[1:]) != (self.instances, 1, self.action_width,
+                                                                  self.action_height):
+                raise AssertionError(f"actions must be (k, {self.instances}, 1, {self.action_width}, "
+                                     f"{self.action_height}), got {tuple(actions.shape)}")
+            k = actions.shape[0]
+            if steps is not None and int(steps) != k:
+                raise ValueError("steps disagrees with actions.shape[0]")
+        else:
+            if steps is None:
+                raise ValueError("run() needs actions or steps")
+            k = int(steps)
+            if agent is not None:
+                if not all(hasattr(agent, a) for a in ("toggle_rate", "seed", "calls")):
+                    raise TypeError("agent must be a carle_amd.agents.RandomAgent")
+                if (agent.action_width, agent.action_height) != (self.action_width, self.action_height):
+                    raise AssertionError("agent action size does not match the environment")
+                if not ((self.height == 64 and self.action_width % 8 == 0) or
+                        (self.height in (256, 512) and self.action_width % 4 == 0 and
+                         (self.width - self.action_width) % 8 == 0)):
+                    raise NotImplementedError("in-kernel toggles need an aligned action window "
+                                              "(carle_ca_step_f32_rand)")
+                p, seed, offset = agent.toggle_rate, agent.seed, agent.calls
+                ah, aw = self.action_height, self.action_width
+        if k < 0:
+            raise ValueError("steps must be >= 0")
+        reward = torch.zeros(self.instances, 1, dtype=torch.float32, device=self.my_device)
+        merge = self.__dict__.get("_final_reward_stats") is not None
+        self._moments_merged = False
+        if k > 0:
+            other = torch.empty_like(u)
+            hip.env_run_f32(u, other, actions, reward, self.rule_mask(), self._status, self._slot, k, ah, aw,
+                            p, seed, offset, merge)
+            self.universe = other if k & 1 else u
+            self._slot = (self._slot + k) & 1
+            self._moments_merged = merge
+            if agent is not None and actions is None:
+                agent.calls += k
+        self.action = None
+        return self.universe, reward, torch.zeros(self.instances, 1), [{}] * self.instances
+
     def multistep(self, steps):
         """``steps`` generations with no action in ONE kernel launch: the state, counters and return
         value of ``steps`` consecutive ``step(zeros)`` calls (env.py:188-242; build-side extension).

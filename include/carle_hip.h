@@ -179,6 +179,26 @@ int carle_env_step_f32(const float *u_in, const float *action, float *u_out, flo
                        int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                        int32_t *status, int slot, int publish_flags, void *stream);
 
+/*
+ * k consecutive CARLE.step calls (carle/env.py:188-242) in one library call -- the inner loop of
+ * carle/train_mcl.py:64-69 / evaluation/eval.py:63-70 when the actions do not depend on the
+ * observations that the loop produces (a device-side RandomAgent, carle/agents.py:35-42, or a
+ * recorded action sequence).  The state ping-pongs between buf_a and buf_b (N*H*W floats each, not
+ * aliased): on entry it is in buf_a, on return in buf_a for even k and in buf_b for odd k.
+ *   actions != NULL        k contiguous (N,1,AH,AW) fp32 tensors; step t uses the t-th
+ *   actions == NULL, p>=0  Bernoulli(p) toggles drawn in the step kernel, step t with Philox offset
+ *                          `offset + t` (= k calls of carle_env_step_f32_rand)
+ *   actions == NULL, p<0   no action (AH/AW ignored)
+ *   reward                 N floats: the reward of the LAST step (zero for the bare environment)
+ *   slot0                  flag slot of the first step; step t uses (slot0 + t) & 1
+ *   step_flags             CARLE_STEP_MERGE_MOMENTS or 0
+ * Every step is complete (master reset, counters, flags) before the next one starts, exactly as k
+ * separate calls of carle_env_step_f32* on the same stream.
+ */
+int carle_env_run_f32(float *buf_a, float *buf_b, const float *actions, float *reward, int64_t n,
+                      int h, int w, int ah, int aw, uint32_t rule, float p, uint64_t seed,
+                      uint64_t offset, int k, int32_t *status, int slot0, int step_flags, void *stream);
+
 /* The same on bit-packed state: carle_ca_step_b1 + carle_ca_finish. */
 int carle_env_step_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out, float *reward,
                       int64_t n, int h, int w, int ah, int aw, uint32_t rule,

@@ -395,3 +395,66 @@ def test_random_geometries_and_rules_hypothesis():
             assert np.array_equal(hip.unpack_b1_f32(outb).cpu().numpy(), exp), (size, asize, n, hex(rule))
 
     run()
+
+
+@pytest.mark.parametrize("name", ["tog64a64_life", "reset64_life", "tog64a32_life", "tog256a64_daynight",
+                                  "reset256_life", "values64_life", "cfg1_life", "odd32a32_life"])
+def test_run_replays_golden_case(name):
+    """CARLE.run (carle_env_run_f32: k steps per library call; N <= 16 at 64x64 = one launch per
+    step) replays the reference's golden cases in chunks: grids and counters at every recorded step."""
+    c = G.ca_case(name)
+    env = _env(width=c.size, height=c.size, action_width=c.asize, action_height=c.asize, instances=c.n)
+    env.birth, env.survive = list(c.birth), list(c.survive)
+    env.reset()
+    env.universe = torch.from_numpy(c.init.copy()).cuda()
+    t, rec = 0, 0
+    marks = sorted(set(c.record))
+    for m in marks:
+        acts = torch.from_numpy(np.ascontiguousarray(c.actions[t:m]))
+        obs, reward, done, info = env.run(actions=acts)
+        t = m
+        assert obs is env.universe and tuple(reward.shape) == (c.n, 1) and len(info) == c.n
+        assert np.array_equal(obs.cpu().numpy(), c.obs[rec]), f"grid mismatch at step {m}"
+        assert env.step_number == c.step_number[m - 1]
+        assert env.steps_since_action == c.steps_since_action[m - 1]
+        assert float(reward.abs().sum()) == 0.0
+        rec += 1
+
+
+@pytest.mark.parametrize("n,size", [(1, 64), (16, 64), (17, 64), (300, 64), (3, 256)])
+def test_run_with_fused_random_agent_equals_step_loop(n, size):
+    """env.run(agent=RandomAgent, steps=k) == k x env.step(agent(obs)): same Philox draws, same
+    grids, counters, and the agent's call counter advances by k."""
+    from carle_amd.agents import RandomAgent
+    outs = []
+    for mode in ("loop", "run"):
+        env = _env(width=size, height=size, instances=n)
+        env.reset()
+        g = torch.Generator().manual_seed(7)
+        env.universe = (torch.rand(n, 1, size, size, generator=g) < 0.4).float().cuda()
+        agent = RandomAgent(action_width=64, action_height=64, fused=True, seed=11)
+        if mode == "loop":
+            for t in range(9):
+                obs = env.step(agent(env.universe))[0]
+        else:
+            env.run(agent=agent, steps=4)
+            obs = env.run(agent=agent, steps=5)[0]
+            env.run(steps=0)
+        assert agent.calls == 9
+        outs.append((obs.cpu().numpy(), env.step_number, env.steps_since_action))
+        # and then a plain step still works (flag slot parity carried over)
+        env.step(torch.zeros(n, 1, 64, 64))
+        assert env.steps_since_action == 1
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:] == (9, 0)
+
+
+def test_run_without_action_equals_multistep():
+    env_a, env_b = _env(width=64, height=64, instances=5), _env(width=64, height=64, instances=5)
+    u = (torch.rand(5, 1, 64, 64) < 0.5).float()
+    for e in (env_a, env_b):
+        e.reset()
+        e.universe = u.clone().cuda()
+    oa = env_a.run(steps=12)[0]
+    ob = env_b.multistep(12)[0]
+    assert torch.equal(oa, ob) and env_a.step_number == env_b.step_number == 12
+    assert env_a.steps_since_action == env_b.steps_since_action == 12
