@@ -1,9 +1,13 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence behind bench.py's numbers on the GPU box (run through gpurun):
-#   kernel-trace stats of the default bench (cfg2), of cfg3 (--rnd), cfg5 (b1 512^2) and the uint8 format,
-#   and the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only) for cfg2.
-# Outputs land in gpurun_out/prof/ ; copy the summaries into profiles/ afterwards.
+#   kernel-trace stats of the headline bench (cfg2), its Infinity-Cache-free variant (N=65536), cfg4
+#   (--rnd), cfg5 (b1 512^2), and the PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace
+#   only) for the dominant kernels of cfg2 / cfg2 at N=65536 / cfg4 / cfg5.
+# Outputs land in gpurun_out/prof/ ; tools/pmc_summary.py folds the PMC passes into
+# profiles/pmc_latest.json (copied back through gpurun_out/prof/pmc_latest.json).
+# Usage: tools/collect_profiles.sh [round-tag]      (default r02)
 set -e
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof
 mkdir -p $O
@@ -11,17 +15,29 @@ cd /tmp && export TMPDIR=/tmp
 stats() {   # name, bench flags...
     name=$1; shift
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -- python3 $R/bench.py "$@" --no-cpu-baseline > $O/$name.log 2>&1
-    cp $(find $O/$name -name "*kernel_stats.csv" | head -1) $O/${name}_kernel_stats.csv
-    echo "done $name"
+    cp $(find $O/$name -name "*kernel_stats.csv" | head -1) $O/${TAG}_${name}_kernel_stats.csv
+    grep '^{' $O/$name.log > $O/${TAG}_${name}_bench.json || true
+    echo "done stats $name"
+}
+pmc() {     # name, kernel substring, instances, size, format, bench flags...
+    name=$1; kern=$2; inst=$3; size=$4; fmt=$5; shift 5
+    for c in FETCH_SIZE WRITE_SIZE; do
+        rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${name}_$c -- python3 $R/bench.py "$@" --steps 16 --warmup 4 --no-cpu-baseline > $O/pmc_${name}_$c.log 2>&1
+        cp $(find $O/pmc_${name}_$c -name "*counter_collection.csv" | head -1) $O/pmc_${name}_$c.csv
+    done
+    python3 $R/tools/pmc_summary.py $O/pmc_${name}_FETCH_SIZE.csv $O/pmc_${name}_WRITE_SIZE.csv "$kern" $inst $size $fmt \
+        "profiles/${TAG}_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py $*)" >> $O/${TAG}_pmc.txt
+    echo "done pmc $name"
 }
 stats cfg2_f32 --steps 256 --warmup 16
-stats cfg3_rnd --rnd --steps 256 --warmup 16
+stats cfg2_f32_n65536 --instances 65536 --steps 64 --warmup 8
+stats cfg4_rnd --rnd --steps 256 --warmup 16
 stats cfg5_b1 --format b1 --size 512 --instances 4096 --rule B36/S23 --steps 64 --warmup 8
-stats u8_64 --format u8 --steps 256 --warmup 16
-stats u8_256 --format u8 --size 256 --steps 64 --warmup 8
 stats f32_256 --size 256 --steps 64 --warmup 8
-for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $O/pmc_$c.log 2>&1
-    cp $(find $O/pmc_$c -name "*counter_collection.csv" | head -1) $O/pmc_$c.csv
-    echo "done pmc $c"
-done
+: > $O/${TAG}_pmc.txt
+pmc cfg2 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 4096 64 f32
+pmc cfg2_n65536 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 65536 64 f32 --instances 65536
+pmc cfg4 "ca_step_rnd64_kernel<true>" 4096 64 f32 --rnd
+pmc cfg5 "ca_step_b1_kernel" 4096 512 b1 --format b1 --size 512 --instances 4096 --rule B36/S23
+cp $R/profiles/pmc_latest.json $O/pmc_latest.json
+echo "all done"
