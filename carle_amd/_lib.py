@@ -78,6 +78,16 @@ SIGNATURES = {
     "carle_env_step_f32_rand": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int,
                                          _c_u32, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64,
                                          _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
+    "carle_ca_step_u8_rand": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32, ctypes.c_float,
+                                       ctypes.c_uint64, ctypes.c_uint64, _c_vp, _c_vp, _c_int, _c_vp]),
+    "carle_ca_step_b1_rand": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32, ctypes.c_float,
+                                       ctypes.c_uint64, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
+    "carle_env_step_u8_rand": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
+                                        ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _c_vp, _c_int, _c_int,
+                                        _c_vp]),
+    "carle_env_step_b1_rand": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
+                                        ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _c_vp, _c_int, _c_int,
+                                        _c_vp]),
     "carle_instance_sums_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "carle_rle_encode_body": (_c_i64, [_c_vp, _c_int, _c_int, _c_vp, _c_i64]),
     "carle_rle_decode_body": (_c_int, [ctypes.c_char_p, _c_i64, _c_vp, _c_int, _c_int]),

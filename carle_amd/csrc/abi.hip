@@ -271,6 +271,32 @@ extern "C" int carle_env_run_f32(float *buf_a, float *buf_b, const float *action
     return 0;
 }
 
+extern "C" int carle_ca_step_u8_rand(const uint8_t *, uint8_t *, int64_t, int, int, int, int, uint32_t, float, uint64_t,
+                                     uint64_t, float *, int32_t *, int, void *);
+extern "C" int carle_ca_step_b1_rand(const uint64_t *, uint64_t *, int64_t, int, int, int, int, uint32_t, float,
+                                     uint64_t, uint64_t, int32_t *, int, void *);
+
+// Whole CARLE.step with the fused device-side random agent on uint8 / bit-packed state.
+extern "C" int carle_env_step_u8_rand(const uint8_t *u_in, uint8_t *u_out, float *reward, int64_t n, int h, int w,
+                                      int ah, int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset,
+                                      int32_t *status, int slot, int step_flags, void *stream) {
+    if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_u8_rand: status is NULL");
+    if (int e = carle_ca_step_u8_rand(u_in, u_out, n, h, w, ah, aw, rule, p, seed, offset, nullptr, status, slot, stream))
+        return e;
+    return ca_finish_impl(u_out, (int64_t)n * h * w, reward, n, status, slot, 1, nullptr, 0, nullptr, 0.0f,
+                          step_flags & CARLE_STEP_MERGE_MOMENTS, stream);
+}
+
+extern "C" int carle_env_step_b1_rand(const uint64_t *u_in, uint64_t *u_out, float *reward, int64_t n, int h, int w,
+                                      int ah, int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset,
+                                      int32_t *status, int slot, int step_flags, void *stream) {
+    if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_b1_rand: status is NULL");
+    if (int e = carle_ca_step_b1_rand(u_in, u_out, n, h, w, ah, aw, rule, p, seed, offset, status, slot, stream))
+        return e;
+    return ca_finish_impl(u_out, (int64_t)n * h * (w / 8), reward, n, status, slot, 1, nullptr, 0, nullptr, 0.0f,
+                          step_flags & CARLE_STEP_MERGE_MOMENTS, stream);
+}
+
 // Orders `to_stream` after everything enqueued so far on `from_stream` (event record + wait):
 // lets the reward networks of step t run on their own stream beside the CA kernel of step t+1.
 extern "C" int carle_stream_fork(void *event, void *from_stream, void *to_stream) {

@@ -12,6 +12,7 @@
 // (ca_bits.hpp).  No MFMA, no LDS.
 #include "ca_bits.hpp"
 #include "common.hpp"
+#include "philox.hpp"
 #include <stdlib.h>
 
 // Diagnostic build only (tools/kbench/ca_b1_variants.hip defines CARLE_B1_STAMPS): every wave records
@@ -105,6 +106,21 @@ __device__ __forceinline__ void toggle_row64(uint64_t (&c)[WW], const uint64_t *
     if (ok) seen_and &= lo & hi;
 }
 
+// The same with the two action dwords already in registers (the in-kernel random agent).
+template <int WW>
+__device__ __forceinline__ void toggle_words64(uint64_t (&c)[WW], uint32_t lo, uint32_t hi, bool ok,
+                                               uint32_t &seen_or, uint32_t &seen_and) {
+    const uint32_t l = ok ? lo : 0u, h = ok ? hi : 0u;
+    if constexpr (WW == 1) {
+        c[0] ^= ((uint64_t)h << 32) | l;
+    } else {
+        c[(WW - 1) / 2] ^= (uint64_t)l << 32;
+        c[(WW - 1) / 2 + 1] ^= (uint64_t)h;
+    }
+    seen_or |= l | h;
+    if (ok) seen_and &= lo & hi;
+}
+
 // RULE_MODE: the two rules of the BASELINE configs get a 2-instruction closed form; everything
 // else goes through the rule-independent 17-instruction multiplexer tree (no per-rule branches,
 // no extra live registers -- the branchy sparse form measured slower here: 142 VGPRs).
@@ -126,12 +142,27 @@ __device__ __forceinline__ uint32_t next_state(const Count4<uint32_t> &n, uint32
     }
 }
 
+// the fused device-side random agent (ACT == 1, RAND): the 64 toggles of an action row are drawn in
+// the kernel with the counter layout of philox.hpp (element index of the (N,1,64,64) action tensor),
+// bit-identical to packing carle_bernoulli_f32's output
+struct RandB1 {
+    float p = 0.0f;
+    uint64_t seed = 0, offset = 0;
+};
+__device__ __forceinline__ uint64_t drawn_row64(int64_t g, int ay, const RandB1 &ra) {
+    const uint64_t q0 = (uint64_t)((g * 64 + ay) * 64) >> 2;        // first quad of action row ay of grid g
+    uint64_t wrd = 0ull;
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) wrd |= (uint64_t)bernoulli_nibble(q0 + c, ra.seed, ra.offset, ra.p) << (4 * c);
+    return wrd;
+}
+
 // ACT: 0 = no action, 1 = 64-column window (toggle_row64), 2 = any packed window (toggle_row)
-template <int WW, int ACT, int RULE_MODE>
+template <int WW, int ACT, int RULE_MODE, bool RAND = false>
 __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     const uint64_t *__restrict__ u_in, const uint64_t *__restrict__ act, uint64_t *__restrict__ u_out,
     int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot,
-    int strip_first, int strip_count) {
+    int strip_first, int strip_count, RandB1 ra = RandB1()) {
     // the launch covers strips [strip_first, strip_first + strip_count) (mod WW) of every grid:
     // wide windows: the host launches the strips that can meet the action window with ACT = 2 and
     // the others with the leaner ACT = 0 instantiation (half the registers)
@@ -171,10 +202,23 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
             const uint64_t *ga = act + g * (int64_t)ah;
             uint32_t s_or = 0u, s_and = 0xFFFFFFFFu, d0 = 0u, d1 = 0xFFFFFFFFu;
             const bool in = r >= oy && r < oy + ah;
+            if (RAND) {
+                // only the lanes under the window draw (a halo row draws the same bits as the strip
+                // that owns the row: the toggles are a pure function of the element index)
+                uint64_t wrd = 0ull, hwrd = 0ull;
+                if (in) wrd = drawn_row64(g, r - oy, ra);
+                toggle_words64<WW>(c, (uint32_t)wrd, (uint32_t)(wrd >> 32), in, s_or, s_and);
+                if (MULTI) {
+                    const bool hin = hr >= oy && hr < oy + ah;
+                    if (hin) hwrd = drawn_row64(g, hr - oy, ra);
+                    toggle_words64<WW>(hal, (uint32_t)hwrd, (uint32_t)(hwrd >> 32), hin, d0, d1);
+                }
+            } else {
             toggle_row64<WW>(c, ga + (in ? r - oy : 0), in, s_or, s_and);
             if (MULTI) {
                 const bool hin = hr >= oy && hr < oy + ah;
                 toggle_row64<WW>(hal, ga + (hin ? hr - oy : 0), hin, d0, d1);
+            }
             }
             if (status != nullptr) {
                 const bool any = __ballot(s_or != 0u) != 0ull;
@@ -450,6 +494,26 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
 }
 
 template <int WW>
+static int launch_b1_rand(const uint64_t *u_in, uint64_t *u_out, int64_t n, uint32_t rule, const RandB1 &ra,
+                          int32_t *status, int slot, hipStream_t s) {
+    const int64_t n8 = (n + 7) / 8 * 8;
+    if (n8 * WW > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1_rand: batch too large");
+    const int64_t wg = n8 * WW, cap = 8 * 1021;
+    const dim3 grid((unsigned)(wg < cap ? wg : cap)), block(64);
+    const uint64_t *none = nullptr;
+    if (rule == kLifeMask)
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleLife, true>), grid, block, 0, s, u_in, none, u_out, n, 64, 64,
+                           rule, status, slot, 0, WW, ra);
+    else if (rule == kHighLifeMask)
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleHighLife, true>), grid, block, 0, s, u_in, none, u_out, n, 64,
+                           64, rule, status, slot, 0, WW, ra);
+    else
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleGeneric, true>), grid, block, 0, s, u_in, none, u_out, n, 64, 64,
+                           rule, status, slot, 0, WW, ra);
+    return check_launch("carle_ca_step_b1_rand");
+}
+
+template <int WW>
 static int launch_b1(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
                      int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
     if (rule == kLifeMask)
@@ -487,6 +551,34 @@ extern "C" int carle_ca_step_b1(const uint64_t *u_in, const uint64_t *action, ui
         case 128: return launch_b1<2>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
         case 256: return launch_b1<4>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
         default: return launch_b1<8>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
+    }
+}
+
+// carle_ca_step_b1 with the 64x64 action window drawn in the kernel (device-side RandomAgent,
+// carle/agents.py:35-42): identical to packing carle_bernoulli_f32(seed, offset) and passing it in.
+extern "C" int carle_ca_step_b1_rand(const uint64_t *u_in, uint64_t *u_out, int64_t n, int h, int w, int ah, int aw,
+                                     uint32_t rule, float p, uint64_t seed, uint64_t offset, int32_t *status,
+                                     int slot, void *stream) {
+    if (n == 0) return 0;
+    if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_step_b1_rand: u_in/u_out is NULL");
+    if (int e = check_dims(n, h, w, true, ah, aw)) return e;
+    if (w != 64 && w != 128 && w != 256 && w != 512)
+        return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1_rand: W must be 64, 128, 256 or 512");
+    if (aw != 64) return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1_rand: the fused random agent covers the 64x64 window");
+    if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_ca_step_b1_rand: rule mask exceeds 18 bits");
+    if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1_rand: slot must be 0 or 1");
+    if (!aligned16(u_in) || !aligned16(u_out))
+        return fail_arg(CARLE_E_ALIGN, "carle_ca_step_b1_rand: pointers must be 16-byte aligned");
+    const size_t bytes = (size_t)n * h * (w / 8);
+    if (overlap(u_in, bytes, u_out, bytes)) return fail_arg(CARLE_E_ALIAS, "carle_ca_step_b1_rand: u_in and u_out overlap");
+    RandB1 ra;
+    ra.p = p; ra.seed = seed; ra.offset = offset;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (w) {
+        case 64: return launch_b1_rand<1>(u_in, u_out, n, rule, ra, status, slot, s);
+        case 128: return launch_b1_rand<2>(u_in, u_out, n, rule, ra, status, slot, s);
+        case 256: return launch_b1_rand<4>(u_in, u_out, n, rule, ra, status, slot, s);
+        default: return launch_b1_rand<8>(u_in, u_out, n, rule, ra, status, slot, s);
     }
 }
 

@@ -600,46 +600,64 @@ extern "C" int carle_ca_toggle_u8(const uint8_t *u_in, const void *action, int a
 }
 
 // CARLE.step with the device-side RandomAgent fused in (carle/agents.py:35-42 + env.py:188-242):
-// Bernoulli(p) toggles over the centred AW x AW window, drawn in the step kernel.
-extern "C" int carle_ca_step_f32_rand(const float *u_in, float *u_out, int64_t n, int h, int w,
-                                      int ah, int aw, uint32_t rule, float p, uint64_t seed,
-                                      uint64_t offset, float *action_out, int32_t *status, int slot,
-                                      void *stream) {
+// Bernoulli(p) toggles over the centred AW x AW window, drawn in the step kernel; fp32 or uint8 state.
+namespace carle {
+template <class C>
+static int ca_step_cells_rand(const typename C::T *u_in, typename C::T *u_out, int64_t n, int h, int w, int ah,
+                              int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset, float *action_out,
+                              int32_t *status, int slot, void *stream, const char *who) {
+    auto fail = [&](int code, const char *what) {
+        char buf[320];
+        snprintf(buf, sizeof buf, "%s: %s", who, what);
+        return fail_arg(code, buf);
+    };
     if (n == 0) return 0;
-    if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_step_f32_rand: u_in/u_out is NULL");
+    if (!u_in || !u_out) return fail(CARLE_E_NULL, "u_in/u_out is NULL");
     if (int e = check_dims(n, h, w, true, ah, aw)) return e;
     const bool fast64 = h == 64 && (aw % 8) == 0;
     const bool wide = (h == 256 || h == 512) && (aw % 4) == 0 && ((w - aw) % 8) == 0;
     if (!fast64 && !wide)
-        return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: fused random toggles need 64x64 grids with "
-                                      "AW % 8 == 0, or 256 / 512 grids with AW % 4 == 0 and (W-AW) % 8 == 0 "
-                                      "(generate the action with carle_bernoulli_f32 otherwise)");
-    if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_ca_step_f32_rand: rule mask exceeds 18 bits");
-    if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: slot must be 0 or 1");
+        return fail(CARLE_E_DIMS, "fused random toggles need 64x64 grids with AW % 8 == 0, or 256 / 512 grids with "
+                                  "AW % 4 == 0 and (W-AW) % 8 == 0 (generate the action with carle_bernoulli_f32 "
+                                  "otherwise)");
+    if (rule >> 18) return fail(CARLE_E_RULE, "rule mask exceeds 18 bits");
+    if (slot != 0 && slot != 1) return fail(CARLE_E_DIMS, "slot must be 0 or 1");
     if (!aligned16(u_in) || !aligned16(u_out) || (action_out && !aligned16(action_out)))
-        return fail_arg(CARLE_E_ALIGN, "carle_ca_step_f32_rand: pointers must be 16-byte aligned");
-    const size_t bytes = (size_t)n * h * w * sizeof(float);
-    if (overlap(u_in, bytes, u_out, bytes))
-        return fail_arg(CARLE_E_ALIAS, "carle_ca_step_f32_rand: u_in and u_out overlap");
-    if (n == 0) return 0;
-    if (n > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: batch too large");
+        return fail(CARLE_E_ALIGN, "pointers must be 16-byte aligned");
+    const size_t bytes = (size_t)n * h * w * sizeof(typename C::T);
+    if (overlap(u_in, bytes, u_out, bytes)) return fail(CARLE_E_ALIAS, "u_in and u_out overlap");
+    if (n > 0x7FFFFFFFll) return fail(CARLE_E_DIMS, "batch too large");
     RandAct ra;
     ra.p = p; ra.seed = seed; ra.offset = offset; ra.action_out = action_out;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     if (wide) {
         const int64_t wgs = n * (h / (16 * kWideRW));
-        if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_f32_rand: batch too large");
+        if (wgs > 0x7FFFFFFFll) return fail(CARLE_E_DIMS, "batch too large");
         if (h == 256)
-            hipLaunchKernelGGL((ca_step_wide_kernel<F32Cells, F32Cells, true, 1, kWideRW, true>), dim3((unsigned)wgs),
-                               dim3(64), 0, static_cast<hipStream_t>(stream), u_in, (const float *)nullptr, u_out, n,
-                               ah, aw, rule, status, slot, ra);
+            hipLaunchKernelGGL((ca_step_wide_kernel<C, F32Cells, true, 1, kWideRW, true>), dim3((unsigned)wgs), dim3(64), 0, s,
+                               u_in, (const float *)nullptr, u_out, n, ah, aw, rule, status, slot, ra);
         else
-            hipLaunchKernelGGL((ca_step_wide_kernel<F32Cells, F32Cells, true, 2, kWideRW, true>), dim3((unsigned)wgs),
-                               dim3(64), 0, static_cast<hipStream_t>(stream), u_in, (const float *)nullptr, u_out, n,
-                               ah, aw, rule, status, slot, ra);
-        return check_launch("carle_ca_step_f32_rand");
+            hipLaunchKernelGGL((ca_step_wide_kernel<C, F32Cells, true, 2, kWideRW, true>), dim3((unsigned)wgs), dim3(64), 0, s,
+                               u_in, (const float *)nullptr, u_out, n, ah, aw, rule, status, slot, ra);
+        return check_launch(who);
     }
-    hipLaunchKernelGGL((ca_step_64_kernel<F32Cells, F32Cells, true, true, true, 64, true>),
-                       dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), u_in,
-                       (const float *)nullptr, u_out, n, aw, rule, status, slot, ra);
-    return check_launch("carle_ca_step_f32_rand");
+    hipLaunchKernelGGL((ca_step_64_kernel<C, F32Cells, true, true, true, 64, true>), dim3((unsigned)n), dim3(64), 0, s,
+                       u_in, (const float *)nullptr, u_out, n, aw, rule, status, slot, ra);
+    return check_launch(who);
+}
+}  // namespace carle
+
+extern "C" int carle_ca_step_f32_rand(const float *u_in, float *u_out, int64_t n, int h, int w,
+                                      int ah, int aw, uint32_t rule, float p, uint64_t seed,
+                                      uint64_t offset, float *action_out, int32_t *status, int slot,
+                                      void *stream) {
+    return ca_step_cells_rand<F32Cells>(u_in, u_out, n, h, w, ah, aw, rule, p, seed, offset, action_out, status, slot,
+                                        stream, "carle_ca_step_f32_rand");
+}
+
+extern "C" int carle_ca_step_u8_rand(const uint8_t *u_in, uint8_t *u_out, int64_t n, int h, int w, int ah, int aw,
+                                     uint32_t rule, float p, uint64_t seed, uint64_t offset, float *action_out,
+                                     int32_t *status, int slot, void *stream) {
+    return ca_step_cells_rand<U8Cells>(u_in, u_out, n, h, w, ah, aw, rule, p, seed, offset, action_out, status, slot,
+                                       stream, "carle_ca_step_u8_rand");
 }

@@ -559,6 +559,18 @@ class CARLEPacked(CARLE):
             act = act.contiguous()
         else:
             if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
+                if (tuple(action.shape) == (self.instances, 1, 64, 64) and self.action_width == 64
+                        and not self.exact_action_predicates):
+                    # the toggles are drawn inside the packed step kernel: no action tensor exists
+                    out = torch.empty_like(bits)
+                    reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
+                    merge = self.__dict__.get("_final_reward_stats") is not None
+                    hip.env_step_b1_rand(bits, out, reward, self.rule_mask(), self._status, slot, 64, 64,
+                                         action.p, action.seed, action.offset, merge)
+                    self._moments_merged = merge
+                    self._slot = slot ^ 1
+                    d["_bits"], d["_f32"] = out, None
+                    return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
                 action = action.materialize()
             a32, cropped, full = self._device_action(action)
             if self.exact_action_predicates:
@@ -691,6 +703,20 @@ class CARLEBytes(CARLE):
         u_in = self._device_universe()
         slot = self._slot
         if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
+            aw = self.action_width
+            if (tuple(action.shape) == (self.instances, 1, aw, self.action_height) and not self.exact_action_predicates
+                    and ((self.height == 64 and aw % 8 == 0) or
+                         (self.height in (256, 512) and aw % 4 == 0 and (self.width - aw) % 8 == 0))):
+                # the toggles are drawn inside the step kernel: no action tensor exists
+                out = torch.empty_like(u_in)
+                reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
+                merge = self.__dict__.get("_final_reward_stats") is not None
+                hip.env_step_u8_rand(u_in, out, reward, self.rule_mask(), self._status, slot, self.action_height, aw,
+                                     action.p, action.seed, action.offset, merge)
+                self._moments_merged = merge
+                self._slot = slot ^ 1
+                self.universe = out
+                return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
             action = action.materialize()
         if (isinstance(action, torch.Tensor) and action.dtype == torch.uint8 and action.is_cuda
                 and tuple(action.shape) == (self.instances, 1, self.action_width, self.action_height)):

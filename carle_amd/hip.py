@@ -486,6 +486,30 @@ def env_step_f32_rand(u_in, u_out, reward, rule, status, slot, ah, aw, p, seed, 
         _lib.check(rc, "carle_env_step_f32_rand")
 
 
+def env_step_u8_rand(u_in, u_out, reward, rule, status, slot, ah, aw, p, seed, offset, merge_moments=False):
+    """CARLE.step on uint8 state with Bernoulli(p) toggles drawn inside the step kernel."""
+    lib = _lib.load()
+    n, _, h, w = u_in.shape
+    with _on_device(u_in.device):
+        rc = lib.carle_env_step_u8_rand(u_in.data_ptr(), u_out.data_ptr(), reward.data_ptr(), n, h, w, ah, aw, rule,
+                                        float(p), int(seed), int(offset), status.data_ptr(), slot,
+                                        _step_flags(False, merge_moments), _stream(u_in))
+    if rc != 0:
+        _lib.check(rc, "carle_env_step_u8_rand")
+
+
+def env_step_b1_rand(u_in, u_out, reward, rule, status, slot, ah, aw, p, seed, offset, merge_moments=False):
+    """CARLE.step on bit-packed state with the 64x64 Bernoulli(p) window drawn inside the step kernel."""
+    lib = _lib.load()
+    n, _, h, ww = u_in.shape
+    with _on_device(u_in.device):
+        rc = lib.carle_env_step_b1_rand(u_in.data_ptr(), u_out.data_ptr(), reward.data_ptr(), n, h, ww * 64, ah, aw,
+                                        rule, float(p), int(seed), int(offset), status.data_ptr(), slot,
+                                        _step_flags(False, merge_moments), _stream(u_in))
+    if rc != 0:
+        _lib.check(rc, "carle_env_step_b1_rand")
+
+
 def instance_sums_f32(x, w0=None, w1=None, w2=None):
     """(N,4) fp32: per-instance [sum x, sum x*w0, sum x*w1, sum x*w2] over all trailing dims; the
     weight planes (same element count as one instance) are optional."""

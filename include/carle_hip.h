@@ -337,6 +337,23 @@ int carle_env_step_f32_rand(const float *u_in, float *u_out, float *reward, int6
                             int ah, int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset,
                             float *action_out, int32_t *status, int slot, int step_flags, void *stream);
 
+/* The fused random agent on uint8 state (same geometries as carle_ca_step_f32_rand) and on bit-packed
+ * state (H == W in {64, 128, 256, 512}, the 64x64 window): bit-identical to generating the action with
+ * carle_bernoulli_f32(seed, offset) and passing it (packed) to carle_ca_step_u8 / carle_ca_step_b1.
+ * (carle/agents.py:35-42 + carle/env.py:150-182, 219-229.)  carle_env_step_*_rand = + carle_ca_finish. */
+int carle_ca_step_u8_rand(const uint8_t *u_in, uint8_t *u_out, int64_t n, int h, int w, int ah, int aw,
+                          uint32_t rule, float p, uint64_t seed, uint64_t offset, float *action_out,
+                          int32_t *status, int slot, void *stream);
+int carle_ca_step_b1_rand(const uint64_t *u_in, uint64_t *u_out, int64_t n, int h, int w, int ah, int aw,
+                          uint32_t rule, float p, uint64_t seed, uint64_t offset, int32_t *status, int slot,
+                          void *stream);
+int carle_env_step_u8_rand(const uint8_t *u_in, uint8_t *u_out, float *reward, int64_t n, int h, int w,
+                           int ah, int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset,
+                           int32_t *status, int slot, int step_flags, void *stream);
+int carle_env_step_b1_rand(const uint64_t *u_in, uint64_t *u_out, float *reward, int64_t n, int h, int w,
+                           int ah, int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset,
+                           int32_t *status, int slot, int step_flags, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-instance sums for the hand-coded reward wrappers: for every instance i
  * of x (n x elems floats): out4[4i] = sum x, out4[4i+k+1] = sum x * w_k for the (nullable) weight

@@ -88,3 +88,41 @@ def test_random_network_agent():
     a = agent((torch.rand(3, 1, 64, 64, device="cuda") < 0.3).float())
     assert tuple(a.shape) == (3, 1, 64, 64) and a.is_cuda
     assert set(torch.unique(a).cpu().tolist()) <= {0.0, 1.0}
+
+
+@pytest.mark.parametrize("storage,n,size", [("u8", 3, 64), ("u8", 37, 64), ("u8", 2, 256), ("u8", 1, 512),
+                                             ("b1", 3, 64), ("b1", 70, 64), ("b1", 2, 128), ("b1", 3, 256),
+                                             ("b1", 2, 512)])
+def test_fused_random_step_on_u8_and_packed_state(storage, n, size, monkeypatch):
+    """RandomAgent(fused=True) on uint8 / bit-packed state: the toggles are drawn inside the step
+    kernel (carle_env_step_u8_rand / carle_env_step_b1_rand), bit-identical to the materialised
+    action through the same storage and to the oracle; counters and flags included."""
+    from carle_amd.agents import RandomAgent
+    from carle_amd.env import CARLE
+    from carle_amd import hip
+    calls = []
+    for name in ("env_step_u8_rand", "env_step_b1_rand"):
+        orig = getattr(hip, name)
+        monkeypatch.setattr(hip, name, (lambda o, nm: lambda *a, **k: (calls.append(nm), o(*a, **k))[1])(orig, name))
+    if True:
+        envs = [CARLE(width=size, height=size, instances=n, device="cuda:0", storage=storage, obs="f32")
+                for _ in range(2)]
+        u0 = (torch.rand(n, 1, size, size) < 0.4).float()
+        for e in envs:
+            e.rules_from_string("B36/S23")
+            e.reset()
+            e.universe = u0.clone().cuda()
+        fused = RandomAgent(action_width=64, action_height=64, fused=True, seed=5)
+        plain = RandomAgent(action_width=64, action_height=64, fused=False, seed=5)
+        u_np = u0.numpy()
+        mask = O.rule_mask([3, 6], [2, 3])
+        for t in range(4):
+            o0 = envs[0].step(fused(envs[0].universe))[0]
+            a = plain(envs[1].universe)
+            o1 = envs[1].step(a)[0]
+            u_np, _, _ = O.c_env_step(u_np, a.cpu().numpy(), mask)
+            assert torch.equal(o0, o1)
+            assert np.array_equal(o0.cpu().numpy(), u_np)
+        assert envs[0].step_number == envs[1].step_number == 4
+        assert envs[0].steps_since_action == envs[1].steps_since_action == 0
+        assert len(calls) == 4 and set(calls) == {"env_step_%s_rand" % storage}     # the fused entry really ran
