@@ -21,6 +21,7 @@
 // the action (fp32 as the reference's agents produce it, or uint8); 1 B + 1 B per cell update.
 //
 // Generic path (any even square size): one thread per cell, neighbours through L1/L2.
+#include <stdlib.h>
 #include "ca_cells.hpp"
 #include "philox.hpp"
 
@@ -232,13 +233,17 @@ __global__ __launch_bounds__(64) void ca_step_wide_kernel(
     constexpr int W = WideGeom<NS, RW>::kW, H = W, R = WideGeom<NS, RW>::kR;
     constexpr int kStrips = H / R;
     const int k = threadIdx.x;                       // lane = column quad
-    // XCD-aware, bijective remap of the workgroup id (cdna_hip_programming.md T1)
-    const int64_t nwg = gridDim.x, b = blockIdx.x;
-    const int64_t qd = nwg / 8, rm = nwg % 8, xcd = b % 8;
+    // XCD-aware bijective remap of the list position (cdna_hip_programming.md T1): positions b, b + 8,
+    // ... share an XCD and map to consecutive strips (halo rows are L2 hits).  The loop runs once per
+    // workgroup in the shipped launch (one workgroup per strip); a capped launch walks the list with
+    // stride gridDim.x (then a multiple of 8).
+    const int64_t nwg = n * kStrips;
+    const int64_t qd = nwg / 8, rm = nwg % 8;
+  for (int64_t b = blockIdx.x; b < nwg; b += gridDim.x) {
+    const int64_t xcd = b % 8;
     const int64_t wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + b / 8;
     const int64_t g = wid / kStrips;
     const int r0 = (int)(wid % kStrips) * R;
-    if (g >= n) return;
     const typename C::T *gin = u_in + g * (int64_t)H * W;
     const int rt = (r0 + H - 1) % H, rb = (r0 + R) % H;      // halo rows (torus in y)
 
@@ -375,6 +380,17 @@ __global__ __launch_bounds__(64) void ca_step_wide_kernel(
                                         (uint32_t)(nx >> (4 * i)) & 0xFu);
         }
     }
+  }
+}
+
+// Launch size of the wavefront-per-strip kernels: one workgroup per strip.  (The kernels can walk the
+// strip list persistently, and the bit-packed kernel gains 9 % that way, but here -- 62-90 VGPRs,
+// 5-8 waves per SIMD, strips of unequal cost under the action window -- the one-shot launch measured
+// 6-20 % faster: profiles/r02_kbench_wide.txt.  CARLE_WIDE_BLOCKS caps the launch for experiments.)
+static unsigned persistent_blocks(int64_t work_items) {
+    int64_t cap = work_items;
+    if (const char *e = getenv("CARLE_WIDE_BLOCKS")) { const int64_t v = atoll(e); if (v >= 8) cap = v / 8 * 8; }
+    return (unsigned)(work_items < cap ? work_items : cap);
 }
 
 template <class C, class A, int NS, int RW>
@@ -384,10 +400,10 @@ static int launch_wide(const typename C::T *u_in, const typename A::T *action, t
     const int64_t wgs = n * (WideGeom<NS, RW>::kW / WideGeom<NS, RW>::kR);
     if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step: batch too large");
     if (action)
-        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW>), dim3((unsigned)wgs), dim3(64), 0,
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW>), dim3(persistent_blocks(wgs)), dim3(64), 0,
                            s, u_in, action, u_out, n, ah, aw, rule, status, slot);
     else
-        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, false, NS, RW>), dim3((unsigned)wgs), dim3(64), 0,
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, false, NS, RW>), dim3(persistent_blocks(wgs)), dim3(64), 0,
                            s, u_in, action, u_out, n, 0, 0, rule, status, slot);
     return check_launch("carle_ca_step(wide)");
 }
@@ -634,10 +650,10 @@ static int ca_step_cells_rand(const typename C::T *u_in, typename C::T *u_out, i
         const int64_t wgs = n * (h / (16 * kWideRW));
         if (wgs > 0x7FFFFFFFll) return fail(CARLE_E_DIMS, "batch too large");
         if (h == 256)
-            hipLaunchKernelGGL((ca_step_wide_kernel<C, F32Cells, true, 1, kWideRW, true>), dim3((unsigned)wgs), dim3(64), 0, s,
+            hipLaunchKernelGGL((ca_step_wide_kernel<C, F32Cells, true, 1, kWideRW, true>), dim3(persistent_blocks(wgs)), dim3(64), 0, s,
                                u_in, (const float *)nullptr, u_out, n, ah, aw, rule, status, slot, ra);
         else
-            hipLaunchKernelGGL((ca_step_wide_kernel<C, F32Cells, true, 2, kWideRW, true>), dim3((unsigned)wgs), dim3(64), 0, s,
+            hipLaunchKernelGGL((ca_step_wide_kernel<C, F32Cells, true, 2, kWideRW, true>), dim3(persistent_blocks(wgs)), dim3(64), 0, s,
                                u_in, (const float *)nullptr, u_out, n, ah, aw, rule, status, slot, ra);
         return check_launch(who);
     }
