@@ -7,12 +7,12 @@
 //     built once per call by rnd_prepare_kernel (1.5k patterns x 9 fma) and sit in LDS;
 //   * one workgroup per grid: the grid sits in LDS as 64 row words, thread = one 4x4 pooling
 //     window reads its 6x6 neighbourhood from them (zero padding = two zero rows + shifts);
-//   * pooled conv1 maps (6 x 16x16) go to a zero-bordered LDS image; conv2 + relu + 2x2 pool, the
-//     64->16 linear layers + tanh and the bonus reduction run from LDS on one wave;
+//   * pooled conv1 maps (6 x 16x16) go to a zero-bordered LDS image; conv2 + relu + 2x2 pool runs
+//     from LDS on all four waves, the 64->16 linear layers + tanh and the bonus on one;
 //   * HBM traffic per grid: 16 KiB in (fp32 obs) or 512 B (bit-packed obs), 4 B out.
 // Workgroups are persistent: they stride over grids, so the 21 KiB table load is amortised, and 4
-// of them per CU (33 KB of LDS each) are in different phases.  (The training kernels further down
-// keep the older wavefront-per-grid decomposition.)
+// of them per CU (33 KB of LDS each) are in different phases.  The training kernels further down
+// (forward + backward) use the same workgroup-per-grid decomposition.
 #include "rnd_device.hpp"
 
 namespace carle {
@@ -168,7 +168,6 @@ int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, con
 //   * A1 (4 x 32x32), A2 (2 x 16x16) and A3 (32x32) live in zero-bordered LDS planes; A3 overlays
 //     A1.  Row strides of 36 / 20 floats spread the 8-byte patch reads over the banks;
 //   * every thread finally reconstructs its own 4x4 cells and accumulates (obs - sigmoid)^2.
-// (The forward+backward kernels further down keep the older wavefront-per-grid decomposition.)
 namespace carle {
 
 static constexpr int kAeLutFloats = 512 * 4;
