@@ -452,6 +452,10 @@ def run_rank(args):
         if rs is not None:
             rs.join()
 
+    if args.train and args.warmup < 136:
+        # the first Adam step of a process loads torch's optimiser kernels (tens of milliseconds, once):
+        # it must fall into the warm-up, i.e. the warm-up has to cover two update windows of 64 steps
+        args.warmup = 136
     for i in range(args.warmup):
         one_step(i)
     join_rewards()
