@@ -46,6 +46,8 @@ SIGNATURES = {
     "carle_ca_step_f32_rnd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
                                        _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
     "carle_rnd2d_train_partial_floats": (_c_i64, [_c_i64]),
+    "carle_rnd2d_train_scratch_floats": (_c_i64, [_c_i64, _c_int, _c_int]),
+    "carle_ae2d_train_scratch_floats": (_c_i64, [_c_i64, _c_int, _c_int]),
     "carle_rnd2d_train_f32": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                        _c_vp, _c_vp, ctypes.c_float, ctypes.c_float, _c_int, _c_vp]),
     "carle_rnd2d_train_b1": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,

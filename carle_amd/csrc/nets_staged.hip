@@ -359,6 +359,8 @@ static inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 25
 
 }  // namespace carle
 
+#include "nets_staged_bwd.hpp"      // staged backward kernels: launch the forward kernels above
+
 namespace carle {
 int64_t rnd2d_fused_workspace_floats();
 int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp,
@@ -496,10 +498,19 @@ static int rnd2d_train_common(const void *obs, int obs_mode, int64_t n, int h, i
                               float reward_scale, float grad_scale, int flags, void *stream) {
     if (!obs || !pred_params || !rand_params || !workspace || !partial || !grad || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_rnd2d_train: NULL pointer");
-    if (h != 64 || w != 64 || n < 0)
-        return fail_arg(CARLE_E_DIMS, "carle_rnd2d_train: the fused gradient kernel supports 64x64 grids");
-    if (obs_mode == 0 && (!(flags & CARLE_NET_OBS_BINARY) || !aligned16(obs)))
-        return fail_arg(CARLE_E_FORMAT, "carle_rnd2d_train: fp32 observations must be binary (flag) and aligned");
+    if (n < 0) return fail_arg(CARLE_E_DIMS, "carle_rnd2d_train: negative batch");
+    const bool fused = h == 64 && w == 64 && (obs_mode == 1 || ((flags & CARLE_NET_OBS_BINARY) && aligned16(obs)));
+    if (!fused) {
+        // any other square size / non-binary fp32 observations: staged forward + staged backward kernels
+        // (nets_staged_bwd.hpp); `partial` must hold carle_rnd2d_train_scratch_floats(n, h, w) floats
+        if (obs_mode == 1)
+            return fail_arg(CARLE_E_DIMS, "carle_rnd2d_train_b1: bit-packed observations are supported for 64x64 grids");
+        if (int e = check_net_dims(n, h, w, "carle_rnd2d_train_f32")) return e;
+        if (n == 0) return 0;
+        return rnd2d_train_staged(static_cast<const float *>(obs), n, h, w, pred_params, rand_params, workspace,
+                                  partial, grad, bonus, reward_accum, reward_scale, grad_scale,
+                                  static_cast<hipStream_t>(stream));
+    }
     if (n == 0) return 0;
     return rnd2d_train64(obs, obs_mode, n, pred_params, rand_params, workspace, bonus, reward_accum,
                          reward_scale, grad_scale, partial, grad, (flags & CARLE_NET_TABLES_VALID) != 0,
@@ -535,10 +546,16 @@ static int ae2d_train_common(const void *obs, bool packed, int64_t n, int h, int
                              void *stream) {
     if (!obs || !params || !workspace || !partial || !grad || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_ae2d_train: NULL pointer");
-    if (h != 64 || w != 64 || n < 0)
-        return fail_arg(CARLE_E_DIMS, "carle_ae2d_train: the fused gradient kernel supports 64x64 grids");
-    if (!packed && (!(flags & CARLE_NET_OBS_BINARY) || !aligned16(obs)))
-        return fail_arg(CARLE_E_FORMAT, "carle_ae2d_train: fp32 observations must be binary (flag) and aligned");
+    if (n < 0) return fail_arg(CARLE_E_DIMS, "carle_ae2d_train: negative batch");
+    const bool fused = h == 64 && w == 64 && (packed || ((flags & CARLE_NET_OBS_BINARY) && aligned16(obs)));
+    if (!fused) {
+        if (packed)
+            return fail_arg(CARLE_E_DIMS, "carle_ae2d_train_b1: bit-packed observations are supported for 64x64 grids");
+        if (int e = check_net_dims(n, h, w, "carle_ae2d_train_f32")) return e;
+        if (n == 0) return 0;
+        return ae2d_train_staged(static_cast<const float *>(obs), n, h, w, params, workspace, partial, grad, bonus,
+                                 reward_accum, reward_scale, grad_scale, static_cast<hipStream_t>(stream));
+    }
     if (n == 0) return 0;
     return ae2d_train64(obs, packed, n, params, workspace, bonus, reward_accum, reward_scale, grad_scale,
                         partial, grad, (flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream));

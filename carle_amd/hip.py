@@ -567,15 +567,19 @@ def ca_step_f32_rnd(u_in, action, u_out, rule, status, slot, pred_params, rand_p
 
 
 def rnd2d_train(obs, pred_params, rand_params, workspace, partial, grad, bonus, reward, reward_scale,
-                grad_scale, tables_valid, stream=None):
-    """RND2D bonus + accumulated predictor gradient in one pass (64x64 binary obs, fp32 or packed)."""
+                grad_scale, tables_valid, stream=None, binary=True):
+    """RND2D bonus + accumulated predictor gradient in one pass: fused kernel for 64x64 binary obs
+    (fp32 or packed), staged forward + backward kernels for any other square fp32 obs (`binary`
+    False selects them at 64x64 too)."""
     lib = _lib.load()
     packed = obs.dtype == torch.int64
     n = obs.shape[0]
-    flags = 1 | (2 if tables_valid else 0)
+    h = obs.shape[2]
+    w = 64 if packed else obs.shape[3]
+    flags = (1 if binary else 0) | (2 if tables_valid else 0)
     with _on_device(obs.device):
         fn = lib.carle_rnd2d_train_b1 if packed else lib.carle_rnd2d_train_f32
-        rc = fn(obs.data_ptr(), n, 64, 64, pred_params.data_ptr(), rand_params.data_ptr(),
+        rc = fn(obs.data_ptr(), n, h, w, pred_params.data_ptr(), rand_params.data_ptr(),
                 workspace.data_ptr(), partial.data_ptr(), grad.data_ptr(), bonus.data_ptr(),
                 _ptr(reward), float(reward_scale), float(grad_scale), flags,
                 stream if stream is not None else _stream(obs))
@@ -584,15 +588,17 @@ def rnd2d_train(obs, pred_params, rand_params, workspace, partial, grad, bonus, 
 
 
 def ae2d_train(obs, params, workspace, partial, grad, bonus, reward, reward_scale, grad_scale,
-               tables_valid, stream=None):
-    """AE2D bonus + accumulated predictor gradient in one pass (64x64 binary obs, fp32 or packed)."""
+               tables_valid, stream=None, binary=True):
+    """AE2D bonus + accumulated predictor gradient in one pass (paths as for rnd2d_train)."""
     lib = _lib.load()
     packed = obs.dtype == torch.int64
     n = obs.shape[0]
-    flags = 1 | (2 if tables_valid else 0)
+    h = obs.shape[2]
+    w = 64 if packed else obs.shape[3]
+    flags = (1 if binary else 0) | (2 if tables_valid else 0)
     with _on_device(obs.device):
         fn = lib.carle_ae2d_train_b1 if packed else lib.carle_ae2d_train_f32
-        rc = fn(obs.data_ptr(), n, 64, 64, params.data_ptr(), workspace.data_ptr(), partial.data_ptr(),
+        rc = fn(obs.data_ptr(), n, h, w, params.data_ptr(), workspace.data_ptr(), partial.data_ptr(),
                 grad.data_ptr(), bonus.data_ptr(), _ptr(reward), float(reward_scale), float(grad_scale),
                 flags, stream if stream is not None else _stream(obs))
     if rc != 0:

@@ -399,41 +399,57 @@ class RND2D(Motivator):
         self._after_update()
         self.buffer_length = 0
 
+    # False: sizes without a fused gradient kernel retain the window and replay it through PyTorch
+    # autograd (the round-1 path; kept for A/B tests) instead of the staged HIP backward kernels
+    hip_backward_any_size = True
+
     def _fused_train(self, obs, reward, bonus_out, stream):
-        """Bonus + gradient in one HIP pass (carle_rnd2d_train_* / carle_ae2d_train_*): 64x64
-        binary observations.  Returns False when the fused kernel does not apply (the caller then
-        retains the observation for the autograd replay)."""
+        """Bonus + gradient in one library call (carle_rnd2d_train_* / carle_ae2d_train_*): the fused
+        forward+backward kernel for 64x64 binary observations, staged forward + staged backward HIP
+        kernels for every other square size that is a multiple of 8 (the reference's default 256x256).
+        Returns False when neither applies (the caller then retains the observation for the autograd
+        replay)."""
         is_ae = type(self) is AE2D
         if not is_ae and type(self) is not RND2D:
             return False
         o, binary = self._obs(obs, allow_packed=True)
-        if not binary or o.shape[2] != 64 or (o.dtype != torch.int64 and o.shape[3] != 64):
-            return False
+        packed = o.dtype == torch.int64
+        fused64 = binary and o.shape[2] == 64 and (packed or o.shape[3] == 64)
+        if not fused64:
+            if not self.hip_backward_any_size:
+                return False
+            if packed:
+                o, binary = self._obs(obs)                 # unpacked fp32
+            if o.dim() != 4 or o.shape[2] != o.shape[3] or o.shape[2] % 8 or o.shape[2] < 8:
+                return False
         from . import _lib
         lib = _lib.load()
-        dev, n = o.device, o.shape[0]
+        dev, n, size = o.device, o.shape[0], o.shape[2]
         pb = self._pred_blob.get(dev)
         rb = None if is_ae else self._rand_blob.get(dev)
-        need = (lib.carle_ae2d_workspace_floats if is_ae else lib.carle_rnd2d_workspace_floats)(n, 64, 64)
+        need = (lib.carle_ae2d_workspace_floats if is_ae else lib.carle_rnd2d_workspace_floats)(n, size, size)
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, dtype=torch.float32, device=dev)
             self._tables_key = None
-        pneed = (lib.carle_ae2d_train_partial_floats if is_ae else lib.carle_rnd2d_train_partial_floats)(n)
+        if fused64:
+            pneed = (lib.carle_ae2d_train_partial_floats if is_ae else lib.carle_rnd2d_train_partial_floats)(n)
+        else:
+            pneed = (lib.carle_ae2d_train_scratch_floats if is_ae else lib.carle_rnd2d_train_scratch_floats)(n, size, size)
         if self._partial is None or self._partial.numel() < pneed or self._partial.device != dev:
             self._partial = torch.empty(pneed, dtype=torch.float32, device=dev)
-        if self._grad is None or self._grad.device != dev:
+        if self._grad is None or self._grad.device != dev or self._grad.numel() != pb.numel():
             self._grad = torch.zeros(pb.numel(), dtype=torch.float32, device=dev)
         versions = (self._pred_blob.version,) if is_ae else (self._pred_blob.version, self._rand_blob.version)
-        valid = self._tables_key == (id(self._ws), versions)
+        valid = fused64 and self._tables_key == (id(self._ws), versions)
         if is_ae:
-            grad_scale = 2.0 / (64 * 64 * n * self.batch_size)
+            grad_scale = 2.0 / (size * size * n * self.batch_size)
             hip.ae2d_train(o, pb, self._ws, self._partial, self._grad, bonus_out, reward,
-                           self.reward_scale, grad_scale, valid, stream)
+                           self.reward_scale, grad_scale, valid, stream, binary=fused64)
         else:
             grad_scale = 2.0 / (self.rnd_dim * n * self.batch_size)
             hip.rnd2d_train(o, pb, rb, self._ws, self._partial, self._grad, bonus_out, reward,
-                            self.reward_scale, grad_scale, valid, stream)
-        self._tables_key = (id(self._ws), versions)
+                            self.reward_scale, grad_scale, valid, stream, binary=fused64)
+        self._tables_key = (id(self._ws), versions) if fused64 else None
         self._grad_used = True
         return True
 

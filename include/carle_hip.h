@@ -245,12 +245,20 @@ int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
                          float *reward_accum, float reward_scale, int flags, void *stream);
 
 /* RND2D bonus AND the predictor's gradient in one pass: replaces the autograd
- * graph the reference keeps alive across the update window (carle/mcl.py:343-386).  64x64 binary
- * observations, eval-mode semantics.  grad[0..1117) (predictor blob order) is ACCUMULATED:
+ * graph the reference keeps alive across the update window (carle/mcl.py:343-386).  Eval-mode
+ * semantics.  grad[0..77 + 16 D + 16) (predictor blob order, D = (H/8)(W/8); 1117 floats at 64x64)
+ * is ACCUMULATED:
  *   grad += d/dtheta [ grad_scale/2 * sum_i sum_k (target_ik - prediction_ik)^2 ],
  * so grad_scale = 2 / (16 * N * batch_size) reproduces sum_t mean_n mean_k(.)^2 / batch_size.
- * partial: scratch of carle_rnd2d_train_partial_floats(n) floats; workspace: as for the bonus. */
+ *   64x64 binary observations (CARLE_NET_OBS_BINARY, or bit-packed): one fused forward+backward
+ *     kernel; partial = scratch of carle_rnd2d_train_partial_floats(n) floats;
+ *   any other H == W multiple of 8 (the reference's default 256x256) or non-binary fp32 observations:
+ *     staged forward + staged backward kernels (pool / relu arg-max routing as ATen's max_pool2d
+ *     backward, gathered convolution gradients, deterministic row reductions); partial = scratch of
+ *     carle_rnd2d_train_scratch_floats(n, h, w) floats.
+ * workspace: carle_rnd2d_workspace_floats(n, h, w) floats, as for the bonus. */
 int64_t carle_rnd2d_train_partial_floats(int64_t n);
+int64_t carle_rnd2d_train_scratch_floats(int64_t n, int h, int w);
 int carle_rnd2d_train_f32(const float *obs, int64_t n, int h, int w, const float *pred_params,
                           const float *rand_params, float *workspace, float *partial, float *grad,
                           float *bonus, float *reward_accum, float reward_scale, float grad_scale,
@@ -261,8 +269,10 @@ int carle_rnd2d_train_b1(const uint64_t *obs, int64_t n, int h, int w, const flo
                          int flags, void *stream);
 
 /* The same for AE2D (carle/mcl.py:504-547): grad[0..164) accumulates
- * d/dtheta [ grad_scale/2 * sum_i sum_hw (obs_i - decoder(obs_i))^2 ]; grad_scale = 2/(H*W*N*batch_size). */
+ * d/dtheta [ grad_scale/2 * sum_i sum_hw (obs_i - decoder(obs_i))^2 ]; grad_scale = 2/(H*W*N*batch_size).
+ * Same two paths; the staged one needs partial = carle_ae2d_train_scratch_floats(n, h, w) floats. */
 int64_t carle_ae2d_train_partial_floats(int64_t n);
+int64_t carle_ae2d_train_scratch_floats(int64_t n, int h, int w);
 int carle_ae2d_train_f32(const float *obs, int64_t n, int h, int w, const float *params,
                          float *workspace, float *partial, float *grad, float *bonus,
                          float *reward_accum, float reward_scale, float grad_scale, int flags,

@@ -1,6 +1,8 @@
 """GPU parity tests of the RND2D / AE2D forward kernels (through the C ABI) against the golden
 outputs of the genuine reference and against the fp32 CPU oracle.  Tolerance: 1e-5 absolute
 (north star), stated per assert."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -500,3 +502,106 @@ def test_cfg3_full_size_against_the_oracle():
             exp = ON.rnd_bonus(torch.from_numpy(u_ref), sd).numpy()
         np.testing.assert_allclose(reward[idx, 0].cpu().numpy(), exp, rtol=0, atol=TOL)
     assert float(reward.min()) > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# staged backward kernels (any size that is a multiple of 8; the reference's default 256x256)
+# ---------------------------------------------------------------------------------------------
+def _autograd_grad(w, g):
+    """flat gradient of mean_n(loss_n) / batch_size through the nn.Sequential (eval mode)."""
+    w.predictor.zero_grad()
+    loss = torch.mean(w._torch_loss(g)) / w.batch_size
+    loss.backward()
+    return torch.cat([p.grad.reshape(-1) for p in w.predictor.parameters()]).cpu().numpy()
+
+
+@pytest.mark.parametrize("size,n,binary", [(8, 3, True), (32, 5, True), (64, 4, False), (128, 3, True),
+                                            (256, 2, True), (256, 16, True), (96, 2, False)])
+def test_staged_backward_matches_autograd(size, n, binary):
+    """carle_rnd2d_train_f32 / carle_ae2d_train_f32 on sizes without a fused gradient kernel (and on
+    non-binary observations): bonus = the forward bonus, accumulated gradient = autograd's, for both
+    nets; accumulation over two calls; deterministic (two runs bit-identical)."""
+    torch.manual_seed(size + n)
+    env, rnd, ae = _stack(size, n)
+    for w in (rnd, ae):
+        w.eval()
+    ae.reset()
+    g = torch.rand(n, 1, size, size, device="cuda")
+    g = (g < 0.3).float() if binary else g * (g < 0.5)
+    for w in (rnd, ae):
+        exp_bonus = w.get_bonus_only(g).clone()
+        ref = _autograd_grad(w, g)
+        runs = []
+        for rep in range(2):
+            w._grad = None
+            bonus = torch.empty(n, device="cuda")
+            reward = torch.zeros(n, 1, device="cuda")
+            for acc in range(2):
+                assert w._fused_train(g, reward, bonus, None)
+            runs.append(w._grad.cpu().numpy().copy())
+            np.testing.assert_allclose(bonus.cpu().numpy(), exp_bonus.cpu().numpy(), rtol=0, atol=1e-6)
+            np.testing.assert_allclose(reward.cpu().numpy()[:, 0], 2 * exp_bonus.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        assert np.array_equal(runs[0], runs[1])                      # deterministic reductions
+        scale = np.abs(ref).max()
+        assert scale > 0
+        np.testing.assert_allclose(runs[0], 2 * ref, rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=w.my_name)
+
+
+@pytest.mark.parametrize("size", [32, 256])
+def test_staged_backward_window_equals_autograd_replay(size):
+    """A whole update window (rewards + Adam) through the staged HIP backward kernels equals the
+    round-1 path (retained window + PyTorch autograd replay) on the same stack."""
+    outs = []
+    for hip_bwd in (True, False):
+        torch.manual_seed(31)
+        env, rnd, ae = _stack(size, 3)
+        for w in (rnd, ae):
+            w.hip_backward_any_size = hip_bwd
+            w.batch_size = 3
+            w.eval()
+        ae.reset()
+        gen = torch.Generator().manual_seed(4)
+        env.universe = (torch.rand(3, 1, size, size, generator=gen) < 0.3).float().cuda()
+        rews = []
+        for t in range(7):                                          # two updates + one pending step
+            a = (torch.rand(3, 1, min(64, size), min(64, size), generator=gen) < 0.2).float()
+            obs, reward, done, info = ae.step(a)
+            rews.append(reward.clone())
+            if hip_bwd:
+                assert not rnd._window and not ae._window            # nothing retained, no autograd
+        assert rnd.updates == 2
+        outs.append((torch.stack(rews).cpu().numpy(),
+                     {k: v.detach().cpu().numpy() for k, v in ae.state_dict().items()}))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
+    for k in outs[0][1]:
+        np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=0, atol=2e-3, err_msg=k)
+
+
+def test_reference_training_trajectory_256():
+    """The reference's default geometry (256x256): AE2D(RND2D(CARLE)) under torch.manual_seed(0),
+    batch_size 2, 6 steps -> 3 Adam updates per wrapper, recorded from the genuine reference
+    (tools/make_golden.py: nets_256_train.npz).  Here: rewards and updated weights through the staged
+    HIP forward + backward kernels (no autograd, no retained window)."""
+    z = np.load(os.path.join(G.GOLDEN, "nets_256_train.npz"))
+    n = 2
+    torch.manual_seed(0)
+    env, rnd, ae = _stack(256, n)
+    ref0 = G.load_sd(z, "init_ae_sd")
+    for k, v in ae.state_dict().items():                             # identical seeded initialisation
+        assert np.array_equal(v.cpu().numpy(), ref0[k]), k
+    rnd.batch_size = ae.batch_size = 2
+    for w in (rnd, ae):
+        w.eval()
+    ae.reset()
+    env.universe = torch.from_numpy(G.unpack(z["init"], (n, 1, 256, 256))).cuda()
+    acts = G.unpack(z["actions"], (6, n, 1, 64, 64))
+    for t in range(6):
+        obs, reward, done, info = ae.step(torch.from_numpy(acts[t]))
+        assert not rnd._window and not ae._window
+        np.testing.assert_allclose(reward.cpu().numpy(), z["rewards"][t], rtol=0, atol=1e-4)
+    assert [rnd.updates, ae.updates] == z["updates"].tolist()
+    assert np.array_equal(obs.cpu().numpy(), G.unpack(z["final_obs"], (n, 1, 256, 256)))
+    for prefix, mod in (("final_rnd_sd", rnd), ("final_ae_sd", ae)):
+        ref = G.load_sd(z, prefix)
+        for k, v in mod.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), ref[k], rtol=0, atol=2e-3, err_msg=k)

@@ -25,6 +25,7 @@ Fixture files
                    wrapper rewards over a few steps, and a predictor-update trajectory
   nets_256.npz     the shipped evaluation/*.pt weights (256x256): state_dicts (as arrays),
                    4 input grids, get_bonus_only outputs (eval mode)
+  nets_256_train.npz  predictor-update trajectory at the default 256x256 geometry (3 Adam updates)
   wrappers.npz     CornerBonus / SpeedDetector / PufferDetector / ParsimonyBonus and the eval.py
                    wrapper stack: inputs and per-step rewards
 """
@@ -346,7 +347,7 @@ def sd_to_npz(prefix, sd, out):
     keys = list(sd.keys())
     out[f"{prefix}/keys"] = np.frombuffer(json.dumps(keys).encode(), dtype=np.uint8)
     for i, k in enumerate(keys):
-        out[f"{prefix}/t{i}"] = sd[k].detach().cpu().numpy()
+        out[f"{prefix}/t{i}"] = sd[k].detach().cpu().numpy().copy()      # (a view would follow later in-place updates)
 
 
 def make_nets(torch, ref_env, ref_mcl, outdir):
@@ -440,6 +441,46 @@ def make_nets(torch, ref_env, ref_mcl, outdir):
     out["ae_bonus"] = ae.get_bonus_only(g).numpy()
     np.savez_compressed(os.path.join(outdir, "nets_256.npz"), **out)
     print("nets_256.npz written")
+
+
+def make_train256(torch, ref_env, ref_mcl, outdir):
+    """Predictor-update trajectory at the reference's DEFAULT geometry (256x256): AE2D(RND2D(CARLE)),
+    seeded construction, eval mode (no dropout), batch_size=2, 6 steps -> 3 Adam updates per wrapper
+    (carle/mcl.py:333-341, 368-386, 498-547)."""
+    import contextlib
+    sink = io.StringIO()
+    out = {}
+    rng = np.random.default_rng(256)
+    n = 2
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sink):
+        env = ref_env.CARLE(instances=n, device="cpu")          # 256x256, 64x64 action window
+        rnd = ref_mcl.RND2D(env)
+        ae = ref_mcl.AE2D(rnd)
+    rnd.eval()
+    ae.eval()
+    rnd.batch_size = 2
+    ae.batch_size = 2
+    ae.reset()
+    sd_to_npz("init_rnd_sd", rnd.state_dict(), out)
+    sd_to_npz("init_ae_sd", ae.state_dict(), out)
+    init = (rng.random((n, 1, 256, 256)) < 0.3).astype(np.float32)
+    env.universe = torch.from_numpy(init.copy())
+    acts, rews = [], []
+    for t in range(6):
+        a = (rng.random((n, 1, 64, 64)) <= 0.1).astype(np.float32)
+        obs, reward, done, info = ae.step(torch.from_numpy(a.copy()))
+        acts.append(a)
+        rews.append(reward.detach().numpy().copy())
+    out["init"], _ = pack(init)
+    out["actions"], _ = pack(np.stack(acts))
+    out["rewards"] = np.stack(rews)
+    out["updates"] = np.array([rnd.updates, ae.updates], np.int64)
+    out["final_obs"], _ = pack(obs.detach().numpy())
+    sd_to_npz("final_rnd_sd", rnd.state_dict(), out)
+    sd_to_npz("final_ae_sd", ae.state_dict(), out)
+    np.savez_compressed(os.path.join(outdir, "nets_256_train.npz"), **out)
+    print("nets_256_train.npz written")
 
 
 def make_wrappers(torch, ref_env, ref_mcl, outdir):
@@ -549,7 +590,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch, ref_env, ref_mcl = import_reference()
     torch.set_num_threads(8)
-    todo = args.only.split(",") if args.only else ["ca", "predicates", "known", "nets", "wrappers", "rle"]
+    todo = args.only.split(",") if args.only else ["ca", "predicates", "known", "nets", "train256", "wrappers", "rle"]
     if "ca" in todo:
         make_ca(torch, ref_env, args.out)
     if "predicates" in todo:
@@ -558,6 +599,8 @@ def main():
         make_known(torch, ref_env, ref_mcl, args.out)
     if "nets" in todo:
         make_nets(torch, ref_env, ref_mcl, args.out)
+    if "train256" in todo:
+        make_train256(torch, ref_env, ref_mcl, args.out)
     if "wrappers" in todo:
         make_wrappers(torch, ref_env, ref_mcl, args.out)
     if "rle" in todo:
