@@ -24,26 +24,36 @@
 
 namespace carle {
 
-// adds `rows` partial rows of `nparams` floats in a fixed order onto grad[0..nparams): one workgroup,
-// thread = (parameter p = tid % 128, row lane = tid / 128); deterministic
+// adds `rows` partial rows of `nparams` floats in a fixed order onto grad[0..nparams): workgroup b
+// takes parameters 32 b .. 32 b + 31, thread = (parameter lane, one of 32 row lanes); deterministic
 __global__ __launch_bounds__(1024) void staged_grad_reduce_kernel(const float *__restrict__ partial, int rows,
                                                                  float *__restrict__ grad, int nparams) {
-    __shared__ float part[8][128];
-    const int p = threadIdx.x & 127, rl = threadIdx.x >> 7;
-    float s0 = 0.0f;
-    if (p < nparams)
-        for (int r = rl; r < rows; r += 8) s0 += partial[(int64_t)r * nparams + p];
-    part[rl][p] = s0;
+    __shared__ float part[32][33];
+    const int pl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int p = blockIdx.x * 32 + pl;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (p < nparams) {
+        int r = rl;
+        for (; r + 32 < rows; r += 64) {
+            s0 += partial[(int64_t)r * nparams + p];
+            s1 += partial[(int64_t)(r + 32) * nparams + p];
+        }
+        if (r < rows) s0 += partial[(int64_t)r * nparams + p];
+    }
+    part[rl][pl] = s0 + s1;
     __syncthreads();
     if (rl == 0 && p < nparams) {
         float t = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t += part[i][p];
+        for (int i = 0; i < 32; ++i) t += part[i][pl];
         grad[p] += t;
     }
 }
 
 static inline unsigned blocks256(int64_t total) { return (unsigned)((total + 255) / 256); }
+// launch size of the backward kernels: at most 256 workgroups (= partial rows, one per CU); they walk their
+// elements with a grid stride and add up in registers first
+static inline unsigned bwd_rows(int64_t total) { const int64_t b = (total + 255) / 256; return (unsigned)(b < 256 ? b : 256); }
 
 // Sums of NV per-thread values over the 256 threads of the workgroup -> row[0..NV).  Every thread of
 // the workgroup must call it (threads without work contribute zeros).
@@ -111,12 +121,12 @@ __global__ __launch_bounds__(256) void rnd_bwd_conv2_kernel(
     const float *__restrict__ pred, const float *__restrict__ targ, float *__restrict__ dsel_d,
     int *__restrict__ dsel_s, float *__restrict__ partial, float gs, int64_t n, int h, int w) {
     const int h4 = h >> 2, w4 = w >> 2, w8 = w >> 3, d = (h >> 3) * w8;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = idx < n * (int64_t)d;
     float v[37];
 #pragma unroll
     for (int i = 0; i < 37; ++i) v[i] = 0.0f;
-    if (valid) {
+    // grid-stride walk (the launch is capped: few partial rows for the fixed-order reduction)
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * (int64_t)d;
+         idx += (int64_t)gridDim.x * blockDim.x) {
         const int f = (int)(idx % d);
         const int64_t g = idx / d;
         const int fx = f % w8, fy = f / w8;
@@ -164,9 +174,9 @@ __global__ __launch_bounds__(256) void rnd_bwd_conv2_kernel(
                 for (int kx = 0; kx < 3; ++kx) {
                     const float p00 = patch[c][ky][kx], p01 = patch[c][ky][kx + 1];
                     const float p10 = patch[c][ky + 1][kx], p11 = patch[c][ky + 1][kx + 1];
-                    v[c * 9 + ky * 3 + kx] = dd * (ay ? (ax ? p11 : p10) : (ax ? p01 : p00));
+                    v[c * 9 + ky * 3 + kx] += dd * (ay ? (ax ? p11 : p10) : (ax ? p01 : p00));
                 }
-        v[36] = dd;
+        v[36] += dd;
     }
     block_row_sums<37>(v, partial + (int64_t)blockIdx.x * 37);
 }
@@ -179,12 +189,12 @@ __global__ __launch_bounds__(256) void rnd_bwd_conv1_kernel(
     const float *__restrict__ dsel_d, const int *__restrict__ dsel_s, float *__restrict__ partial,
     int64_t n, int h, int w) {
     const int h4 = h >> 2, w4 = w >> 2, w8 = w >> 3, d = (h >> 3) * w8;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = idx < n * (int64_t)h4 * w4;
     float v[40];
 #pragma unroll
     for (int i = 0; i < 40; ++i) v[i] = 0.0f;
-    if (valid) {
+    // grid-stride walk (the launch is capped: few partial rows for the fixed-order reduction)
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * (int64_t)h4 * w4;
+         idx += (int64_t)gridDim.x * blockDim.x) {
         const int px = (int)(idx % w4), py = (int)((idx / w4) % h4);
         const int64_t g = idx / ((int64_t)h4 * w4);
         // d loss / d conv2 output at the nine positions this pooled pixel feeds
@@ -257,9 +267,9 @@ __global__ __launch_bounds__(256) void rnd_bwd_conv1_kernel(
                 for (int kx = 0; kx < 3; ++kx) {
                     const int y = y0 + ky, x = x0 + kx;
                     const float in = (y >= 0 && y < h && x >= 0 && x < w) ? go[y * w + x] : 0.0f;
-                    v[ch * 9 + ky * 3 + kx] = g1 * in;
+                    v[ch * 9 + ky * 3 + kx] += g1 * in;
                 }
-            v[36 + ch] = g1;
+            v[36 + ch] += g1;
         }
     }
     block_row_sums<40>(v, partial + (int64_t)blockIdx.x * 40);
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256) void rnd_bwd_conv1_kernel(
 
 int64_t rnd2d_train_staged_scratch_floats(int64_t n, int h, int w) {
     const int64_t d = (int64_t)(h / 8) * (w / 8), p1 = n * (int64_t)(h / 4) * (w / 4);
-    return 2 * n * kRndK + 2 * n * d + ((n * d + 255) / 256) * 37 + ((p1 + 255) / 256) * 40 + 64;
+    return 2 * n * kRndK + 2 * n * d + 1024 * (37 + 40) + 64;
 }
 
 // bonus (staged forward) + accumulated predictor gradient; validated by the caller
@@ -281,7 +291,7 @@ int rnd2d_train_staged(const float *obs, int64_t n, int h, int w, const float *p
     float *pred = scratch, *targ = pred + n * kRndK, *dsel_d = targ + n * kRndK;
     int *dsel_s = reinterpret_cast<int *>(dsel_d + n * (int64_t)d);
     float *part2 = reinterpret_cast<float *>(dsel_s + n * (int64_t)d);
-    const unsigned rows2 = blocks256(n * (int64_t)d), rows1 = blocks256(p1);
+    const unsigned rows2 = bwd_rows(n * (int64_t)d), rows1 = bwd_rows(p1);
     float *part1 = part2 + (int64_t)rows2 * 37;
     hipLaunchKernelGGL(rnd_conv1_pool4_kernel, dim3(blocks256(p1)), dim3(256), 0, s, obs, pp, rp, ws1, n, h, w);
     hipLaunchKernelGGL(rnd_conv2_pool2_kernel, dim3(blocks256(n * 2 * (int64_t)d)), dim3(256), 0, s, ws1, pp, rp, ws2,
@@ -293,8 +303,8 @@ int rnd2d_train_staged(const float *obs, int64_t n, int h, int w, const float *p
     hipLaunchKernelGGL(rnd_bwd_conv2_kernel, dim3(rows2), dim3(256), 0, s, ws1, ws2, pp, pred, targ, dsel_d, dsel_s,
                        part2, grad_scale, n, h, w);
     hipLaunchKernelGGL(rnd_bwd_conv1_kernel, dim3(rows1), dim3(256), 0, s, obs, ws1, pp, dsel_d, dsel_s, part1, n, h, w);
-    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(1), dim3(1024), 0, s, part2, (int)rows2, grad + 40, 37);
-    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(1), dim3(1024), 0, s, part1, (int)rows1, grad, 40);
+    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(2), dim3(1024), 0, s, part2, (int)rows2, grad + 40, 37);
+    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(2), dim3(1024), 0, s, part1, (int)rows1, grad, 40);
     return check_launch("carle_rnd2d_train(staged)");
 }
 
@@ -316,12 +326,12 @@ __global__ __launch_bounds__(256) void ae_bwd_out_kernel(
     const float *__restrict__ obs, const float *__restrict__ a3, const float *__restrict__ ap,
     float *__restrict__ dpre4, float *__restrict__ partial, float gs, int64_t n, int h, int w) {
     const int h2 = h >> 1, w2 = w >> 1;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = idx < n * (int64_t)h * w;
     float v[17];
 #pragma unroll
     for (int i = 0; i < 17; ++i) v[i] = 0.0f;
-    if (valid) {
+    // grid-stride walk (the launch is capped: few partial rows for the fixed-order reduction)
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * (int64_t)h * w;
+         idx += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(idx % w), y = (int)((idx / w) % h);
         const int64_t g = idx / ((int64_t)h * w);
         const float *pl = a3 + g * (int64_t)h2 * w2;
@@ -342,8 +352,8 @@ __global__ __launch_bounds__(256) void ae_bwd_out_kernel(
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 4; ++kx) v[ky * 4 + kx] = dd * in[ky][kx];
-        v[16] = dd;
+            for (int kx = 0; kx < 4; ++kx) v[ky * 4 + kx] += dd * in[ky][kx];
+        v[16] += dd;
     }
     block_row_sums<17>(v, partial + (int64_t)blockIdx.x * 17);
 }
@@ -354,12 +364,12 @@ __global__ __launch_bounds__(256) void ae_bwd_a3_kernel(
     const float *__restrict__ dpre4, float *__restrict__ dpre3, float *__restrict__ partial, int64_t n,
     int h, int w) {
     const int h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = idx < n * (int64_t)h2 * w2;
     float v[33];
 #pragma unroll
     for (int i = 0; i < 33; ++i) v[i] = 0.0f;
-    if (valid) {
+    // grid-stride walk (the launch is capped: few partial rows for the fixed-order reduction)
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * (int64_t)h2 * w2;
+         idx += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(idx % w2), y = (int)((idx / w2) % h2);
         const int64_t g = idx / ((int64_t)h2 * w2);
         const float *dp = dpre4 + g * (int64_t)h * w;
@@ -381,9 +391,9 @@ __global__ __launch_bounds__(256) void ae_bwd_a3_kernel(
                 const bool ok = ct_tap(y, ky, h4, iy) & ct_tap(x, kx, w4, ix);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    v[c * 16 + ky * 4 + kx] = ok ? d3 * a2[((g * 2 + c) * h4 + iy) * (int64_t)w4 + ix] : 0.0f;
+                    v[c * 16 + ky * 4 + kx] += ok ? d3 * a2[((g * 2 + c) * h4 + iy) * (int64_t)w4 + ix] : 0.0f;
             }
-        v[32] = d3;
+        v[32] += d3;
     }
     block_row_sums<33>(v, partial + (int64_t)blockIdx.x * 33);
 }
@@ -395,12 +405,12 @@ __global__ __launch_bounds__(256) void ae_bwd_a2_kernel(
     const float *__restrict__ dpre3, float *__restrict__ dsel_d, int *__restrict__ dsel_s,
     float *__restrict__ partial, int64_t n, int h, int w) {
     const int h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = idx < n * (int64_t)h4 * w4;
     float v[74];
 #pragma unroll
     for (int i = 0; i < 74; ++i) v[i] = 0.0f;
-    if (valid) {
+    // grid-stride walk (the launch is capped: few partial rows for the fixed-order reduction)
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * (int64_t)h4 * w4;
+         idx += (int64_t)gridDim.x * blockDim.x) {
         const int px = (int)(idx % w4), py = (int)((idx / w4) % h4);
         const int64_t g = idx / ((int64_t)h4 * w4);
         const float *d3 = dpre3 + g * (int64_t)h2 * w2;
@@ -456,9 +466,9 @@ __global__ __launch_bounds__(256) void ae_bwd_a2_kernel(
                     for (int kx = 0; kx < 3; ++kx) {
                         const float p00 = patch[c][ky][kx], p01 = patch[c][ky][kx + 1];
                         const float p10 = patch[c][ky + 1][kx], p11 = patch[c][ky + 1][kx + 1];
-                        v[(oc * 4 + c) * 9 + ky * 3 + kx] = dd * (ay ? (ax ? p11 : p10) : (ax ? p01 : p00));
+                        v[(oc * 4 + c) * 9 + ky * 3 + kx] += dd * (ay ? (ax ? p11 : p10) : (ax ? p01 : p00));
                     }
-            v[72 + oc] = dd;
+            v[72 + oc] += dd;
         }
     }
     block_row_sums<74>(v, partial + (int64_t)blockIdx.x * 74);
@@ -471,12 +481,12 @@ __global__ __launch_bounds__(256) void ae_bwd_a1_kernel(
     const float *__restrict__ dsel_d, const int *__restrict__ dsel_s, float *__restrict__ partial,
     int64_t n, int h, int w) {
     const int h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = idx < n * (int64_t)h2 * w2;
     float v[40];
 #pragma unroll
     for (int i = 0; i < 40; ++i) v[i] = 0.0f;
-    if (valid) {
+    // grid-stride walk (the launch is capped: few partial rows for the fixed-order reduction)
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * (int64_t)h2 * w2;
+         idx += (int64_t)gridDim.x * blockDim.x) {
         const int px = (int)(idx % w2), py = (int)((idx / w2) % h2);
         const int64_t g = idx / ((int64_t)h2 * w2);
         float dm[2][3][3];
@@ -537,9 +547,9 @@ __global__ __launch_bounds__(256) void ae_bwd_a1_kernel(
                 for (int kx = 0; kx < 3; ++kx) {
                     const float p00 = patch[ky][kx], p01 = patch[ky][kx + 1];
                     const float p10 = patch[ky + 1][kx], p11 = patch[ky + 1][kx + 1];
-                    v[ch * 9 + ky * 3 + kx] = g1 * (ay ? (ax ? p11 : p10) : (ax ? p01 : p00));
+                    v[ch * 9 + ky * 3 + kx] += g1 * (ay ? (ax ? p11 : p10) : (ax ? p01 : p00));
                 }
-            v[36 + ch] = g1;
+            v[36 + ch] += g1;
         }
     }
     block_row_sums<40>(v, partial + (int64_t)blockIdx.x * 40);
@@ -548,8 +558,7 @@ __global__ __launch_bounds__(256) void ae_bwd_a1_kernel(
 
 int64_t ae2d_train_staged_scratch_floats(int64_t n, int h, int w) {
     const int64_t q = (int64_t)(h / 2) * (w / 2), px = n * (int64_t)h * w;
-    return px + n * q + 2 * (n * 2 * (q / 4)) + ((px + 255) / 256) * 17 + ((n * q + 255) / 256) * (33 + 40) +
-           ((n * (q / 4) + 255) / 256) * 74 + 64;
+    return px + n * q + 2 * (n * 2 * (q / 4)) + 1024 * (17 + 33 + 40 + 74) + 64;
 }
 
 int ae2d_train_staged(const float *obs, int64_t n, int h, int w, const float *ap, float *ws, float *scratch,
@@ -563,7 +572,7 @@ int ae2d_train_staged(const float *obs, int64_t n, int h, int w, const float *ap
     float *dpre4 = scratch, *dpre3 = dpre4 + px, *dsel_d = dpre3 + n * q;
     int *dsel_s = reinterpret_cast<int *>(dsel_d + n * 2 * (q / 4));
     float *part4 = reinterpret_cast<float *>(dsel_s + n * 2 * (q / 4));
-    const unsigned rows4 = blocks256(px), rows3 = blocks256(n * q), rows2 = blocks256(n * (q / 4)), rows1 = rows3;
+    const unsigned rows4 = bwd_rows(px), rows3 = bwd_rows(n * q), rows2 = bwd_rows(n * (q / 4)), rows1 = rows3;
     float *part3 = part4 + (int64_t)rows4 * 17, *part2 = part3 + (int64_t)rows3 * 33;
     float *part1 = part2 + (int64_t)rows2 * 74;
     // forward (nets_staged.hip), activations stay in the workspace
@@ -580,9 +589,9 @@ int ae2d_train_staged(const float *obs, int64_t n, int h, int w, const float *ap
     hipLaunchKernelGGL(ae_bwd_a2_kernel, dim3(rows2), dim3(256), 0, s, a1, a2, ap, dpre3, dsel_d, dsel_s, part2, n, h, w);
     hipLaunchKernelGGL(ae_bwd_a1_kernel, dim3(rows1), dim3(256), 0, s, obs, a1, ap, dsel_d, dsel_s, part1, n, h, w);
     hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(1), dim3(1024), 0, s, part4, (int)rows4, grad + 147, 17);
-    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(1), dim3(1024), 0, s, part3, (int)rows3, grad + 114, 33);
-    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(1), dim3(1024), 0, s, part2, (int)rows2, grad + 40, 74);
-    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(1), dim3(1024), 0, s, part1, (int)rows1, grad, 40);
+    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(2), dim3(1024), 0, s, part3, (int)rows3, grad + 114, 33);
+    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(3), dim3(1024), 0, s, part2, (int)rows2, grad + 40, 74);
+    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(2), dim3(1024), 0, s, part1, (int)rows1, grad, 40);
     return check_launch("carle_ae2d_train(staged)");
 }
 
