@@ -761,34 +761,107 @@ namespace carle {
 
 static constexpr int kAeParams = 164;
 
-// ONE WORKGROUP per grid.  Forward as ae_block64_kernel (thread (py,px) owns the 4x4
-// cell block at (4py,4px) in every layer), A3 in its own plane (A1 is needed again on the way
-// back).  Backward:
-//   convT2 / convT1: each thread accumulates the contributions of its own outputs to the 4x4
-//     (3x3) input neighbourhood in registers, then ds_add_f32's them into the d3 / d2 planes;
+// ONE WORKGROUP per grid, persistent, 3 workgroups per CU (<= 168 VGPRs, 49 KB of LDS).  Forward as
+// ae_block64_kernel (thread (py,px) owns the 4x4 cell block at (4py,4px) in every layer).  Backward:
+//   convT2 / convT1: a thread accumulates the contributions of its own outputs to the 4x4 (3x3) input
+//     neighbourhood in registers; the columns that belong to the threads px-1 / px+1 travel by DPP
+//     row shifts (px = lane % 16 is a DPP row; the shift's zero fill IS the plane border), the rows that
+//     belong to py-1 / py+1 through a halo buffer in LDS that the owner reads behind the next barrier:
+//     no atomics, a fixed summation order;
 //   conv2: the gradient w.r.t. its outputs goes to a sparse map (one entry per 2x2 pooling block);
 //   conv2 + conv1 weights: CHANNEL-SPLIT -- wave c walks all 32x32 positions of A1 plane c (16 per
 //     lane), gathers  d A1[c](P) = sum_{o,k} w2[o][c][k] map[o](P-k+1),  accumulates
 //     d w2[o][c][k] += A1[c](P) map[o](P-k+1)  and, through the relu gate and the arg-max pattern
 //     of P, the conv1 gradients of channel c: 18 + 9 + 1 accumulators per lane instead of 72 + 36 + 4.
-// 80 accumulators per thread in all (the first version, one wave per grid: 164 per lane, 512
-// registers, 1.6 KB of scratch, 3 waves per CU, twice the time); 62 KB of LDS -> 2 workgroups
-// (8 waves) per CU.
+//     The arg-max patterns are not stored: per A1 position the 4x4 cell neighbourhood (16 bits, shared
+//     by the four channels) + a 2-bit arg-max index per channel.
+// LDS: the map overlays A3 + the convT2 halo (both dead by then; the 132 border entries of its
+// second plane that the gather reads are re-zeroed every grid).
+// History: round 1 (62 KB of LDS, ds_add_f32 scatters, 256 VGPRs + 72 spilled, 2 workgroups per CU):
+// 288-304 us per 4096 grids.
 struct AeTrainShared {
     float4 lut[512];
     float a1[4 * kA1Plane];
     float a2[2 * kA2Plane];
-    float a3[kA1Plane];
-    float d3[kA1Plane];              // d loss / d A3 (before its relu gate)
-    float d2[2 * kA2Plane];          // d loss / d A2 (after the pool)
-    float map2[2 * kA1Plane];        // d loss / d conv2 output: one non-zero per 2x2 pooling block
-    uint16_t pat[4][1024];           // arg-max input pattern of every A1 position (32x32, row-major)
+    union {
+        struct {
+            float a3[kA1Plane];
+            float2 halo3[2][256];    // [0]: for the thread above (its row 2), [1]: for the thread below (its row 1)
+            float pad[(kA1Plane * 4 - 4096) / 4];
+        } f;
+        float map2[2 * kA1Plane];    // d loss / d conv2 output: one non-zero per 2x2 pooling block
+    } u;
+    float2 halo2[2][256];            // convT1 backward: (cc0, cc1) for the thread above / below
+    uint16_t nb[1024];               // 4x4 cell neighbourhood of every A1 position (32x32, row-major)
+    uint8_t am[1024];                // 2-bit arg-max index (dy * 2 + dx) of the four conv1 channels
     uint64_t rows[66];
     float red[4][52];
 };
+static_assert(sizeof(AeTrainShared) <= 54272, "three workgroups per CU");
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov0(float x) {   // DPP move, lanes without a source read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+static constexpr int kRowShr1 = 0x111, kRowShl1 = 0x101;   // value of lane - 1 / lane + 1 of the 16-lane row
+
+// sum over the 64 lanes without LDS round trips; the result is valid in every lane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_quad_xor1(v);
+    v += dpp_quad_xor2(v);
+    v += dpp_row_ror(v, 0x124);
+    v += dpp_row_ror(v, 0x128);
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+
+// Reduce per-thread contributions c[0..N) over the four lanes of a DPP quad while transposing them:
+// afterwards lane l of the quad has added the quad's sum of entry 4m + (l & 3) to acc[m] -- N / 4
+// accumulators per thread instead of N, 2.25 N extra VALU operations, a fixed summation order.
+template <int N>
+__device__ __forceinline__ void quad_transpose_add(const float (&c)[N], float (&acc)[N / 4], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float h[N / 2];
+#pragma unroll
+    for (int m = 0; m < N / 2; ++m) {
+        const float mine = b0 ? c[2 * m + 1] : c[2 * m], send = b0 ? c[2 * m] : c[2 * m + 1];
+        h[m] = mine + dpp_quad_xor1(send);
+    }
+#pragma unroll
+    for (int m = 0; m < N / 4; ++m) {
+        const float mine = b1 ? h[2 * m + 1] : h[2 * m], send = b1 ? h[2 * m] : h[2 * m + 1];
+        acc[m] += mine + dpp_quad_xor2(send);
+    }
+}
+
+// total over the wave of a quad-transposed accumulator: every lane ends with the sum of the lanes
+// that share its (lane & 3)
+__device__ __forceinline__ float quad_class_sum(float v) {
+    v += dpp_row_ror(v, 0x124);
+    v += dpp_row_ror(v, 0x128);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) {   // v_exp_f32 + v_rcp_f32: ~2 ulp
+    return __frcp_rn(1.0f + __expf(-x));
+}
+
+// Hides a uniform pointer from loop-invariant code motion: the scalar loads behind it stay in the phase
+// that uses them (from the scalar cache) instead of being hoisted out of the grid loop, where 140
+// weights would overflow the SGPR file and spill into VGPR lanes.
+typedef const float __attribute__((address_space(4))) kfloat;   // constant address space: s_load
+__device__ __forceinline__ kfloat *opaque_uniform(const float *p) {
+    asm volatile("" : "+s"(p));
+    return (kfloat *)p;
+}
 
 template <bool PACKED_OBS>
-__global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
+__global__ __launch_bounds__(256, 3) void ae_train_block64_kernel(
     const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
     float *__restrict__ reward, float reward_scale, float grad_scale, float *__restrict__ partial,
     int64_t n) {
@@ -798,39 +871,42 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
         const float4 *src = reinterpret_cast<const float4 *>(ws);
         for (int i = tid; i < 512; i += 256) s.lut[i] = src[i];
         for (int i = tid; i < 4 * kA1Plane; i += 256) s.a1[i] = 0.0f;
-        for (int i = tid; i < 2 * kA2Plane; i += 256) { s.a2[i] = 0.0f; s.d2[i] = 0.0f; }
-        for (int i = tid; i < kA1Plane; i += 256) { s.a3[i] = 0.0f; s.d3[i] = 0.0f; }
-        for (int i = tid; i < 2 * kA1Plane; i += 256) s.map2[i] = 0.0f;
+        for (int i = tid; i < 2 * kA2Plane; i += 256) s.a2[i] = 0.0f;
+        for (int i = tid; i < 2 * kA1Plane; i += 256) s.u.map2[i] = 0.0f;       // A3's border with it
         if (tid < 66) s.rows[tid] = 0ull;
     }
     __syncthreads();
-    const float *prm = ws + kAeLutFloats;            // uniform parameter block
-    const float *w2 = prm, *b2 = prm + 72, *wt1 = prm + 74, *wt2 = prm + 107;
-    const float bt1 = prm[106], bt2 = prm[123];
+    const float *prm = ws + kAeLutFloats;            // uniform parameter block:
+    // conv2.w[72] b[2] | convT1.w[32] b[1] | convT2.w[16] b[1]
 
     const int q = lane >> 4, k = lane & 15;          // load mapping
     const int py = tid >> 4, px = tid & 15;          // cell-block mapping
 
-    float gwt2[16], gbt2 = 0.0f, gwt1[32], gbt1 = 0.0f, gb2[2] = {0.0f, 0.0f};
+    // convT2 / convT1 weight gradients, quad-transposed: lane l holds entries 4m + (l & 3)
+    float gwt2q[4] = {0.f, 0.f, 0.f, 0.f}, gbt2 = 0.0f, gwt1q[8], gbt1 = 0.0f, gb2[2] = {0.0f, 0.0f};
     float gw2c[18], gw1c[9], gb1c = 0.0f;            // conv2 / conv1 gradients of input channel wv
 #pragma unroll
-    for (int i = 0; i < 16; ++i) gwt2[i] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) gwt1[i] = 0.0f;
+    for (int i = 0; i < 8; ++i) gwt1q[i] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 18; ++i) gw2c[i] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) gw1c[i] = 0.0f;
     const int wvs = __builtin_amdgcn_readfirstlane(wv);   // provably wave-uniform: scalar loads below
-    float wc[18];                                    // w2[oc][wv][k], oc-major (SGPRs)
-#pragma unroll
-    for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-        for (int kq = 0; kq < 9; ++kq) wc[oc * 9 + kq] = w2[(oc * 4 + wvs) * 9 + kq];
 
     const int64_t first = blockIdx.x, stride = gridDim.x;
     uint4 v[4];
+    uint32_t xr[4];                                  // fp32 observations: this lane's dword of rows 16wv+4i+q
     uint64_t word = 0;
+    auto convert = [&]() {                            // waits for the loads; 4 live registers instead of 16
+        if (!PACKED_OBS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t nib = nz_bit(v[i].x) | (nz_bit(v[i].y) << 1) | (nz_bit(v[i].z) << 2) |
+                                     (nz_bit(v[i].w) << 3);
+                xr[i] = row_nibbles_to_dword(nib, k);
+            }
+        }
+    };
     auto issue = [&](int64_t g) {
         if (PACKED_OBS) {
             if (tid < 64) word = reinterpret_cast<const uint64_t *>(obs_v)[g * 64 + tid];
@@ -840,7 +916,7 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
             for (int i = 0; i < 4; ++i) v[i] = gin[i * 64];
         }
     };
-    if (first < n) issue(first);
+    if (first < n) { issue(first); convert(); }
     for (int64_t g = first; g < n; g += stride) {
         // ---- the grid as 64 row words in LDS
         if (PACKED_OBS) {
@@ -848,17 +924,14 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
         } else {
             uint32_t *rows32 = reinterpret_cast<uint32_t *>(&s.rows[1]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t nib = nz_bit(v[i].x) | (nz_bit(v[i].y) << 1) | (nz_bit(v[i].z) << 2) |
-                                     (nz_bit(v[i].w) << 3);
-                const uint32_t x = row_nibbles_to_dword(nib, k);
-                if ((k & 7) == 7) rows32[2 * (16 * wv + 4 * i + q) + (k >> 3)] = x;
-            }
+            for (int i = 0; i < 4; ++i)
+                if ((k & 7) == 7) rows32[2 * (16 * wv + 4 * i + q) + (k >> 3)] = xr[i];
         }
-        if (g + stride < n) issue(g + stride);
         __syncthreads();
 
-        // ---- conv1 (table) + relu + 2x2 pool -> A1 (2py+a, 2px+b) with arg-max patterns
+        // ---- conv1 (table) + relu + 2x2 pool -> A1 (2py+a, 2px+b); arg-max index per channel and
+        //      the 4x4 cell neighbourhood of every A1 position
+        uint32_t own_bits;                            // the thread's own 4x4 cells, row-major
         {
             uint32_t seg[6];
 #pragma unroll
@@ -866,122 +939,149 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
                 const uint64_t row = s.rows[4 * py + r];
                 seg[r] = (uint32_t)(px == 0 ? row << 1 : row >> (4 * px - 1)) & 0x3Fu;
             }
+            own_bits = ((seg[1] >> 1) & 15u) | (((seg[2] >> 1) & 15u) << 4) | (((seg[3] >> 1) & 15u) << 8) |
+                       (((seg[4] >> 1) & 15u) << 12);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a) {
+                float4 e[2][4];                       // the eight lookups of A1 row 2py+a in flight together
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int r = 2 * a + (d >> 1), cx = 2 * b + (d & 1);
+                        const uint32_t p = ((seg[r] >> cx) & 7u) | (((seg[r + 1] >> cx) & 7u) << 3) |
+                                           (((seg[r + 2] >> cx) & 7u) << 6);
+                        e[b][d] = s.lut[p];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                float m[2][4];
+                uint32_t amx[2], nbx[2];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
-                    uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+                    uint32_t i0 = 0, i1 = 0, i2 = 0, i3 = 0;
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 2; ++dx) {
-                            const int r = 2 * a + dy, cx = 2 * b + dx;
-                            const uint32_t p = ((seg[r] >> cx) & 7u) | (((seg[r + 1] >> cx) & 7u) << 3) |
-                                               (((seg[r + 2] >> cx) & 7u) << 6);
-                            const float4 e = s.lut[p];
-                            if (e.x > m0) { m0 = e.x; p0 = p; }
-                            if (e.y > m1) { m1 = e.y; p1 = p; }
-                            if (e.z > m2) { m2 = e.z; p2 = p; }
-                            if (e.w > m3) { m3 = e.w; p3 = p; }
-                        }
-                    const int off = (2 * py + a + 1) * kA1Stride + 2 * px + b + 1;
-                    s.a1[0 * kA1Plane + off] = m0;
-                    s.a1[1 * kA1Plane + off] = m1;
-                    s.a1[2 * kA1Plane + off] = m2;
-                    s.a1[3 * kA1Plane + off] = m3;
-                    const int pos = (2 * py + a) * 32 + 2 * px + b;
-                    s.pat[0][pos] = (uint16_t)p0;
-                    s.pat[1][pos] = (uint16_t)p1;
-                    s.pat[2][pos] = (uint16_t)p2;
-                    s.pat[3][pos] = (uint16_t)p3;
+                    for (int d = 0; d < 4; ++d) {     // strict >: the first maximum in scan order (ATen)
+                        if (e[b][d].x > m0) { m0 = e[b][d].x; i0 = d; }
+                        if (e[b][d].y > m1) { m1 = e[b][d].y; i1 = d; }
+                        if (e[b][d].z > m2) { m2 = e[b][d].z; i2 = d; }
+                        if (e[b][d].w > m3) { m3 = e[b][d].w; i3 = d; }
+                    }
+                    m[b][0] = m0; m[b][1] = m1; m[b][2] = m2; m[b][3] = m3;
+                    amx[b] = i0 | (i1 << 2) | (i2 << 4) | (i3 << 6);
+                    nbx[b] = ((seg[2 * a] >> (2 * b)) & 15u) | (((seg[2 * a + 1] >> (2 * b)) & 15u) << 4) |
+                             (((seg[2 * a + 2] >> (2 * b)) & 15u) << 8) | (((seg[2 * a + 3] >> (2 * b)) & 15u) << 12);
                 }
+                const int off = (2 * py + a + 1) * kA1Stride + 2 * px + 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s.a1[c * kA1Plane + off] = m[0][c];
+                    s.a1[c * kA1Plane + off + 1] = m[1][c];
+                }
+                const int pos = (2 * py + a) * 32 + 2 * px;
+                *reinterpret_cast<uint32_t *>(&s.nb[pos]) = nbx[0] | (nbx[1] << 16);
+                *reinterpret_cast<uint16_t *>(&s.am[pos]) = (uint16_t)(amx[0] | (amx[1] << 8));
+            }
         }
         __syncthreads();
 
         // ---- conv2 (4->2) + relu + 2x2 pool -> A2 (py, px); arg-max position + gate
-        int am2[2];
-        bool on2[2];
+        uint32_t flags = 0;                           // bits 0-1 / 2-3: arg-max of oc 0 / 1; 4, 5: gates; 8-11: A3 gates
         {
+            kfloat *w2 = opaque_uniform(prm), *b2 = w2 + 72;
             float acc2[2][2][2];
 #pragma unroll
             for (int oc = 0; oc < 2; ++oc) { acc2[oc][0][0] = 0.f; acc2[oc][0][1] = 0.f; acc2[oc][1][0] = 0.f; acc2[oc][1][1] = 0.f; }
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const float *pl = s.a1 + cc * kA1Plane + (2 * py) * kA1Stride + 2 * px;
-                float patch[4][4];
+            for (int ch = 0; ch < 2; ++ch) {          // two input channels per LDS round trip
+                float patch[2][4][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
-                    const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
-                    patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const float *pl = s.a1 + (2 * ch + c2) * kA1Plane + (2 * py) * kA1Stride + 2 * px;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
+                        const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
+                        patch[c2][r][0] = lo.x; patch[c2][r][1] = lo.y; patch[c2][r][2] = hi.x; patch[c2][r][3] = hi.y;
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int oc = 0; oc < 2; ++oc)
+                for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
+                    for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
-                        for (int dx = 0; dx < 2; ++dx)
+                        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                            for (int ky = 0; ky < 3; ++ky)
+                            for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
-                                for (int kx = 0; kx < 3; ++kx)
-                                    acc2[oc][dy][dx] = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx],
-                                                            patch[dy + ky][dx + kx], acc2[oc][dy][dx]);
+                                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                                    for (int kx = 0; kx < 3; ++kx)
+                                        acc2[oc][dy][dx] = fmaf(w2[(oc * 4 + 2 * ch + c2) * 9 + ky * 3 + kx],
+                                                                patch[c2][dy + ky][dx + kx], acc2[oc][dy][dx]);
             }
 #pragma unroll
             for (int oc = 0; oc < 2; ++oc) {
-                float mx = acc2[oc][0][0]; int am = 0;
+                float mx = acc2[oc][0][0]; uint32_t am = 0;
                 if (acc2[oc][0][1] > mx) { mx = acc2[oc][0][1]; am = 1; }
                 if (acc2[oc][1][0] > mx) { mx = acc2[oc][1][0]; am = 2; }
                 if (acc2[oc][1][1] > mx) { mx = acc2[oc][1][1]; am = 3; }
                 mx += b2[oc];
-                am2[oc] = am;
-                on2[oc] = mx > 0.0f;
+                flags |= am << (2 * oc);
+                if (mx > 0.0f) flags |= 16u << oc;
                 s.a2[oc * kA2Plane + (py + 1) * kA2Stride + px + 1] = fmaxf(mx, 0.0f);
             }
         }
         __syncthreads();
 
         // ---- convT1 (2->1, k4 s2 p1) + relu -> A3 (2py+j, 2px+i)
-        bool on3[2][2];
         {
-        float r2[2][3][3];                            // A2 rows py-1..py+1, cols px-1..px+1 (padded)
+            kfloat *wt1 = opaque_uniform(prm) + 74;
+            const float bt1 = wt1[32];
+            float r2[2][3][3];                        // A2 rows py-1..py+1, cols px-1..px+1 (padded)
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
+            for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+                for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int x = 0; x < 3; ++x)
-                    r2[cc][r][x] = s.a2[cc * kA2Plane + (py + r) * kA2Stride + px + x];
+                    for (int x = 0; x < 3; ++x)
+                        r2[cc][r][x] = s.a2[cc * kA2Plane + (py + r) * kA2Stride + px + x];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ry0 = 1, ky0 = j ? 2 : 1;
-                const int ry1 = j ? 2 : 0, ky1 = j ? 0 : 3;
-                const int cx0 = 1, kx0 = i ? 2 : 1;
-                const int cx1 = i ? 2 : 0, kx1 = i ? 0 : 3;
-                float acc = 0.0f;
+                for (int i = 0; i < 2; ++i) {
+                    const int ry0 = 1, ky0 = j ? 2 : 1;
+                    const int ry1 = j ? 2 : 0, ky1 = j ? 0 : 3;
+                    const int cx0 = 1, kx0 = i ? 2 : 1;
+                    const int cx1 = i ? 2 : 0, kx1 = i ? 0 : 3;
+                    float acc = 0.0f;
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    acc = fmaf(r2[cc][ry0][cx0], wt1[cc * 16 + ky0 * 4 + kx0], acc);
-                    acc = fmaf(r2[cc][ry0][cx1], wt1[cc * 16 + ky0 * 4 + kx1], acc);
-                    acc = fmaf(r2[cc][ry1][cx0], wt1[cc * 16 + ky1 * 4 + kx0], acc);
-                    acc = fmaf(r2[cc][ry1][cx1], wt1[cc * 16 + ky1 * 4 + kx1], acc);
+                    for (int cc = 0; cc < 2; ++cc) {
+                        acc = fmaf(r2[cc][ry0][cx0], wt1[cc * 16 + ky0 * 4 + kx0], acc);
+                        acc = fmaf(r2[cc][ry0][cx1], wt1[cc * 16 + ky0 * 4 + kx1], acc);
+                        acc = fmaf(r2[cc][ry1][cx0], wt1[cc * 16 + ky1 * 4 + kx0], acc);
+                        acc = fmaf(r2[cc][ry1][cx1], wt1[cc * 16 + ky1 * 4 + kx1], acc);
+                    }
+                    const float a3 = fmaxf(acc + bt1, 0.0f);
+                    if (a3 > 0.0f) flags |= 256u << (2 * j + i);
+                    s.u.f.a3[(2 * py + j + 1) * kA1Stride + 2 * px + i + 1] = a3;
                 }
-                const float a3 = fmaxf(acc + bt1, 0.0f);
-                on3[j][i] = a3 > 0.0f;
-                s.a3[(2 * py + j + 1) * kA1Stride + 2 * px + i + 1] = a3;
-            }
         }
         __syncthreads();
 
         // ---- convT2 + sigmoid + loss on the thread's own 4x4 cells; backward of convT2
         float sq = 0.0f;
+        float g3[2][2];                               // d loss / d A3 of the own 2x2 outputs, before the halo rows
         {
+            kfloat *wt2 = opaque_uniform(prm) + 107;
+            const float bt2 = wt2[16];
             float t3[4][4], dt3[4][4];                // A3 rows 2py-1..2py+2, cols 2px-1..2px+2 (padded)
-            const float *pl = s.a3 + (2 * py) * kA1Stride + 2 * px;
+            float gwt2[16];                           // this grid's convT2 weight-gradient contributions
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gwt2[i] = 0.0f;
+            const float *pl = s.u.f.a3 + (2 * py) * kA1Stride + 2 * px;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
@@ -989,9 +1089,9 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
                 t3[r][0] = lo.x; t3[r][1] = lo.y; t3[r][2] = hi.x; t3[r][3] = hi.y;
                 dt3[r][0] = 0.f; dt3[r][1] = 0.f; dt3[r][2] = 0.f; dt3[r][3] = 0.f;
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t bits = (uint32_t)(s.rows[1 + 4 * py + r] >> (4 * px)) & 0xFu;
 #pragma unroll
                 for (int cx = 0; cx < 4; ++cx) {
                     const int my = r >> 1, mx = cx >> 1;
@@ -1004,8 +1104,8 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
                     acc = fmaf(t3[ry0][cx1], wt2[ky0 * 4 + kx1], acc);
                     acc = fmaf(t3[ry1][cx0], wt2[ky1 * 4 + kx0], acc);
                     acc = fmaf(t3[ry1][cx1], wt2[ky1 * 4 + kx1], acc);
-                    const float pr = 1.0f / (1.0f + expf(-(acc + bt2)));
-                    const float ob = (float)((bits >> cx) & 1u);
+                    const float pr = fast_sigmoid(acc + bt2);
+                    const float ob = (float)((own_bits >> (4 * r + cx)) & 1u);
                     const float df = ob - pr;
                     sq = fmaf(df, df, sq);
                     const float dz = grad_scale * (pr - ob) * pr * (1.0f - pr);     // d loss / d (pre-sigmoid)
@@ -1020,17 +1120,21 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
                     dt3[ry1][cx1] = fmaf(dz, wt2[ky1 * 4 + kx1], dt3[ry1][cx1]);
                 }
             }
-            // scatter into d3 (interior positions only: the border is never read)
-            float *dp = s.d3 + (2 * py) * kA1Stride + 2 * px;
+            // columns: local column x is A3 column 2px-1+x; x = 1, 2 are the thread's own, x = 3 belongs to
+            // px+1 (its x = 1), x = 0 to px-1 (its x = 2).  Rows likewise: r = 1, 2 own, r = 0 -> py-1 (its
+            // r = 2), r = 3 -> py+1 (its r = 1).
+            float c1[4], c2[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const int Y = 2 * py + r, X = 2 * px + x;                 // padded coordinates
-                    if (Y >= 1 && Y <= 32 && X >= 1 && X <= 32) atomicAdd(dp + r * kA1Stride + x, dt3[r][x]);
-                }
+            for (int r = 0; r < 4; ++r) {
+                c1[r] = dt3[r][1] + dpp_mov0<kRowShr1>(dt3[r][3]);
+                c2[r] = dt3[r][2] + dpp_mov0<kRowShl1>(dt3[r][0]);
+            }
+            s.u.f.halo3[0][tid] = make_float2(c1[0], c2[0]);
+            s.u.f.halo3[1][tid] = make_float2(c1[3], c2[3]);
+            g3[0][0] = c1[1]; g3[0][1] = c2[1]; g3[1][0] = c1[2]; g3[1][1] = c2[2];
+            quad_transpose_add<16>(gwt2, gwt2q, lane);
         }
-        sq = wave_sum_f32(sq);
+        sq = wave_sum_dpp(sq);
         if (lane == 0) s.red[wv][0] = sq;
         __syncthreads();
         if (tid == 0) {
@@ -1040,8 +1144,15 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
         }
 
         // ---- relu gate of A3, convT1 backward (thread's own 2x2 outputs)
+        // fp32 observations: the next grid's 16 registers travel during this phase and the next (few live
+        // registers) and are folded into 4 before the gather phase (the register peak)
+        if (!PACKED_OBS && g + stride < n) issue(g + stride);
+        float g2[2];                                  // d loss / d A2 of the own entry, before the halo rows
         {
+            kfloat *wt1 = opaque_uniform(prm) + 74;
             float r2[2][3][3], dr2[2][3][3];          // A2 neighbourhood re-read: cheaper than 18 live registers
+            const float2 from_above = py > 0 ? s.u.f.halo3[1][tid - 16] : make_float2(0.f, 0.f);
+            const float2 from_below = py < 15 ? s.u.f.halo3[0][tid + 16] : make_float2(0.f, 0.f);
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
@@ -1049,17 +1160,19 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
 #pragma unroll
                     for (int x = 0; x < 3; ++x)
                         r2[cc][r][x] = s.a2[cc * kA2Plane + (py + r) * kA2Stride + px + x];
+            __builtin_amdgcn_sched_barrier(0);
+            g3[0][0] += from_above.x; g3[0][1] += from_above.y;
+            g3[1][0] += from_below.x; g3[1][1] += from_below.y;
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) { dr2[cc][r][0] = 0.f; dr2[cc][r][1] = 0.f; dr2[cc][r][2] = 0.f; }
+            float gwt1[32];                           // every entry receives exactly one product per grid
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    float *own = s.d3 + (2 * py + j + 1) * kA1Stride + 2 * px + i + 1;
-                    const float gz = on3[j][i] ? *own : 0.0f;
-                    *own = 0.0f;                                   // ready for the next grid
+                    const float gz = (flags >> (8 + 2 * j + i)) & 1u ? g3[j][i] : 0.0f;
                     gbt1 += gz;
                     const int ry0 = 1, ky0 = j ? 2 : 1;
                     const int ry1 = j ? 2 : 0, ky1 = j ? 0 : 3;
@@ -1067,49 +1180,71 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
                     const int cx1 = i ? 2 : 0, kx1 = i ? 0 : 3;
 #pragma unroll
                     for (int cc = 0; cc < 2; ++cc) {
-                        gwt1[cc * 16 + ky0 * 4 + kx0] = fmaf(gz, r2[cc][ry0][cx0], gwt1[cc * 16 + ky0 * 4 + kx0]);
-                        gwt1[cc * 16 + ky0 * 4 + kx1] = fmaf(gz, r2[cc][ry0][cx1], gwt1[cc * 16 + ky0 * 4 + kx1]);
-                        gwt1[cc * 16 + ky1 * 4 + kx0] = fmaf(gz, r2[cc][ry1][cx0], gwt1[cc * 16 + ky1 * 4 + kx0]);
-                        gwt1[cc * 16 + ky1 * 4 + kx1] = fmaf(gz, r2[cc][ry1][cx1], gwt1[cc * 16 + ky1 * 4 + kx1]);
+                        gwt1[cc * 16 + ky0 * 4 + kx0] = gz * r2[cc][ry0][cx0];
+                        gwt1[cc * 16 + ky0 * 4 + kx1] = gz * r2[cc][ry0][cx1];
+                        gwt1[cc * 16 + ky1 * 4 + kx0] = gz * r2[cc][ry1][cx0];
+                        gwt1[cc * 16 + ky1 * 4 + kx1] = gz * r2[cc][ry1][cx1];
                         dr2[cc][ry0][cx0] = fmaf(gz, wt1[cc * 16 + ky0 * 4 + kx0], dr2[cc][ry0][cx0]);
                         dr2[cc][ry0][cx1] = fmaf(gz, wt1[cc * 16 + ky0 * 4 + kx1], dr2[cc][ry0][cx1]);
                         dr2[cc][ry1][cx0] = fmaf(gz, wt1[cc * 16 + ky1 * 4 + kx0], dr2[cc][ry1][cx0]);
                         dr2[cc][ry1][cx1] = fmaf(gz, wt1[cc * 16 + ky1 * 4 + kx1], dr2[cc][ry1][cx1]);
                     }
                 }
+            // local column x is A2 column px-1+x: x = 1 own, x = 2 -> px+1 (its x = 1 ... seen from there
+            // as the value of px-1), x = 0 -> px-1; rows: r = 1 own, r = 0 -> py-1, r = 2 -> py+1
+            float col[2][3];
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int x = 0; x < 3; ++x) {
-                        const int Y = py + r, X = px + x;                    // padded coordinates
-                        if (Y >= 1 && Y <= 16 && X >= 1 && X <= 16)
-                            atomicAdd(&s.d2[cc * kA2Plane + Y * kA2Stride + X], dr2[cc][r][x]);
-                    }
+                    col[cc][r] = (dr2[cc][r][1] + dpp_mov0<kRowShr1>(dr2[cc][r][2])) + dpp_mov0<kRowShl1>(dr2[cc][r][0]);
+            s.halo2[0][tid] = make_float2(col[0][0], col[1][0]);
+            s.halo2[1][tid] = make_float2(col[0][2], col[1][2]);
+            g2[0] = col[0][1]; g2[1] = col[1][1];
+            quad_transpose_add<32>(gwt1, gwt1q, lane);
         }
         __syncthreads();
 
-        // ---- 2x2 pool arg-max + relu gate of A2 -> the conv2-output gradient map
+        // ---- 2x2 pool arg-max + relu gate of A2 -> the conv2-output gradient map (overlays A3 / halo3)
+        {
+            const float2 from_above = py > 0 ? s.halo2[1][tid - 16] : make_float2(0.f, 0.f);
+            const float2 from_below = py < 15 ? s.halo2[0][tid + 16] : make_float2(0.f, 0.f);
+            g2[0] = (g2[0] + from_above.x) + from_below.x;
+            g2[1] = (g2[1] + from_above.y) + from_below.y;
 #pragma unroll
-        for (int oc = 0; oc < 2; ++oc) {
-            float *own = &s.d2[oc * kA2Plane + (py + 1) * kA2Stride + px + 1];
-            const float gz = on2[oc] ? *own : 0.0f;
-            *own = 0.0f;
-            gb2[oc] += gz;
+            for (int oc = 0; oc < 2; ++oc) {
+                const float gz = (flags >> (4 + oc)) & 1u ? g2[oc] : 0.0f;
+                gb2[oc] += gz;
+                const uint32_t am = (flags >> (2 * oc)) & 3u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                s.map2[oc * kA1Plane + (2 * py + (e >> 1) + 1) * kA1Stride + 2 * px + (e & 1) + 1] =
-                    e == am2[oc] ? gz : 0.0f;
+                for (int e = 0; e < 4; ++e)
+                    s.u.map2[oc * kA1Plane + (2 * py + (e >> 1) + 1) * kA1Stride + 2 * px + (e & 1) + 1] =
+                        e == (int)am ? gz : 0.0f;
+            }
+            // the border of plane 1 that the gather reads (rows 0, 33 and columns 0, 33) held halo3 values
+            if (tid < 132) {
+                const int o = tid < 34 ? tid : tid < 68 ? 33 * kA1Stride + (tid - 34)
+                            : tid < 100 ? (tid - 68 + 1) * kA1Stride : (tid - 100 + 1) * kA1Stride + 33;
+                s.u.map2[kA1Plane + o] = 0.0f;
+            }
         }
+        if (!PACKED_OBS && g + stride < n) convert();
         __syncthreads();
 
         // ---- conv2 and conv1 weight gradients of input channel wv: lane = 16 positions of A1
         //      row Y = lane / 2, columns 16 * (lane & 1) ..
+        if (PACKED_OBS && g + stride < n) issue(g + stride);
         {
+            kfloat *w2 = opaque_uniform(prm);
+            float wc[18];                             // w2[oc][wv][k], oc-major (SGPRs)
+#pragma unroll
+            for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+                for (int kq = 0; kq < 9; ++kq) wc[oc * 9 + kq] = w2[(oc * 4 + wvs) * 9 + kq];
             const int Y = lane >> 1, X0 = 16 * (lane & 1);
             const float *ap = s.a1 + wvs * kA1Plane + (Y + 1) * kA1Stride + X0 + 1;
-            const uint16_t *pp = &s.pat[wvs][Y * 32 + X0];
+            const uint16_t *nbp = &s.nb[Y * 32 + X0];
+            const uint8_t *amp = &s.am[Y * 32 + X0];
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 float mp[2][3][6];                    // map rows Y..Y+2, cols X0+4ch .. +5 (padded)
@@ -1117,17 +1252,21 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
                 for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
-                        const float *mr = s.map2 + oc * kA1Plane + (Y + r) * kA1Stride + X0 + 4 * ch;
+                        const float *mr = s.u.map2 + oc * kA1Plane + (Y + r) * kA1Stride + X0 + 4 * ch;
                         const float2 m01 = *reinterpret_cast<const float2 *>(mr);
                         const float2 m23 = *reinterpret_cast<const float2 *>(mr + 2);
                         const float2 m45 = *reinterpret_cast<const float2 *>(mr + 4);
                         mp[oc][r][0] = m01.x; mp[oc][r][1] = m01.y; mp[oc][r][2] = m23.x;
                         mp[oc][r][3] = m23.y; mp[oc][r][4] = m45.x; mp[oc][r][5] = m45.y;
                     }
+                float av[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) av[i] = ap[4 * ch + i];
+                const uint2 nb4 = *reinterpret_cast<const uint2 *>(nbp + 4 * ch);
+                const uint32_t am4 = *reinterpret_cast<const uint32_t *>(amp + 4 * ch);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float av = ap[4 * ch + i];
-                    const uint32_t pt = pp[4 * ch + i];
                     float d = 0.0f;
 #pragma unroll
                     for (int oc = 0; oc < 2; ++oc)
@@ -1136,29 +1275,41 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
 #pragma unroll
                             for (int kx = 0; kx < 3; ++kx) {
                                 const float mv = mp[oc][2 - ky][i + 2 - kx];
-                                gw2c[oc * 9 + ky * 3 + kx] = fmaf(av, mv, gw2c[oc * 9 + ky * 3 + kx]);
+                                gw2c[oc * 9 + ky * 3 + kx] = fmaf(av[i], mv, gw2c[oc * 9 + ky * 3 + kx]);
                                 d = fmaf(wc[oc * 9 + ky * 3 + kx], mv, d);
                             }
-                    const float gz = av > 0.0f ? d : 0.0f;
+                    const float gz = av[i] > 0.0f ? d : 0.0f;
                     gb1c += gz;
+                    // the arg-max cell (dy, dx) of channel wv inside the position's 4x4 neighbourhood
+                    const uint32_t idx = (am4 >> (8 * i + 2 * wvs)) & 3u;
+                    const uint32_t nbw = ((i & 2) ? nb4.y : nb4.x) >> (16 * (i & 1));
+                    const uint32_t t = (nbw & 0xFFFFu) >> (((idx & 2u) << 1) | (idx & 1u));
 #pragma unroll
                     for (int tt = 0; tt < 9; ++tt)
-                        gw1c[tt] = fmaf(gz, (float)((pt >> tt) & 1u), gw1c[tt]);
+                        gw1c[tt] = fmaf(gz, (float)((t >> (4 * (tt / 3) + tt % 3)) & 1u), gw1c[tt]);
                 }
             }
         }
-        // the next iteration's barriers order its writes to rows / A1 / pat / map2 behind these reads
+        // the next iteration's barriers order its writes to rows / A1 / nb / am / A3 / halo3 behind these reads
     }
 
     // ---- one partial gradient row per workgroup, parameter order of the AE blob
     float *row = partial + (int64_t)blockIdx.x * kAeParams;
     __syncthreads();
+    // red[wv][.]: 0..15 convT2.w, 16 convT2.b, 17..48 convT1.w, 49 convT1.b, 50..51 conv2.b
 #pragma unroll
-    for (int i = 0; i < 52; ++i) {
-        // 0..15 convT2.w, 16 convT2.b, 17..48 convT1.w, 49 convT1.b, 50..51 conv2.b
-        float a = i < 16 ? gwt2[i] : i == 16 ? gbt2 : i < 49 ? gwt1[i - 17] : i == 49 ? gbt1 : gb2[i - 50];
-        a = wave_sum_f32(a);
-        if (lane == 0) s.red[wv][i] = a;
+    for (int m = 0; m < 4; ++m) {
+        const float a = quad_class_sum(gwt2q[m]);
+        if (lane < 4) s.red[wv][4 * m + lane] = a;
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const float a = quad_class_sum(gwt1q[m]);
+        if (lane < 4) s.red[wv][17 + 4 * m + lane] = a;
+    }
+    {
+        const float a0 = wave_sum_dpp(gbt2), a1 = wave_sum_dpp(gbt1), a2 = wave_sum_dpp(gb2[0]), a3 = wave_sum_dpp(gb2[1]);
+        if (lane == 0) { s.red[wv][16] = a0; s.red[wv][49] = a1; s.red[wv][50] = a2; s.red[wv][51] = a3; }
     }
     __syncthreads();
     if (tid < 52) {
@@ -1169,24 +1320,24 @@ __global__ __launch_bounds__(256, 2) void ae_train_block64_kernel(
     // channel-split parts: wave wv owns conv1 channel wv and conv2 input channel wv
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const float a = wave_sum_f32(gw1c[i]);
+        const float a = wave_sum_dpp(gw1c[i]);
         if (lane == 0) row[wv * 9 + i] = a;
     }
     {
-        const float a = wave_sum_f32(gb1c);
+        const float a = wave_sum_dpp(gb1c);
         if (lane == 0) row[36 + wv] = a;
     }
 #pragma unroll
     for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
         for (int kq = 0; kq < 9; ++kq) {
-            const float a = wave_sum_f32(gw2c[oc * 9 + kq]);
+            const float a = wave_sum_dpp(gw2c[oc * 9 + kq]);
             if (lane == 0) row[40 + (oc * 4 + wv) * 9 + kq] = a;
         }
 }
 
 int ae2d_train64_rows(int64_t n) {                 // = workgroups of ae_train_block64_kernel
-    int64_t rows = n < 512 ? n : 512;                  // persistent: 2 workgroups are resident per CU
+    int64_t rows = n < 768 ? n : 768;                  // persistent: 3 workgroups are resident per CU
     return (int)(rows < 1 ? 1 : rows);
 }
 
