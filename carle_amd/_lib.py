@@ -74,6 +74,9 @@ SIGNATURES = {
                                    _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp]),
     "carle_bernoulli_f32": (_c_int, [_c_vp, _c_i64, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64,
                                      _c_vp]),
+    "carle_agent_rn_workspace_floats": (_c_i64, [_c_i64, _c_int, _c_int, _c_int]),
+    "carle_agent_rn_forward_f32": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_int,
+                                            ctypes.c_float, _c_vp, _c_vp, _c_vp, _c_vp]),
     "carle_ca_step_f32_rand": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
                                         ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _c_vp, _c_vp,
                                         _c_int, _c_vp]),

@@ -54,15 +54,19 @@ class RandomAgent(nn.Module):
 
 
 class RandomNetworkAgent(nn.Module):
-    """Frozen random convnet -> sigmoid <= toggle_rate (carle/agents.py:45-102).  A caller of
-    the hot path, not part of it: the small network runs through PyTorch-ROCm modules on the
-    observation's device (no host round trip)."""
+    """Frozen random convnet -> sigmoid <= toggle_rate (carle/agents.py:45-102).  ``network`` is the
+    reference's ``nn.Sequential`` (same indices: its state_dict loads strictly); the forward pass runs
+    in two HIP kernels (``carle_agent_rn_forward_f32``: tiled convolutions + pooling, then the linear
+    layer on the fp32 matrix cores with sigmoid and threshold fused) on the observation's device.
+    Deviation: the reference reads ``observation_width`` only when the misspelt key
+    ``observatoin_width`` is present (agents.py:56-58) and otherwise builds for width 256; here
+    either spelling sets it."""
 
     def __init__(self, **kwargs):
         super().__init__()
         self.action_width = kwargs.get("action_width", 64)
         self.action_height = kwargs.get("action_height", 64)
-        self.observation_width = kwargs.get("observation_width", 256)
+        self.observation_width = kwargs.get("observation_width", kwargs.get("observatoin_width", 256))
         self.observation_height = kwargs.get("observation_height", 256)
         self.depth = 3
         self.filter_dim = 4
@@ -85,14 +89,22 @@ class RandomNetworkAgent(nn.Module):
         for param in self.network.parameters():
             param.requires_grad = False
 
-    def forward(self, obs):
+    def forward(self, obs, want_output=False):
+        if not torch.is_tensor(obs):
+            obs = torch.as_tensor(obs)
+        if not obs.is_cuda:
+            obs = obs.to(torch.device("cuda", torch.cuda.current_device()))
+        obs = obs.to(torch.float32).contiguous()
+        if obs.dim() == 3:
+            obs = obs.unsqueeze(1)
         instances = obs.shape[0]
         if next(self.network.parameters()).device != obs.device:
             self.network.to(obs.device)
-        with torch.no_grad():
-            output = self.network(obs)
-        action = 1.0 * (output <= self.toggle_rate)
-        return action.reshape(instances, 1, self.action_width, self.action_height)
+        w1, w2, wl = (self.network[i].weight.detach().contiguous() for i in (0, 3, 7))
+        action, output, self._ws = hip.agent_rn_forward(obs, w1, w2, wl, self.toggle_rate,
+                                                        getattr(self, "_ws", None), want_output)
+        action = action.reshape(instances, 1, self.action_width, self.action_height)
+        return (action, output) if want_output else action
 
 
 class DemoAgent(RandomAgent):

@@ -472,6 +472,31 @@ def bernoulli_f32(shape, p, seed, offset, device, out=None):
     return out
 
 
+def agent_rn_forward(obs, conv1_w, conv2_w, lin_w, toggle_rate, workspace=None, want_output=False):
+    """RandomNetworkAgent.forward on the device (carle/agents.py:91-102): returns (action (N, OUT) fp32,
+    sigmoid output (N, OUT) or None, workspace)."""
+    lib = _lib.load()
+    _chk_grid(obs, "obs", torch.float32)
+    n, _, h, w = obs.shape
+    out_nodes, dense = lin_w.shape
+    if dense != (h // 4) * (w // 4) or h % 8 or w % 8:
+        raise ValueError(f"RandomNetworkAgent: observation {h}x{w} does not match the linear layer ({dense} inputs)")
+    for t in (conv1_w, conv2_w, lin_w):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != obs.device:
+            raise ValueError("RandomNetworkAgent: weights must be contiguous fp32 tensors on the observation's device")
+    need = lib.carle_agent_rn_workspace_floats(n, h, w, out_nodes)
+    if workspace is None or workspace.numel() < need or workspace.device != obs.device:
+        workspace = torch.empty(max(need, 4), dtype=torch.float32, device=obs.device)
+    action = torch.empty((n, out_nodes), dtype=torch.float32, device=obs.device)
+    output = torch.empty((n, out_nodes), dtype=torch.float32, device=obs.device) if want_output else None
+    with _on_device(obs.device):
+        rc = lib.carle_agent_rn_forward_f32(obs.data_ptr(), n, h, w, conv1_w.data_ptr(), conv2_w.data_ptr(),
+                                            lin_w.data_ptr(), out_nodes, float(toggle_rate), workspace.data_ptr(),
+                                            _ptr(output), action.data_ptr(), _stream(obs))
+    _lib.check(rc, "carle_agent_rn_forward_f32")
+    return action, output, workspace
+
+
 def env_step_f32_rand(u_in, u_out, reward, rule, status, slot, ah, aw, p, seed, offset, action_out=None,
                       merge_moments=False):
     """CARLE.step with Bernoulli(p) toggles drawn inside the step kernel (64x64 grids)."""

@@ -334,6 +334,19 @@ int carle_stream_fork(void *event, void *from_stream, void *to_stream);
 /* out[0..count) := Bernoulli(p) as 0.0f / 1.0f; count % 4 == 0 */
 int carle_bernoulli_f32(float *out, int64_t count, float p, uint64_t seed, uint64_t offset,
                         void *stream);
+/* RandomNetworkAgent.forward (carle/agents.py:45-102): obs (N,1,H,W) fp32 ->
+ *   Conv2d(1,4,3,p1) - ReLU - MaxPool(2) - Conv2d(4,1,3,p1) - ReLU - MaxPool(2) - Flatten - Linear(dense, OUT) -
+ *   Sigmoid, all without bias (agents.py:78-87);  action[n][o] = 1.0f if sigmoid <= toggle_rate else 0.0f
+ *   (agents.py:98), laid out (N, OUT) = the reference's reshape to (N,1,AW,AH).
+ * conv1_w [4][1][3][3], conv2_w [1][4][3][3], lin_w [OUT][dense] with dense = (H/4)*(W/4): the
+ * state_dict tensors `network.0.weight`, `network.3.weight`, `network.7.weight`.  H, W multiples of 8.
+ * workspace: carle_agent_rn_workspace_floats(n, h, w, out_nodes) floats (the pooled features and, for small
+ * batches, the K-split partial logits).  output (nullable): the (N, OUT) sigmoid values.  The linear layer runs
+ * on the fp32 matrix cores (MFMA). */
+int64_t carle_agent_rn_workspace_floats(int64_t n, int h, int w, int out_nodes);
+int carle_agent_rn_forward_f32(const float *obs, int64_t n, int h, int w, const float *conv1_w,
+                               const float *conv2_w, const float *lin_w, int out_nodes, float toggle_rate,
+                               float *workspace, float *output, float *action, void *stream);
 /* carle_ca_step_f32 with the action drawn IN the kernel (identical to generating the action with
  * carle_bernoulli_f32(seed, offset) and passing it in): no action tensor is read.  64x64 grids
  * with AW % 8 == 0, or 256 / 512 grids with AW % 4 == 0 and (W-AW) % 8 == 0.  action_out (nullable):

@@ -11,10 +11,14 @@ reference (riveSunder/carle, carle/mcl.py), evaluated in eval mode (dropout = id
                                   convT(2->1,k4,s2,p1) relu convT(1->1,k4,s2,p1) sigmoid
   ae_bonus       mcl.py:504-512   mean_{h,w} |(obs - prediction)^2|           -> (N,)
 
+  agent_output   agents.py:78-87   RandomNetworkAgent.network: conv(1->4) relu pool2 conv(4->1) relu pool2
+                                  flatten linear(dense -> AW*AH) sigmoid, no biases
+  agent_action   agents.py:91-102  1.0 * (output <= toggle_rate)            -> (N, AW*AH)
+
 Parameters are passed as a dict name -> array using the reference's state_dict names
 ("predictor.0.weight", "random_network.8.bias", ...), so the golden state_dicts feed it directly.
 
-Parity status: PINNED against tests/golden/nets_64.npz and nets_256.npz (tests/test_oracle_nets.py),
+Parity status: PINNED against tests/golden/nets_64.npz, nets_256.npz and agent_net.npz (tests/test_oracle_nets.py),
 tolerance 1e-6 absolute (same ATen kernels, same machine -> typically bit-identical).
 """
 import numpy as np
@@ -58,3 +62,14 @@ def ae_predictor(obs, sd, prefix="predictor."):
 def ae_bonus(obs, sd):
     o = _t(obs)
     return torch.mean(torch.abs((o - ae_predictor(o, sd)) ** 2), dim=[1, 2, 3])
+
+
+def agent_output(obs, sd, prefix="network."):
+    p = lambda k: _t(sd[prefix + k]).float()
+    x = F.max_pool2d(F.relu(F.conv2d(_t(obs), p("0.weight"), None, padding=1)), 2)
+    x = F.max_pool2d(F.relu(F.conv2d(x, p("3.weight"), None, padding=1)), 2)
+    return torch.sigmoid(F.linear(x.flatten(1), p("7.weight"), None))
+
+
+def agent_action(obs, sd, toggle_rate=0.1):
+    return 1.0 * (agent_output(obs, sd) <= toggle_rate)

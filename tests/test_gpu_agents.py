@@ -81,13 +81,95 @@ def test_fused_token_on_other_geometries(size, asize):
     assert env.step_number == 4
 
 
-def test_random_network_agent():
+def _agent_check(agent, obs, scale=None):
+    """HIP forward of a RandomNetworkAgent against the oracle (oracle/nets.py, pinned to the reference's
+    fixture): sigmoid outputs within 1e-5, actions identical wherever the output is not within that tolerance
+    of the threshold (the comparison itself is exact: fp32 output <= fp32(0.1), agents.py:98).  With the
+    linear layer scaled by 40 the logits -- and the fp32 summation-order noise of their up to 4096-term dot
+    products -- are 40 times larger: 1e-4 there."""
+    from oracle import nets as ON
+    if scale is not None:
+        with torch.no_grad():
+            agent.network[7].weight.mul_(scale)
+    action, output = agent(obs, want_output=True)
+    sd = {"network." + k: v.detach().cpu().numpy() for k, v in agent.network.state_dict().items()}
+    with torch.no_grad():
+        ref_out = ON.agent_output(obs.cpu().numpy(), sd).numpy()
+    ref_act = (ref_out <= np.float32(agent.toggle_rate)).astype(np.float32)
+    n = obs.shape[0]
+    assert tuple(action.shape) == (n, 1, agent.action_width, agent.action_height) and action.is_cuda
+    got_out = output.cpu().numpy()
+    tol = 1e-5 if scale is None else 1e-4
+    np.testing.assert_allclose(got_out, ref_out, rtol=0, atol=tol)
+    got_act = action.reshape(n, -1).cpu().numpy()
+    clear = np.abs(ref_out - np.float32(agent.toggle_rate)) > tol
+    assert np.array_equal(got_act[clear], ref_act[clear])
+    assert set(np.unique(got_act).tolist()) <= {0.0, 1.0}
+    assert np.array_equal(agent(obs).cpu().numpy(), action.cpu().numpy())        # without the outputs
+    return got_act.mean()
+
+
+@pytest.mark.parametrize("n,h,w,aw", [(3, 64, 64, 64), (70, 16, 256, 8), (1, 8, 8, 8), (5, 128, 64, 16),
+                                      (16, 256, 256, 64), (130, 64, 64, 64)])
+def test_random_network_agent_matches_oracle(n, h, w, aw):
+    """carle_agent_rn_forward_f32 (tiled convolutions + the linear layer on the fp32 matrix cores) vs the
+    oracle; square, non-square, one-tile, partial-tile and multi-tile geometries; default-init weights and
+    a scaled linear layer (so that both sides of the threshold occur)."""
     from carle_amd.agents import RandomNetworkAgent
-    torch.manual_seed(0)
-    agent = RandomNetworkAgent(observation_width=64, observation_height=64)
-    a = agent((torch.rand(3, 1, 64, 64, device="cuda") < 0.3).float())
-    assert tuple(a.shape) == (3, 1, 64, 64) and a.is_cuda
-    assert set(torch.unique(a).cpu().tolist()) <= {0.0, 1.0}
+    torch.manual_seed(100 + n)
+    agent = RandomNetworkAgent(observation_width=w, observation_height=h, action_width=aw, action_height=aw)
+    dens = torch.linspace(0.02, 0.8, n, device="cuda").reshape(n, 1, 1, 1)
+    obs = (torch.rand(n, 1, h, w, device="cuda") < dens).float()
+    _agent_check(agent, obs)
+    rate = _agent_check(agent, obs, scale=40.0)
+    if rate < 0.01:                                         # few inputs per output: scale further
+        rate = _agent_check(agent, obs, scale=8.0)
+    if n * aw * aw >= 4096:
+        assert 0.001 < rate < 0.999
+    # non-binary observations go through the same arithmetic (the reference feeds the tensor itself)
+    _agent_check(agent, torch.randn(n, 1, h, w, device="cuda"))
+
+
+def test_random_network_agent_reference_fixture():
+    """The fixture recorded from the reference's RandomNetworkAgent (tools/make_golden.py: observations
+    (6,1,16,256), action 8x8, default-init and scaled linear layer)."""
+    import os
+    import golden_util as G
+    from carle_amd.agents import RandomNetworkAgent
+    z = np.load(os.path.join(G.GOLDEN, "agent_net.npz"))
+    obs = torch.from_numpy(G.unpack(z["obs"], tuple(z["obs_shape"]))).cuda()
+    agent = RandomNetworkAgent(observation_width=256, observation_height=16, action_width=8, action_height=8)
+    sd = {k: torch.from_numpy(v) for k, v in G.load_sd(z, "sd").items()}
+    agent.load_state_dict(sd, strict=True)
+    for lin, tag in ((None, "default"), (z["lin_scaled"], "scaled")):
+        if lin is not None:
+            with torch.no_grad():
+                agent.network[7].weight.copy_(torch.from_numpy(lin))
+        action, output = agent(obs, want_output=True)
+        ref_out, ref_act = z[f"output_{tag}"], z[f"action_{tag}"]
+        np.testing.assert_allclose(output.cpu().numpy(), ref_out, rtol=0, atol=1e-5)
+        clear = (np.abs(ref_out - z["toggle_rate"]) > 1e-5).reshape(ref_act.shape)
+        assert np.array_equal(action.cpu().numpy()[clear], ref_act[clear])
+        assert clear.mean() > 0.99
+
+
+def test_random_network_agent_drives_the_environment():
+    """agents.py:91-102 in the loop of train_mcl.py:64-69: the agent's action steps a 256x256 environment."""
+    from carle_amd.agents import RandomNetworkAgent
+    from carle_amd.env import CARLE
+    torch.manual_seed(1)
+    env = CARLE(width=256, height=256, instances=4, device="cuda:0")
+    agent = RandomNetworkAgent()
+    with torch.no_grad():
+        agent.network[7].weight.mul_(40.0)
+    obs = env.reset()
+    env.universe = (torch.rand(4, 1, 256, 256, device="cuda") < 0.3).float()
+    obs = env.universe
+    for _ in range(3):
+        action = agent(obs)
+        assert tuple(action.shape) == (4, 1, 64, 64)
+        obs, reward, done, info = env.step(action)
+    assert env.step_number == 3
 
 
 @pytest.mark.parametrize("storage,n,size", [("u8", 3, 64), ("u8", 37, 64), ("u8", 2, 256), ("u8", 1, 512),

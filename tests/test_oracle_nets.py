@@ -44,3 +44,19 @@ def test_state_dict_key_layout():
         "random_network.4.bias", "random_network.8.weight", "random_network.8.bias"]
     ak = list(G.load_sd(z, "ae_sd").keys())
     assert len(ak) == 23 and "env.random_network.8.bias" in ak and "predictor.11.bias" in ak
+
+
+def test_agent_oracle_matches_reference():
+    """oracle.nets.agent_output / agent_action reproduce the RandomNetworkAgent fixture recorded from the
+    reference (carle/agents.py:45-102), default-init and scaled linear layer."""
+    import os
+    z = np.load(os.path.join(G.GOLDEN, "agent_net.npz"))
+    obs = G.unpack(z["obs"], tuple(z["obs_shape"]))
+    sd = G.load_sd(z, "sd")
+    assert list(sd.keys()) == ["network.0.weight", "network.3.weight", "network.7.weight"]
+    with torch.no_grad():
+        np.testing.assert_allclose(ON.agent_output(obs, sd).numpy(), z["output_default"], rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(ON.agent_action(obs, sd, float(z["toggle_rate"])).numpy(), z["action_default"].reshape(6, -1))
+        sd["network.7.weight"] = z["lin_scaled"]
+        np.testing.assert_allclose(ON.agent_output(obs, sd).numpy(), z["output_scaled"], rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(ON.agent_action(obs, sd, float(z["toggle_rate"])).numpy(), z["action_scaled"].reshape(6, -1))

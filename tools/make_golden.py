@@ -26,6 +26,9 @@ Fixture files
   nets_256.npz     the shipped evaluation/*.pt weights (256x256): state_dicts (as arrays),
                    4 input grids, get_bonus_only outputs (eval mode)
   nets_256_train.npz  predictor-update trajectory at the default 256x256 geometry (3 Adam updates)
+  agent_net.npz    RandomNetworkAgent (carle/agents.py:45-102): weights, observations, the network's sigmoid
+                   outputs and the thresholded actions (default-init weights, and the same weights with the
+                   linear layer scaled up so that toggles actually occur)
   wrappers.npz     CornerBonus / SpeedDetector / PufferDetector / ParsimonyBonus and the eval.py
                    wrapper stack: inputs and per-step rewards
 """
@@ -548,6 +551,39 @@ def make_wrappers(torch, ref_env, ref_mcl, outdir):
     print("wrappers.npz written")
 
 
+def make_agent_net(torch, ref_env, outdir):
+    """RandomNetworkAgent of the reference.  Its constructor ignores ``observation_width`` (the key it
+    tests for is misspelt, agents.py:56-58) and always builds for width 256; ``observation_height``
+    works.  Geometry here: observations (n,1,16,256) -> dense 256, action 8x8 -> a 64 KB linear layer."""
+    import carle.agents as ref_agents
+    assert ref_agents.__file__.startswith(REF)
+    out = {}
+    torch.manual_seed(5)
+    agent = ref_agents.RandomNetworkAgent(observation_height=16, action_width=8, action_height=8)
+    assert agent.observation_width == 256 and agent.network[7].weight.shape == (64, 256)
+    rng = np.random.default_rng(9)
+    n = 6
+    dens = np.array([0.0, 1.0, 0.1, 0.3, 0.5, 0.8]).reshape(n, 1, 1, 1)
+    obs = (rng.random((n, 1, 16, 256)) < dens).astype(np.float32)
+    out["obs"], out["obs_shape"] = pack(obs)
+    sd_to_npz("sd", agent.state_dict(), out)
+    g = torch.from_numpy(obs)
+    out["output_default"] = agent.network(g).numpy()
+    out["action_default"] = agent(g).numpy().astype(np.float32)
+    # the freshly initialised agent practically never toggles (sigmoid(x) <= 0.1 needs x <= -2.2): scale the
+    # linear layer so that both sides of the threshold occur
+    with torch.no_grad():
+        agent.network[7].weight.mul_(40.0)
+    out["lin_scaled"] = agent.network[7].weight.numpy().copy()
+    out["output_scaled"] = agent.network(g).numpy()
+    out["action_scaled"] = agent(g).numpy().astype(np.float32)
+    out["toggle_rate"] = np.float32(agent.toggle_rate)
+    frac = float(out["action_scaled"].mean())
+    assert 0.02 < frac < 0.98, frac
+    np.savez_compressed(os.path.join(outdir, "agent_net.npz"), **out)
+    print("agent_net.npz: toggled fraction (scaled weights) %.3f" % frac)
+
+
 def make_rle(torch, ref_env, outdir):
     """RLE codec: get_rle strings and rle_to_grid grids of the reference."""
     import base64
@@ -590,7 +626,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch, ref_env, ref_mcl = import_reference()
     torch.set_num_threads(8)
-    todo = args.only.split(",") if args.only else ["ca", "predicates", "known", "nets", "train256", "wrappers", "rle"]
+    todo = args.only.split(",") if args.only else ["ca", "predicates", "known", "nets", "train256", "wrappers", "rle", "agent"]
     if "ca" in todo:
         make_ca(torch, ref_env, args.out)
     if "predicates" in todo:
@@ -605,6 +641,8 @@ def main():
         make_wrappers(torch, ref_env, ref_mcl, args.out)
     if "rle" in todo:
         make_rle(torch, ref_env, args.out)
+    if "agent" in todo:
+        make_agent_net(torch, ref_env, args.out)
 
 
 if __name__ == "__main__":
