@@ -27,6 +27,9 @@ __device__ unsigned long long *g_b1_stamps = nullptr;       // [work item][4]
 
 namespace carle {
 
+// Multi-strip grids use plain (cached) loads and stores: a lane reads its row as W/128 loads of 16 B and the
+// lines have to stay cached between them -- with the streaming (nt) hint the 512x512 step takes 110 us
+// instead of 48 us (measured, round 2).
 template <int WW>
 __device__ __forceinline__ void load_row(const uint64_t *__restrict__ p, uint64_t (&r)[WW]) {
     if constexpr (WW == 1) {
@@ -162,26 +165,66 @@ template <int WW, int ACT, int RULE_MODE, bool RAND = false>
 __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     const uint64_t *__restrict__ u_in, const uint64_t *__restrict__ act, uint64_t *__restrict__ u_out,
     int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot,
-    int strip_first, int strip_count, RandB1 ra = RandB1()) {
+    int strip_first, int strip_count, RandB1 ra = RandB1(), int dbg = 0) {
     // the launch covers strips [strip_first, strip_first + strip_count) (mod WW) of every grid:
     // wide windows: the host launches the strips that can meet the action window with ACT = 2 and
     // the others with the leaner ACT = 0 instantiation (half the registers)
     constexpr int H = 64 * WW;
     constexpr bool MULTI = WW > 1;                          // more than one 64-row strip per grid
     const int lane = threadIdx.x;
-    // Persistent waves: the launch has just under 32 waves per CU and every wave walks the (grid,
-    // strip) list with stride gridDim.x.  One-shot waves spent more time being launched and retired
-    // than running (profiles/r02_b1_stamps.txt: 5 us of instructions per strip in 13 us of wave slot).
+    // Persistent waves: the launch has at most 32 waves per CU and every wave walks a list of work units
+    // with stride gridDim.x.  One-shot waves spent more time being launched and retired than running
+    // (profiles/r02_b1_stamps.txt: 5 us of instructions per strip in 13 us of wave slot).
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD,
-    // and gridDim.x is a multiple of 8), so XCD x takes the grids g = x (mod 8) and walks their strips
-    // one after the other: the strips of a grid share an L2 (halo rows are L2 hits) and every XCD
-    // gets every strip.  (Placement is not guaranteed: any other dealing only changes the speed.)
-    const int64_t total = ((n + 7) / 8) * 8 * strip_count;
-  for (int64_t wid = blockIdx.x; wid < total; wid += gridDim.x) {
-    const int64_t j = wid >> 3;
-    const int64_t g = 8 * (j / strip_count) + (wid & 7);
-    const int r0 = ((strip_first + (int)(j % strip_count)) % WW) * 64;
+    // and gridDim.x is a multiple of 8), so XCD x takes the grids g = x (mod 8): the strips of a grid
+    // share an L2 (halo rows are L2 hits).  (Placement is not guaranteed: any other dealing only changes
+    // the speed.)  Partial launches (wide windows: strip_count < WW) walk single strips.
+    // Launches with the 64-column action window (ACT == 1) on multi-strip grids walk HALF-GRID units -- WW / 2
+    // consecutive strips per wave -- instead of single strips.  What the window costs is not its toggle but its
+    // 4096 small, cold action records: with ONE shared, L2-hot record the 512x512 step takes 48.5 us against 47.5 us
+    // without a window, with one record per grid 55-57 us.  The window is centred, so both halves of a grid hold
+    // one window strip: every unit costs the same (a wave that walks single strips with a fixed stride draws a
+    // binomial number of the dearer window strips), a unit walks its window strip FIRST -- the records are
+    // cheapest to fetch at the very start of the launch, before the state streams saturate the memory system --
+    // and fetches its window words before anything else.  Same-box A/B (profiles/r02_kbench_b1_units.txt):
+    // 52.3 us against 55.8 us for the single-strip walk (0.645 against 0.606 of 8 TB/s).  What did not help or
+    // hurt: consecutive instead of interleaved grids per XCD, L2 prefetch of the records by a few waves, the nt
+    // hint on the state traffic (2.3x slower), the window strip later in the unit, peeling the first strip out
+    // of the loop.  Launches without a window keep the single-strip walk (47.9 us; half-grid units: 48.7 us).
+    const int64_t n8 = ((n + 7) / 8) * 8;
+    const bool halves = MULTI && strip_count == WW && ACT == 1;
+    const int per_unit = halves ? WW / 2 : 1;
+    const int64_t total = halves ? n8 * 2 : n8 * strip_count;
+    constexpr int HS = WW / 2 > 0 ? WW / 2 : 1;
+  for (int64_t unit = blockIdx.x; unit < total; unit += gridDim.x) {
+    const int64_t j = unit >> 3;
+    const int64_t g = halves ? 8 * (j >> 1) + (unit & 7) : 8 * (j / strip_count) + (unit & 7);
     if (g >= n) continue;
+    // the window words of the unit's window strip (HS >= 2: exactly one strip of a unit meets the 64-row
+    // window, the one at the middle of the grid) and of that strip's bordering row
+    uint32_t pa_lo = 0u, pa_hi = 0u, ph_lo = 0u, ph_hi = 0u;
+    const bool preload = ACT == 1 && !RAND && halves && HS >= 2 && !(dbg & 1);
+    if (preload) {
+        const int r0w = ((j & 1) ? WW - HS : HS - 1) * 64, oyw = (H - ah) >> 1;
+        const int rw = r0w + lane;
+        const int hrw = lane == 0 ? (r0w + H - 1) % H : (lane == 63 ? (r0w + 64) % H : -1);
+        const bool inw = rw >= oyw && rw < oyw + ah, hinw = hrw >= oyw && hrw < oyw + ah;
+        const uint32_t *a32 = reinterpret_cast<const uint32_t *>(act + g * (int64_t)ah + (inw ? rw - oyw : 0));
+        const uint32_t *h32 = reinterpret_cast<const uint32_t *>(act + g * (int64_t)ah + (hinw ? hrw - oyw : 0));
+        pa_lo = a32[0]; pa_hi = a32[1]; ph_lo = h32[0]; ph_hi = h32[1];
+        // ... and waited for: the records arrive while the memory system is still idle (measured faster than
+        // letting them travel beside the first strip's state loads: 52.3 against 53.8-57.9 us)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa_lo), "+v"(pa_hi), "+v"(ph_lo), "+v"(ph_hi));
+    }
+    // one strip: `first` = the unit's first strip (its window strip when the window words were fetched above)
+    auto strip = [&](const int sub, const bool first) __attribute__((always_inline)) {
+    const int64_t wid = halves ? unit * per_unit + sub : unit;          // stamp index
+    // strip order inside a half: from the middle of the grid (the window strip) outwards; the lower half
+    // mirrors the upper one
+    const int li = HS - 1 - sub;
+    const int r0 = halves ? ((j & 1) ? WW - 1 - li : li) * 64
+                          : ((strip_first + (int)(j % strip_count)) % WW) * 64;
+    (void)wid;
     B1_STAMP(0);
     const int r = r0 + lane;
     const uint64_t *gin = u_in + g * (int64_t)H * WW;
@@ -213,6 +256,10 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
                     if (hin) hwrd = drawn_row64(g, hr - oy, ra);
                     toggle_words64<WW>(hal, (uint32_t)hwrd, (uint32_t)(hwrd >> 32), hin, d0, d1);
                 }
+            } else if (preload && first) {
+                toggle_words64<WW>(c, pa_lo, pa_hi, in, s_or, s_and);
+                const bool hin = hr >= oy && hr < oy + ah;
+                toggle_words64<WW>(hal, ph_lo, ph_hi, hin, d0, d1);
             } else {
             toggle_row64<WW>(c, ga + (in ? r - oy : 0), in, s_or, s_and);
             if (MULTI) {
@@ -307,6 +354,8 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     B1_STAMP(2);
     store_row<WW>(u_out + (g * (int64_t)H + r) * WW, nx);
     B1_STAMP(3);
+    };
+    for (int sub = 0; sub < per_unit; ++sub) strip(sub, sub == 0);
   }
 }
 
@@ -464,6 +513,11 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     int64_t cap = 8 * 1021;
     if (const char *e = getenv("CARLE_B1_BLOCKS")) { const int64_t v = atoll(e); if (v >= 8) cap = v / 8 * 8; }   // experiment knob
     auto blocks = [&](int64_t wg) { return (unsigned)(wg < cap ? wg : cap); };
+    // window launches of multi-strip grids walk half-grid units (see the kernel): 8192 waves = 32 per CU, all
+    // resident at once, and the batch sizes of the BASELINE configs divide evenly over them
+    int64_t ucap = 8192;
+    if (const char *e = getenv("CARLE_B1_UNITS")) { const int64_t v = atoll(e); if (v >= 8) ucap = v / 8 * 8; }       // experiment knob
+    const unsigned full = WW > 1 ? (unsigned)(n8 * 2 < ucap ? n8 * 2 : ucap) : blocks(n8 * WW);
     if (!act) {
         hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE>), dim3(blocks(n8 * WW)), dim3(64), 0,
                            s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW);
@@ -471,8 +525,10 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     }
     if (aw == 64) {
         // the usual 64x64 window: its toggle fits the full-occupancy instantiation -> one launch
-        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE>), dim3(blocks(n8 * WW)), dim3(64), 0,
-                           s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW);
+        int dbg = 0;
+        if (const char *e = getenv("CARLE_B1_DBG")) dbg = atoi(e);       // experiment knob: 1 = window words fetched at their use
+        hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE>), dim3(full), dim3(64), 0,
+                           s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg);
         return check_launch("carle_ca_step_b1");
     }
     // wider windows: the strips whose rows, or whose two bordering rows, intersect the window rows
@@ -498,7 +554,7 @@ static int launch_b1_rand(const uint64_t *u_in, uint64_t *u_out, int64_t n, uint
                           int32_t *status, int slot, hipStream_t s) {
     const int64_t n8 = (n + 7) / 8 * 8;
     if (n8 * WW > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1_rand: batch too large");
-    const int64_t wg = n8 * WW, cap = 8 * 1021;
+    const int64_t wg = WW > 1 ? n8 * 2 : n8, cap = WW > 1 ? 8192 : 8 * 1021;     // half-grid units (see the kernel)
     const dim3 grid((unsigned)(wg < cap ? wg : cap)), block(64);
     const uint64_t *none = nullptr;
     if (rule == kLifeMask)

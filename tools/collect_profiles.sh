@@ -34,6 +34,9 @@ stats cfg2_f32_n65536 --instances 65536 --steps 64 --warmup 8
 stats cfg4_rnd --rnd --steps 256 --warmup 16
 stats cfg5_b1 --format b1 --size 512 --instances 4096 --rule B36/S23 --steps 64 --warmup 8
 stats f32_256 --size 256 --steps 64 --warmup 8
+stats train_rnd_ae --rnd --ae --train --steps 256
+python3 $R/tools/train_kernel_time.py > $O/${TAG}_train_kernel_time.txt 2>&1
+python3 $R/tools/agent_time.py > $O/${TAG}_agent_net.txt 2>&1
 : > $O/${TAG}_pmc.txt
 pmc cfg2 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 4096 64 f32
 pmc cfg2_n65536 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 65536 64 f32 --instances 65536

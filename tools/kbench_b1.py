@@ -23,7 +23,11 @@ cases = {"noact": lambda i: hip.ca_step_b1(bufs[i & 1], None, bufs[(i & 1) ^ 1],
          "act_nostatus": lambda i: hip.ca_step_b1(bufs[i & 1], ring[i % 6], bufs[(i & 1) ^ 1], rule, None, 0)}
 alg = {"noact": n * size * size // 4, "act": n * (size * size // 4 + 512), "act_nostatus": n * (size * size // 4 + 512)}
 blocks = sys.argv[3].split(",") if len(sys.argv) > 3 else ["0"]
-for rep in range(2):
+gridmaps = sys.argv[4].split(",") if len(sys.argv) > 4 else [os.environ.get("CARLE_B1_DBG", "")]
+for rep in range(3 if len(gridmaps) > 1 else 2):
+ for gmap in gridmaps:                       # experiment knob of the half-grid-unit kernel, interleaved A/B
+  if gmap:
+      os.environ["CARLE_B1_DBG"] = gmap
   for blk in blocks:
     if blk == "0":
         os.environ.pop("CARLE_B1_BLOCKS", None)
@@ -40,4 +44,4 @@ for rep in range(2):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 10
-        print(f"N={n} {size}x{size} blocks={blk:>6} {name:13s}: {us:7.2f} us  {alg[name] / us / 1e6:5.2f} TB/s  frac {alg[name] / us / 8e6:.3f}", flush=True)
+        print(f"N={n} {size}x{size} gridmap={gmap:>5} blocks={blk:>6} {name:13s}: {us:7.2f} us  {alg[name] / us / 1e6:5.2f} TB/s  frac {alg[name] / us / 8e6:.3f}", flush=True)
