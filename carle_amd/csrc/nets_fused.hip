@@ -190,6 +190,12 @@ __global__ __launch_bounds__(512) void ae_prepare_kernel(const float *__restrict
     if (p < 124) ws[kAeLutFloats + p] = ap[40 + p];
 }
 
+// sigmoid through v_exp_f32 + v_rcp_f32 (~2 ulp each; |error| < 5e-7 absolute): the libm expf + IEEE division
+// pair costs ~25 instructions per cell, a third of the AE2D forward kernel
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __frcp_rn(1.0f + __expf(-x));
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
                     acc = fmaf(t3[ry0][cx1], wt2[ky0 * 4 + kx1], acc);
                     acc = fmaf(t3[ry1][cx0], wt2[ky1 * 4 + kx0], acc);
                     acc = fmaf(t3[ry1][cx1], wt2[ky1 * 4 + kx1], acc);
-                    const float pr = 1.0f / (1.0f + expf(-(acc + bt2)));
+                    const float pr = fast_sigmoid(acc + bt2);
                     out4[cx] = pr;
                     const float df = (float)((bits >> cx) & 1u) - pr;
                     sq = fmaf(df, df, sq);
@@ -847,9 +853,6 @@ __device__ __forceinline__ float quad_class_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float fast_sigmoid(float x) {   // v_exp_f32 + v_rcp_f32: ~2 ulp
-    return __frcp_rn(1.0f + __expf(-x));
-}
 
 // Hides a uniform pointer from loop-invariant code motion: the scalar loads behind it stay in the phase
 // that uses them (from the scalar cache) instead of being hoisted out of the grid loop, where 140
