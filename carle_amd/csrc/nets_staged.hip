@@ -167,6 +167,73 @@ __global__ __launch_bounds__(256) void rnd_linear_bonus_kernel(
     }
 }
 
+// The same for D a multiple of 128 (H = W a multiple of 32: the reference's default 256x256 has D = 1024):
+// 1024 threads per grid, thread = (net, k, one of 32 slices of D), the slice's D/128 float4 pairs all in
+// flight at once -- ONE memory latency instead of D/32 dependent ones (the 256-thread kernel above: 25 us at
+// N=16, 256x256; this one: see profiles/r02_fwd256.txt).  Fixed summation order.
+struct __attribute__((aligned(4))) F4U { float x, y, z, w; };   // 16 bytes at 4-byte alignment: the weight rows sit
+                                                                 // 77 / 39 floats into the state_dict-ordered blobs
+__global__ __launch_bounds__(1024) void rnd_linear_bonus_wide_kernel(
+    const float *__restrict__ ws2, const float *__restrict__ pp, const float *__restrict__ rp,
+    float *__restrict__ bonus, float *__restrict__ pred_out, float *__restrict__ target_out,
+    float *__restrict__ reward, float reward_scale, int64_t n, int d) {
+    __shared__ float s_out[2][kRndDim];
+    const int64_t g = blockIdx.x;
+    const int t = threadIdx.x;
+    const int seg = t & 31, k = (t >> 5) & 15, net = t >> 9;
+    const int len4 = d >> 7;                              // float4 pairs per slice
+    const float4 *f4 = reinterpret_cast<const float4 *>(ws2 + (g * 2 + net) * (int64_t)d) + seg * len4;
+    const float *base = net == 0 ? pp + 77 : rp + 39;
+    const F4U *w4 = reinterpret_cast<const F4U *>(base + (int64_t)k * d) + seg * len4;
+    float acc = 0.0f;
+    for (int i0 = 0; i0 < len4; i0 += 8) {
+        F4U a[8];
+        float4 b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i0 + i < len4) { a[i] = w4[i0 + i]; b[i] = f4[i0 + i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i0 + i < len4) {
+                acc = fmaf(a[i].x, b[i].x, acc); acc = fmaf(a[i].y, b[i].y, acc);
+                acc = fmaf(a[i].z, b[i].z, acc); acc = fmaf(a[i].w, b[i].w, acc);
+            }
+    }
+#pragma unroll
+    for (int sh = 1; sh < 32; sh <<= 1) acc += __shfl_xor(acc, sh, 64);
+    if (seg == 0) {
+        const float out = tanhf(acc + base[(int64_t)kRndDim * d + k]);
+        s_out[net][k] = out;
+        if (net == 0 && pred_out) pred_out[g * kRndDim + k] = out;
+        if (net == 1 && target_out) target_out[g * kRndDim + k] = out;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float sq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kRndDim; ++i) {
+            const float df = s_out[1][i] - s_out[0][i];
+            sq = fmaf(df, df, sq);
+        }
+        const float b = sq * (1.0f / kRndDim);
+        bonus[g] = b;
+        if (reward) reward[g] += reward_scale * b;        // mcl.py:403-405
+    }
+}
+
+// launches the linear stage: the wide kernel where its float4 slices exist and are aligned
+static inline void launch_rnd_linear(const float *ws2, const float *pp, const float *rp, float *bonus, float *pred_out,
+                                     float *target_out, float *reward, float reward_scale, int64_t n, int d,
+                                     hipStream_t s) {
+    const bool wide = (d & 127) == 0 && ((uintptr_t)ws2 & 15u) == 0;
+    if (wide)
+        hipLaunchKernelGGL(rnd_linear_bonus_wide_kernel, dim3((unsigned)n), dim3(1024), 0, s, ws2, pp, rp, bonus,
+                           pred_out, target_out, reward, reward_scale, n, d);
+    else
+        hipLaunchKernelGGL(rnd_linear_bonus_kernel, dim3((unsigned)n), dim3(256), 0, s, ws2, pp, rp, bonus, pred_out,
+                           target_out, reward, reward_scale, n, d);
+}
+
 // ---------------------------------------------------------------------------------------------
 // AE2D stage 1: conv1 (1->4) + relu + 2x2 pool; thread per (grid, A1 pixel)
 // ---------------------------------------------------------------------------------------------
@@ -294,7 +361,7 @@ __global__ __launch_bounds__(256) void ae_convt1_kernel(
 // Workgroup (g, c) covers pixels [c*chunk, (c+1)*chunk) of grid g and leaves one partial sum; the
 // finish kernel adds the partials of a grid in a fixed order (deterministic).  (One workgroup per
 // whole grid took 223 us at N=16, 256x256: the reference's default geometry.)
-static constexpr int kMseChunk = 4096;
+static constexpr int kMseChunk = 1024;                 // 4 pixels per thread (4096: 16 dependent iterations, 16 us at N=16 256x256)
 
 __global__ __launch_bounds__(256) void ae_convt2_mse_kernel(
     const float *__restrict__ obs, const float *__restrict__ a3, const float *__restrict__ ap,
@@ -309,6 +376,7 @@ __global__ __launch_bounds__(256) void ae_convt2_mse_kernel(
     const float *go = obs + g * (int64_t)h * w;
     const int p_end = min((c + 1) * kMseChunk, h * w);
     float sum = 0.0f;
+#pragma unroll 4
     for (int p = c * kMseChunk + threadIdx.x; p < p_end; p += 256) {
         const int x = p % w, y = p / w;
         int iy[2], ky[2], ix[2], kx[2];
@@ -426,15 +494,14 @@ extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
                        pred_params, rand_params, ws1, n, h, w);
     hipLaunchKernelGGL(rnd_conv2_pool2_kernel, dim3(blocks_for(n * 2 * (int64_t)d)), dim3(256), 0, s,
                        ws1, pred_params, rand_params, ws2, n, h, w);
-    hipLaunchKernelGGL(rnd_linear_bonus_kernel, dim3((unsigned)n), dim3(256), 0, s, ws2, pred_params,
-                       rand_params, bonus, pred_out, target_out, reward_accum, reward_scale, n, d);
+    launch_rnd_linear(ws2, pred_params, rand_params, bonus, pred_out, target_out, reward_accum, reward_scale, n, d, s);
     return check_launch("carle_rnd2d_bonus_f32");
 }
 
 extern "C" int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w) {
     if (n < 0 || h < 8 || w < 8) return 0;
     const int64_t q = (int64_t)(h / 2) * (w / 2);
-    const int64_t chunks = ((int64_t)h * w + 4095) / 4096;
+    const int64_t chunks = ((int64_t)h * w + 1023) / 1024;           // = kMseChunk
     const int64_t staged = n * (4 * q + 2 * (q / 4) + q + chunks);   // A1 (4ch) + A2 (2ch) + A3 + MSE partials
     const int64_t fused = ae2d_fused_workspace_floats();
     return staged > fused ? staged : fused;

@@ -296,8 +296,7 @@ int rnd2d_train_staged(const float *obs, int64_t n, int h, int w, const float *p
     hipLaunchKernelGGL(rnd_conv1_pool4_kernel, dim3(blocks256(p1)), dim3(256), 0, s, obs, pp, rp, ws1, n, h, w);
     hipLaunchKernelGGL(rnd_conv2_pool2_kernel, dim3(blocks256(n * 2 * (int64_t)d)), dim3(256), 0, s, ws1, pp, rp, ws2,
                        n, h, w);
-    hipLaunchKernelGGL(rnd_linear_bonus_kernel, dim3((unsigned)n), dim3(256), 0, s, ws2, pp, rp, bonus, pred, targ,
-                       reward, reward_scale, n, d);
+    launch_rnd_linear(ws2, pp, rp, bonus, pred, targ, reward, reward_scale, n, d, s);
     hipLaunchKernelGGL(rnd_bwd_linear_kernel, dim3(blocks256((int64_t)kRndK * d + kRndK)), dim3(256), 0, s, ws2, pred,
                        targ, grad, grad_scale, n, d);
     hipLaunchKernelGGL(rnd_bwd_conv2_kernel, dim3(rows2), dim3(256), 0, s, ws1, ws2, pp, pred, targ, dsel_d, dsel_s,
