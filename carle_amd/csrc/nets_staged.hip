@@ -438,6 +438,11 @@ int rnd2d_train64_rows(int64_t n);
 int rnd2d_train64(const void *obs, int obs_mode, int64_t n, const float *pp, const float *rp, float *ws,
                   float *bonus, float *reward, float reward_scale, float grad_scale, float *partial,
                   float *grad, bool tables_valid, hipStream_t s);
+bool rnd2d_tiled_applies(int h, int w);
+int64_t rnd2d_tiled_workspace_floats(int64_t n, int size);
+int rnd2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *ws,
+                float *bonus, float *pred_out, float *target_out, float *reward, float reward_scale, bool tables_valid,
+                hipStream_t s);
 int ae2d_train64_rows(int64_t n);
 int ae2d_train64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *reward, float reward_scale, float grad_scale, float *partial, float *grad,
@@ -452,7 +457,8 @@ using namespace carle;
 extern "C" int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w) {
     if (n < 0 || h < 8 || w < 8) return 0;
     const int64_t staged = n * (6 * (int64_t)(h / 4) * (w / 4) + 2 * (int64_t)(h / 8) * (w / 8));
-    const int64_t fused = rnd2d_fused_workspace_floats();
+    int64_t fused = rnd2d_fused_workspace_floats();
+    if (rnd2d_tiled_applies(h, w)) fused = rnd2d_tiled_workspace_floats(n, h);
     return staged > fused ? staged : fused;
 }
 
@@ -463,9 +469,15 @@ extern "C" int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w
                                     int flags, void *stream) {
     if (!obs || !pred_params || !rand_params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_rnd2d_bonus_b1: NULL pointer");
+    if (n >= 0 && rnd2d_tiled_applies(h, w)) {
+        if (n == 0) return 0;
+        return rnd2d_tiled(obs, true, n, h, pred_params, rand_params, workspace, bonus, pred_out, target_out,
+                           reward_accum, reward_scale, (flags & CARLE_NET_TABLES_VALID) != 0,
+                           static_cast<hipStream_t>(stream));
+    }
     if (h != 64 || w != 64 || n < 0)
         return fail_arg(CARLE_E_DIMS, "carle_rnd2d_bonus_b1: bit-packed observations are supported "
-                                      "for 64x64 grids (unpack larger grids first)");
+                                      "for square grids with H = W a multiple of 64");
     if (n == 0) return 0;
     return rnd2d_fused64(obs, 1, n, pred_params, rand_params, workspace, bonus, pred_out,
                          target_out, reward_accum, reward_scale, (flags & CARLE_NET_TABLES_VALID) != 0,
@@ -486,6 +498,9 @@ extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
         return rnd2d_fused64(obs, 0, n, pred_params, rand_params, workspace, bonus, pred_out,
                              target_out, reward_accum, reward_scale,
                              (flags & CARLE_NET_TABLES_VALID) != 0, s);
+    if ((flags & CARLE_NET_OBS_BINARY) && rnd2d_tiled_applies(h, w))
+        return rnd2d_tiled(obs, false, n, h, pred_params, rand_params, workspace, bonus, pred_out, target_out,
+                           reward_accum, reward_scale, (flags & CARLE_NET_TABLES_VALID) != 0, s);
     const int64_t p1 = n * (int64_t)(h / 4) * (w / 4);
     const int d = (h / 8) * (w / 8);
     if (p1 * 6 / 256 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_rnd2d_bonus_f32: batch too large");

@@ -196,6 +196,8 @@ class RND2D(Motivator):
         if obs.dtype == torch.int64:                      # bit-packed observation (storage="b1")
             if obs.device != dev or not obs.is_contiguous():
                 obs = obs.to(dev).contiguous()
+            if allow_packed and obs.shape[2] == 64 * obs.shape[3] and self._packed_any_size:
+                return obs, True
             if allow_packed and obs.shape[2] == 64 and obs.shape[3] == 1:
                 return obs, True
             return hip.unpack_b1_f32(obs), True
@@ -216,7 +218,9 @@ class RND2D(Motivator):
     def _tables_valid(self, obs, binary, versions):
         """True iff the fused 64x64 kernel can reuse the lookup tables already in ``self._ws``:
         same workspace tensor, same parameter-blob versions, and the previous call was fused too."""
-        fused = binary and obs.shape[2] == 64 and (obs.shape[3] == 64 or obs.dtype == torch.int64)
+        h = obs.shape[2]
+        w = obs.shape[3] * 64 if obs.dtype == torch.int64 else obs.shape[3]
+        fused = binary and h == w and h % 64 == 0        # 64x64: workgroup per grid; larger: per 64x64 tile
         key = (id(self._ws), versions) if fused and self._ws is not None else None
         valid = key is not None and key == self._tables_key
         self._tables_key_next = (fused, versions)
@@ -399,6 +403,10 @@ class RND2D(Motivator):
         self._after_update()
         self.buffer_length = 0
 
+    # bit-packed observations of any square size that is a multiple of 64 go to the kernels as they are
+    # (tiled forward, nets_tiled.hip); AE2D overrides this until it has a tiled kernel of its own
+    _packed_any_size = True
+
     # False: sizes without a fused gradient kernel retain the window and replay it through PyTorch
     # autograd (the round-1 path; kept for A/B tests) instead of the staged HIP backward kernels
     hip_backward_any_size = True
@@ -549,6 +557,7 @@ class RND2D(Motivator):
 
 class AE2D(RND2D):
     """Convolutional auto-encoder reconstruction-error bonus (mcl.py:424-556)."""
+    _packed_any_size = False
 
     def __init__(self, env, **kwargs):
         super().__init__(env, **kwargs)

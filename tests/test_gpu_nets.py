@@ -605,3 +605,63 @@ def test_reference_training_trajectory_256():
         ref = G.load_sd(z, prefix)
         for k, v in mod.state_dict().items():
             np.testing.assert_allclose(v.cpu().numpy(), ref[k], rtol=0, atol=2e-3, err_msg=k)
+
+
+def test_tiled_rnd_matches_reference_and_staged_256():
+    """The tiled RND2D forward (nets_tiled.hip: workgroup per 64x64 tile + halo, per-grid finish) at the
+    reference's default 256x256 geometry with the SHIPPED weights (evaluation/RND2D_mcl.pt via nets_256.npz):
+    bonuses of the genuine reference within 1e-5, staged path within 1e-6, packed input bit-identical."""
+    from carle_amd import hip
+    z = G.nets(256)
+    env, rnd, ae = _stack(256, 4, G.load_sd(z, "rnd_sd"), G.load_sd(z, "ae_sd"))
+    ae.reset()
+    g = torch.from_numpy(G.unpack(z["grids"], (4, 1, 256, 256))).cuda()
+    staged = rnd.get_bonus_only(g).clone()
+    staged_pred, staged_targ = rnd.forward(g).clone(), rnd.random_forward(g).clone()
+    rnd.assume_binary_obs = True                           # binary observations: the tiled kernels
+    tiled = rnd.get_bonus_only(g).clone()
+    np.testing.assert_allclose(tiled.cpu().numpy(), z["rnd_bonus"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(tiled.cpu().numpy(), staged.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rnd.forward(g).cpu().numpy(), staged_pred.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rnd.random_forward(g).cpu().numpy(), staged_targ.cpu().numpy(), rtol=0, atol=1e-6)
+    assert rnd.get_bonus_only(g).equal(tiled)              # second call: tables reused
+    packed = hip.pack_f32_b1(g)                            # (4,1,256,4) int64
+    assert rnd.get_bonus_only(packed).equal(tiled)
+
+
+@pytest.mark.parametrize("size,n", [(128, 5), (192, 3), (256, 33), (512, 2)])
+def test_tiled_rnd_sizes_against_staged_and_oracle(size, n):
+    """Random weights, every tile count per side (2, 3, 4, 8), all-dead / all-alive / sparse / dense grids."""
+    from oracle import nets as ON
+    torch.manual_seed(300 + size)
+    env, rnd, ae = _stack(size, n)
+    ae.reset()
+    dens = torch.linspace(0.0, 1.0, n, device="cuda").reshape(n, 1, 1, 1)
+    g = (torch.rand(n, 1, size, size, device="cuda") < dens).float()
+    staged = rnd.get_bonus_only(g).clone()
+    rnd.assume_binary_obs = True
+    tiled = rnd.get_bonus_only(g).clone()
+    np.testing.assert_allclose(tiled.cpu().numpy(), staged.cpu().numpy(), rtol=0, atol=1e-6)
+    sd = {k: v.detach().cpu().numpy() for k, v in rnd.state_dict().items()}
+    with torch.no_grad():
+        ref = ON.rnd_bonus(g.cpu().numpy(), sd).numpy()
+    np.testing.assert_allclose(tiled.cpu().numpy(), ref, rtol=0, atol=TOL)
+    # arbitrary non-zero values are alive (the truthiness of the packed path); -0.0 is dead
+    vals = torch.where(g > 0, torch.randn_like(g).abs() + 0.25, torch.full_like(g, -0.0))
+    assert rnd.get_bonus_only(vals).equal(tiled)
+
+
+def test_tiled_rnd_through_the_environment_256():
+    """RND2D on a 256x256 CARLE: the observation IS env.universe (binary) -> tiled kernels; rewards equal the
+    staged evaluation of the same observations."""
+    torch.manual_seed(5)
+    env, rnd, ae = _stack(256, 6)
+    rnd.reset()
+    env.universe = (torch.rand(6, 1, 256, 256, device="cuda") < 0.3).float()
+    for t in range(3):
+        a = (torch.rand(6, 1, 64, 64, device="cuda") < 0.1).float()
+        obs, reward, done, info = rnd.step(a)
+        rnd.assume_binary_obs = False
+        expected = rnd.get_bonus_only(obs.clone() * 1.0)   # a copy: not known to be binary -> staged path
+        np.testing.assert_allclose(reward.detach().cpu().numpy()[:, 0], expected.cpu().numpy() * rnd.reward_scale,
+                                   rtol=0, atol=2e-6)
