@@ -413,6 +413,11 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
 
 int64_t ae2d_fused_workspace_floats() { return kAeWsFloats; }
 
+// conv1 table + the uniform parameter block, ws[0 .. kAeWsFloats): shared with the tiled kernel (nets_tiled.hip)
+void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s) {
+    hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
+}
+
 int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s) {
     if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);

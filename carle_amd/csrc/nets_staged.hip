@@ -443,6 +443,9 @@ int64_t rnd2d_tiled_workspace_floats(int64_t n, int size);
 int rnd2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *ws,
                 float *bonus, float *pred_out, float *target_out, float *reward, float reward_scale, bool tables_valid,
                 hipStream_t s);
+int64_t ae2d_tiled_workspace_floats(int64_t n, int size);
+int ae2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *recon,
+               bool tables_valid, hipStream_t s);
 int ae2d_train64_rows(int64_t n);
 int ae2d_train64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *reward, float reward_scale, float grad_scale, float *partial, float *grad,
@@ -518,7 +521,8 @@ extern "C" int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w) {
     const int64_t q = (int64_t)(h / 2) * (w / 2);
     const int64_t chunks = ((int64_t)h * w + 1023) / 1024;           // = kMseChunk
     const int64_t staged = n * (4 * q + 2 * (q / 4) + q + chunks);   // A1 (4ch) + A2 (2ch) + A3 + MSE partials
-    const int64_t fused = ae2d_fused_workspace_floats();
+    int64_t fused = ae2d_fused_workspace_floats();
+    if (rnd2d_tiled_applies(h, w)) fused = ae2d_tiled_workspace_floats(n, h);
     return staged > fused ? staged : fused;
 }
 
@@ -527,9 +531,19 @@ extern "C" int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
                                    float *reward_accum, float reward_scale, int flags, void *stream) {
     if (!obs || !params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_ae2d_bonus_b1: NULL pointer");
+    if (n >= 0 && rnd2d_tiled_applies(h, w)) {
+        if (n == 0) return 0;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (int e = ae2d_tiled(obs, true, n, h, params, workspace, recon_out, (flags & CARLE_NET_TABLES_VALID) != 0, s))
+            return e;
+        const int tiles = (h >> 6) * (h >> 6);
+        hipLaunchKernelGGL(ae_mse_finish_kernel, dim3(blocks_for(n)), dim3(256), 0, s, workspace + 2048 + 128, bonus,
+                           reward_accum, reward_scale, n, tiles, 1.0f / ((float)h * (float)w));
+        return check_launch("carle_ae2d_bonus_b1");
+    }
     if (h != 64 || w != 64 || n < 0)
         return fail_arg(CARLE_E_DIMS, "carle_ae2d_bonus_b1: bit-packed observations are supported "
-                                      "for 64x64 grids (unpack larger grids first)");
+                                      "for square grids with H = W a multiple of 64");
     if (recon_out && !aligned16(recon_out)) return fail_arg(CARLE_E_ALIGN, "carle_ae2d_bonus_b1: recon_out alignment");
     if (n == 0) return 0;
     return ae2d_fused64(obs, true, n, params, workspace, bonus, recon_out, reward_accum, reward_scale,
@@ -548,6 +562,14 @@ extern "C" int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, c
         (!recon_out || aligned16(recon_out)))
         return ae2d_fused64(obs, false, n, params, workspace, bonus, recon_out, reward_accum,
                             reward_scale, (flags & CARLE_NET_TABLES_VALID) != 0, s);
+    if ((flags & CARLE_NET_OBS_BINARY) && rnd2d_tiled_applies(h, w) && (!recon_out || aligned16(recon_out))) {
+        if (int e = ae2d_tiled(obs, false, n, h, params, workspace, recon_out, (flags & CARLE_NET_TABLES_VALID) != 0, s))
+            return e;
+        const int tiles = (h >> 6) * (h >> 6);
+        hipLaunchKernelGGL(ae_mse_finish_kernel, dim3(blocks_for(n)), dim3(256), 0, s, workspace + 2048 + 128, bonus,
+                           reward_accum, reward_scale, n, tiles, 1.0f / ((float)h * (float)w));
+        return check_launch("carle_ae2d_bonus_f32");
+    }
     const int64_t q = (int64_t)(h / 2) * (w / 2);
     if (n * q / 256 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ae2d_bonus_f32: batch too large");
     float *a1 = workspace, *a2 = a1 + n * 4 * q, *a3 = a2 + n * 2 * (q / 4);

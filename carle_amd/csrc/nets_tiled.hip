@@ -79,39 +79,60 @@ __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict
     const int tps = size >> 6, tiles = tps * tps;      // tiles per side / per grid
     const int d8 = size >> 3, dfeat = d8 * d8;          // feature columns per row / per net
     const int64_t total = n * tiles;
+    // loads of one tile into registers (fp32: the wave's rows, 2 values per lane and row; packed: thread r < kTileRows
+    // assembles row r's two words): issued a whole iteration ahead
+    constexpr int kPer = (kTileRows + 3) / 4;
+    uint32_t va[kPer], vb[kPer];
+    uint64_t plo = 0ull, phi = 0ull;
+    auto issue = [&](int64_t t) {
+        const int64_t g = t / tiles;
+        const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
+        const int y0 = 64 * ty - 5, x0 = 64 * tx - 5;
+        if (PACKED) {
+            plo = 0ull; phi = 0ull;
+            const int y = y0 + tid;
+            if (tid < kTileRows && y >= 0 && y < size) {
+                const uint64_t *row = reinterpret_cast<const uint64_t *>(obs_v) + (g * size + y) * tps;
+                const uint64_t wm = tx > 0 ? row[tx - 1] : 0ull, w0 = row[tx], wp = tx + 1 < tps ? row[tx + 1] : 0ull;
+                plo = (wm >> 59) | (w0 << 5);
+                phi = (w0 >> 59) | ((wp & 0x1Full) << 5);
+            }
+        } else {
+            const float *gin = reinterpret_cast<const float *>(obs_v) + g * (int64_t)size * size;
+            const int xa = x0 + lane, xb = x0 + 64 + lane;
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int r = wv + 4 * i, y = y0 + r;
+                const bool yin = r < kTileRows && y >= 0 && y < size;
+                va[i] = 0u; vb[i] = 0u;
+                if (yin && xa >= 0 && xa < size) va[i] = __float_as_uint(gin[(int64_t)y * size + xa]);
+                if (yin && lane < 10 && xb < size) vb[i] = __float_as_uint(gin[(int64_t)y * size + xb]);
+            }
+        }
+    };
+    if ((int64_t)blockIdx.x < total) issue(blockIdx.x);
     __syncthreads();
     for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
         const int64_t g = t / tiles;
         const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
         const int y0 = 64 * ty - 5, x0 = 64 * tx - 5;
-        // ---- the tile's 74 rows as 74-bit words
+        // ---- the tile's kTileRows rows as bit words: from the registers the previous iteration (or the prologue) filled
         if (PACKED) {
-            if (tid < kTileRows) {
-                const int y = y0 + tid;
-                uint64_t lo = 0ull, hi = 0ull;
-                if (y >= 0 && y < size) {
-                    const uint64_t *row = reinterpret_cast<const uint64_t *>(obs_v) + (g * size + y) * tps;
-                    const uint64_t wm = tx > 0 ? row[tx - 1] : 0ull, w0 = row[tx], wp = tx + 1 < tps ? row[tx + 1] : 0ull;
-                    lo = (wm >> 59) | (w0 << 5);
-                    hi = (w0 >> 59) | ((wp & 0x1Full) << 5);
-                }
-                s.rows[tid][0] = lo;
-                s.rows[tid][1] = hi;
-            }
+            if (tid < kTileRows) { s.rows[tid][0] = plo; s.rows[tid][1] = phi; }
         } else {
-            const float *gin = reinterpret_cast<const float *>(obs_v) + g * (int64_t)size * size;
-            for (int r = wv; r < kTileRows; r += 4) {   // wave = row: two coalesced loads, two ballots
-                const int y = y0 + r;
-                const bool yin = y >= 0 && y < size;
-                const int xa = x0 + lane, xb = x0 + 64 + lane;
-                uint32_t va = 0u, vb = 0u;
-                if (yin && xa >= 0 && xa < size) va = __float_as_uint(gin[(int64_t)y * size + xa]);
-                if (yin && lane < 10 && xb < size) vb = __float_as_uint(gin[(int64_t)y * size + xb]);
-                const uint64_t lo = __ballot((va & 0x7FFFFFFFu) != 0u);
-                const uint64_t hi = __ballot((vb & 0x7FFFFFFFu) != 0u);
-                if (lane == 0) { s.rows[r][0] = lo; s.rows[r][1] = hi; }
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int r = wv + 4 * i;
+                const uint64_t lo = __ballot((va[i] & 0x7FFFFFFFu) != 0u);
+                const uint64_t hi = __ballot((vb[i] & 0x7FFFFFFFu) != 0u);
+                if (lane == 0 && r < kTileRows) { s.rows[r][0] = lo; s.rows[r][1] = hi; }
             }
         }
+        if (t + gridDim.x < total) issue(t + gridDim.x);          // the next tile travels during this one's layers
+        // this tile's 8 weights per thread of the linear layers: requested now, used after conv2
+        const int lfy = tid & 7, lk = (tid >> 3) & 15, lnet = tid >> 7;
+        const float *wrow = (lnet == 0 ? pp + 77 : rp + 39) + (int64_t)lk * dfeat + (int64_t)(8 * ty + lfy) * d8 + 8 * tx;
+        const F4T wa = *reinterpret_cast<const F4T *>(wrow), wb = *reinterpret_cast<const F4T *>(wrow + 4);
         __syncthreads();
         // ---- conv1 + pool of the 18x18 windows (window (wy, wx) = pooled position (16ty - 1 + wy, 16tx - 1 + wx))
         {
@@ -127,9 +148,8 @@ __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict
         __syncthreads();
         // ---- the tile's share of the linear layers: thread = (net, k, feature row fy of the tile)
         {
-            const int fy = tid & 7, k = (tid >> 3) & 15, net = tid >> 7;
-            const float *wrow = (net == 0 ? pp + 77 : rp + 39) + (int64_t)k * dfeat + (int64_t)(8 * ty + fy) * d8 + 8 * tx;
-            const F4T a = *reinterpret_cast<const F4T *>(wrow), b = *reinterpret_cast<const F4T *>(wrow + 4);
+            const int fy = lfy, k = lk, net = lnet;
+            const F4T a = wa, b = wb;
             const float *f = &s.feat[net][8 * fy];
             float acc = a.x * f[0];
             acc = fmaf(a.y, f[1], acc); acc = fmaf(a.z, f[2], acc); acc = fmaf(a.w, f[3], acc);
@@ -173,6 +193,278 @@ __global__ __launch_bounds__(256) void rnd_tile_finish_kernel(const float *__res
         bonus[g] = b;
         if (reward) reward[g] += reward_scale * b;        // mcl.py:403-405
     }
+}
+
+// =============================================================================================
+// AE2D forward, tiled (carle/mcl.py:452-467, 504-512; eval mode): the 64x64 kernel of nets_fused.hip with the
+// halos its four layers need -- cells +7, A1 (pooled conv1) +3, A2 (pooled conv2) +1, A3 (convT1) +1 -- every
+// halo value computed from the tile's own cells (27-41 % more conv work than the interior alone), values
+// outside the grid zero (each layer's padding).  One partial sum of squared errors per tile; the staged
+// path's finish kernel adds a grid's tiles in a fixed order.
+// =============================================================================================
+static constexpr int kAeLutFloatsT = 512 * 4;          // = kAeLutFloats of nets_fused.hip (workspace layout)
+static constexpr int kAeRows = 78;
+static constexpr int kT1 = 38, kT1S = 40, kT1Plane = kT1 * kT1S;
+static constexpr int kT2S = 20, kT2Plane = 20 * kT2S;  // A2 with a zero ring: local index + 1
+static constexpr int kT3S = 36;
+
+struct AeTileShared {
+    float4 lut[512];
+    float a1[4 * kT1Plane];            // A3 (34 x 36) overlays plane 0 once conv2 has read A1
+    float a2[2 * kT2Plane];
+    uint64_t rows[kAeRows + 2][2];
+    float red[4];
+};
+
+// 4 bits of a 78-bit row starting at local column c (0 <= c <= 74)
+__device__ __forceinline__ uint32_t row_seg4(uint64_t lo, uint64_t hi, int c) {
+    const uint64_t v = c < 64 ? ((lo >> c) | (c > 0 ? hi << (64 - c) : 0ull)) : (hi >> (c - 64));
+    return (uint32_t)v & 0xFu;
+}
+
+__device__ __forceinline__ float tile_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }   // as nets_fused.hip
+
+template <bool PACKED>
+__global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
+                                                         float *__restrict__ partial, float *__restrict__ recon,
+                                                         int64_t n, int size) {
+    __shared__ AeTileShared s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(ws);
+        for (int i = tid; i < 512; i += 256) s.lut[i] = src[i];
+        for (int i = tid; i < 2 * kT2Plane; i += 256) s.a2[i] = 0.0f;       // the ring stays zero
+    }
+    const float *prm = ws + kAeLutFloatsT;             // conv2.w[72] b[2] | convT1.w[32] b[1] | convT2.w[16] b[1]
+    const float *w2 = prm, *b2 = prm + 72, *wt1 = prm + 74, *wt2 = prm + 107;
+    const float bt1 = prm[106], bt2 = prm[123];
+    const int tps = size >> 6, tiles = tps * tps;
+    const int h2 = size >> 1, h4 = size >> 2;
+    const int64_t total = n * tiles;
+    const int py = tid >> 4, px = tid & 15;
+    // loads of one tile into registers (fp32: the wave's rows, 2 values per lane and row; packed: thread r < kAeRows
+    // assembles row r's two words): issued a whole iteration ahead
+    constexpr int kPer = (kAeRows + 3) / 4;
+    uint32_t va[kPer], vb[kPer];
+    uint64_t plo = 0ull, phi = 0ull;
+    auto issue = [&](int64_t t) {
+        const int64_t g = t / tiles;
+        const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
+        const int y0 = 64 * ty - 7, x0 = 64 * tx - 7;
+        if (PACKED) {
+            plo = 0ull; phi = 0ull;
+            const int y = y0 + tid;
+            if (tid < kAeRows && y >= 0 && y < size) {
+                const uint64_t *row = reinterpret_cast<const uint64_t *>(obs_v) + (g * size + y) * tps;
+                const uint64_t wm = tx > 0 ? row[tx - 1] : 0ull, w0 = row[tx], wp = tx + 1 < tps ? row[tx + 1] : 0ull;
+                plo = (wm >> 57) | (w0 << 7);
+                phi = (w0 >> 57) | ((wp & 0x7Full) << 7);
+            }
+        } else {
+            const float *gin = reinterpret_cast<const float *>(obs_v) + g * (int64_t)size * size;
+            const int xa = x0 + lane, xb = x0 + 64 + lane;
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int r = wv + 4 * i, y = y0 + r;
+                const bool yin = r < kAeRows && y >= 0 && y < size;
+                va[i] = 0u; vb[i] = 0u;
+                if (yin && xa >= 0 && xa < size) va[i] = __float_as_uint(gin[(int64_t)y * size + xa]);
+                if (yin && lane < 14 && xb < size) vb[i] = __float_as_uint(gin[(int64_t)y * size + xb]);
+            }
+        }
+    };
+    if ((int64_t)blockIdx.x < total) issue(blockIdx.x);
+    __syncthreads();
+    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const int64_t g = t / tiles;
+        const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
+        const int y0 = 64 * ty - 7, x0 = 64 * tx - 7;
+        // ---- the tile's kAeRows rows as bit words: from the registers the previous iteration (or the prologue) filled
+        if (PACKED) {
+            if (tid < kAeRows) { s.rows[tid][0] = plo; s.rows[tid][1] = phi; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int r = wv + 4 * i;
+                const uint64_t lo = __ballot((va[i] & 0x7FFFFFFFu) != 0u);
+                const uint64_t hi = __ballot((vb[i] & 0x7FFFFFFFu) != 0u);
+                if (lane == 0 && r < kAeRows) { s.rows[r][0] = lo; s.rows[r][1] = hi; }
+            }
+        }
+        if (t + gridDim.x < total) issue(t + gridDim.x);          // the next tile travels during this one's layers
+        __syncthreads();
+
+        // ---- conv1 (table) + relu + 2x2 pool -> A1, positions (32ty-3+pl, 32tx-3+ql), pl, ql in [0, 38)
+        for (int i = tid; i < kT1 * kT1; i += 256) {
+            const int pl = i / kT1, ql = i % kT1;
+            const int P = 32 * ty - 3 + pl, Q = 32 * tx - 3 + ql;
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+            if (P >= 0 && P < h2 && Q >= 0 && Q < h2) {
+                uint32_t seg[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) seg[r] = row_seg4(s.rows[2 * pl + r][0], s.rows[2 * pl + r][1], 2 * ql);
+                float4 e[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int dy = d >> 1, dx = d & 1;
+                    const uint32_t p = ((seg[dy] >> dx) & 7u) | (((seg[dy + 1] >> dx) & 7u) << 3) |
+                                       (((seg[dy + 2] >> dx) & 7u) << 6);
+                    e[d] = s.lut[p];
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    m0 = fmaxf(m0, e[d].x); m1 = fmaxf(m1, e[d].y); m2 = fmaxf(m2, e[d].z); m3 = fmaxf(m3, e[d].w);
+                }
+            }
+            const int off = pl * kT1S + ql;
+            s.a1[0 * kT1Plane + off] = m0;
+            s.a1[1 * kT1Plane + off] = m1;
+            s.a1[2 * kT1Plane + off] = m2;
+            s.a1[3 * kT1Plane + off] = m3;
+        }
+        __syncthreads();
+
+        // ---- conv2 (4->2) + relu + 2x2 pool -> A2, positions (16ty-1+il, 16tx-1+jl), il, jl in [0, 18); the
+        //      output channel is wave-uniform (scalar weights): passes (oc 0, first 256), (oc 1, first 256), and
+        //      the remaining 68 positions of both channels on waves 0-1 / 2-3
+        auto conv2_item = [&](int pos, int oc) {
+            const int il = pos / 18, jl = pos % 18;
+            const int I = 16 * ty - 1 + il, J = 16 * tx - 1 + jl;
+            float out = 0.0f;
+            if (I >= 0 && I < h4 && J >= 0 && J < h4) {
+                float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float *pl = s.a1 + cc * kT1Plane + (2 * il) * kT1S + 2 * jl;
+                    float patch[4][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kT1S);
+                        const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kT1S + 2);
+                        patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+                    }
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                                for (int kx = 0; kx < 3; ++kx)
+                                    acc[dy][dx] = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx], patch[dy + ky][dx + kx], acc[dy][dx]);
+                }
+                const float mx = fmaxf(fmaxf(acc[0][0], acc[0][1]), fmaxf(acc[1][0], acc[1][1])) + b2[oc];
+                out = fmaxf(mx, 0.0f);
+            }
+            s.a2[oc * kT2Plane + (il + 1) * kT2S + jl + 1] = out;
+        };
+        conv2_item(tid, 0);
+        conv2_item(tid, 1);
+        {
+            const int ocw = __builtin_amdgcn_readfirstlane(wv >> 1), rem = tid & 127;
+            if (rem < 18 * 18 - 256) conv2_item(256 + rem, ocw);
+        }
+        __syncthreads();                               // A1 reads done: A3 may overlay plane 0
+
+        // ---- convT1 (2->1, k4 s2 p1) + relu -> A3 rows 32ty-1 .. 32ty+32: thread = the 2x2 outputs (2B, 2B+1) of
+        //      A2 index B = 16ty-1+bl (as the 64x64 kernel: compile-time taps); outputs outside the range are dropped
+        for (int i = tid; i < 18 * 18; i += 256) {
+            const int bl = i / 18, cl = i % 18;
+            float r2[2][3][3];                         // A2 rows B-1 .. B+1 (zero ring), cols C-1 .. C+1
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) r2[cc][r][x] = s.a2[cc * kT2Plane + (bl + r) * kT2S + cl + x];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int ry0 = 1, ky0 = j ? 2 : 1;
+                    const int ry1 = j ? 2 : 0, ky1 = j ? 0 : 3;
+                    const int cx0 = 1, kx0 = ii ? 2 : 1;
+                    const int cx1 = ii ? 2 : 0, kx1 = ii ? 0 : 3;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        acc = fmaf(r2[cc][ry0][cx0], wt1[cc * 16 + ky0 * 4 + kx0], acc);
+                        acc = fmaf(r2[cc][ry0][cx1], wt1[cc * 16 + ky0 * 4 + kx1], acc);
+                        acc = fmaf(r2[cc][ry1][cx0], wt1[cc * 16 + ky1 * 4 + kx0], acc);
+                        acc = fmaf(r2[cc][ry1][cx1], wt1[cc * 16 + ky1 * 4 + kx1], acc);
+                    }
+                    const int lr = 2 * bl - 1 + j, lc = 2 * cl - 1 + ii;          // local A3 index (0 = global 32t - 1)
+                    const int gr = 32 * ty - 1 + lr, gc = 32 * tx - 1 + lc;
+                    if (lr >= 0 && lr < 34 && lc >= 0 && lc < 34)
+                        s.a1[lr * kT3S + lc] = (gr >= 0 && gr < h2 && gc >= 0 && gc < h2) ? fmaxf(acc + bt1, 0.0f) : 0.0f;
+                }
+        }
+        __syncthreads();
+
+        // ---- convT2 + sigmoid + squared error on the thread's own 4x4 cells (as the 64x64 kernel)
+        float sq = 0.0f;
+        {
+            float t3[4][4];                            // A3 local rows 2py .. 2py+3, cols 2px .. 2px+3
+            const float *pl = s.a1 + (2 * py) * kT3S + 2 * px;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kT3S);
+                const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kT3S + 2);
+                t3[r][0] = lo.x; t3[r][1] = lo.y; t3[r][2] = hi.x; t3[r][3] = hi.y;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t bits = row_seg4(s.rows[7 + 4 * py + r][0], s.rows[7 + 4 * py + r][1], 7 + 4 * px);
+                float out4[4];
+#pragma unroll
+                for (int cx = 0; cx < 4; ++cx) {
+                    const int my = r >> 1, mx = cx >> 1;
+                    const int ry0 = my + 1, ky0 = (r & 1) ? 2 : 1;
+                    const int ry1 = (r & 1) ? my + 2 : my, ky1 = (r & 1) ? 0 : 3;
+                    const int cx0 = mx + 1, kx0 = (cx & 1) ? 2 : 1;
+                    const int cx1 = (cx & 1) ? mx + 2 : mx, kx1 = (cx & 1) ? 0 : 3;
+                    float acc = 0.0f;
+                    acc = fmaf(t3[ry0][cx0], wt2[ky0 * 4 + kx0], acc);
+                    acc = fmaf(t3[ry0][cx1], wt2[ky0 * 4 + kx1], acc);
+                    acc = fmaf(t3[ry1][cx0], wt2[ky1 * 4 + kx0], acc);
+                    acc = fmaf(t3[ry1][cx1], wt2[ky1 * 4 + kx1], acc);
+                    const float pr = tile_sigmoid(acc + bt2);
+                    out4[cx] = pr;
+                    const float df = (float)((bits >> cx) & 1u) - pr;
+                    sq = fmaf(df, df, sq);
+                }
+                if (recon)
+                    *reinterpret_cast<float4 *>(recon + g * (int64_t)size * size + (int64_t)(64 * ty + 4 * py + r) * size +
+                                                64 * tx + 4 * px) = make_float4(out4[0], out4[1], out4[2], out4[3]);
+            }
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) sq += __shfl_xor(sq, sft, 64);
+        if (lane == 0) s.red[wv] = sq;
+        __syncthreads();                               // also: rows / A3 reads done before the next tile
+        if (tid == 0) partial[t] = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+    }
+}
+
+int64_t ae2d_tiled_workspace_floats(int64_t n, int size) {
+    const int64_t tiles = (int64_t)(size >> 6) * (size >> 6);
+    return kAeLutFloatsT + 128 + n * tiles;
+}
+
+void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
+
+// tables in ws[0 .. 2176), one partial per tile behind them; the caller's finish kernel sums them
+int ae2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *recon,
+               bool tables_valid, hipStream_t s) {
+    if (!tables_valid) ae2d_prepare_tables(ap, ws, s);
+    const int64_t total = n * (int64_t)(size >> 6) * (size >> 6);
+    const unsigned blocks = (unsigned)(total < 1024 ? total : 1024);
+    float *partial = ws + kAeLutFloatsT + 128;
+    if (packed)
+        hipLaunchKernelGGL(ae_tile_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, ws, partial, recon, n, size);
+    else
+        hipLaunchKernelGGL(ae_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, ws, partial, recon, n, size);
+    return check_launch("carle_ae2d_bonus(tiled)");
 }
 
 void rnd2d_prepare_tables(const float *pp, const float *rp, float *ws, hipStream_t s);

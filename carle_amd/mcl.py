@@ -404,7 +404,7 @@ class RND2D(Motivator):
         self.buffer_length = 0
 
     # bit-packed observations of any square size that is a multiple of 64 go to the kernels as they are
-    # (tiled forward, nets_tiled.hip); AE2D overrides this until it has a tiled kernel of its own
+    # (tiled forward, nets_tiled.hip)
     _packed_any_size = True
 
     # False: sizes without a fused gradient kernel retain the window and replay it through PyTorch
@@ -557,7 +557,6 @@ class RND2D(Motivator):
 
 class AE2D(RND2D):
     """Convolutional auto-encoder reconstruction-error bonus (mcl.py:424-556)."""
-    _packed_any_size = False
 
     def __init__(self, env, **kwargs):
         super().__init__(env, **kwargs)

@@ -665,3 +665,62 @@ def test_tiled_rnd_through_the_environment_256():
         expected = rnd.get_bonus_only(obs.clone() * 1.0)   # a copy: not known to be binary -> staged path
         np.testing.assert_allclose(reward.detach().cpu().numpy()[:, 0], expected.cpu().numpy() * rnd.reward_scale,
                                    rtol=0, atol=2e-6)
+
+
+def test_tiled_ae_matches_reference_and_staged_256():
+    """The tiled AE2D forward at the reference's default 256x256 geometry with the shipped weights
+    (evaluation/AE2D_mcl.pt via nets_256.npz): bonuses and reconstructions vs the reference fixture within
+    1e-5, vs the staged path within 1e-6, packed input bit-identical."""
+    from carle_amd import hip
+    z = G.nets(256)
+    env, rnd, ae = _stack(256, 4, G.load_sd(z, "rnd_sd"), G.load_sd(z, "ae_sd"))
+    ae.reset()
+    g = torch.from_numpy(G.unpack(z["grids"], (4, 1, 256, 256))).cuda()
+    staged = ae.get_bonus_only(g).clone()
+    staged_rec = ae.forward(g).clone()
+    ae.assume_binary_obs = True
+    tiled = ae.get_bonus_only(g).clone()
+    np.testing.assert_allclose(tiled.cpu().numpy(), z["ae_bonus"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(tiled.cpu().numpy(), staged.cpu().numpy(), rtol=0, atol=1e-6)
+    rec = ae.forward(g)
+    assert tuple(rec.shape) == (4, 1, 256, 256)
+    np.testing.assert_allclose(rec.cpu().numpy(), staged_rec.cpu().numpy(), rtol=0, atol=1e-6)
+    if "ae_pred" in z.files:
+        np.testing.assert_allclose(rec.cpu().numpy(), z["ae_pred"], rtol=0, atol=TOL)
+    assert ae.get_bonus_only(g).equal(tiled)               # second call: tables reused
+    assert ae.get_bonus_only(hip.pack_f32_b1(g)).equal(tiled)
+
+
+@pytest.mark.parametrize("size,n", [(128, 5), (192, 3), (256, 19), (512, 2)])
+def test_tiled_ae_sizes_against_staged_and_oracle(size, n):
+    from oracle import nets as ON
+    torch.manual_seed(400 + size)
+    env, rnd, ae = _stack(size, n)
+    ae.reset()
+    dens = torch.linspace(0.0, 1.0, n, device="cuda").reshape(n, 1, 1, 1)
+    g = (torch.rand(n, 1, size, size, device="cuda") < dens).float()
+    staged = ae.get_bonus_only(g).clone()
+    staged_rec = ae.forward(g).clone()
+    ae.assume_binary_obs = True
+    tiled = ae.get_bonus_only(g).clone()
+    np.testing.assert_allclose(tiled.cpu().numpy(), staged.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ae.forward(g).cpu().numpy(), staged_rec.cpu().numpy(), rtol=0, atol=1e-6)
+    sd = {k: v.detach().cpu().numpy() for k, v in ae.state_dict().items()}
+    with torch.no_grad():
+        ref = ON.ae_bonus(g.cpu().numpy(), sd).numpy()
+    np.testing.assert_allclose(tiled.cpu().numpy(), ref, rtol=0, atol=TOL)
+
+
+def test_tiled_stack_through_the_environment_256():
+    """AE2D(RND2D(CARLE)) at 256x256 stepped through the wrappers (tiled kernels: the observation is
+    env.universe) against the staged evaluation of the same observations."""
+    torch.manual_seed(6)
+    env, rnd, ae = _stack(256, 5)
+    ae.reset()
+    env.universe = (torch.rand(5, 1, 256, 256, device="cuda") < 0.3).float()
+    for t in range(3):
+        a = (torch.rand(5, 1, 64, 64, device="cuda") < 0.1).float()
+        obs, reward, done, info = ae.step(a)
+        copy = obs.clone() * 1.0                            # not known to be binary -> staged path
+        expected = rnd.reward_scale * rnd.get_bonus_only(copy) + ae.reward_scale * ae.get_bonus_only(copy)
+        np.testing.assert_allclose(reward.detach().cpu().numpy()[:, 0], expected.cpu().numpy(), rtol=0, atol=4e-6)
