@@ -238,13 +238,14 @@ def test_multistep_through_the_env():
     assert torch.equal(env.universe, ref.universe) and env.step_number == 4
 
 
-def test_cfg5_full_size_with_action_against_the_oracle():
+@pytest.mark.parametrize("n,size", [(4096, 512), (4101, 512), (16389, 256)])
+def test_cfg5_full_size_with_action_against_the_oracle(n, size):
     """BASELINE configs[4] at its full size (B36/S23, N=4096, 512x512 bit-packed) WITH the 64x64
     action window, against oracle/ca_oracle.c on sampled instances (incl. the first / last instance
-    and a workgroup boundary), three consecutive steps through CARLE(storage='b1')."""
+    and a workgroup boundary), three consecutive steps through CARLE(storage='b1').  N=4101 / 16389: batches that
+    are not a multiple of 8 and need more than one round of the 8192 half-grid work units."""
     from carle_amd import hip
     from carle_amd.env import CARLE
-    n, size = 4096, 512
     env = CARLE(width=size, height=size, instances=n, device="cuda:0", storage="b1")
     env.rules_from_string("B36/S23")
     env.reset()
@@ -252,7 +253,7 @@ def test_cfg5_full_size_with_action_against_the_oracle():
     bits = torch.randint(-2 ** 63, 2 ** 63 - 1, (n, 1, size, size // 64), device="cuda", generator=g,
                          dtype=torch.int64)
     env.universe_bits = bits.clone()
-    idx = [0, 1, 7, 8, 2047, 2048, 4094, 4095]
+    idx = [0, 1, 7, 8, 2047, 2048, 4094, 4095, n - 6, n - 2, n - 1]
     u_ref = hip.unpack_b1_f32(bits[idx].contiguous()).cpu().numpy()
     high = O.rule_mask([3, 6], [2, 3])
     for t in range(3):
