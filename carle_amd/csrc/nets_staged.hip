@@ -443,6 +443,10 @@ int64_t rnd2d_tiled_workspace_floats(int64_t n, int size);
 int rnd2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *ws,
                 float *bonus, float *pred_out, float *target_out, float *reward, float reward_scale, bool tables_valid,
                 hipStream_t s);
+int rnd2d_tiled_bwd_rows(int64_t n, int size);
+int rnd2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *ws,
+                      float *featbuf, float *pred, float *targ, float *rows, float *bonus, float *reward,
+                      float reward_scale, float grad_scale, bool tables_valid, hipStream_t s);
 int64_t ae2d_tiled_workspace_floats(int64_t n, int size);
 int ae2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *recon,
                bool tables_valid, hipStream_t s);
@@ -604,11 +608,28 @@ static int rnd2d_train_common(const void *obs, int obs_mode, int64_t n, int h, i
         return fail_arg(CARLE_E_NULL, "carle_rnd2d_train: NULL pointer");
     if (n < 0) return fail_arg(CARLE_E_DIMS, "carle_rnd2d_train: negative batch");
     const bool fused = h == 64 && w == 64 && (obs_mode == 1 || ((flags & CARLE_NET_OBS_BINARY) && aligned16(obs)));
+    if (!fused && n >= 0 && rnd2d_tiled_applies(h, w) && (obs_mode == 1 || (flags & CARLE_NET_OBS_BINARY))) {
+        // binary grids with H = W a multiple of 64: tiled forward (features kept) + tiled conv gradients
+        // (nets_tiled.hip) + the staged path's linear-layer gradient and row reduction; `partial` holds
+        // carle_rnd2d_train_scratch_floats(n, h, w) floats: pred | targ | features (N,2,D) | rows
+        if (n == 0) return 0;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const int d = (h / 8) * (w / 8);
+        float *pred = partial, *targ = pred + n * kRndK, *featbuf = targ + n * kRndK, *rows = featbuf + n * 2 * (int64_t)d;
+        if (int e = rnd2d_tiled_train(obs, obs_mode == 1, n, h, pred_params, rand_params, workspace, featbuf, pred, targ,
+                                      rows, bonus, reward_accum, reward_scale, grad_scale,
+                                      (flags & CARLE_NET_TABLES_VALID) != 0, s))
+            return e;
+        hipLaunchKernelGGL(rnd_bwd_linear_kernel, dim3(blocks256((int64_t)kRndK * d + kRndK)), dim3(256), 0, s, featbuf,
+                           pred, targ, grad, grad_scale, n, d);
+        hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(3), dim3(1024), 0, s, rows, rnd2d_tiled_bwd_rows(n, h), grad, 77);
+        return check_launch("carle_rnd2d_train(tiled)");
+    }
     if (!fused) {
         // any other square size / non-binary fp32 observations: staged forward + staged backward kernels
         // (nets_staged_bwd.hpp); `partial` must hold carle_rnd2d_train_scratch_floats(n, h, w) floats
         if (obs_mode == 1)
-            return fail_arg(CARLE_E_DIMS, "carle_rnd2d_train_b1: bit-packed observations are supported for 64x64 grids");
+            return fail_arg(CARLE_E_DIMS, "carle_rnd2d_train_b1: bit-packed observations need H = W a multiple of 64");
         if (int e = check_net_dims(n, h, w, "carle_rnd2d_train_f32")) return e;
         if (n == 0) return 0;
         return rnd2d_train_staged(static_cast<const float *>(obs), n, h, w, pred_params, rand_params, workspace,

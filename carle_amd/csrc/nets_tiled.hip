@@ -15,6 +15,8 @@
 
 namespace carle {
 
+void rnd2d_prepare_tables(const float *pp, const float *rp, float *ws, hipStream_t s);      // nets_fused.hip
+
 static constexpr int kTileRows = 74;                   // 64 + 2 * 5 cells
 static constexpr int kTileWin = 18;                    // pooled windows per side: 16 + 2
 
@@ -72,7 +74,8 @@ struct __attribute__((aligned(4))) F4T { float x, y, z, w; };   // 16 bytes at 4
 template <bool PACKED>
 __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
                                                           const float *__restrict__ pp, const float *__restrict__ rp,
-                                                          float *__restrict__ partial, int64_t n, int size) {
+                                                          float *__restrict__ partial, float *__restrict__ featbuf,
+                                                          int64_t n, int size) {
     __shared__ RndTileShared s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     rnd_block_init(s.net, ws, tid);
@@ -115,7 +118,6 @@ __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict
     for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
         const int64_t g = t / tiles;
         const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
-        const int y0 = 64 * ty - 5, x0 = 64 * tx - 5;
         // ---- the tile's kTileRows rows as bit words: from the registers the previous iteration (or the prologue) filled
         if (PACKED) {
             if (tid < kTileRows) { s.rows[tid][0] = plo; s.rows[tid][1] = phi; }
@@ -146,6 +148,10 @@ __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict
         __syncthreads();
         rnd_block_conv2(s.net, s.feat, tid);            // the tile's 8x8 features of both nets
         __syncthreads();
+        if (featbuf && tid < 128) {                     // training: the features, (N, 2, D) as the staged path keeps them
+            const int net = tid >> 6, f = tid & 63;
+            featbuf[(g * 2 + net) * (int64_t)dfeat + (int64_t)(8 * ty + (f >> 3)) * d8 + 8 * tx + (f & 7)] = s.feat[net][f];
+        }
         // ---- the tile's share of the linear layers: thread = (net, k, feature row fy of the tile)
         {
             const int fy = lfy, k = lk, net = lnet;
@@ -193,6 +199,246 @@ __global__ __launch_bounds__(256) void rnd_tile_finish_kernel(const float *__res
         bonus[g] = b;
         if (reward) reward[g] += reward_scale * b;        // mcl.py:403-405
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RND2D predictor GRADIENT, tiled (carle/mcl.py:343-386; eval mode): conv1 / conv2 weight and bias gradients of
+//   gs/2 * sum_n sum_k (target - prediction)^2
+// by the decomposition of the staged backward (nets_staged_bwd.hpp) on LDS tiles.  A tile owns the gradient paths
+// that START at its own 8x8 features: it recomputes its activations with their halos (as the forward kernel), so
+// no gradient crosses a tile border, and the sum over tiles is the whole gradient.  The linear layer's gradient
+// comes from the features the forward kernel stored (rnd_bwd_linear_kernel of the staged path).  The arg-max of a
+// 4x4 pooling window is the first maximum in scan order among its 16 table values (ties: equal neighbourhood
+// patterns or the relu floor -- the routing is immaterial, as in the fused 64x64 kernel).  One partial row of 77
+// sums per workgroup; staged_grad_reduce_kernel adds the rows in a fixed order.
+// ---------------------------------------------------------------------------------------------
+struct RndTileBwdShared {
+    RndTileShared f;
+    uint16_t pat[4][kTileWin * kTileWin];              // arg-max neighbourhood pattern per window and predictor channel
+    float dmap[20][20];                                // d loss / d conv2 output (tile-local position + 2), zero ring
+    float red[4][80];
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(256, 2) void rnd_tile_bwd_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
+                                                              const float *__restrict__ pp, const float *__restrict__ pred,
+                                                              const float *__restrict__ targ, float *__restrict__ rows_out,
+                                                              float gs, int64_t n, int size) {
+    __shared__ RndTileBwdShared s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    rnd_block_init(s.f.net, ws, tid);
+    for (int i = tid; i < 400; i += 256) (&s.dmap[0][0])[i] = 0.0f;
+    const int tps = size >> 6, tiles = tps * tps;
+    const int d8 = size >> 3, dfeat = d8 * d8, q4 = size >> 2;
+    const int64_t total = n * tiles;
+    float acc1[36], accb1[4] = {0.f, 0.f, 0.f, 0.f}, acc2[9], accb2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc1[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc2[i] = 0.0f;
+    __syncthreads();
+    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const int64_t g = t / tiles;
+        const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
+        const int y0 = 64 * ty - 5, x0 = 64 * tx - 5;
+        // ---- rows (as the forward kernel, not pipelined)
+        if (PACKED) {
+            if (tid < kTileRows) {
+                const int y = y0 + tid;
+                uint64_t lo = 0ull, hi = 0ull;
+                if (y >= 0 && y < size) {
+                    const uint64_t *row = reinterpret_cast<const uint64_t *>(obs_v) + (g * size + y) * tps;
+                    const uint64_t wm = tx > 0 ? row[tx - 1] : 0ull, w0 = row[tx], wp = tx + 1 < tps ? row[tx + 1] : 0ull;
+                    lo = (wm >> 59) | (w0 << 5);
+                    hi = (w0 >> 59) | ((wp & 0x1Full) << 5);
+                }
+                s.f.rows[tid][0] = lo;
+                s.f.rows[tid][1] = hi;
+            }
+        } else {
+            const float *gin = reinterpret_cast<const float *>(obs_v) + g * (int64_t)size * size;
+            constexpr int kPer = (kTileRows + 3) / 4;
+            uint32_t va[kPer], vb[kPer];
+            const int xa = x0 + lane, xb = x0 + 64 + lane;
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int r = wv + 4 * i, y = y0 + r;
+                const bool yin = r < kTileRows && y >= 0 && y < size;
+                va[i] = 0u; vb[i] = 0u;
+                if (yin && xa >= 0 && xa < size) va[i] = __float_as_uint(gin[(int64_t)y * size + xa]);
+                if (yin && lane < 10 && xb < size) vb[i] = __float_as_uint(gin[(int64_t)y * size + xb]);
+            }
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int r = wv + 4 * i;
+                const uint64_t lo = __ballot((va[i] & 0x7FFFFFFFu) != 0u);
+                const uint64_t hi = __ballot((vb[i] & 0x7FFFFFFFu) != 0u);
+                if (lane == 0 && r < kTileRows) { s.f.rows[r][0] = lo; s.f.rows[r][1] = hi; }
+            }
+        }
+        __syncthreads();
+        // ---- conv1 (predictor table) + relu + 4x4 pool with the arg-max pattern of every channel
+        for (int i = tid; i < kTileWin * kTileWin; i += 256) {
+            const int wy = i / kTileWin, wx = i % kTileWin;
+            const int Y = 16 * ty - 1 + wy, X = 16 * tx - 1 + wx;
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+            uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            if (Y >= 0 && Y < q4 && X >= 0 && X < q4) {
+                uint32_t seg[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) seg[r] = row_seg6(s.f.rows[4 * wy + r][0], s.f.rows[4 * wy + r][1], 4 * wx);
+#pragma unroll
+                for (int dy = 0; dy < 4; ++dy) {
+                    float4 e[4];
+                    uint32_t pt[4];
+#pragma unroll
+                    for (int dx = 0; dx < 4; ++dx) {
+                        pt[dx] = ((seg[dy] >> dx) & 7u) | (((seg[dy + 1] >> dx) & 7u) << 3) | (((seg[dy + 2] >> dx) & 7u) << 6);
+                        e[dx] = s.f.net.lut_p[pt[dx]];
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < 4; ++dx) {
+                        if (e[dx].x > m0) { m0 = e[dx].x; p0 = pt[dx]; }
+                        if (e[dx].y > m1) { m1 = e[dx].y; p1 = pt[dx]; }
+                        if (e[dx].z > m2) { m2 = e[dx].z; p2 = pt[dx]; }
+                        if (e[dx].w > m3) { m3 = e[dx].w; p3 = pt[dx]; }
+                    }
+                }
+            }
+            const int off = wy * kPlaneStride + wx;
+            s.f.net.planes[0][off] = m0; s.f.net.planes[1][off] = m1; s.f.net.planes[2][off] = m2; s.f.net.planes[3][off] = m3;
+            s.pat[0][i] = (uint16_t)p0; s.pat[1][i] = (uint16_t)p1; s.pat[2][i] = (uint16_t)p2; s.pat[3][i] = (uint16_t)p3;
+        }
+        __syncthreads();
+        // ---- conv2 forward (predictor), its gradient and weight gradients: thread = (feature f, channel c)
+        {
+            const int f = tid >> 2, c = tid & 3, fy = f >> 3, fx = f & 7;
+            const float *pl = &s.f.net.planes[c][(2 * fy) * kPlaneStride + 2 * fx];
+            float patch[4][4], w[9];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride);
+                const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride + 2);
+                patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) w[i] = s.f.net.w2[0][c][i];
+            float o[2][2];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) a = fmaf(w[ky * 3 + kx], patch[dy + ky][dx + kx], a);
+                    a += dpp_quad_xor1(a);
+                    a += dpp_quad_xor2(a);
+                    o[dy][dx] = a;
+                }
+            int sel = 0;
+            float mx = o[0][0];
+            if (o[0][1] > mx) { mx = o[0][1]; sel = 1; }
+            if (o[1][0] > mx) { mx = o[1][0]; sel = 2; }
+            if (o[1][1] > mx) { mx = o[1][1]; sel = 3; }
+            const float featv = mx + s.f.net.b2[0];
+            // d loss / d feature through the linear layer: lane c takes outputs 4c .. 4c+3
+            const int64_t col = (int64_t)(8 * ty + fy) * d8 + 8 * tx + fx;
+            float df = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * c + j;
+                const float pk = pred[g * 16 + k], tk = targ[g * 16 + k];
+                const float dz = gs * (pk - tk) * (1.0f - pk * pk);
+                df = fmaf(pp[77 + (int64_t)k * dfeat + col], dz, df);
+            }
+            df += dpp_quad_xor1(df);
+            df += dpp_quad_xor2(df);
+            const float dd = featv > 0.0f ? df : 0.0f;
+            const int ay = sel >> 1, ax = sel & 1;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float p00 = patch[ky][kx], p01 = patch[ky][kx + 1], p10 = patch[ky + 1][kx], p11 = patch[ky + 1][kx + 1];
+                    acc2[ky * 3 + kx] = fmaf(dd, ay ? (ax ? p11 : p10) : (ax ? p01 : p00), acc2[ky * 3 + kx]);
+                }
+            if (c == 0) {
+                accb2 += dd;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s.dmap[2 * fy + (e >> 1) + 2][2 * fx + (e & 1) + 2] = e == sel ? dd : 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- conv1 weight / bias gradients: thread = window; the gradient of the pooled value is gathered from dmap
+        for (int i = tid; i < kTileWin * kTileWin; i += 256) {
+            const int wy = i / kTileWin, wx = i % kTileWin;
+            float dm[3][3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) dm[ky][kx] = s.dmap[wy - ky + 2][wx - kx + 2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float dp = 0.0f;
+#pragma unroll
+                for (int tq = 0; tq < 9; ++tq) dp = fmaf(s.f.net.w2[0][c][tq], dm[tq / 3][tq % 3], dp);
+                const float g1 = s.f.net.planes[c][wy * kPlaneStride + wx] > 0.0f ? dp : 0.0f;
+                const uint32_t pt = s.pat[c][i];
+                accb1[c] += g1;
+#pragma unroll
+                for (int tq = 0; tq < 9; ++tq) acc1[c * 9 + tq] = fmaf(g1, (float)((pt >> tq) & 1u), acc1[c * 9 + tq]);
+            }
+        }
+        // the next tile's barriers order its writes to rows / planes / pat / dmap behind these reads
+    }
+    // ---- one partial row per workgroup: conv1.w[36] conv1.b[4] conv2.w[36] conv2.b[1]
+    __syncthreads();
+    const int cme = tid & 3;
+#pragma unroll
+    for (int i = 0; i < 77; ++i) {
+        float x = i < 36 ? acc1[i] : i < 40 ? accb1[i - 36] : i < 76 ? (((i - 40) / 9 == cme) ? acc2[(i - 40) % 9] : 0.0f) : accb2;
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) x += __shfl_xor(x, sh, 64);
+        if (lane == 0) s.red[wv][i] = x;
+    }
+    __syncthreads();
+    if (tid < 77) rows_out[(int64_t)blockIdx.x * 77 + tid] = (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
+}
+
+// number of partial rows (= workgroups) of the tiled backward kernel
+int rnd2d_tiled_bwd_rows(int64_t n, int size) {
+    const int64_t total = n * (int64_t)(size >> 6) * (size >> 6);
+    return (int)(total < 512 ? total : 512);
+}
+
+// forward with the features kept, outputs -> pred / targ, then the conv gradients -> rows (the caller runs the
+// linear-layer gradient and the row reduction of the staged path)
+int rnd2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *ws,
+                      float *featbuf, float *pred, float *targ, float *rows, float *bonus, float *reward,
+                      float reward_scale, float grad_scale, bool tables_valid, hipStream_t s) {
+    if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
+    const int tiles = (size >> 6) * (size >> 6);
+    const int64_t total = n * tiles;
+    if ((n + 15) / 16 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_rnd2d_train: batch too large");
+    const unsigned blocks = (unsigned)(total < 1024 ? total : 1024);
+    float *partial = ws + kFusedWsTotal;
+    const int d8 = size >> 3;
+    if (packed)
+        hipLaunchKernelGGL(rnd_tile_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, ws, pp, rp, partial, featbuf, n, size);
+    else
+        hipLaunchKernelGGL(rnd_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, ws, pp, rp, partial, featbuf, n, size);
+    hipLaunchKernelGGL(rnd_tile_finish_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, partial, pp, rp, bonus,
+                       pred, targ, reward, reward_scale, n, tiles, d8 * d8);
+    const unsigned brows = (unsigned)rnd2d_tiled_bwd_rows(n, size);
+    if (packed)
+        hipLaunchKernelGGL(rnd_tile_bwd_kernel<true>, dim3(brows), dim3(256), 0, s, obs, ws, pp, pred, targ, rows,
+                           grad_scale, n, size);
+    else
+        hipLaunchKernelGGL(rnd_tile_bwd_kernel<false>, dim3(brows), dim3(256), 0, s, obs, ws, pp, pred, targ, rows,
+                           grad_scale, n, size);
+    return check_launch("carle_rnd2d_train(tiled)");
 }
 
 // =============================================================================================
@@ -278,7 +524,6 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
     for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
         const int64_t g = t / tiles;
         const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
-        const int y0 = 64 * ty - 7, x0 = 64 * tx - 7;
         // ---- the tile's kAeRows rows as bit words: from the registers the previous iteration (or the prologue) filled
         if (PACKED) {
             if (tid < kAeRows) { s.rows[tid][0] = plo; s.rows[tid][1] = phi; }
@@ -467,7 +712,6 @@ int ae2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *a
     return check_launch("carle_ae2d_bonus(tiled)");
 }
 
-void rnd2d_prepare_tables(const float *pp, const float *rp, float *ws, hipStream_t s);
 
 bool rnd2d_tiled_applies(int h, int w) { return h == w && h > 64 && (h & 63) == 0; }
 
@@ -487,9 +731,9 @@ int rnd2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *
     const unsigned blocks = (unsigned)(total < 1024 ? total : 1024);      // persistent: 4 workgroups per CU
     float *partial = ws + kFusedWsTotal;
     if (packed)
-        hipLaunchKernelGGL(rnd_tile_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, ws, pp, rp, partial, n, size);
+        hipLaunchKernelGGL(rnd_tile_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, ws, pp, rp, partial, static_cast<float *>(nullptr), n, size);
     else
-        hipLaunchKernelGGL(rnd_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, ws, pp, rp, partial, n, size);
+        hipLaunchKernelGGL(rnd_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, ws, pp, rp, partial, static_cast<float *>(nullptr), n, size);
     const int d8 = size >> 3;
     hipLaunchKernelGGL(rnd_tile_finish_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, partial, pp, rp, bonus,
                        pred_out, target_out, reward, reward_scale, n, tiles, d8 * d8);

@@ -423,13 +423,20 @@ class RND2D(Motivator):
         o, binary = self._obs(obs, allow_packed=True)
         packed = o.dtype == torch.int64
         fused64 = binary and o.shape[2] == 64 and (packed or o.shape[3] == 64)
-        if not fused64:
+        size_w = o.shape[3] * 64 if packed else o.shape[3]
+        # binary grids with H = W a multiple of 64 (the reference's default 256x256): tiled kernels (RND2D; AE2D's
+        # backward is staged)
+        tiled = (binary and not fused64 and not is_ae and self.hip_backward_any_size and o.dim() == 4
+                 and o.shape[2] == size_w and o.shape[2] % 64 == 0 and o.shape[2] > 64)
+        if not fused64 and not tiled:
             if not self.hip_backward_any_size:
                 return False
             if packed:
                 o, binary = self._obs(obs)                 # unpacked fp32
+                packed = False
             if o.dim() != 4 or o.shape[2] != o.shape[3] or o.shape[2] % 8 or o.shape[2] < 8:
                 return False
+        uses_tables = fused64 or tiled
         from . import _lib
         lib = _lib.load()
         dev, n, size = o.device, o.shape[0], o.shape[2]
@@ -448,7 +455,7 @@ class RND2D(Motivator):
         if self._grad is None or self._grad.device != dev or self._grad.numel() != pb.numel():
             self._grad = torch.zeros(pb.numel(), dtype=torch.float32, device=dev)
         versions = (self._pred_blob.version,) if is_ae else (self._pred_blob.version, self._rand_blob.version)
-        valid = fused64 and self._tables_key == (id(self._ws), versions)
+        valid = uses_tables and self._tables_key == (id(self._ws), versions)
         if is_ae:
             grad_scale = 2.0 / (size * size * n * self.batch_size)
             hip.ae2d_train(o, pb, self._ws, self._partial, self._grad, bonus_out, reward,
@@ -456,8 +463,8 @@ class RND2D(Motivator):
         else:
             grad_scale = 2.0 / (self.rnd_dim * n * self.batch_size)
             hip.rnd2d_train(o, pb, rb, self._ws, self._partial, self._grad, bonus_out, reward,
-                            self.reward_scale, grad_scale, valid, stream, binary=fused64)
-        self._tables_key = (id(self._ws), versions) if fused64 else None
+                            self.reward_scale, grad_scale, valid, stream, binary=uses_tables)
+        self._tables_key = (id(self._ws), versions) if uses_tables else None
         self._grad_used = True
         return True
 
