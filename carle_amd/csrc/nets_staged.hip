@@ -447,6 +447,9 @@ int rnd2d_tiled_bwd_rows(int64_t n, int size);
 int rnd2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *ws,
                       float *featbuf, float *pred, float *targ, float *rows, float *bonus, float *reward,
                       float reward_scale, float grad_scale, bool tables_valid, hipStream_t s);
+int ae2d_tiled_train_rows(int64_t n, int size);
+int ae2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *rows,
+                     float grad_scale, bool tables_valid, hipStream_t s);
 int64_t ae2d_tiled_workspace_floats(int64_t n, int size);
 int ae2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *recon,
                bool tables_valid, hipStream_t s);
@@ -673,9 +676,24 @@ static int ae2d_train_common(const void *obs, bool packed, int64_t n, int h, int
         return fail_arg(CARLE_E_NULL, "carle_ae2d_train: NULL pointer");
     if (n < 0) return fail_arg(CARLE_E_DIMS, "carle_ae2d_train: negative batch");
     const bool fused = h == 64 && w == 64 && (packed || ((flags & CARLE_NET_OBS_BINARY) && aligned16(obs)));
+    if (!fused && rnd2d_tiled_applies(h, w) && (packed || (flags & CARLE_NET_OBS_BINARY))) {
+        // binary grids with H = W a multiple of 64: ONE tiled kernel evaluates the bonus partials and the gradient
+        // rows (nets_tiled.hip); finish kernel + row reduction of the staged path.  `partial`: the rows.
+        if (n == 0) return 0;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (int e = ae2d_tiled_train(obs, packed, n, h, params, workspace, partial, grad_scale,
+                                     (flags & CARLE_NET_TABLES_VALID) != 0, s))
+            return e;
+        const int tiles = (h >> 6) * (h >> 6);
+        hipLaunchKernelGGL(ae_mse_finish_kernel, dim3(blocks_for(n)), dim3(256), 0, s, workspace + 2048 + 128, bonus,
+                           reward_accum, reward_scale, n, tiles, 1.0f / ((float)h * (float)w));
+        hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(6), dim3(1024), 0, s, partial, ae2d_tiled_train_rows(n, h), grad,
+                           164);
+        return check_launch("carle_ae2d_train(tiled)");
+    }
     if (!fused) {
         if (packed)
-            return fail_arg(CARLE_E_DIMS, "carle_ae2d_train_b1: bit-packed observations are supported for 64x64 grids");
+            return fail_arg(CARLE_E_DIMS, "carle_ae2d_train_b1: bit-packed observations need H = W a multiple of 64");
         if (int e = check_net_dims(n, h, w, "carle_ae2d_train_f32")) return e;
         if (n == 0) return 0;
         return ae2d_train_staged(static_cast<const float *>(obs), n, h, w, params, workspace, partial, grad, bonus,

@@ -691,12 +691,431 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// AE2D forward + BACKWARD, tiled (carle/mcl.py:504-547; eval mode): the bonus partial AND the gradient of
+//   gs/2 * sum (obs - decoder(obs))^2  with respect to the 164 predictor parameters, per 64x64 tile in ONE kernel.
+// A tile owns the gradient paths that start at its own 64x64 output cells; all activations on those paths lie
+// inside the halos the forward needs (A3 +1, A2 +1, A1 +3, cells +7), so nothing crosses a tile border.  The
+// layer-by-layer decomposition is the staged backward's (nets_staged_bwd.hpp: gathers, no atomics, first maximum
+// in scan order) on LDS planes; transposed-convolution taps are compile-time constants because a thread handles
+// 2x2 blocks aligned to even coordinates.  164 accumulators per thread over all tiles of the workgroup, one
+// partial row per workgroup, staged_grad_reduce_kernel adds the rows in a fixed order.  77 KB of LDS: 2 per CU.
+// ---------------------------------------------------------------------------------------------
+struct AeTileTrainShared {
+    float4 lut[512];
+    float a1[4 * kT1Plane];
+    float a2[2 * kT2Plane];            // zero ring (local index + 1)
+    float a3[34 * kT3S];               // A3, later its gated gradient in place
+    float g2[2 * 18 * 18];             // gated d loss / d A2
+    float dpre[64][64];                // d loss / d pre-sigmoid of the tile's own cells
+    float dmap[2][40][40];             // d loss / d conv2 output (local position + 2), zero ring
+    uint64_t rows[kAeRows + 2][2];
+    uint16_t nb[kT1 * kT1];            // 4x4 cell neighbourhood of every A1 position
+    uint8_t am[kT1 * kT1];             // 2-bit arg-max index of the four conv1 channels
+    uint8_t sel2[2][18 * 18];          // arg-max of the 2x2 conv2 outputs under every A2 position
+    float red[4][164];
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
+                                                               float *__restrict__ partial, float *__restrict__ rows_out,
+                                                               float gs, int64_t n, int size) {
+    __shared__ AeTileTrainShared s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(ws);
+        for (int i = tid; i < 512; i += 256) s.lut[i] = src[i];
+        for (int i = tid; i < 2 * kT2Plane; i += 256) s.a2[i] = 0.0f;
+        for (int i = tid; i < 2 * 40 * 40; i += 256) (&s.dmap[0][0][0])[i] = 0.0f;
+    }
+    const float *prm = ws + kAeLutFloatsT;
+    const float *w2 = prm, *b2 = prm + 72, *wt1 = prm + 74, *wt2 = prm + 107;
+    const float bt1 = prm[106], bt2 = prm[123];
+    const int tps = size >> 6, tiles = tps * tps;
+    const int h2 = size >> 1, h4 = size >> 2;
+    const int64_t total = n * tiles;
+    const int py = tid >> 4, px = tid & 15;
+    float gw1[36], gb1[4], gw2[72], gb2[2], gwt1[32], gbt1 = 0.0f, gwt2[16], gbt2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) gw1[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gb1[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 72; ++i) gw2[i] = 0.0f;
+    gb2[0] = 0.0f; gb2[1] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) gwt1[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gwt2[i] = 0.0f;
+    __syncthreads();
+    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const int64_t g = t / tiles;
+        const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
+        const int y0 = 64 * ty - 7, x0 = 64 * tx - 7;
+        // ---- P0: rows
+        if (PACKED) {
+            if (tid < kAeRows) {
+                const int y = y0 + tid;
+                uint64_t lo = 0ull, hi = 0ull;
+                if (y >= 0 && y < size) {
+                    const uint64_t *row = reinterpret_cast<const uint64_t *>(obs_v) + (g * size + y) * tps;
+                    const uint64_t wm = tx > 0 ? row[tx - 1] : 0ull, w0 = row[tx], wp = tx + 1 < tps ? row[tx + 1] : 0ull;
+                    lo = (wm >> 57) | (w0 << 7);
+                    hi = (w0 >> 57) | ((wp & 0x7Full) << 7);
+                }
+                s.rows[tid][0] = lo;
+                s.rows[tid][1] = hi;
+            }
+        } else {
+            const float *gin = reinterpret_cast<const float *>(obs_v) + g * (int64_t)size * size;
+            constexpr int kPer = (kAeRows + 3) / 4;
+            uint32_t va[kPer], vb[kPer];
+            const int xa = x0 + lane, xb = x0 + 64 + lane;
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int r = wv + 4 * i, y = y0 + r;
+                const bool yin = r < kAeRows && y >= 0 && y < size;
+                va[i] = 0u; vb[i] = 0u;
+                if (yin && xa >= 0 && xa < size) va[i] = __float_as_uint(gin[(int64_t)y * size + xa]);
+                if (yin && lane < 14 && xb < size) vb[i] = __float_as_uint(gin[(int64_t)y * size + xb]);
+            }
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int r = wv + 4 * i;
+                const uint64_t lo = __ballot((va[i] & 0x7FFFFFFFu) != 0u);
+                const uint64_t hi = __ballot((vb[i] & 0x7FFFFFFFu) != 0u);
+                if (lane == 0 && r < kAeRows) { s.rows[r][0] = lo; s.rows[r][1] = hi; }
+            }
+        }
+        __syncthreads();
+
+        // ---- P1: conv1 (table) + relu + 2x2 pool -> A1 with arg-max index and 4x4 cell neighbourhood
+        for (int i = tid; i < kT1 * kT1; i += 256) {
+            const int pl = i / kT1, ql = i % kT1;
+            const int P = 32 * ty - 3 + pl, Q = 32 * tx - 3 + ql;
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+            uint32_t i0 = 0, i1 = 0, i2 = 0, i3 = 0, nbv = 0;
+            if (P >= 0 && P < h2 && Q >= 0 && Q < h2) {
+                uint32_t seg[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) seg[r] = row_seg4(s.rows[2 * pl + r][0], s.rows[2 * pl + r][1], 2 * ql);
+                nbv = seg[0] | (seg[1] << 4) | (seg[2] << 8) | (seg[3] << 12);
+                float4 e[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int dy = d >> 1, dx = d & 1;
+                    const uint32_t p = ((seg[dy] >> dx) & 7u) | (((seg[dy + 1] >> dx) & 7u) << 3) |
+                                       (((seg[dy + 2] >> dx) & 7u) << 6);
+                    e[d] = s.lut[p];
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {          // strict >: the first maximum in scan order
+                    if (e[d].x > m0) { m0 = e[d].x; i0 = d; }
+                    if (e[d].y > m1) { m1 = e[d].y; i1 = d; }
+                    if (e[d].z > m2) { m2 = e[d].z; i2 = d; }
+                    if (e[d].w > m3) { m3 = e[d].w; i3 = d; }
+                }
+            }
+            const int off = pl * kT1S + ql;
+            s.a1[0 * kT1Plane + off] = m0; s.a1[1 * kT1Plane + off] = m1;
+            s.a1[2 * kT1Plane + off] = m2; s.a1[3 * kT1Plane + off] = m3;
+            s.nb[i] = (uint16_t)nbv;
+            s.am[i] = (uint8_t)(i0 | (i1 << 2) | (i2 << 4) | (i3 << 6));
+        }
+        __syncthreads();
+
+        // ---- P2: conv2 (4->2) + relu + 2x2 pool -> A2 (zero ring) with the arg-max of the window
+        auto conv2_item = [&](int pos, int oc) {
+            const int il = pos / 18, jl = pos % 18;
+            const int I = 16 * ty - 1 + il, J = 16 * tx - 1 + jl;
+            float out = 0.0f;
+            int sel = 0;
+            if (I >= 0 && I < h4 && J >= 0 && J < h4) {
+                float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float *pl = s.a1 + cc * kT1Plane + (2 * il) * kT1S + 2 * jl;
+                    float patch[4][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kT1S);
+                        const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kT1S + 2);
+                        patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+                    }
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                                for (int kx = 0; kx < 3; ++kx)
+                                    acc[dy][dx] = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx], patch[dy + ky][dx + kx], acc[dy][dx]);
+                }
+                float mx = acc[0][0];
+                if (acc[0][1] > mx) { mx = acc[0][1]; sel = 1; }
+                if (acc[1][0] > mx) { mx = acc[1][0]; sel = 2; }
+                if (acc[1][1] > mx) { mx = acc[1][1]; sel = 3; }
+                out = fmaxf(mx + b2[oc], 0.0f);
+            }
+            s.a2[oc * kT2Plane + (il + 1) * kT2S + jl + 1] = out;
+            s.sel2[oc][pos] = (uint8_t)sel;
+        };
+        conv2_item(tid, 0);
+        conv2_item(tid, 1);
+        {
+            const int ocw = __builtin_amdgcn_readfirstlane(wv >> 1), rem = tid & 127;
+            if (rem < 18 * 18 - 256) conv2_item(256 + rem, ocw);
+        }
+        __syncthreads();
+
+        // ---- P3: convT1 + relu -> A3 (rows 32ty-1 .. 32ty+32), blocks of 2x2 outputs per A2 index
+        for (int i = tid; i < 18 * 18; i += 256) {
+            const int bl = i / 18, cl = i % 18;
+            float r2[2][3][3];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) r2[cc][r][x] = s.a2[cc * kT2Plane + (bl + r) * kT2S + cl + x];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int ry0 = 1, ky0 = j ? 2 : 1;
+                    const int ry1 = j ? 2 : 0, ky1 = j ? 0 : 3;
+                    const int cx0 = 1, kx0 = ii ? 2 : 1;
+                    const int cx1 = ii ? 2 : 0, kx1 = ii ? 0 : 3;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        acc = fmaf(r2[cc][ry0][cx0], wt1[cc * 16 + ky0 * 4 + kx0], acc);
+                        acc = fmaf(r2[cc][ry0][cx1], wt1[cc * 16 + ky0 * 4 + kx1], acc);
+                        acc = fmaf(r2[cc][ry1][cx0], wt1[cc * 16 + ky1 * 4 + kx0], acc);
+                        acc = fmaf(r2[cc][ry1][cx1], wt1[cc * 16 + ky1 * 4 + kx1], acc);
+                    }
+                    const int lr = 2 * bl - 1 + j, lc = 2 * cl - 1 + ii;
+                    const int gr = 32 * ty - 1 + lr, gc = 32 * tx - 1 + lc;
+                    if (lr >= 0 && lr < 34 && lc >= 0 && lc < 34)
+                        s.a3[lr * kT3S + lc] = (gr >= 0 && gr < h2 && gc >= 0 && gc < h2) ? fmaxf(acc + bt1, 0.0f) : 0.0f;
+                }
+        }
+        __syncthreads();
+
+        // ---- P4: convT2 + sigmoid + loss on the thread's own 4x4 cells; d loss / d pre-sigmoid; convT2 gradients
+        float sq = 0.0f;
+        {
+            float t3[4][4];
+            const float *pl = s.a3 + (2 * py) * kT3S + 2 * px;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kT3S);
+                const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kT3S + 2);
+                t3[r][0] = lo.x; t3[r][1] = lo.y; t3[r][2] = hi.x; t3[r][3] = hi.y;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t bits = row_seg4(s.rows[7 + 4 * py + r][0], s.rows[7 + 4 * py + r][1], 7 + 4 * px);
+                float d4[4];
+#pragma unroll
+                for (int cx = 0; cx < 4; ++cx) {
+                    const int my = r >> 1, mx = cx >> 1;
+                    const int ry0 = my + 1, ky0 = (r & 1) ? 2 : 1;
+                    const int ry1 = (r & 1) ? my + 2 : my, ky1 = (r & 1) ? 0 : 3;
+                    const int cx0 = mx + 1, kx0 = (cx & 1) ? 2 : 1;
+                    const int cx1 = (cx & 1) ? mx + 2 : mx, kx1 = (cx & 1) ? 0 : 3;
+                    float acc = 0.0f;
+                    acc = fmaf(t3[ry0][cx0], wt2[ky0 * 4 + kx0], acc);
+                    acc = fmaf(t3[ry0][cx1], wt2[ky0 * 4 + kx1], acc);
+                    acc = fmaf(t3[ry1][cx0], wt2[ky1 * 4 + kx0], acc);
+                    acc = fmaf(t3[ry1][cx1], wt2[ky1 * 4 + kx1], acc);
+                    const float pr = tile_sigmoid(acc + bt2);
+                    const float ob = (float)((bits >> cx) & 1u);
+                    const float df = ob - pr;
+                    sq = fmaf(df, df, sq);
+                    const float dz = gs * (pr - ob) * pr * (1.0f - pr);
+                    d4[cx] = dz;
+                    gbt2 += dz;
+                    gwt2[ky0 * 4 + kx0] = fmaf(dz, t3[ry0][cx0], gwt2[ky0 * 4 + kx0]);
+                    gwt2[ky0 * 4 + kx1] = fmaf(dz, t3[ry0][cx1], gwt2[ky0 * 4 + kx1]);
+                    gwt2[ky1 * 4 + kx0] = fmaf(dz, t3[ry1][cx0], gwt2[ky1 * 4 + kx0]);
+                    gwt2[ky1 * 4 + kx1] = fmaf(dz, t3[ry1][cx1], gwt2[ky1 * 4 + kx1]);
+                }
+                *reinterpret_cast<float4 *>(&s.dpre[4 * py + r][4 * px]) = make_float4(d4[0], d4[1], d4[2], d4[3]);
+            }
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) sq += __shfl_xor(sq, sft, 64);
+        if (lane == 0) s.red[wv][0] = sq;
+        __syncthreads();
+        if (tid == 0) partial[t] = (s.red[0][0] + s.red[1][0]) + (s.red[2][0] + s.red[3][0]);
+
+        // ---- P5: d loss / d A3 gathered from the own cells each A3 position feeds, relu gate, in place
+        for (int i = tid; i < 34 * 34; i += 256) {
+            const int jl = i / 34, kl = i % 34;
+            float da = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int oy = 2 * jl - 3 + ky, ox = 2 * kl - 3 + kx;      // local output cell fed through tap (ky, kx)
+                    if (oy >= 0 && oy < 64 && ox >= 0 && ox < 64) da = fmaf(s.dpre[oy][ox], wt2[ky * 4 + kx], da);
+                }
+            float *a = &s.a3[jl * kT3S + kl];
+            *a = *a > 0.0f ? da : 0.0f;
+        }
+        __syncthreads();
+
+        // ---- P6: convT1 weight gradients (2x2 blocks, compile-time taps) and d loss / d A2 (gather), relu gate
+        for (int i = tid; i < 18 * 18; i += 256) {
+            const int bl = i / 18, cl = i % 18;
+            float r2[2][3][3];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) r2[cc][r][x] = s.a2[cc * kT2Plane + (bl + r) * kT2S + cl + x];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int lr = 2 * bl - 1 + j, lc = 2 * cl - 1 + ii;
+                    const float gz = (lr >= 0 && lr < 34 && lc >= 0 && lc < 34) ? s.a3[lr * kT3S + lc] : 0.0f;
+                    gbt1 += gz;
+                    const int ry0 = 1, ky0 = j ? 2 : 1;
+                    const int ry1 = j ? 2 : 0, ky1 = j ? 0 : 3;
+                    const int cx0 = 1, kx0 = ii ? 2 : 1;
+                    const int cx1 = ii ? 2 : 0, kx1 = ii ? 0 : 3;
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        gwt1[cc * 16 + ky0 * 4 + kx0] = fmaf(gz, r2[cc][ry0][cx0], gwt1[cc * 16 + ky0 * 4 + kx0]);
+                        gwt1[cc * 16 + ky0 * 4 + kx1] = fmaf(gz, r2[cc][ry0][cx1], gwt1[cc * 16 + ky0 * 4 + kx1]);
+                        gwt1[cc * 16 + ky1 * 4 + kx0] = fmaf(gz, r2[cc][ry1][cx0], gwt1[cc * 16 + ky1 * 4 + kx0]);
+                        gwt1[cc * 16 + ky1 * 4 + kx1] = fmaf(gz, r2[cc][ry1][cx1], gwt1[cc * 16 + ky1 * 4 + kx1]);
+                    }
+                }
+            // A2 (il, jl2) = this block's index: it feeds A3 local rows 2 il - 2 + ky, columns 2 jl2 - 2 + kx
+            float d2[2] = {0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int lr = 2 * bl - 2 + ky, lc = 2 * cl - 2 + kx;
+                    if (lr >= 0 && lr < 34 && lc >= 0 && lc < 34) {
+                        const float gz = s.a3[lr * kT3S + lc];
+                        d2[0] = fmaf(gz, wt1[ky * 4 + kx], d2[0]);
+                        d2[1] = fmaf(gz, wt1[16 + ky * 4 + kx], d2[1]);
+                    }
+                }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+                s.g2[cc * 324 + i] = s.a2[cc * kT2Plane + (bl + 1) * kT2S + cl + 1] > 0.0f ? d2[cc] : 0.0f;
+        }
+        __syncthreads();
+
+        // ---- P7: conv2 weight gradients and the sparse conv2-output gradient map; thread = (A2 position, oc)
+        auto conv2_bwd = [&](int pos, int oc) {
+            const int il = pos / 18, jl = pos % 18;
+            const float dd = s.g2[oc * 324 + pos];
+            const int sel = s.sel2[oc][pos], ay = sel >> 1, ax = sel & 1;
+            gb2[oc] += dd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s.dmap[oc][2 * il + (e >> 1) + 2][2 * jl + (e & 1) + 2] = e == sel ? dd : 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const float *pl = s.a1 + cc * kT1Plane + (2 * il) * kT1S + 2 * jl;
+                float patch[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kT1S);
+                    const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kT1S + 2);
+                    patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float p00 = patch[ky][kx], p01 = patch[ky][kx + 1], p10 = patch[ky + 1][kx], p11 = patch[ky + 1][kx + 1];
+                        const float v = ay ? (ax ? p11 : p10) : (ax ? p01 : p00);
+                        if (oc == 0) gw2[cc * 9 + ky * 3 + kx] = fmaf(dd, v, gw2[cc * 9 + ky * 3 + kx]);
+                        else gw2[36 + cc * 9 + ky * 3 + kx] = fmaf(dd, v, gw2[36 + cc * 9 + ky * 3 + kx]);
+                    }
+            }
+        };
+        conv2_bwd(tid, 0);
+        conv2_bwd(tid, 1);
+        if (tid < 18 * 18 - 256) { conv2_bwd(256 + tid, 0); conv2_bwd(256 + tid, 1); }
+        __syncthreads();
+
+        // ---- P8: conv1 weight / bias gradients; thread = A1 position, gradient gathered from the map
+        for (int i = tid; i < kT1 * kT1; i += 256) {
+            const int pl = i / kT1, ql = i % kT1;
+            float dm[2][3][3];
+#pragma unroll
+            for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) dm[oc][ky][kx] = s.dmap[oc][pl - ky + 2][ql - kx + 2];
+            const uint32_t nbv = s.nb[i], amv = s.am[i];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                float da = 0.0f;
+#pragma unroll
+                for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+                    for (int tq = 0; tq < 9; ++tq) da = fmaf(w2[(oc * 4 + ch) * 9 + tq], dm[oc][tq / 3][tq % 3], da);
+                const float g1 = s.a1[ch * kT1Plane + pl * kT1S + ql] > 0.0f ? da : 0.0f;
+                gb1[ch] += g1;
+                const uint32_t idx = (amv >> (2 * ch)) & 3u;
+                const uint32_t tb = nbv >> (((idx & 2u) << 1) | (idx & 1u));
+#pragma unroll
+                for (int tq = 0; tq < 9; ++tq)
+                    gw1[ch * 9 + tq] = fmaf(g1, (float)((tb >> (4 * (tq / 3) + tq % 3)) & 1u), gw1[ch * 9 + tq]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- one partial row per workgroup, blob order: conv1.w[36] b[4] | conv2.w[72] b[2] | convT1.w[32] b[1] | convT2.w[16] b[1]
+#pragma unroll
+    for (int i = 0; i < 164; ++i) {
+        float x = i < 36 ? gw1[i] : i < 40 ? gb1[i - 36] : i < 112 ? gw2[i - 40] : i < 114 ? gb2[i - 112]
+                : i < 146 ? gwt1[i - 114] : i == 146 ? gbt1 : i < 163 ? gwt2[i - 147] : gbt2;
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) x += __shfl_xor(x, sh, 64);
+        if (lane == 0) s.red[wv][i] = x;
+    }
+    __syncthreads();
+    if (tid < 164) rows_out[(int64_t)blockIdx.x * 164 + tid] = (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
+}
+
+int ae2d_tiled_train_rows(int64_t n, int size) {
+    const int64_t total = n * (int64_t)(size >> 6) * (size >> 6);
+    return (int)(total < 512 ? total : 512);
+}
+
+void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
+
+// tables in ws[0 .. 2176), one squared-error partial per tile behind them; gradient rows -> rows
+int ae2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *rows,
+                     float grad_scale, bool tables_valid, hipStream_t s) {
+    if (!tables_valid) ae2d_prepare_tables(ap, ws, s);
+    const unsigned blocks = (unsigned)ae2d_tiled_train_rows(n, size);
+    float *partial = ws + kAeLutFloatsT + 128;
+    if (packed)
+        hipLaunchKernelGGL(ae_tile_train_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+    else
+        hipLaunchKernelGGL(ae_tile_train_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+    return check_launch("carle_ae2d_train(tiled)");
+}
+
 int64_t ae2d_tiled_workspace_floats(int64_t n, int size) {
     const int64_t tiles = (int64_t)(size >> 6) * (size >> 6);
     return kAeLutFloatsT + 128 + n * tiles;
 }
 
-void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
 
 // tables in ws[0 .. 2176), one partial per tile behind them; the caller's finish kernel sums them
 int ae2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *recon,

@@ -619,7 +619,7 @@ def ae2d_train(obs, params, workspace, partial, grad, bonus, reward, reward_scal
     packed = obs.dtype == torch.int64
     n = obs.shape[0]
     h = obs.shape[2]
-    w = 64 if packed else obs.shape[3]
+    w = 64 * obs.shape[3] if packed else obs.shape[3]
     flags = (1 if binary else 0) | (2 if tables_valid else 0)
     with _on_device(obs.device):
         fn = lib.carle_ae2d_train_b1 if packed else lib.carle_ae2d_train_f32

@@ -424,9 +424,8 @@ class RND2D(Motivator):
         packed = o.dtype == torch.int64
         fused64 = binary and o.shape[2] == 64 and (packed or o.shape[3] == 64)
         size_w = o.shape[3] * 64 if packed else o.shape[3]
-        # binary grids with H = W a multiple of 64 (the reference's default 256x256): tiled kernels (RND2D; AE2D's
-        # backward is staged)
-        tiled = (binary and not fused64 and not is_ae and self.hip_backward_any_size and o.dim() == 4
+        # binary grids with H = W a multiple of 64 (the reference's default 256x256): tiled kernels (nets_tiled.hip)
+        tiled = (binary and not fused64 and self.hip_backward_any_size and o.dim() == 4
                  and o.shape[2] == size_w and o.shape[2] % 64 == 0 and o.shape[2] > 64)
         if not fused64 and not tiled:
             if not self.hip_backward_any_size:
@@ -459,7 +458,7 @@ class RND2D(Motivator):
         if is_ae:
             grad_scale = 2.0 / (size * size * n * self.batch_size)
             hip.ae2d_train(o, pb, self._ws, self._partial, self._grad, bonus_out, reward,
-                           self.reward_scale, grad_scale, valid, stream, binary=fused64)
+                           self.reward_scale, grad_scale, valid, stream, binary=uses_tables)
         else:
             grad_scale = 2.0 / (self.rnd_dim * n * self.batch_size)
             hip.rnd2d_train(o, pb, rb, self._ws, self._partial, self._grad, bonus_out, reward,

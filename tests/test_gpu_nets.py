@@ -763,3 +763,42 @@ def test_tiled_rnd_training_matches_autograd_and_staged(size, n, packed):
     assert scale > 0
     np.testing.assert_allclose(runs[0], 2 * ref, rtol=2e-4, atol=2e-6 * scale + 1e-9)
     np.testing.assert_allclose(runs[0], staged, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+
+
+@pytest.mark.parametrize("size,n,packed", [(128, 5, False), (256, 4, False), (256, 9, True), (192, 2, False)])
+def test_tiled_ae_training_matches_autograd_and_staged(size, n, packed):
+    """carle_ae2d_train_* on binary grids with H = W a multiple of 64: ONE tiled kernel (forward + backward per
+    tile) + finish + row reduction.  Bonus = the forward bonus, accumulated gradient = autograd's (2e-4) and the
+    staged backward's, accumulation over two calls, deterministic."""
+    from carle_amd import hip
+    torch.manual_seed(600 + size + n)
+    env, rnd, ae = _stack(size, n)
+    ae.eval()
+    ae.reset()
+    dens = torch.linspace(0.05, 0.7, n, device="cuda").reshape(n, 1, 1, 1)
+    g = (torch.rand(n, 1, size, size, device="cuda") < dens).float()
+    exp_bonus = ae.get_bonus_only(g).clone()                # staged forward
+    ref = _autograd_grad(ae, g)
+    ae._grad = None
+    bonus = torch.empty(n, device="cuda")
+    reward = torch.zeros(n, 1, device="cuda")
+    for acc in range(2):
+        assert ae._fused_train(g, reward, bonus, None)      # staged backward
+    staged = ae._grad.cpu().numpy().copy()
+    ae.assume_binary_obs = True
+    obs = hip.pack_f32_b1(g) if packed else g
+    runs = []
+    for rep in range(2):
+        ae._grad = None
+        bonus = torch.empty(n, device="cuda")
+        reward = torch.zeros(n, 1, device="cuda")
+        for acc in range(2):
+            assert ae._fused_train(obs, reward, bonus, None)
+        runs.append(ae._grad.cpu().numpy().copy())
+        np.testing.assert_allclose(bonus.cpu().numpy(), exp_bonus.cpu().numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(reward.cpu().numpy()[:, 0], 2 * exp_bonus.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert np.array_equal(runs[0], runs[1])
+    scale = np.abs(ref).max()
+    assert scale > 0
+    np.testing.assert_allclose(runs[0], 2 * ref, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+    np.testing.assert_allclose(runs[0], staged, rtol=2e-4, atol=2e-6 * scale + 1e-9)
