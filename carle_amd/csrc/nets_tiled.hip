@@ -735,14 +735,19 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
     const int h2 = size >> 1, h4 = size >> 2;
     const int64_t total = n * tiles;
     const int py = tid >> 4, px = tid & 15;
-    float gw1[36], gb1[4], gw2[72], gb2[2], gwt1[32], gbt1 = 0.0f, gwt2[16], gbt2 = 0.0f;
+    // conv1 / conv2 gradients are CHANNEL-SPLIT over the threads (as the 64x64 kernel): thread tid accumulates conv1
+    // channel tid & 3 and conv2 (output, input) channel pair tid & 7 -- 9 + 1 + 9 + 1 accumulators instead of 36 + 4 +
+    // 72 + 2 (the first version kept all 164 per thread: 256 VGPRs + 132 spilled, 134 us per tile)
+    float gw1[9], gb1 = 0.0f, gw2[9], gb2 = 0.0f, gwt1[32], gbt1 = 0.0f, gwt2[16], gbt2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 36; ++i) gw1[i] = 0.0f;
+    for (int i = 0; i < 9; ++i) { gw1[i] = 0.0f; gw2[i] = 0.0f; }
+    const int ch1 = tid & 3;                           // conv1 channel of this thread (P8)
+    const int oc7 = (tid >> 2) & 1, cc7 = tid & 3;     // conv2 (oc, cc) pair of this thread (P7)
+    float wch[18];                                     // w2[oc][ch1][tap], oc-major: the gather weights of P8
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gb1[i] = 0.0f;
+    for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
-    for (int i = 0; i < 72; ++i) gw2[i] = 0.0f;
-    gb2[0] = 0.0f; gb2[1] = 0.0f;
+        for (int tq = 0; tq < 9; ++tq) wch[oc * 9 + tq] = w2[(oc * 4 + ch1) * 9 + tq];
 #pragma unroll
     for (int i = 0; i < 32; ++i) gwt1[i] = 0.0f;
 #pragma unroll
@@ -1015,73 +1020,50 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
         }
         __syncthreads();
 
-        // ---- P7: conv2 weight gradients and the sparse conv2-output gradient map; thread = (A2 position, oc)
-        auto conv2_bwd = [&](int pos, int oc) {
+        // ---- P7: conv2 weight gradients and the sparse conv2-output gradient map; thread = ((oc, cc) pair, 1 of 32 slots)
+        for (int pos = tid >> 3; pos < 18 * 18; pos += 32) {
             const int il = pos / 18, jl = pos % 18;
-            const float dd = s.g2[oc * 324 + pos];
-            const int sel = s.sel2[oc][pos], ay = sel >> 1, ax = sel & 1;
-            gb2[oc] += dd;
+            const float dd = s.g2[oc7 * 324 + pos];
+            const int sel = s.sel2[oc7][pos], ay = sel >> 1, ax = sel & 1;
+            if (cc7 == 0) {
+                gb2 += dd;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s.dmap[oc][2 * il + (e >> 1) + 2][2 * jl + (e & 1) + 2] = e == sel ? dd : 0.0f;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const float *pl = s.a1 + cc * kT1Plane + (2 * il) * kT1S + 2 * jl;
-                float patch[4][4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kT1S);
-                    const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kT1S + 2);
-                    patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
-                }
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float p00 = patch[ky][kx], p01 = patch[ky][kx + 1], p10 = patch[ky + 1][kx], p11 = patch[ky + 1][kx + 1];
-                        const float v = ay ? (ax ? p11 : p10) : (ax ? p01 : p00);
-                        if (oc == 0) gw2[cc * 9 + ky * 3 + kx] = fmaf(dd, v, gw2[cc * 9 + ky * 3 + kx]);
-                        else gw2[36 + cc * 9 + ky * 3 + kx] = fmaf(dd, v, gw2[36 + cc * 9 + ky * 3 + kx]);
-                    }
+                for (int e = 0; e < 4; ++e) s.dmap[oc7][2 * il + (e >> 1) + 2][2 * jl + (e & 1) + 2] = e == sel ? dd : 0.0f;
             }
-        };
-        conv2_bwd(tid, 0);
-        conv2_bwd(tid, 1);
-        if (tid < 18 * 18 - 256) { conv2_bwd(256 + tid, 0); conv2_bwd(256 + tid, 1); }
+            const float *pl = s.a1 + cc7 * kT1Plane + (2 * il + ay) * kT1S + 2 * jl + ax;     // the 3x3 window under the arg-max
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) gw2[ky * 3 + kx] = fmaf(dd, pl[ky * kT1S + kx], gw2[ky * 3 + kx]);
+        }
         __syncthreads();
 
-        // ---- P8: conv1 weight / bias gradients; thread = A1 position, gradient gathered from the map
-        for (int i = tid; i < kT1 * kT1; i += 256) {
+        // ---- P8: conv1 weight / bias gradients; thread = (channel, 1 of 64 slots), gradient gathered from the map
+        for (int i = tid >> 2; i < kT1 * kT1; i += 64) {
             const int pl = i / kT1, ql = i % kT1;
-            float dm[2][3][3];
+            float da = 0.0f;
 #pragma unroll
             for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) dm[oc][ky][kx] = s.dmap[oc][pl - ky + 2][ql - kx + 2];
-            const uint32_t nbv = s.nb[i], amv = s.am[i];
+                    for (int kx = 0; kx < 3; ++kx) da = fmaf(wch[oc * 9 + ky * 3 + kx], s.dmap[oc][pl - ky + 2][ql - kx + 2], da);
+            const float g1 = s.a1[ch1 * kT1Plane + pl * kT1S + ql] > 0.0f ? da : 0.0f;
+            gb1 += g1;
+            const uint32_t idx = ((uint32_t)s.am[i] >> (2 * ch1)) & 3u;
+            const uint32_t tb = (uint32_t)s.nb[i] >> (((idx & 2u) << 1) | (idx & 1u));
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                float da = 0.0f;
-#pragma unroll
-                for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-                    for (int tq = 0; tq < 9; ++tq) da = fmaf(w2[(oc * 4 + ch) * 9 + tq], dm[oc][tq / 3][tq % 3], da);
-                const float g1 = s.a1[ch * kT1Plane + pl * kT1S + ql] > 0.0f ? da : 0.0f;
-                gb1[ch] += g1;
-                const uint32_t idx = (amv >> (2 * ch)) & 3u;
-                const uint32_t tb = nbv >> (((idx & 2u) << 1) | (idx & 1u));
-#pragma unroll
-                for (int tq = 0; tq < 9; ++tq)
-                    gw1[ch * 9 + tq] = fmaf(g1, (float)((tb >> (4 * (tq / 3) + tq % 3)) & 1u), gw1[ch * 9 + tq]);
-            }
+            for (int tq = 0; tq < 9; ++tq) gw1[tq] = fmaf(g1, (float)((tb >> (4 * (tq / 3) + tq % 3)) & 1u), gw1[tq]);
         }
         __syncthreads();
     }
     // ---- one partial row per workgroup, blob order: conv1.w[36] b[4] | conv2.w[72] b[2] | convT1.w[32] b[1] | convT2.w[16] b[1]
 #pragma unroll
     for (int i = 0; i < 164; ++i) {
-        float x = i < 36 ? gw1[i] : i < 40 ? gb1[i - 36] : i < 112 ? gw2[i - 40] : i < 114 ? gb2[i - 112]
+        float x = i < 36 ? (i / 9 == ch1 ? gw1[i % 9] : 0.0f)
+                : i < 40 ? (i - 36 == ch1 ? gb1 : 0.0f)
+                : i < 112 ? ((i - 40) / 9 == oc7 * 4 + cc7 ? gw2[(i - 40) % 9] : 0.0f)
+                : i < 114 ? ((i - 112 == oc7 && cc7 == 0) ? gb2 : 0.0f)
                 : i < 146 ? gwt1[i - 114] : i == 146 ? gbt1 : i < 163 ? gwt2[i - 147] : gbt2;
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) x += __shfl_xor(x, sh, 64);
