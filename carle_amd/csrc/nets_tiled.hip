@@ -70,6 +70,18 @@ __device__ __forceinline__ void rnd_tile_window(RndTileShared &s, int wy, int wx
 
 struct __attribute__((aligned(4))) F4T { float x, y, z, w; };   // 16 bytes at 4-byte alignment (weight rows)
 
+// sum over the 64 lanes by DPP (no LDS crossbar round trips: a chain of six ds_bpermute per value made the
+// 164-value row reduction at the end of the training kernels cost more than a whole tile); valid in every lane
+__device__ __forceinline__ float tile_wave_sum(float v) {
+    v += dpp_quad_xor1(v);
+    v += dpp_quad_xor2(v);
+    v += dpp_row_ror(v, 0x124);
+    v += dpp_row_ror(v, 0x128);
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+
 // PACKED: obs = bit-packed grids (H rows of W/64 words); else fp32 (N,1,H,W), any non-zero number = alive
 template <bool PACKED>
 __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
@@ -399,8 +411,7 @@ __global__ __launch_bounds__(256, 2) void rnd_tile_bwd_kernel(const void *__rest
 #pragma unroll
     for (int i = 0; i < 77; ++i) {
         float x = i < 36 ? acc1[i] : i < 40 ? accb1[i - 36] : i < 76 ? (((i - 40) / 9 == cme) ? acc2[(i - 40) % 9] : 0.0f) : accb2;
-#pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) x += __shfl_xor(x, sh, 64);
+        x = tile_wave_sum(x);
         if (lane == 0) s.red[wv][i] = x;
     }
     __syncthreads();
@@ -735,19 +746,16 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
     const int h2 = size >> 1, h4 = size >> 2;
     const int64_t total = n * tiles;
     const int py = tid >> 4, px = tid & 15;
-    // conv1 / conv2 gradients are CHANNEL-SPLIT over the threads (as the 64x64 kernel): thread tid accumulates conv1
-    // channel tid & 3 and conv2 (output, input) channel pair tid & 7 -- 9 + 1 + 9 + 1 accumulators instead of 36 + 4 +
-    // 72 + 2 (the first version kept all 164 per thread: 256 VGPRs + 132 spilled, 134 us per tile)
-    float gw1[9], gb1 = 0.0f, gw2[9], gb2 = 0.0f, gwt1[32], gbt1 = 0.0f, gwt2[16], gbt2 = 0.0f;
+    // the conv2 gradients are CHANNEL-SPLIT over the threads: thread tid accumulates the (output, input) channel pair
+    // tid & 7 -- 9 + 1 accumulators instead of 72 + 2 (all 164 per thread: 256 VGPRs + 132 spilled, 134 us per tile);
+    // conv1 stays per position (the gather of the map is shared by the four channels: 1 400 instead of 4 000
+    // instructions per tile)
+    float gw1[36], gb1[4] = {0.f, 0.f, 0.f, 0.f}, gw2[9], gb2 = 0.0f, gwt1[32], gbt1 = 0.0f, gwt2[16], gbt2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { gw1[i] = 0.0f; gw2[i] = 0.0f; }
-    const int ch1 = tid & 3;                           // conv1 channel of this thread (P8)
+    for (int i = 0; i < 36; ++i) gw1[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gw2[i] = 0.0f;
     const int oc7 = (tid >> 2) & 1, cc7 = tid & 3;     // conv2 (oc, cc) pair of this thread (P7)
-    float wch[18];                                     // w2[oc][ch1][tap], oc-major: the gather weights of P8
-#pragma unroll
-    for (int oc = 0; oc < 2; ++oc)
-#pragma unroll
-        for (int tq = 0; tq < 9; ++tq) wch[oc * 9 + tq] = w2[(oc * 4 + ch1) * 9 + tq];
 #pragma unroll
     for (int i = 0; i < 32; ++i) gwt1[i] = 0.0f;
 #pragma unroll
@@ -1038,35 +1046,43 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
         }
         __syncthreads();
 
-        // ---- P8: conv1 weight / bias gradients; thread = (channel, 1 of 64 slots), gradient gathered from the map
-        for (int i = tid >> 2; i < kT1 * kT1; i += 64) {
+        // ---- P8: conv1 weight / bias gradients; thread = A1 position, gradient gathered from the map
+        for (int i = tid; i < kT1 * kT1; i += 256) {
             const int pl = i / kT1, ql = i % kT1;
-            float da = 0.0f;
+            float dm[2][3][3];
 #pragma unroll
             for (int oc = 0; oc < 2; ++oc)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) da = fmaf(wch[oc * 9 + ky * 3 + kx], s.dmap[oc][pl - ky + 2][ql - kx + 2], da);
-            const float g1 = s.a1[ch1 * kT1Plane + pl * kT1S + ql] > 0.0f ? da : 0.0f;
-            gb1 += g1;
-            const uint32_t idx = ((uint32_t)s.am[i] >> (2 * ch1)) & 3u;
-            const uint32_t tb = (uint32_t)s.nb[i] >> (((idx & 2u) << 1) | (idx & 1u));
+                    for (int kx = 0; kx < 3; ++kx) dm[oc][ky][kx] = s.dmap[oc][pl - ky + 2][ql - kx + 2];
+            const uint32_t nbv = s.nb[i], amv = s.am[i];
 #pragma unroll
-            for (int tq = 0; tq < 9; ++tq) gw1[tq] = fmaf(g1, (float)((tb >> (4 * (tq / 3) + tq % 3)) & 1u), gw1[tq]);
+            for (int ch = 0; ch < 4; ++ch) {
+                float da = 0.0f;
+#pragma unroll
+                for (int oc = 0; oc < 2; ++oc)
+#pragma unroll
+                    for (int tq = 0; tq < 9; ++tq) da = fmaf(w2[(oc * 4 + ch) * 9 + tq], dm[oc][tq / 3][tq % 3], da);
+                const float g1 = s.a1[ch * kT1Plane + pl * kT1S + ql] > 0.0f ? da : 0.0f;
+                gb1[ch] += g1;
+                const uint32_t idx = (amv >> (2 * ch)) & 3u;
+                const uint32_t tb = nbv >> (((idx & 2u) << 1) | (idx & 1u));
+#pragma unroll
+                for (int tq = 0; tq < 9; ++tq)
+                    gw1[ch * 9 + tq] = fmaf(g1, (float)((tb >> (4 * (tq / 3) + tq % 3)) & 1u), gw1[ch * 9 + tq]);
+            }
         }
         __syncthreads();
     }
     // ---- one partial row per workgroup, blob order: conv1.w[36] b[4] | conv2.w[72] b[2] | convT1.w[32] b[1] | convT2.w[16] b[1]
 #pragma unroll
     for (int i = 0; i < 164; ++i) {
-        float x = i < 36 ? (i / 9 == ch1 ? gw1[i % 9] : 0.0f)
-                : i < 40 ? (i - 36 == ch1 ? gb1 : 0.0f)
+        float x = i < 36 ? gw1[i] : i < 40 ? gb1[i - 36]
                 : i < 112 ? ((i - 40) / 9 == oc7 * 4 + cc7 ? gw2[(i - 40) % 9] : 0.0f)
                 : i < 114 ? ((i - 112 == oc7 && cc7 == 0) ? gb2 : 0.0f)
                 : i < 146 ? gwt1[i - 114] : i == 146 ? gbt1 : i < 163 ? gwt2[i - 147] : gbt2;
-#pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) x += __shfl_xor(x, sh, 64);
+        x = tile_wave_sum(x);
         if (lane == 0) s.red[wv][i] = x;
     }
     __syncthreads();
