@@ -204,8 +204,8 @@ class RND2D(Motivator):
         if obs.dtype == torch.uint8:                      # uint8 observation (storage="u8"): alive bits
             if obs.device != dev or not obs.is_contiguous():
                 obs = obs.to(dev).contiguous()
-            if allow_packed and obs.dim() == 4 and obs.shape[2] == 64 and obs.shape[3] == 64:
-                return hip.pack_u8_b1(obs), True
+            if allow_packed and obs.dim() == 4 and obs.shape[2] == obs.shape[3] and obs.shape[2] % 64 == 0:
+                return hip.pack_u8_b1(obs), True             # 64x64: fused kernels; larger: tiled kernels
             return (obs != 0).to(torch.float32), True
         binary = self.assume_binary_obs or (getattr(env, "storage", "f32") == "f32" and
                                             obs is env.__dict__.get("universe"))

@@ -802,3 +802,27 @@ def test_tiled_ae_training_matches_autograd_and_staged(size, n, packed):
     assert scale > 0
     np.testing.assert_allclose(runs[0], 2 * ref, rtol=2e-4, atol=2e-6 * scale + 1e-9)
     np.testing.assert_allclose(runs[0], staged, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+
+
+@pytest.mark.parametrize("storage", ["u8", "b1"])
+def test_tiled_nets_on_byte_and_packed_environments(storage):
+    """RND2D / AE2D on a 256x256 CARLE(storage=u8 | b1): the observation is packed once (uint8) or passed as it
+    is (bit-packed) and goes through the tiled kernels; rewards equal the fp32 environment's."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D
+    torch.manual_seed(8)
+    ref_env, ref_rnd, ref_ae = _stack(256, 3)
+    env = CARLE(width=256, height=256, action_width=64, action_height=64, instances=3, device="cuda:0", storage=storage)
+    rnd = RND2D(env)
+    ae = AE2D(rnd)
+    ae.load_state_dict({k: v for k, v in ref_ae.state_dict().items()}, strict=True)
+    ae.eval()
+    ref_ae.reset(); ae.reset()
+    u = (torch.rand(3, 1, 256, 256, device="cuda") < 0.3).float()
+    ref_env.universe = u.clone()
+    env.universe = u.clone()
+    for t in range(3):
+        a = (torch.rand(3, 1, 64, 64, device="cuda") < 0.1).float()
+        r0 = ref_ae.step(a)[1]
+        r1 = ae.step(a)[1]
+        np.testing.assert_allclose(r1.detach().cpu().numpy(), r0.detach().cpu().numpy(), rtol=0, atol=1e-6)
