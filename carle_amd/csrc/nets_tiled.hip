@@ -12,6 +12,7 @@
 // Two launches instead of the staged path's three, and nothing but the observation is read from HBM
 // (staged: 6 pooled planes + 2 feature planes written and re-read).
 #include "rnd_device.hpp"
+#include <type_traits>
 
 namespace carle {
 
@@ -724,20 +725,23 @@ struct AeTileTrainShared {
     uint16_t nb[kT1 * kT1];            // 4x4 cell neighbourhood of every A1 position
     uint8_t am[kT1 * kT1];             // 2-bit arg-max index of the four conv1 channels
     uint8_t sel2[2][18 * 18];          // arg-max of the 2x2 conv2 outputs under every A2 position
-    float red[4][164];
+    float red_sq[8];                   // per-tile squared-error sums of the waves (the 164-wide rows at the end overlay dpre)
 };
 
-template <bool PACKED>
-__global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
+// NT threads per tile: 512 (one workgroup per CU) for small batches -- a tile is a chain of dependent LDS round trips,
+// twice the waves halve it (N=16: 67 -> 41 us per call) -- 256 (two workgroups per CU) for large ones (N=256: 374
+// against 399 us)
+template <bool PACKED, int NT>
+__global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
                                                                float *__restrict__ partial, float *__restrict__ rows_out,
                                                                float gs, int64_t n, int size) {
     __shared__ AeTileTrainShared s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const float4 *src = reinterpret_cast<const float4 *>(ws);
-        for (int i = tid; i < 512; i += 256) s.lut[i] = src[i];
-        for (int i = tid; i < 2 * kT2Plane; i += 256) s.a2[i] = 0.0f;
-        for (int i = tid; i < 2 * 40 * 40; i += 256) (&s.dmap[0][0][0])[i] = 0.0f;
+        for (int i = tid; i < 512; i += NT) s.lut[i] = src[i];
+        for (int i = tid; i < 2 * kT2Plane; i += NT) s.a2[i] = 0.0f;
+        for (int i = tid; i < 2 * 40 * 40; i += NT) (&s.dmap[0][0][0])[i] = 0.0f;
     }
     const float *prm = ws + kAeLutFloatsT;
     const float *w2 = prm, *b2 = prm + 72, *wt1 = prm + 74, *wt2 = prm + 107;
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
     const int tps = size >> 6, tiles = tps * tps;
     const int h2 = size >> 1, h4 = size >> 2;
     const int64_t total = n * tiles;
-    const int py = tid >> 4, px = tid & 15;
+    const int py = (tid & 255) >> 4, px = tid & 15, hf = tid >> 8;      // P4: rows 2 hf, 2 hf + 1 of the 4x4 cell block (py, px)
     // the conv2 gradients are CHANNEL-SPLIT over the threads: thread tid accumulates the (output, input) channel pair
     // tid & 7 -- 9 + 1 accumulators instead of 72 + 2 (all 164 per thread: 256 VGPRs + 132 spilled, 134 us per tile);
     // conv1 stays per position (the gather of the map is shared by the four channels: 1 400 instead of 4 000
@@ -781,12 +785,12 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
             }
         } else {
             const float *gin = reinterpret_cast<const float *>(obs_v) + g * (int64_t)size * size;
-            constexpr int kPer = (kAeRows + 3) / 4;
+            constexpr int kWaves = NT / 64, kPer = (kAeRows + kWaves - 1) / kWaves;
             uint32_t va[kPer], vb[kPer];
             const int xa = x0 + lane, xb = x0 + 64 + lane;
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
-                const int r = wv + 4 * i, y = y0 + r;
+                const int r = wv + kWaves * i, y = y0 + r;
                 const bool yin = r < kAeRows && y >= 0 && y < size;
                 va[i] = 0u; vb[i] = 0u;
                 if (yin && xa >= 0 && xa < size) va[i] = __float_as_uint(gin[(int64_t)y * size + xa]);
@@ -794,7 +798,7 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
             }
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
-                const int r = wv + 4 * i;
+                const int r = wv + kWaves * i;
                 const uint64_t lo = __ballot((va[i] & 0x7FFFFFFFu) != 0u);
                 const uint64_t hi = __ballot((vb[i] & 0x7FFFFFFFu) != 0u);
                 if (lane == 0 && r < kAeRows) { s.rows[r][0] = lo; s.rows[r][1] = hi; }
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
         __syncthreads();
 
         // ---- P1: conv1 (table) + relu + 2x2 pool -> A1 with arg-max index and 4x4 cell neighbourhood
-        for (int i = tid; i < kT1 * kT1; i += 256) {
+        for (int i = tid; i < kT1 * kT1; i += NT) {
             const int pl = i / kT1, ql = i % kT1;
             const int P = 32 * ty - 3 + pl, Q = 32 * tx - 3 + ql;
             float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
@@ -874,16 +878,20 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
             s.a2[oc * kT2Plane + (il + 1) * kT2S + jl + 1] = out;
             s.sel2[oc][pos] = (uint8_t)sel;
         };
-        conv2_item(tid, 0);
-        conv2_item(tid, 1);
-        {
+        if (NT == 512) {
+            const int ocw = __builtin_amdgcn_readfirstlane(wv >> 2), rem = tid & 255;      // waves 0-3: oc 0, waves 4-7: oc 1
+            conv2_item(rem, ocw);
+            if (rem < 18 * 18 - 256) conv2_item(256 + rem, ocw);
+        } else {
+            conv2_item(tid, 0);
+            conv2_item(tid, 1);
             const int ocw = __builtin_amdgcn_readfirstlane(wv >> 1), rem = tid & 127;
             if (rem < 18 * 18 - 256) conv2_item(256 + rem, ocw);
         }
         __syncthreads();
 
         // ---- P3: convT1 + relu -> A3 (rows 32ty-1 .. 32ty+32), blocks of 2x2 outputs per A2 index
-        for (int i = tid; i < 18 * 18; i += 256) {
+        for (int i = tid; i < 18 * 18; i += NT) {
             const int bl = i / 18, cl = i % 18;
             float r2[2][3][3];
 #pragma unroll
@@ -927,8 +935,8 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
                 const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kT3S + 2);
                 t3[r][0] = lo.x; t3[r][1] = lo.y; t3[r][2] = hi.x; t3[r][3] = hi.y;
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            auto cell_row = [&](auto rc) {               // rc: compile-time row of the 4x4 block
+                constexpr int r = decltype(rc)::value;
                 const uint32_t bits = row_seg4(s.rows[7 + 4 * py + r][0], s.rows[7 + 4 * py + r][1], 7 + 4 * px);
                 float d4[4];
 #pragma unroll
@@ -956,16 +964,26 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
                     gwt2[ky1 * 4 + kx1] = fmaf(dz, t3[ry1][cx1], gwt2[ky1 * 4 + kx1]);
                 }
                 *reinterpret_cast<float4 *>(&s.dpre[4 * py + r][4 * px]) = make_float4(d4[0], d4[1], d4[2], d4[3]);
+            };
+            if (NT == 256 || hf == 0) {                  // wave-uniform (hf = wave / 4)
+                cell_row(std::integral_constant<int, 0>());
+                cell_row(std::integral_constant<int, 1>());
+            }
+            if (NT == 256 || hf == 1) {
+                cell_row(std::integral_constant<int, 2>());
+                cell_row(std::integral_constant<int, 3>());
             }
         }
 #pragma unroll
         for (int sft = 32; sft > 0; sft >>= 1) sq += __shfl_xor(sq, sft, 64);
-        if (lane == 0) s.red[wv][0] = sq;
+        if (lane == 0) s.red_sq[wv] = sq;
         __syncthreads();
-        if (tid == 0) partial[t] = (s.red[0][0] + s.red[1][0]) + (s.red[2][0] + s.red[3][0]);
+        if (tid == 0)
+            partial[t] = ((s.red_sq[0] + s.red_sq[1]) + (s.red_sq[2] + s.red_sq[3])) +
+                         (NT == 512 ? ((s.red_sq[4] + s.red_sq[5]) + (s.red_sq[6] + s.red_sq[7])) : 0.0f);
 
         // ---- P5: d loss / d A3 gathered from the own cells each A3 position feeds, relu gate, in place
-        for (int i = tid; i < 34 * 34; i += 256) {
+        for (int i = tid; i < 34 * 34; i += NT) {
             const int jl = i / 34, kl = i % 34;
             float da = 0.0f;
 #pragma unroll
@@ -981,7 +999,7 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
         __syncthreads();
 
         // ---- P6: convT1 weight gradients (2x2 blocks, compile-time taps) and d loss / d A2 (gather), relu gate
-        for (int i = tid; i < 18 * 18; i += 256) {
+        for (int i = tid; i < 18 * 18; i += NT) {
             const int bl = i / 18, cl = i % 18;
             float r2[2][3][3];
 #pragma unroll
@@ -1029,7 +1047,7 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
         __syncthreads();
 
         // ---- P7: conv2 weight gradients and the sparse conv2-output gradient map; thread = ((oc, cc) pair, 1 of 32 slots)
-        for (int pos = tid >> 3; pos < 18 * 18; pos += 32) {
+        for (int pos = tid >> 3; pos < 18 * 18; pos += NT / 8) {
             const int il = pos / 18, jl = pos % 18;
             const float dd = s.g2[oc7 * 324 + pos];
             const int sel = s.sel2[oc7][pos], ay = sel >> 1, ax = sel & 1;
@@ -1047,7 +1065,7 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
         __syncthreads();
 
         // ---- P8: conv1 weight / bias gradients; thread = A1 position, gradient gathered from the map
-        for (int i = tid; i < kT1 * kT1; i += 256) {
+        for (int i = tid; i < kT1 * kT1; i += NT) {
             const int pl = i / kT1, ql = i % kT1;
             float dm[2][3][3];
 #pragma unroll
@@ -1076,17 +1094,33 @@ __global__ __launch_bounds__(256, 2) void ae_tile_train_kernel(const void *__res
         __syncthreads();
     }
     // ---- one partial row per workgroup, blob order: conv1.w[36] b[4] | conv2.w[72] b[2] | convT1.w[32] b[1] | convT2.w[16] b[1]
-#pragma unroll
-    for (int i = 0; i < 164; ++i) {
-        float x = i < 36 ? gw1[i] : i < 40 ? gb1[i - 36]
-                : i < 112 ? ((i - 40) / 9 == oc7 * 4 + cc7 ? gw2[(i - 40) % 9] : 0.0f)
-                : i < 114 ? ((i - 112 == oc7 && cc7 == 0) ? gb2 : 0.0f)
-                : i < 146 ? gwt1[i - 114] : i == 146 ? gbt1 : i < 163 ? gwt2[i - 147] : gbt2;
+    // (one loop over all 164 entries is not unrolled by the compiler: the accumulator arrays would be indexed
+    // dynamically and move to LDS)
+    float (*red)[164] = reinterpret_cast<float (*)[164]>(&s.dpre[0][0]);     // dpre is dead: every wave passed the last barrier
+    auto put = [&](int i, float x) {
         x = tile_wave_sum(x);
-        if (lane == 0) s.red[wv][i] = x;
-    }
+        if (lane == 0) red[wv][i] = x;
+    };
+#pragma unroll
+    for (int i = 0; i < 36; ++i) put(i, gw1[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put(36 + i, gb1[i]);
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) put(40 + pr * 9 + i, pr == oc7 * 4 + cc7 ? gw2[i] : 0.0f);
+    put(112, (oc7 == 0 && cc7 == 0) ? gb2 : 0.0f);
+    put(113, (oc7 == 1 && cc7 == 0) ? gb2 : 0.0f);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) put(114 + i, gwt1[i]);
+    put(146, gbt1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) put(147 + i, gwt2[i]);
+    put(163, gbt2);
     __syncthreads();
-    if (tid < 164) rows_out[(int64_t)blockIdx.x * 164 + tid] = (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
+    if (tid < 164)
+        rows_out[(int64_t)blockIdx.x * 164 + tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) +
+                                                    (NT == 512 ? ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid])) : 0.0f);
 }
 
 int ae2d_tiled_train_rows(int64_t n, int size) {
@@ -1102,10 +1136,18 @@ int ae2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const fl
     if (!tables_valid) ae2d_prepare_tables(ap, ws, s);
     const unsigned blocks = (unsigned)ae2d_tiled_train_rows(n, size);
     float *partial = ws + kAeLutFloatsT + 128;
-    if (packed)
-        hipLaunchKernelGGL(ae_tile_train_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size);
-    else
-        hipLaunchKernelGGL(ae_tile_train_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+    const int64_t total = n * (int64_t)(size >> 6) * (size >> 6);
+    if (total <= 512) {                                // at most two tiles per CU: 512 threads per tile
+        if (packed)
+            hipLaunchKernelGGL((ae_tile_train_kernel<true, 512>), dim3(blocks), dim3(512), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+        else
+            hipLaunchKernelGGL((ae_tile_train_kernel<false, 512>), dim3(blocks), dim3(512), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+    } else {
+        if (packed)
+            hipLaunchKernelGGL((ae_tile_train_kernel<true, 256>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+        else
+            hipLaunchKernelGGL((ae_tile_train_kernel<false, 256>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+    }
     return check_launch("carle_ae2d_train(tiled)");
 }
 
