@@ -110,11 +110,12 @@ def _agent_check(agent, obs, scale=None):
 
 
 @pytest.mark.parametrize("n,h,w,aw", [(3, 64, 64, 64), (70, 16, 256, 8), (1, 8, 8, 8), (5, 128, 64, 16),
-                                      (16, 256, 256, 64), (130, 64, 64, 64)])
+                                      (16, 256, 256, 64), (130, 64, 64, 64), (1029, 64, 64, 64)])
 def test_random_network_agent_matches_oracle(n, h, w, aw):
     """carle_agent_rn_forward_f32 (tiled convolutions + the linear layer on the fp32 matrix cores) vs the
     oracle; square, non-square, one-tile, partial-tile and multi-tile geometries; default-init weights and
-    a scaled linear layer (so that both sides of the threshold occur)."""
+    a scaled linear layer (so that both sides of the threshold occur).  N=1029: the 128x128-tile kernel of large
+    batches (ragged last tile); the others the 64x64-tile kernel with and without the K split."""
     from carle_amd.agents import RandomNetworkAgent
     torch.manual_seed(100 + n)
     agent = RandomNetworkAgent(observation_width=w, observation_height=h, action_width=aw, action_height=aw)
