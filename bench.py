@@ -26,6 +26,7 @@ Prints ONE JSON line on rank 0 (contract in the task description), with two extr
                 reference itself cannot travel) timed on this host's cores, bounded sample
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -460,6 +461,11 @@ def run_rank(args):
         one_step(i)
     join_rewards()
     stats.flush()                       # first collective (RCCL setup) stays out of the timing
+    # a full collection of the cyclic garbage collector takes 40-90 ms with torch imported (measured:
+    # tools/big_n_steps.py, one such pause at step 16 of a bare step loop); collect now and move the survivors
+    # to the permanent generation, so that no such pause can fall into a short timed region
+    gc.collect()
+    gc.freeze()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
