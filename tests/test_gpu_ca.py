@@ -458,3 +458,28 @@ def test_run_without_action_equals_multistep():
     ob = env_b.multistep(12)[0]
     assert torch.equal(oa, ob) and env_a.step_number == env_b.step_number == 12
     assert env_a.steps_since_action == env_b.steps_since_action == 12
+
+
+def test_c_consumer_steps_on_the_gpu(tmp_path):
+    """The boundary used the way a non-Python host would: tests/c_abi/abi_step_gpu.c (gcc -std=c99, HIP runtime C
+    API, no Python / torch in the process) steps a batch through carle_env_step_f32 and carle_ca_step_b1 and
+    compares every cell with oracle/ca_oracle.c, incl. the master reset and the status-block counters."""
+    import os
+    import shutil
+    import subprocess
+    from carle_amd import _lib
+    _lib.load()
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    odir = os.path.dirname(O.build())
+    exe = tmp_path / "abi_step_gpu"
+    subprocess.run([gcc, "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    "-I", "/opt/rocm/include", os.path.join(root, "tests", "c_abi", "abi_step_gpu.c"), "-o", str(exe),
+                    "-L", libdir, "-lcarle_hip", "-L", odir, "-lca_oracle", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath," + odir, "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "abi gpu ok" in out.stdout, out.stdout + out.stderr
