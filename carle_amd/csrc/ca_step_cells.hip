@@ -225,27 +225,82 @@ __device__ __forceinline__ void horiz_neighbours(uint64_t c, uint64_t cw, uint64
     est = ((c >> 1) & 0x7777777777777777ull) | ((ce << 3) & 0x8888888888888888ull);
 }
 
+// CARLE_WIDE_WAVES (WV) consecutive strips of a grid form one workgroup: a strip's first and last row reach the
+// neighbouring waves through LDS (one nibble per lane, after the toggle), so only the workgroup's outer two halo
+// rows are read from memory -- 2 extra row loads per 16 * WV rows instead of per 16 (12.5 % -> 3 % more load
+// instructions, and the halo rows no longer miss the L2: 4 % less HBM traffic).  Same-box A/B, fp32, kernel alone
+// (tools/kbench_wide.py, profiles/r02_kbench_wide.txt): WV = 1 / 2 / 4 / 8 -> 256x256 N=4096 372-394 / 373 /
+// 345-359 / 340-352 us, 512x512 N=1024 393 / 363 / 345-348 / 353 us; with the action window 4 is best.
+#ifndef CARLE_WIDE_WAVES
+#define CARLE_WIDE_WAVES 4
+#endif
+static constexpr int kWideWaves = CARLE_WIDE_WAVES;
+
 template <class C, class A, bool HAS_ACT, int NS, int RW, bool RAND_ACT = false>
-__global__ __launch_bounds__(64) void ca_step_wide_kernel(
+__global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
     const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
     typename C::T *__restrict__ u_out, int64_t n, int ah, int aw, uint32_t rule,
     int32_t *__restrict__ status, int slot, RandAct ra = RandAct()) {
     constexpr int W = WideGeom<NS, RW>::kW, H = W, R = WideGeom<NS, RW>::kR;
-    constexpr int kStrips = H / R;
-    const int k = threadIdx.x;                       // lane = column quad
+    constexpr int WV = kWideWaves;
+    constexpr int kStrips = H / R, kGroups = kStrips / WV;
+    static_assert(kStrips % WV == 0, "strips per grid must be a multiple of the waves per workgroup");
+    const int k = threadIdx.x & 63;                  // lane = column quad
+    const int wv = threadIdx.x >> 6;
+    const bool top_global = WV == 1 || wv == 0, bot_global = WV == 1 || wv == WV - 1;   // halo row comes from memory
+    __shared__ uint32_t edge[WV][2][NS][64];         // [wave][first / last row][segment][lane]: nibbles
     // XCD-aware bijective remap of the list position (cdna_hip_programming.md T1): positions b, b + 8,
     // ... share an XCD and map to consecutive strips (halo rows are L2 hits).  The loop runs once per
-    // workgroup in the shipped launch (one workgroup per strip); a capped launch walks the list with
+    // workgroup in the shipped launch (one workgroup per group of WV strips); a capped launch walks the list with
     // stride gridDim.x (then a multiple of 8).
-    const int64_t nwg = n * kStrips;
+    const int64_t nwg = n * kGroups;
     const int64_t qd = nwg / 8, rm = nwg % 8;
   for (int64_t b = blockIdx.x; b < nwg; b += gridDim.x) {
     const int64_t xcd = b % 8;
     const int64_t wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + b / 8;
-    const int64_t g = wid / kStrips;
-    const int r0 = (int)(wid % kStrips) * R;
+    const int64_t g = wid / kGroups;
+    const int r0 = ((int)(wid % kGroups) * WV + wv) * R;
     const typename C::T *gin = u_in + g * (int64_t)H * W;
     const int rt = (r0 + H - 1) % H, rb = (r0 + R) % H;      // halo rows (torus in y)
+
+    // Action window, 64 columns wide (the reference's default, env.py:25-26), read from memory: its quads are
+    // requested BEFORE the state rows, compactly -- one load covers four window rows (16 lanes each) instead
+    // of one row on 16 of the 64 lanes -- and meet their column lanes by three lane permutes further down.
+    // (Loaded in the state's own mapping after the state had been packed, the window cost the strips that touch
+    // it a second, dependent memory round trip: 417 against 392 us per step at 256x256, N=4096.)
+    const int oy = HAS_ACT ? (H - ah) >> 1 : 0, ox = HAS_ACT ? (W - aw) >> 1 : 0;   // ox % 4 == 0 (host guarantees)
+    // does this strip (with its halo rows) touch the window rows at all?  (wave-uniform)
+    const bool touches = HAS_ACT && ((r0 + R > oy && r0 < oy + ah) || (top_global && rt >= oy && rt < oy + ah) ||
+                                     (bot_global && rb >= oy && rb < oy + ah));
+    const bool compact = touches && !RAND_ACT && aw == 64;
+    const typename A::T *ga = (HAS_ACT && !RAND_ACT) ? act + g * (int64_t)ah * aw : nullptr;
+    typename A::Quad aq[RW][4], aht[NS], ahb[NS];
+    uint32_t arow_ok = 0;                            // bit 4m+j: this lane's row of load (m, j) is a window row
+#pragma unroll
+    for (int m = 0; m < RW; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aq[m][j] = typename A::Quad{};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { aht[s] = typename A::Quad{}; ahb[s] = typename A::Quad{}; }
+    if (HAS_ACT && !RAND_ACT && compact) {
+#pragma unroll
+        for (int m = 0; m < RW; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ay = r0 + 16 * m + 4 * j + (k >> 4) - oy;
+                if (ay >= 0 && ay < ah) {
+                    aq[m][j] = A::template load<true>(ga + (int64_t)ay * 64 + 4 * (k & 15));
+                    arow_ok |= 1u << (4 * m + j);
+                }
+            }
+        const int ayt = rt - oy, ayb = rb - oy;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int ax = 256 * s + 4 * k - ox;
+            if (top_global && ax >= 0 && ax < 64 && ayt >= 0 && ayt < ah) aht[s] = A::template load<false>(ga + (int64_t)ayt * 64 + ax);
+            if (bot_global && ax >= 0 && ax < 64 && ayb >= 0 && ayb < ah) ahb[s] = A::template load<false>(ga + (int64_t)ayb * 64 + ax);
+        }
+    }
 
     uint64_t c[NS][RW];
     uint32_t halo[NS];                               // bits 0-3: row above, bits 4-7: row below
@@ -263,18 +318,36 @@ __global__ __launch_bounds__(64) void ca_step_wide_kernel(
             c[s][m] = acc;
         }
         // halo rows are re-read by the neighbouring strip: default cache policy keeps them in L2
-        const typename C::Quad vt = C::template load<false>(gin + (int64_t)rt * W + 256 * s + 4 * k);
-        const typename C::Quad vb = C::template load<false>(gin + (int64_t)rb * W + 256 * s + 4 * k);
+        typename C::Quad vt = typename C::Quad{}, vb = typename C::Quad{};
+        if (top_global) vt = C::template load<false>(gin + (int64_t)rt * W + 256 * s + 4 * k);
+        if (bot_global) vb = C::template load<false>(gin + (int64_t)rb * W + 256 * s + 4 * k);
         halo[s] = C::nibble(vt) | (C::nibble(vb) << 4);
     }
 
     if (HAS_ACT) {
-        const int oy = (H - ah) >> 1, ox = (W - aw) >> 1;   // ox % 4 == 0 (host guarantees)
-        // does this strip (with its halo rows) touch the window rows at all?  (wave-uniform)
-        const bool touches = (r0 + R > oy && r0 < oy + ah) || (rt >= oy && rt < oy + ah) ||
-                             (rb >= oy && rb < oy + ah);
-        if (touches) {
-            const typename A::T *ga = RAND_ACT ? nullptr : act + g * (int64_t)ah * aw;
+        if (compact) {
+            ActionSeen seen;
+#pragma unroll
+            for (int m = 0; m < RW; ++m) {
+                uint64_t part = 0;                   // this lane's rows 4j + k/16 of window column quad k%16
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if ((arow_ok >> (4 * m + j)) & 1u) see(seen, aq[m][j]);
+                    part |= (uint64_t)A::nibble(aq[m][j]) << (4 * (4 * j + (k >> 4)));
+                }
+                part |= shfl64(part, k ^ 16);
+                part |= shfl64(part, k ^ 32);        // all 16 rows of column quad k%16, on four lanes
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int kq = 64 * s + k - (ox >> 2);           // this lane's column quad inside the window
+                    const uint64_t t = shfl64(part, kq & 15);
+                    c[s][m] ^= (kq >= 0 && kq < 16) ? t : 0ull;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) halo[s] ^= A::nibble(aht[s]) | (A::nibble(ahb[s]) << 4);
+            publish_flags<A>(seen, status, slot);
+        } else if (touches) {
             // in-kernel random agent: the nibble of action quad (ay, ax) is a pure function of its
             // index, so halo rows draw the same toggles as the strip that owns the row
             auto drawn = [&](int ay, int ax) -> uint32_t {
@@ -314,15 +387,29 @@ __global__ __launch_bounds__(64) void ca_step_wide_kernel(
                     c[s][m] ^= tog;
                 }
                 const int ayt = rt - oy, ayb = rb - oy;
-                if (col_in && ayt >= 0 && ayt < ah)
+                if (top_global && col_in && ayt >= 0 && ayt < ah)
                     halo[s] ^= RAND_ACT ? drawn(ayt, ax) : A::nibble(A::template load<false>(ga + (int64_t)ayt * aw + ax));
-                if (col_in && ayb >= 0 && ayb < ah)
+                if (bot_global && col_in && ayb >= 0 && ayb < ah)
                     halo[s] ^= (RAND_ACT ? drawn(ayb, ax) : A::nibble(A::template load<false>(ga + (int64_t)ayb * aw + ax))) << 4;
             }
             publish_flags<A>(seen, status, slot);
         } else if (status != nullptr && k == 0) {
             // a strip outside the window sees no action element; the flags describe the whole
             // action, which the in-window strips publish.  Nothing to do.
+        }
+    }
+
+    if (WV > 1) {                                    // the inner halo rows: the neighbouring waves' edge rows, toggled
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            edge[wv][0][s][k] = (uint32_t)c[s][0] & 0xFu;
+            edge[wv][1][s][k] = (uint32_t)(c[s][RW - 1] >> 60);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!top_global) halo[s] |= edge[wv - 1][1][s][k];
+            if (!bot_global) halo[s] |= edge[wv + 1][0][s][k] << 4;
         }
     }
 
@@ -380,10 +467,11 @@ __global__ __launch_bounds__(64) void ca_step_wide_kernel(
                                         (uint32_t)(nx >> (4 * i)) & 0xFu);
         }
     }
+    if (WV > 1 && b + gridDim.x < nwg) __syncthreads();      // capped launch only: `edge` is rewritten
   }
 }
 
-// Launch size of the wavefront-per-strip kernels: one workgroup per strip.  (The kernels can walk the
+// Launch size of the wavefront-per-strip kernels: one workgroup per group of kWideWaves strips.  (The kernels can walk the
 // strip list persistently, and the bit-packed kernel gains 9 % that way, but here -- 62-90 VGPRs,
 // 5-8 waves per SIMD, strips of unequal cost under the action window -- the one-shot launch measured
 // 6-20 % faster: profiles/r02_kbench_wide.txt.  CARLE_WIDE_BLOCKS caps the launch for experiments.)
@@ -397,13 +485,13 @@ template <class C, class A, int NS, int RW>
 static int launch_wide(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
                        int64_t n, int ah, int aw, uint32_t rule, int32_t *status, int slot,
                        hipStream_t s) {
-    const int64_t wgs = n * (WideGeom<NS, RW>::kW / WideGeom<NS, RW>::kR);
+    const int64_t wgs = n * (WideGeom<NS, RW>::kW / WideGeom<NS, RW>::kR / kWideWaves);
     if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step: batch too large");
     if (action)
-        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW>), dim3(persistent_blocks(wgs)), dim3(64), 0,
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW>), dim3(persistent_blocks(wgs)), dim3(64 * kWideWaves), 0,
                            s, u_in, action, u_out, n, ah, aw, rule, status, slot);
     else
-        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, false, NS, RW>), dim3(persistent_blocks(wgs)), dim3(64), 0,
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, false, NS, RW>), dim3(persistent_blocks(wgs)), dim3(64 * kWideWaves), 0,
                            s, u_in, action, u_out, n, 0, 0, rule, status, slot);
     return check_launch("carle_ca_step(wide)");
 }
@@ -647,13 +735,13 @@ static int ca_step_cells_rand(const typename C::T *u_in, typename C::T *u_out, i
     ra.p = p; ra.seed = seed; ra.offset = offset; ra.action_out = action_out;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (wide) {
-        const int64_t wgs = n * (h / (16 * kWideRW));
+        const int64_t wgs = n * (h / (16 * kWideRW * kWideWaves));
         if (wgs > 0x7FFFFFFFll) return fail(CARLE_E_DIMS, "batch too large");
         if (h == 256)
-            hipLaunchKernelGGL((ca_step_wide_kernel<C, F32Cells, true, 1, kWideRW, true>), dim3(persistent_blocks(wgs)), dim3(64), 0, s,
+            hipLaunchKernelGGL((ca_step_wide_kernel<C, F32Cells, true, 1, kWideRW, true>), dim3(persistent_blocks(wgs)), dim3(64 * kWideWaves), 0, s,
                                u_in, (const float *)nullptr, u_out, n, ah, aw, rule, status, slot, ra);
         else
-            hipLaunchKernelGGL((ca_step_wide_kernel<C, F32Cells, true, 2, kWideRW, true>), dim3(persistent_blocks(wgs)), dim3(64), 0, s,
+            hipLaunchKernelGGL((ca_step_wide_kernel<C, F32Cells, true, 2, kWideRW, true>), dim3(persistent_blocks(wgs)), dim3(64 * kWideWaves), 0, s,
                                u_in, (const float *)nullptr, u_out, n, ah, aw, rule, status, slot, ra);
         return check_launch(who);
     }

@@ -31,7 +31,7 @@ for fmt, n, size in (("f32", 4096, 256), ("f32", 1024, 512), ("u8", 4096, 256), 
                                n * (size * size * 2 + 4096) * es)):
             for i in range(4):
                 fn(i)
-            reps = 30
+            reps = 100
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
