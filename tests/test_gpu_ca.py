@@ -315,6 +315,49 @@ def test_index_width_beyond_2_31_cells():
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("n,size", [(4099, 256), (1027, 512)])
+def test_wide_full_size_properties(n, size):
+    """BASELINE configs[2] shape (256x256) and 512x512 at full batch, ragged N, dense 64x64 action with arbitrary
+    non-zero values: sampled instances against the C oracle, batch-permutation equivariance, toggle-twice identity,
+    and the action predicates.  (Four strips per workgroup share edge rows through LDS; the window is read in a
+    compact mapping: ca_step_cells.hip.)"""
+    from carle_amd import hip
+    g = torch.Generator(device="cuda").manual_seed(n + size)
+    u = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.45).float()
+    a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.5).float()
+    a[3] = 1.0                                     # one instance with an all-ones window (no reset: others differ)
+    a[5] = 0.0
+    a[7, 0, 0, :] = -2.5                           # first / last window rows: the strips' halo rows see them
+    a[7, 0, 63, :] = float("nan")
+    rule = O.rule_mask([3, 6], [2, 3])
+    out = torch.empty_like(u)
+    st = hip.new_status("cuda:0")
+    hip.ca_step_f32(u, a, out, rule, st, 0)
+    idx = [0, 1, 2, 3, 5, 7, n // 2, n - 2, n - 1]
+    exp, _, _ = O.c_env_step(u[idx].cpu().numpy(), a[idx].cpu().numpy(), rule)
+    assert np.array_equal(out[idx].cpu().numpy(), exp)
+    s_ = st.cpu().tolist()
+    assert s_[0] == 1 and s_[2] == 1
+    perm = torch.randperm(n, device="cuda", generator=g)
+    out_p = torch.empty_like(u)
+    hip.ca_step_f32(u[perm].contiguous(), a[perm].contiguous(), out_p, rule, None, 0)
+    assert torch.equal(out_p, out[perm])
+    del out_p
+    pad = (size - 64) // 2
+    ua = torch.logical_xor(u, torch.nn.functional.pad(a != 0, (pad, pad, pad, pad))).float()
+    o1 = torch.empty_like(u)
+    hip.ca_step_f32(ua, a, o1, rule, None, 0)
+    hip.ca_step_f32(u, None, out, rule, None, 0)
+    assert torch.equal(o1, out)
+    # all-ones action everywhere: the reset predicate stays clear (NOT_ALL_ONES == 0)
+    st.zero_()
+    hip.ca_step_f32(u, torch.ones_like(a), o1, rule, st, 1)
+    s_ = st.cpu().tolist()
+    assert s_[1] == 1 and s_[3] == 0
+    del u, a, ua, o1, out
+    torch.cuda.empty_cache()
+
+
 def test_zero_instances_and_tiny_batches():
     env = _env(width=64, height=64, instances=0)
     obs = env.reset()
