@@ -234,6 +234,24 @@ class CARLE(RLEMixin, nn.Module):
     def get_observation(self):
         return self.universe
 
+    # --- hooks of carle_amd.graphs.StepGraph (the state buffers of a captured step are fixed) ---
+    def _new_out(self, like):
+        """The buffer the next step writes its state to: fresh (the reference returns a new tensor every step,
+        env.py:229), unless a StepGraph capture has named one."""
+        o = self.__dict__.pop("_out_override", None)
+        if o is not None:
+            if o.shape != like.shape or o.dtype != like.dtype or o.device != like.device:
+                raise RuntimeError("StepGraph state buffer does not match the environment's state")
+            return o
+        return torch.empty_like(like)
+
+    def _raw_state(self):
+        """The tensor the step kernels read (fp32 / uint8 universe; the packed words for storage='b1')."""
+        return self._device_universe()
+
+    def _set_raw_state(self, t):
+        self.universe = t
+
     def _device_action(self, action):
         """Tensor conversion / rank padding / device move of env.py:152-159, then the centre crop
         of an oversize action (env.py:164-169).  Returns (cropped fp32 action, was_cropped,
@@ -318,7 +336,7 @@ class CARLE(RLEMixin, nn.Module):
         u_in = self._device_universe()
         rule = self.rule_mask()
         slot = self._slot
-        out = torch.empty_like(u_in)
+        out = self._new_out(u_in)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
         # the step's reward is final (this env is the outermost one a RunningRewardStats is attached
         # to): the epilogue kernel reduces it, no separate moments launch
@@ -516,6 +534,14 @@ class CARLEPacked(CARLE):
     def _obs(self):
         return self.universe if self.obs_format == "f32" else self.__dict__["_bits"]
 
+    def _raw_state(self):
+        if self.__dict__["_bits"] is None:
+            raise RuntimeError("call reset() before step()")
+        return self.__dict__["_bits"]
+
+    def _set_raw_state(self, t):
+        self.universe_bits = t
+
     def reset(self):
         hip.require_gpu()
         self._check_domain()
@@ -562,7 +588,7 @@ class CARLEPacked(CARLE):
                 if (tuple(action.shape) == (self.instances, 1, 64, 64) and self.action_width == 64
                         and not self.exact_action_predicates):
                     # the toggles are drawn inside the packed step kernel: no action tensor exists
-                    out = torch.empty_like(bits)
+                    out = self._new_out(bits)
                     reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
                     merge = self.__dict__.get("_final_reward_stats") is not None
                     hip.env_step_b1_rand(bits, out, reward, self.rule_mask(), self._status, slot, 64, 64,
@@ -582,7 +608,7 @@ class CARLEPacked(CARLE):
             else:
                 act = hip.pack_f32_b1(a32, self._status, slot)   # predicates of the fp32 values
             publish = False
-        out = torch.empty_like(bits)
+        out = self._new_out(bits)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
         merge = self.__dict__.get("_final_reward_stats") is not None
         hip.env_step_b1(bits, act, out, reward, self.rule_mask(), self._status, slot, publish, merge)
@@ -708,7 +734,7 @@ class CARLEBytes(CARLE):
                     and ((self.height == 64 and aw % 8 == 0) or
                          (self.height in (256, 512) and aw % 4 == 0 and (self.width - aw) % 8 == 0))):
                 # the toggles are drawn inside the step kernel: no action tensor exists
-                out = torch.empty_like(u_in)
+                out = self._new_out(u_in)
                 reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
                 merge = self.__dict__.get("_final_reward_stats") is not None
                 hip.env_step_u8_rand(u_in, out, reward, self.rule_mask(), self._status, slot, self.action_height, aw,
@@ -731,7 +757,7 @@ class CARLEBytes(CARLE):
                 cropped = True
             elif cropped:
                 hip.action_flags_f32(full.contiguous(), self._status, slot)
-        out = torch.empty_like(u_in)
+        out = self._new_out(u_in)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
         merge = self.__dict__.get("_final_reward_stats") is not None
         hip.env_step_u8(u_in, act, out, reward, self.rule_mask(), self._status, slot, not cropped, merge)

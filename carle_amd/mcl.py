@@ -669,6 +669,18 @@ class ParsimonyBonus(Motivator):
         return obs, reward, done, info
 
 
+def _cached_device(owner, name, dev):
+    """Device fp32 copy of a host-side weight plane attribute, re-made only when the attribute was replaced or
+    modified in place (the reference keeps these planes on the CPU and moves them every step, mcl.py:218-224)."""
+    t = getattr(owner, name)
+    key = (id(t), t._version, str(dev))
+    cache = owner.__dict__.setdefault("_dev_cache", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = cache[name] = (key, t.to(dev, torch.float32).contiguous())
+    return hit[1]
+
+
 class CornerBonus(Motivator):
     """Masked-sum reward / punishment regions (mcl.py:197-231)."""
 
@@ -687,8 +699,9 @@ class CornerBonus(Motivator):
 
     def step(self, action):
         obs, reward, done, info = self.env.step(action)
-        sums = hip.instance_sums_f32(_as_device_f32(obs, self.inner_env.my_device), self.reward_mask,
-                                     self.punish_mask)
+        dev = self.inner_env.my_device
+        sums = hip.instance_sums_f32(_as_device_f32(obs, dev), _cached_device(self, "reward_mask", dev),
+                                     _cached_device(self, "punish_mask", dev))
         reward += self.reward_scale * sums[:, 1:2]
         reward += self.reward_scale * sums[:, 2:3]
         return obs, reward, done, info
@@ -721,7 +734,8 @@ class SpeedDetector(Motivator):
         universe = self.inner_env.universe
         # sum(obs * w) over the whole grid with the action window masked out of the weights;
         # live cells are counted on the inner universe (= obs) as in the reference (mcl.py:769)
-        sums = hip.instance_sums_f32(_as_device_f32(obs, dev), self.mass_weight_h, self.mass_weight_w)
+        sums = hip.instance_sums_f32(_as_device_f32(obs, dev), _cached_device(self, "mass_weight_h", dev),
+                                     _cached_device(self, "mass_weight_w", dev))
         live_cells = sums[:, 0] if universe is obs else hip.instance_sums_f32(_as_device_f32(universe, dev))[:, 0]
         center_of_mass_h = sums[:, 1] / (live_cells + 1e-7)
         center_of_mass_w = sums[:, 2] / (live_cells + 1e-7)

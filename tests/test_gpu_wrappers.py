@@ -127,3 +127,80 @@ def test_train_and_evaluate_loops(tmp_path):
     score, trace = evaluate(SubmissionAgent, [[[3], [2, 3]], [[2], [0]]], wrappers, steps=5, verbose=False,
                             width=64, height=64)
     assert len(trace) == 10 and np.isfinite(score) and score > 0
+
+
+@pytest.mark.parametrize("storage,n,size,stack", [
+    ("f32", 3, 64, False), ("f32", 1, 64, False), ("f32", 16, 256, True), ("f32", 5, 64, True),
+    ("u8", 3, 64, False), ("b1", 2, 128, False), ("u8", 2, 256, True),
+])
+def test_step_graph_replays_eager_steps(storage, n, size, stack):
+    """carle_amd.graphs.StepGraph: a HIP graph of env.step(action) gives the eager loop's observations, rewards and
+    counters -- bare CARLE in every storage, and the RND2D + AE2D + CornerBonus stack (forward only); survives
+    reset(), an assigned universe, an eager step in between, a master reset and a rule change."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D, CornerBonus
+    from carle_amd.graphs import StepGraph
+
+    def make():
+        torch.manual_seed(5)
+        env = CARLE(instances=n, width=size, height=size, device="cuda:0", storage=storage,
+                    **({"obs": "f32"} if storage != "f32" else {}))
+        if stack:
+            env = CornerBonus(AE2D(RND2D(env, train_predictor=False), train_predictor=False))
+        env.reset()
+        return env
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    acts = [(torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.12).float() for _ in range(9)]
+    acts[4] = torch.ones_like(acts[0])                      # master reset
+    pattern = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+
+    def drive(env, stepper, copy_in):
+        out = []
+        for t, a in enumerate(acts):
+            if t == 2:
+                env.reset()
+            if t == 3:
+                (env if env.inner_env is None else env.inner_env).universe = pattern.clone()
+            if t == 6:
+                env.rules_from_string("B36/S23")
+            if t == 7:
+                o, r, d, i = env.step(a)                     # an eager step between replays
+            else:
+                if copy_in is not None:
+                    copy_in.copy_(a)
+                o, r, d, i = stepper(a)
+            base = env if env.inner_env is None else env.inner_env
+            out.append((o.float().clone(), r.clone(), base.step_number, base.steps_since_action))
+        return out
+
+    ref_env = make()
+    ref = drive(ref_env, ref_env.step, None)
+    env = make()
+    static = torch.zeros_like(acts[0])
+    graph = StepGraph(env, static)
+    got = drive(env, lambda a: graph(), static)
+    for t, ((o0, r0, s0, a0), (o1, r1, s1, a1)) in enumerate(zip(ref, got)):
+        assert torch.equal(o0, o1), t
+        assert torch.allclose(r0, r1, atol=1e-6, rtol=0), (t, (r0 - r1).abs().max())
+        assert (s0, a0) == (s1, a1), t
+
+
+def test_step_graph_refuses_what_it_cannot_replay():
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, SpeedDetector
+    from carle_amd.agents import RandomAgent
+    from carle_amd.graphs import StepGraph
+    env = CARLE(instances=2, width=64, height=64, device="cuda:0")
+    a = torch.zeros(2, 1, 64, 64, device="cuda")
+    with pytest.raises(RuntimeError):
+        StepGraph(env, a)                                   # before reset()
+    env.reset()
+    with pytest.raises(TypeError):
+        StepGraph(env, a.cpu())
+    with pytest.raises(TypeError):
+        StepGraph(env, RandomAgent(instances=2, action_width=64, action_height=64, device="cuda:0", fused=True)(env.universe))
+    with pytest.raises(NotImplementedError):
+        StepGraph(RND2D(env), a)                            # trains its predictor
+    with pytest.raises(NotImplementedError):
+        StepGraph(SpeedDetector(env), a)
