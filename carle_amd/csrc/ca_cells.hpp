@@ -79,6 +79,7 @@ struct F32Cells {
     template <bool NT>
     static __device__ __forceinline__ Quad load(const T *p) { return ld16<NT>(reinterpret_cast<const uint4 *>(p)); }
     static __device__ __forceinline__ uint32_t nibble(const Quad &v) { return nibble_of(v); }
+    static __device__ __forceinline__ Quad splat(uint32_t w) { return make_uint4(w, w, w, w); }
     template <bool NT>
     static __device__ __forceinline__ void store(T *p, uint32_t nib) {
         uint4 o4;
@@ -103,6 +104,7 @@ struct U8Cells {
         const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
         return NT ? __builtin_nontemporal_load(q) : *q;
     }
+    static __device__ __forceinline__ Quad splat(uint32_t w) { return w; }
     // byte j non-zero -> bit j: high bit of every non-zero byte, then a multiply gathers them
     static __device__ __forceinline__ uint32_t nibble(Quad x) {
         const uint32_t t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;

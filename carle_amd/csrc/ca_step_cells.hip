@@ -38,6 +38,11 @@ struct RandAct {
     float *action_out = nullptr;   // optional: also materialise the (N,1,AW,AW) action
 };
 
+#ifndef CARLE_ACT_EARLY
+#define CARLE_ACT_EARLY 0
+#endif
+static constexpr int kActEarly = CARLE_ACT_EARLY;     // action loads requested before the state is packed
+
 template <class C, class A, bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256,
           bool RAND_ACT = false>
 __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
@@ -54,8 +59,10 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = C::template load<NT_LD>(gin + i * 256);
     uint64_t c = 0;
+    if (!(HAS_ACT && !RAND_ACT)) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c |= (uint64_t)C::nibble(v[i]) << (4 * i);
+        for (int i = 0; i < 16; ++i) c |= (uint64_t)C::nibble(v[i]) << (4 * i);
+    }
 
     if (HAS_ACT) {
         // window offset o = (64-aw)/2 is a multiple of 4 (host guarantees aw % 8 == 0), so a
@@ -63,14 +70,15 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
         const int o = (64 - aw) >> 1;
         const int ax = 4 * k - o;
         const bool col_in = ax >= 0 && ax < aw;
-        const typename A::T *abase = act + g * (int64_t)aw * aw + ax;
+        const typename A::T *abase0 = act + g * (int64_t)aw * aw;      // the grid's action: always a valid address
+        const typename A::T *abase = abase0 + ax;
         ActionSeen seen;
         uint64_t tog = 0;
+        if (RAND_ACT) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ay = 4 * i + q - o;
-            if (col_in && ay >= 0 && ay < aw) {
-                if (RAND_ACT) {
+            for (int i = 0; i < 16; ++i) {
+                const int ay = 4 * i + q - o;
+                if (col_in && ay >= 0 && ay < aw) {
                     const uint64_t quad = (uint64_t)((g * aw + ay) * (int64_t)aw + ax) >> 2;
                     const uint32_t nib = bernoulli_nibble(quad, ra.seed, ra.offset, ra.p);
                     uint4 a;
@@ -82,10 +90,38 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
                     tog |= (uint64_t)nib << (4 * i);
                     if (ra.action_out)
                         *reinterpret_cast<uint4 *>(ra.action_out + (g * aw + ay) * (int64_t)aw + ax) = a;
-                } else {
-                    const typename A::Quad a = A::template load<NT_LD>(abase + (int64_t)ay * aw);
-                    see(seen, a);
-                    tog |= (uint64_t)A::nibble(a) << (4 * i);
+                }
+            }
+        } else {
+            // The 16 action loads are UNCONDITIONAL (lanes / rows outside the window read the grid's first quad and
+            // drop it): a load inside a per-row `if` is followed by its own s_waitcnt vmcnt(0) -- sixteen
+            // dependent memory round trips per wave instead of one (round 2, seen in the disassembly).
+            typename A::Quad a[16];
+#pragma unroll
+            for (int i = 0; i < kActEarly; ++i) {
+                const int ay = 4 * i + q - o;
+                const bool in = col_in && ay >= 0 && ay < aw;
+                a[i] = A::template load<NT_LD>(in ? abase + (int64_t)ay * aw : abase0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c |= (uint64_t)C::nibble(v[i]) << (4 * i);
+            // the remaining loads reuse the state's registers: their addresses are made to depend on the packed
+            // state (an opaque zero), or the compiler requests all 32 quads at once (137 VGPRs, 3 waves per SIMD)
+            uint32_t z = 0;
+            if (kActEarly < 16)
+                asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"((uint32_t)c), "v"((uint32_t)(c >> 32)));
+#pragma unroll
+            for (int i = kActEarly; i < 16; ++i) {
+                const int ay = 4 * i + q - o;
+                const bool in = col_in && ay >= 0 && ay < aw;
+                a[i] = A::template load<NT_LD>((in ? abase + (int64_t)ay * aw : abase0) + z);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ay = 4 * i + q - o;
+                if (col_in && ay >= 0 && ay < aw) {
+                    see(seen, a[i]);
+                    tog |= (uint64_t)A::nibble(a[i]) << (4 * i);
                 }
             }
         }
@@ -129,14 +165,15 @@ __global__ __launch_bounds__(1024) void ca_env_step_small64_kernel(
         const int o = (64 - aw) >> 1;
         const int ax = 4 * k - o;
         const bool col_in = ax >= 0 && ax < aw;
-        const float *abase = act + g * (int64_t)aw * aw + ax;
+        const float *abase0 = act + g * (int64_t)aw * aw;   // the grid's action: always a valid address
+        const float *abase = abase0 + ax;
         uint64_t tog = 0;
+        if (RAND_ACT) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ay = 4 * i + q - o;
-            if (col_in && ay >= 0 && ay < aw) {
-                uint4 a;
-                if (RAND_ACT) {
+            for (int i = 0; i < 16; ++i) {
+                const int ay = 4 * i + q - o;
+                if (col_in && ay >= 0 && ay < aw) {
+                    uint4 a;
                     const uint64_t quad = (uint64_t)((g * aw + ay) * (int64_t)aw + ax) >> 2;
                     const uint32_t nib = bernoulli_nibble(quad, ra.seed, ra.offset, ra.p);
                     a.x = (nib & 1u) ? kOneBits : 0u;
@@ -145,11 +182,29 @@ __global__ __launch_bounds__(1024) void ca_env_step_small64_kernel(
                     a.w = (nib & 8u) ? kOneBits : 0u;
                     if (ra.action_out)
                         *reinterpret_cast<uint4 *>(ra.action_out + (g * aw + ay) * (int64_t)aw + ax) = a;
-                } else {
-                    a = ld16<false>(reinterpret_cast<const uint4 *>(abase + (int64_t)ay * aw));
+                    seen.add(a);
+                    tog |= (uint64_t)nibble_of(a) << (4 * i);
                 }
-                seen.add(a);
-                tog |= (uint64_t)nibble_of(a) << (4 * i);
+            }
+        } else {
+            // unconditional loads behind the packed state (see ca_step_64_kernel): two memory round trips per wave
+            // instead of seventeen, within the 128 registers a 1024-thread workgroup allows
+            uint32_t z;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"((uint32_t)c), "v"((uint32_t)(c >> 32)));
+            uint4 a[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ay = 4 * i + q - o;
+                const bool in = col_in && ay >= 0 && ay < aw;
+                a[i] = ld16<false>(reinterpret_cast<const uint4 *>((in ? abase + (int64_t)ay * aw : abase0) + z));
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ay = 4 * i + q - o;
+                if (col_in && ay >= 0 && ay < aw) {
+                    seen.add(a[i]);
+                    tog |= (uint64_t)nibble_of(a[i]) << (4 * i);
+                }
             }
         }
         c ^= tog;                                          // toggle, env.py:182
@@ -302,6 +357,22 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
         }
     }
 
+    // The workgroup's outer halo rows (waves 0 and WV-1 only) are requested before the strip's own rows.  The
+    // rows the other waves do not load start as an OPAQUE zero: with a literal zero the compiler folds the nibble
+    // of the unloaded path, sinks the conversion into the `if` and waits for the load there -- a second, dependent
+    // memory round trip for the edge waves (seen in the disassembly, round 2).
+    uint32_t oz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+    typename C::Quad vt[NS], vb[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        vt[s] = C::splat(oz);
+        vb[s] = C::splat(oz);
+        // halo rows are re-read by the neighbouring workgroup: default cache policy keeps them in L2
+        if (top_global) vt[s] = C::template load<false>(gin + (int64_t)rt * W + 256 * s + 4 * k);
+        if (bot_global) vb[s] = C::template load<false>(gin + (int64_t)rb * W + 256 * s + 4 * k);
+    }
+
     uint64_t c[NS][RW];
     uint32_t halo[NS];                               // bits 0-3: row above, bits 4-7: row below
 #pragma unroll
@@ -317,12 +388,9 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
             for (int i = 0; i < 16; ++i) acc |= (uint64_t)C::nibble(v[i]) << (4 * i);
             c[s][m] = acc;
         }
-        // halo rows are re-read by the neighbouring strip: default cache policy keeps them in L2
-        typename C::Quad vt = typename C::Quad{}, vb = typename C::Quad{};
-        if (top_global) vt = C::template load<false>(gin + (int64_t)rt * W + 256 * s + 4 * k);
-        if (bot_global) vb = C::template load<false>(gin + (int64_t)rb * W + 256 * s + 4 * k);
-        halo[s] = C::nibble(vt) | (C::nibble(vb) << 4);
     }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) halo[s] = C::nibble(vt[s]) | (C::nibble(vb[s]) << 4);
 
     if (HAS_ACT) {
         if (compact) {
@@ -362,11 +430,11 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
 #pragma unroll
                 for (int m = 0; m < RW; ++m) {
                     uint64_t tog = 0;
+                    if (RAND_ACT) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int ay = r0 + 16 * m + i - oy;
-                        if (col_in && ay >= 0 && ay < ah) {
-                            if (RAND_ACT) {
+                        for (int i = 0; i < 16; ++i) {
+                            const int ay = r0 + 16 * m + i - oy;
+                            if (col_in && ay >= 0 && ay < ah) {
                                 const uint32_t nib = drawn(ay, ax);
                                 uint4 a;
                                 a.x = (nib & 1u) ? kOneBits : 0u;
@@ -377,20 +445,38 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
                                 tog |= (uint64_t)nib << (4 * i);
                                 if (ra.action_out)
                                     *reinterpret_cast<uint4 *>(ra.action_out + (g * ah + ay) * (int64_t)aw + ax) = a;
-                            } else {
-                                const typename A::Quad a = A::template load<true>(ga + (int64_t)ay * aw + ax);
-                                see(seen, a);
-                                tog |= (uint64_t)A::nibble(a) << (4 * i);
+                            }
+                        }
+                    } else {
+                        // windows of other widths: a window row per load, unconditional (lanes / rows outside the
+                        // window read the grid's first quad and drop it) -- no wait per load
+                        typename A::Quad a[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int ay = r0 + 16 * m + i - oy;
+                            a[i] = A::template load<true>((col_in && ay >= 0 && ay < ah) ? ga + (int64_t)ay * aw + ax : ga);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int ay = r0 + 16 * m + i - oy;
+                            if (col_in && ay >= 0 && ay < ah) {
+                                see(seen, a[i]);
+                                tog |= (uint64_t)A::nibble(a[i]) << (4 * i);
                             }
                         }
                     }
                     c[s][m] ^= tog;
                 }
                 const int ayt = rt - oy, ayb = rb - oy;
-                if (top_global && col_in && ayt >= 0 && ayt < ah)
-                    halo[s] ^= RAND_ACT ? drawn(ayt, ax) : A::nibble(A::template load<false>(ga + (int64_t)ayt * aw + ax));
-                if (bot_global && col_in && ayb >= 0 && ayb < ah)
-                    halo[s] ^= (RAND_ACT ? drawn(ayb, ax) : A::nibble(A::template load<false>(ga + (int64_t)ayb * aw + ax))) << 4;
+                const bool tin = top_global && col_in && ayt >= 0 && ayt < ah, bin = bot_global && col_in && ayb >= 0 && ayb < ah;
+                if (RAND_ACT) {
+                    if (tin) halo[s] ^= drawn(ayt, ax);
+                    if (bin) halo[s] ^= drawn(ayb, ax) << 4;
+                } else {
+                    const typename A::Quad at = A::template load<false>(tin ? ga + (int64_t)ayt * aw + ax : ga);
+                    const typename A::Quad ab = A::template load<false>(bin ? ga + (int64_t)ayb * aw + ax : ga);
+                    halo[s] ^= (tin ? A::nibble(at) : 0u) | ((bin ? A::nibble(ab) : 0u) << 4);
+                }
             }
             publish_flags<A>(seen, status, slot);
         } else if (status != nullptr && k == 0) {
@@ -499,7 +585,7 @@ static int launch_wide(const typename C::T *u_in, const typename A::T *action, t
 // ---------------------------------------------------------------------------------------------
 // generic path: any even square grid, one thread per cell
 // ---------------------------------------------------------------------------------------------
-template <class C, class A>
+template <class C, class A, bool HAS_ACT>
 __global__ __launch_bounds__(256) void ca_step_generic_kernel(
     const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
     typename C::T *__restrict__ u_out, int64_t n, int h, int w, int ah, int aw, uint32_t rule,
@@ -513,11 +599,15 @@ __global__ __launch_bounds__(256) void ca_step_generic_kernel(
         const int y = (int)((idx / w) % h);
         const int64_t g = idx / ((int64_t)h * w);
         const typename C::T *gu = u_in + g * (int64_t)h * w;
-        const typename A::T *ga = act ? act + g * (int64_t)ah * aw : nullptr;
+        const typename A::T *ga = HAS_ACT ? act + g * (int64_t)ah * aw : nullptr;
         auto alive = [&](int yy, int xx) -> uint32_t {
             uint32_t a = C::alive(gu[yy * w + xx]);
-            const int ay = yy - oy, ax = xx - ox;
-            if (ga && ay >= 0 && ay < ah && ax >= 0 && ax < aw) a ^= A::alive(ga[ay * aw + ax]);
+            if (HAS_ACT) {                           // unconditional load (element 0 outside the window): no wait per tap
+                const int ay = yy - oy, ax = xx - ox;
+                const bool in = ay >= 0 && ay < ah && ax >= 0 && ax < aw;
+                const typename A::T t = ga[in ? ay * aw + ax : 0];
+                a ^= in ? A::alive(t) : 0u;
+            }
             return a;
         };
         const int ym = y == 0 ? h - 1 : y - 1, yp = y == h - 1 ? 0 : y + 1;
@@ -528,9 +618,9 @@ __global__ __launch_bounds__(256) void ca_step_generic_kernel(
         const uint32_t nxt = (rule >> (c ? cnt : 9 + cnt)) & 1u;
         u_out[idx] = C::make(nxt);
         const int ay = y - oy, ax = x - ox;           // this cell owns its own action element
-        if (ga && ay >= 0 && ay < ah && ax >= 0 && ax < aw) seen.add(A::raw(ga[ay * aw + ax]));
+        if (HAS_ACT && ay >= 0 && ay < ah && ax >= 0 && ax < aw) seen.add(A::raw(ga[ay * aw + ax]));
     }
-    if (act) publish_flags<A>(seen, status, slot);
+    if (HAS_ACT) publish_flags<A>(seen, status, slot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -601,8 +691,12 @@ static int ca_step_cells(const typename C::T *u_in, const typename A::T *action,
     const int64_t cells = n * (int64_t)h * w;
     const int64_t blocks = (cells + 255) / 256;
     if (blocks > 0x7FFFFFFFll) return fail(CARLE_E_DIMS, "batch too large");
-    hipLaunchKernelGGL((ca_step_generic_kernel<C, A>), dim3((unsigned)blocks), dim3(256), 0, s, u_in,
-                       action, u_out, n, h, w, action ? ah : 0, action ? aw : 0, rule, status, slot);
+    if (action)
+        hipLaunchKernelGGL((ca_step_generic_kernel<C, A, true>), dim3((unsigned)blocks), dim3(256), 0, s, u_in,
+                           action, u_out, n, h, w, ah, aw, rule, status, slot);
+    else
+        hipLaunchKernelGGL((ca_step_generic_kernel<C, A, false>), dim3((unsigned)blocks), dim3(256), 0, s, u_in,
+                           action, u_out, n, h, w, 0, 0, rule, status, slot);
     return check_launch(who);
 }
 

@@ -21,6 +21,16 @@
 #include "common.hpp"
 
 namespace carle {
+// A padded read: zero outside the plane.  The load is UNCONDITIONAL (index 0 of the plane when outside): behind a
+// load inside a branch or a select the compiler places the consumer in the branch and waits for that one load --
+// a dependent memory round trip per tap (round 2, seen in the disassembly of the staged kernels).
+__device__ __forceinline__ float ldz(const float *__restrict__ p, int64_t i, bool ok) {
+    const float t = p[ok ? i : 0];
+    return ok ? t : 0.0f;
+}
+}  // namespace carle
+
+namespace carle {
 
 static constexpr int kRndDim = 16;
 
@@ -45,7 +55,7 @@ __global__ __launch_bounds__(256) void rnd_conv1_pool4_kernel(
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const int x = 4 * px - 1 + c;
-            patch[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? go[y * w + x] : 0.0f;
+            patch[r][c] = ldz(go, y * w + x, y >= 0 && y < h && x >= 0 && x < w);
         }
     }
 #pragma unroll
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(256) void rnd_conv2_pool2_kernel(
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 const int x = 2 * fx - 1 + cc;
-                patch[r][cc] = (y >= 0 && y < h4 && x >= 0 && x < w4) ? pl[y * w4 + x] : 0.0f;
+                patch[r][cc] = ldz(pl, y * w4 + x, y >= 0 && y < h4 && x >= 0 && x < w4);
             }
         }
 #pragma unroll
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(256) void ae_conv1_pool2_kernel(
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int x = 2 * px - 1 + c;
-            patch[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? go[y * w + x] : 0.0f;
+            patch[r][c] = ldz(go, y * w + x, y >= 0 && y < h && x >= 0 && x < w);
         }
     }
 #pragma unroll
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(256) void ae_conv2_pool2_kernel(
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 const int x = 2 * px - 1 + cc;
-                patch[r][cc] = (y >= 0 && y < h2 && x >= 0 && x < w2) ? pl[y * w2 + x] : 0.0f;
+                patch[r][cc] = ldz(pl, y * w2 + x, y >= 0 && y < h2 && x >= 0 && x < w2);
             }
         }
 #pragma unroll
@@ -351,8 +361,8 @@ __global__ __launch_bounds__(256) void ae_convt1_kernel(
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-                if (iy[a] >= 0 && iy[a] < h4 && ix[b] >= 0 && ix[b] < w4)
-                    acc = fmaf(pl[iy[a] * w4 + ix[b]], wt[c * 16 + ky[a] * 4 + kx[b]], acc);
+                acc = fmaf(ldz(pl, iy[a] * w4 + ix[b], iy[a] >= 0 && iy[a] < h4 && ix[b] >= 0 && ix[b] < w4),
+                           wt[c * 16 + ky[a] * 4 + kx[b]], acc);
     }
     a3[idx] = fmaxf(acc + ap[146], 0.0f);
 }
@@ -387,8 +397,8 @@ __global__ __launch_bounds__(256) void ae_convt2_mse_kernel(
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-                if (iy[a] >= 0 && iy[a] < h2 && ix[b] >= 0 && ix[b] < w2)
-                    acc = fmaf(pl[iy[a] * w2 + ix[b]], wt[ky[a] * 4 + kx[b]], acc);
+                acc = fmaf(ldz(pl, iy[a] * w2 + ix[b], iy[a] >= 0 && iy[a] < h2 && ix[b] >= 0 && ix[b] < w2),
+                           wt[ky[a] * 4 + kx[b]], acc);
         const float pr = 1.0f / (1.0f + expf(-(acc + bias)));
         if (recon) recon[g * (int64_t)h * w + p] = pr;
         const float df = go[p] - pr;

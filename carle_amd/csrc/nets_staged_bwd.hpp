@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void rnd_bwd_conv2_kernel(
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     const int x = 2 * fx - 1 + cc;
-                    patch[c][r][cc] = (y >= 0 && y < h4 && x >= 0 && x < w4) ? pl[y * w4 + x] : 0.0f;
+                    patch[c][r][cc] = ldz(pl, y * w4 + x, y >= 0 && y < h4 && x >= 0 && x < w4);
                 }
             }
 #pragma unroll
@@ -204,12 +204,11 @@ __global__ __launch_bounds__(256) void rnd_bwd_conv1_kernel(
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int y = py - ky + 1, x = px - kx + 1;
-                float val = 0.0f;
-                if (y >= 0 && y < h4 && x >= 0 && x < w4) {
-                    const int64_t fi = g * (int64_t)d + (y >> 1) * w8 + (x >> 1);
-                    if (dsel_s[fi] == (((y & 1) << 1) | (x & 1))) val = dsel_d[fi];
-                }
-                dm[ky][kx] = val;
+                const bool in = y >= 0 && y < h4 && x >= 0 && x < w4;
+                const int64_t fi = in ? g * (int64_t)d + (y >> 1) * w8 + (x >> 1) : 0;      // unconditional loads
+                const int sel = dsel_s[fi];
+                const float dv = dsel_d[fi];
+                dm[ky][kx] = (in && sel == (((y & 1) << 1) | (x & 1))) ? dv : 0.0f;
             }
         const float *go = obs + g * (int64_t)h * w;
         float patch[6][6];
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(256) void rnd_bwd_conv1_kernel(
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const int x = 4 * px - 1 + c;
-                patch[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? go[y * w + x] : 0.0f;
+                patch[r][c] = ldz(go, y * w + x, y >= 0 && y < h && x >= 0 && x < w);
             }
         }
 #pragma unroll
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(256) void rnd_bwd_conv1_kernel(
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int y = y0 + ky, x = x0 + kx;
-                    const float in = (y >= 0 && y < h && x >= 0 && x < w) ? go[y * w + x] : 0.0f;
+                    const float in = ldz(go, y * w + x, y >= 0 && y < h && x >= 0 && x < w);
                     v[ch * 9 + ky * 3 + kx] += g1 * in;
                 }
             v[36 + ch] += g1;
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(256) void rnd_bwd_conv1_kernel(
 }
 
 int64_t rnd2d_train_staged_scratch_floats(int64_t n, int h, int w) {
-    const int64_t d = (int64_t)(h / 8) * (w / 8), p1 = n * (int64_t)(h / 4) * (w / 4);
+    const int64_t d = (int64_t)(h / 8) * (w / 8);
     return 2 * n * kRndK + 2 * n * d + 1024 * (37 + 40) + 64;
 }
 
@@ -341,8 +340,8 @@ __global__ __launch_bounds__(256) void ae_bwd_out_kernel(
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
                 int iy, ix;
-                const bool ok = ct_tap(y, ky, h2, iy) & ct_tap(x, kx, w2, ix);
-                in[ky][kx] = ok ? pl[iy * w2 + ix] : 0.0f;
+                const bool ok = ((int)ct_tap(y, ky, h2, iy) & (int)ct_tap(x, kx, w2, ix)) != 0;   // both evaluated: out-params
+                in[ky][kx] = ldz(pl, iy * w2 + ix, ok);
                 acc = fmaf(in[ky][kx], ap[147 + ky * 4 + kx], acc);
             }
         const float r = 1.0f / (1.0f + expf(-(acc + ap[163])));
@@ -378,7 +377,7 @@ __global__ __launch_bounds__(256) void ae_bwd_a3_kernel(
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
                 const int oy = 2 * y + ky - 1, ox = 2 * x + kx - 1;      // output pixel fed through tap (ky, kx)
-                if (oy >= 0 && oy < h && ox >= 0 && ox < w) da = fmaf(dp[oy * w + ox], ap[147 + ky * 4 + kx], da);
+                da = fmaf(ldz(dp, oy * w + ox, oy >= 0 && oy < h && ox >= 0 && ox < w), ap[147 + ky * 4 + kx], da);
             }
         const float d3 = a3[idx] > 0.0f ? da : 0.0f;
         dpre3[idx] = d3;
@@ -387,10 +386,10 @@ __global__ __launch_bounds__(256) void ae_bwd_a3_kernel(
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
                 int iy, ix;
-                const bool ok = ct_tap(y, ky, h4, iy) & ct_tap(x, kx, w4, ix);
+                const bool ok = ((int)ct_tap(y, ky, h4, iy) & (int)ct_tap(x, kx, w4, ix)) != 0;   // both evaluated: out-params
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    v[c * 16 + ky * 4 + kx] += ok ? d3 * a2[((g * 2 + c) * h4 + iy) * (int64_t)w4 + ix] : 0.0f;
+                    v[c * 16 + ky * 4 + kx] += d3 * ldz(a2, ((g * 2 + c) * h4 + iy) * (int64_t)w4 + ix, ok);
             }
         v[32] += d3;
     }
@@ -423,7 +422,7 @@ __global__ __launch_bounds__(256) void ae_bwd_a2_kernel(
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     const int x = 2 * px - 1 + cc;
-                    patch[c][r][cc] = (y >= 0 && y < h2 && x >= 0 && x < w2) ? pl[y * w2 + x] : 0.0f;
+                    patch[c][r][cc] = ldz(pl, y * w2 + x, y >= 0 && y < h2 && x >= 0 && x < w2);
                 }
             }
         }
@@ -435,8 +434,8 @@ __global__ __launch_bounds__(256) void ae_bwd_a2_kernel(
 #pragma unroll
                 for (int kx = 0; kx < 4; ++kx) {
                     const int oy = 2 * py + ky - 1, ox = 2 * px + kx - 1;
-                    if (oy >= 0 && oy < h2 && ox >= 0 && ox < w2)
-                        da = fmaf(d3[oy * w2 + ox], ap[114 + oc * 16 + ky * 4 + kx], da);
+                    da = fmaf(ldz(d3, oy * w2 + ox, oy >= 0 && oy < h2 && ox >= 0 && ox < w2),
+                              ap[114 + oc * 16 + ky * 4 + kx], da);
                 }
             const int64_t ai = ((g * 2 + oc) * h4 + py) * (int64_t)w4 + px;
             const float dd = a2[ai] > 0.0f ? da : 0.0f;
@@ -496,12 +495,11 @@ __global__ __launch_bounds__(256) void ae_bwd_a1_kernel(
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int y = py - ky + 1, x = px - kx + 1;
-                    float val = 0.0f;
-                    if (y >= 0 && y < h2 && x >= 0 && x < w2) {
-                        const int64_t ai = ((g * 2 + oc) * h4 + (y >> 1)) * (int64_t)w4 + (x >> 1);
-                        if (dsel_s[ai] == (((y & 1) << 1) | (x & 1))) val = dsel_d[ai];
-                    }
-                    dm[oc][ky][kx] = val;
+                    const bool in = y >= 0 && y < h2 && x >= 0 && x < w2;
+                    const int64_t ai = in ? ((g * 2 + oc) * h4 + (y >> 1)) * (int64_t)w4 + (x >> 1) : 0;   // unconditional loads
+                    const int sel = dsel_s[ai];
+                    const float dv = dsel_d[ai];
+                    dm[oc][ky][kx] = (in && sel == (((y & 1) << 1) | (x & 1))) ? dv : 0.0f;
                 }
         const float *go = obs + g * (int64_t)h * w;
         float patch[4][4];
@@ -511,7 +509,7 @@ __global__ __launch_bounds__(256) void ae_bwd_a1_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int x = 2 * px - 1 + c;
-                patch[r][c] = (y >= 0 && y < h && x >= 0 && x < w) ? go[y * w + x] : 0.0f;
+                patch[r][c] = ldz(go, y * w + x, y >= 0 && y < h && x >= 0 && x < w);
             }
         }
 #pragma unroll

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict
             const int y = y0 + tid;
             if (tid < kTileRows && y >= 0 && y < size) {
                 const uint64_t *row = reinterpret_cast<const uint64_t *>(obs_v) + (g * size + y) * tps;
-                const uint64_t wm = tx > 0 ? row[tx - 1] : 0ull, w0 = row[tx], wp = tx + 1 < tps ? row[tx + 1] : 0ull;
+                const uint64_t wml = row[tx > 0 ? tx - 1 : tx], w0 = row[tx], wpl = row[tx + 1 < tps ? tx + 1 : tx];   // unconditional: no wait per load
+                    const uint64_t wm = tx > 0 ? wml : 0ull, wp = tx + 1 < tps ? wpl : 0ull;
                 plo = (wm >> 59) | (w0 << 5);
                 phi = (w0 >> 59) | ((wp & 0x1Full) << 5);
             }
@@ -261,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void rnd_tile_bwd_kernel(const void *__rest
                 uint64_t lo = 0ull, hi = 0ull;
                 if (y >= 0 && y < size) {
                     const uint64_t *row = reinterpret_cast<const uint64_t *>(obs_v) + (g * size + y) * tps;
-                    const uint64_t wm = tx > 0 ? row[tx - 1] : 0ull, w0 = row[tx], wp = tx + 1 < tps ? row[tx + 1] : 0ull;
+                    const uint64_t wml = row[tx > 0 ? tx - 1 : tx], w0 = row[tx], wpl = row[tx + 1 < tps ? tx + 1 : tx];   // unconditional: no wait per load
+                    const uint64_t wm = tx > 0 ? wml : 0ull, wp = tx + 1 < tps ? wpl : 0ull;
                     lo = (wm >> 59) | (w0 << 5);
                     hi = (w0 >> 59) | ((wp & 0x1Full) << 5);
                 }
@@ -272,20 +274,23 @@ __global__ __launch_bounds__(256, 2) void rnd_tile_bwd_kernel(const void *__rest
             const float *gin = reinterpret_cast<const float *>(obs_v) + g * (int64_t)size * size;
             constexpr int kPer = (kTileRows + 3) / 4;
             uint32_t va[kPer], vb[kPer];
+            // UNCONDITIONAL loads of clamped addresses, validity applied in the ballot: behind a load inside an `if`
+            // whose only use follows directly, the compiler folds the other path, sinks the compare into the branch
+            // and waits there -- one dependent memory round trip per row (19 per tile; seen in the disassembly)
             const int xa = x0 + lane, xb = x0 + 64 + lane;
+            const int xac = min(max(xa, 0), size - 1), xbc = min(x0 + 64 + min(lane, 9), size - 1);
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int yc = min(max(y0 + wv + 4 * i, 0), size - 1);
+                va[i] = __float_as_uint(gin[(int64_t)yc * size + xac]);
+                vb[i] = __float_as_uint(gin[(int64_t)yc * size + xbc]);
+            }
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
                 const int r = wv + 4 * i, y = y0 + r;
                 const bool yin = r < kTileRows && y >= 0 && y < size;
-                va[i] = 0u; vb[i] = 0u;
-                if (yin && xa >= 0 && xa < size) va[i] = __float_as_uint(gin[(int64_t)y * size + xa]);
-                if (yin && lane < 10 && xb < size) vb[i] = __float_as_uint(gin[(int64_t)y * size + xb]);
-            }
-#pragma unroll
-            for (int i = 0; i < kPer; ++i) {
-                const int r = wv + 4 * i;
-                const uint64_t lo = __ballot((va[i] & 0x7FFFFFFFu) != 0u);
-                const uint64_t hi = __ballot((vb[i] & 0x7FFFFFFFu) != 0u);
+                const uint64_t lo = __ballot(yin && xa >= 0 && xa < size && (va[i] & 0x7FFFFFFFu) != 0u);
+                const uint64_t hi = __ballot(yin && lane < 10 && xb < size && (vb[i] & 0x7FFFFFFFu) != 0u);
                 if (lane == 0 && r < kTileRows) { s.f.rows[r][0] = lo; s.f.rows[r][1] = hi; }
             }
         }
@@ -514,7 +519,8 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
             const int y = y0 + tid;
             if (tid < kAeRows && y >= 0 && y < size) {
                 const uint64_t *row = reinterpret_cast<const uint64_t *>(obs_v) + (g * size + y) * tps;
-                const uint64_t wm = tx > 0 ? row[tx - 1] : 0ull, w0 = row[tx], wp = tx + 1 < tps ? row[tx + 1] : 0ull;
+                const uint64_t wml = row[tx > 0 ? tx - 1 : tx], w0 = row[tx], wpl = row[tx + 1 < tps ? tx + 1 : tx];   // unconditional: no wait per load
+                    const uint64_t wm = tx > 0 ? wml : 0ull, wp = tx + 1 < tps ? wpl : 0ull;
                 plo = (wm >> 57) | (w0 << 7);
                 phi = (w0 >> 57) | ((wp & 0x7Full) << 7);
             }
@@ -776,7 +782,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
                 uint64_t lo = 0ull, hi = 0ull;
                 if (y >= 0 && y < size) {
                     const uint64_t *row = reinterpret_cast<const uint64_t *>(obs_v) + (g * size + y) * tps;
-                    const uint64_t wm = tx > 0 ? row[tx - 1] : 0ull, w0 = row[tx], wp = tx + 1 < tps ? row[tx + 1] : 0ull;
+                    const uint64_t wml = row[tx > 0 ? tx - 1 : tx], w0 = row[tx], wpl = row[tx + 1 < tps ? tx + 1 : tx];   // unconditional: no wait per load
+                    const uint64_t wm = tx > 0 ? wml : 0ull, wp = tx + 1 < tps ? wpl : 0ull;
                     lo = (wm >> 57) | (w0 << 7);
                     hi = (w0 >> 57) | ((wp & 0x7Full) << 7);
                 }
@@ -787,20 +794,21 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
             const float *gin = reinterpret_cast<const float *>(obs_v) + g * (int64_t)size * size;
             constexpr int kWaves = NT / 64, kPer = (kAeRows + kWaves - 1) / kWaves;
             uint32_t va[kPer], vb[kPer];
+            // unconditional loads of clamped addresses, validity applied in the ballot (see rnd_tile_bwd_kernel)
             const int xa = x0 + lane, xb = x0 + 64 + lane;
+            const int xac = min(max(xa, 0), size - 1), xbc = min(x0 + 64 + min(lane, 13), size - 1);
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int yc = min(max(y0 + wv + kWaves * i, 0), size - 1);
+                va[i] = __float_as_uint(gin[(int64_t)yc * size + xac]);
+                vb[i] = __float_as_uint(gin[(int64_t)yc * size + xbc]);
+            }
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
                 const int r = wv + kWaves * i, y = y0 + r;
                 const bool yin = r < kAeRows && y >= 0 && y < size;
-                va[i] = 0u; vb[i] = 0u;
-                if (yin && xa >= 0 && xa < size) va[i] = __float_as_uint(gin[(int64_t)y * size + xa]);
-                if (yin && lane < 14 && xb < size) vb[i] = __float_as_uint(gin[(int64_t)y * size + xb]);
-            }
-#pragma unroll
-            for (int i = 0; i < kPer; ++i) {
-                const int r = wv + kWaves * i;
-                const uint64_t lo = __ballot((va[i] & 0x7FFFFFFFu) != 0u);
-                const uint64_t hi = __ballot((vb[i] & 0x7FFFFFFFu) != 0u);
+                const uint64_t lo = __ballot(yin && xa >= 0 && xa < size && (va[i] & 0x7FFFFFFFu) != 0u);
+                const uint64_t hi = __ballot(yin && lane < 14 && xb < size && (vb[i] & 0x7FFFFFFFu) != 0u);
                 if (lane == 0 && r < kAeRows) { s.rows[r][0] = lo; s.rows[r][1] = hi; }
             }
         }

@@ -7,21 +7,58 @@
 
 namespace carle {
 
-__global__ __launch_bounds__(256) void instance_sums_kernel(const float *__restrict__ x, int64_t elems,
-                                                            const float *__restrict__ w0,
-                                                            const float *__restrict__ w1,
-                                                            const float *__restrict__ w2,
-                                                            float *__restrict__ out) {
-    __shared__ double part[4][4];
+// One workgroup per instance.  WM = which weight planes exist (bit j = w_j): the loads are unconditional in every
+// instantiation -- with `if (w0)` inside the loop every load was followed by its own s_waitcnt, four dependent
+// memory round trips per element (round 2, seen in the disassembly).  VEC: float4 accesses (elems % 4 == 0 and
+// 16-byte aligned planes), four independent quads per thread and iteration in flight.
+template <int WM, bool VEC>
+__global__ __launch_bounds__(1024) void instance_sums_kernel(const float *__restrict__ x, int64_t elems,
+                                                             const float *__restrict__ w0,
+                                                             const float *__restrict__ w1,
+                                                             const float *__restrict__ w2,
+                                                             float *__restrict__ out) {
+    __shared__ double part[4][16];
     const int64_t g = blockIdx.x;
     const float *gx = x + g * elems;
     double s = 0.0, a = 0.0, b = 0.0, c = 0.0;
-    for (int64_t i = threadIdx.x; i < elems; i += 256) {
-        const double v = (double)gx[i];
-        s += v;
-        if (w0) a = fma(v, (double)w0[i], a);
-        if (w1) b = fma(v, (double)w1[i], b);
-        if (w2) c = fma(v, (double)w2[i], c);
+    if (VEC) {
+        const int64_t quads = elems >> 2;
+        const float4 *x4 = reinterpret_cast<const float4 *>(gx);
+        const float4 *a4 = reinterpret_cast<const float4 *>(w0), *b4 = reinterpret_cast<const float4 *>(w1),
+                     *c4 = reinterpret_cast<const float4 *>(w2);
+        auto acc = [&](const float4 &v, const float4 &wa, const float4 &wb, const float4 &wc) {
+            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            if (WM & 1) a = fma((double)v.x, (double)wa.x, fma((double)v.y, (double)wa.y, fma((double)v.z, (double)wa.z, fma((double)v.w, (double)wa.w, a))));
+            if (WM & 2) b = fma((double)v.x, (double)wb.x, fma((double)v.y, (double)wb.y, fma((double)v.z, (double)wb.z, fma((double)v.w, (double)wb.w, b))));
+            if (WM & 4) c = fma((double)v.x, (double)wc.x, fma((double)v.y, (double)wc.y, fma((double)v.z, (double)wc.z, fma((double)v.w, (double)wc.w, c))));
+        };
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int nt = blockDim.x;                         // 256 (small instances) or 1024
+        for (int64_t i = threadIdx.x; i < quads; i += 4 * nt) {
+            float4 v[4], wa[4], wb[4], wc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = i + (int64_t)nt * u;
+                const int64_t jc = j < quads ? j : i;              // unconditional, clamped; dropped below
+                v[u] = x4[jc];
+                wa[u] = (WM & 1) ? a4[jc] : zero;
+                wb[u] = (WM & 2) ? b4[jc] : zero;
+                wc[u] = (WM & 4) ? c4[jc] : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + (int64_t)nt * u < quads) acc(v[u], wa[u], wb[u], wc[u]);
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < elems; i += blockDim.x) {
+            const float xv = gx[i];
+            const float fa = (WM & 1) ? w0[i] : 0.f, fb = (WM & 2) ? w1[i] : 0.f, fc = (WM & 4) ? w2[i] : 0.f;
+            const double v = (double)xv;
+            s += v;
+            if (WM & 1) a = fma(v, (double)fa, a);
+            if (WM & 2) b = fma(v, (double)fb, b);
+            if (WM & 4) c = fma(v, (double)fc, c);
+        }
     }
 #pragma unroll
     for (int k = 32; k > 0; k >>= 1) {
@@ -32,9 +69,19 @@ __global__ __launch_bounds__(256) void instance_sums_kernel(const float *__restr
     if ((threadIdx.x & 63) == 0) { part[0][wv] = s; part[1][wv] = a; part[2][wv] = b; part[3][wv] = c; }
     __syncthreads();
     if (threadIdx.x < 4) {
-        const double t = (part[threadIdx.x][0] + part[threadIdx.x][1]) + (part[threadIdx.x][2] + part[threadIdx.x][3]);
+        double t = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += part[threadIdx.x][k];
         out[g * 4 + threadIdx.x] = (float)t;
     }
+}
+
+template <int WM>
+static void launch_instance_sums(bool vec, unsigned n, hipStream_t st, const float *x, int64_t elems, const float *w0,
+                                 const float *w1, const float *w2, float *out) {
+    // small instances (64x64: one unrolled iteration of 256 threads): the 16-wave reduction would dominate
+    const unsigned nt = elems <= 16384 ? 256u : 1024u;
+    if (vec) hipLaunchKernelGGL((instance_sums_kernel<WM, true>), dim3(n), dim3(nt), 0, st, x, elems, w0, w1, w2, out);
+    else hipLaunchKernelGGL((instance_sums_kernel<WM, false>), dim3(n), dim3(nt), 0, st, x, elems, w0, w1, w2, out);
 }
 
 }  // namespace carle
@@ -47,7 +94,20 @@ extern "C" int carle_instance_sums_f32(const float *x, int64_t n, int64_t elems,
     if (n < 0 || elems < 0) return fail_arg(CARLE_E_DIMS, "carle_instance_sums_f32: negative size");
     if (n == 0) return 0;
     if (n > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_instance_sums_f32: batch too large");
-    hipLaunchKernelGGL(instance_sums_kernel, dim3((unsigned)n), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, elems, w0, w1, w2, out4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool vec = elems % 4 == 0 && al16(x) && (!w0 || al16(w0)) && (!w1 || al16(w1)) && (!w2 || al16(w2));
+    const int wm = (w0 ? 1 : 0) | (w1 ? 2 : 0) | (w2 ? 4 : 0);
+    const unsigned nb = (unsigned)n;
+    switch (wm) {
+        case 0: launch_instance_sums<0>(vec, nb, st, x, elems, w0, w1, w2, out4); break;
+        case 1: launch_instance_sums<1>(vec, nb, st, x, elems, w0, w1, w2, out4); break;
+        case 2: launch_instance_sums<2>(vec, nb, st, x, elems, w0, w1, w2, out4); break;
+        case 3: launch_instance_sums<3>(vec, nb, st, x, elems, w0, w1, w2, out4); break;
+        case 4: launch_instance_sums<4>(vec, nb, st, x, elems, w0, w1, w2, out4); break;
+        case 5: launch_instance_sums<5>(vec, nb, st, x, elems, w0, w1, w2, out4); break;
+        case 6: launch_instance_sums<6>(vec, nb, st, x, elems, w0, w1, w2, out4); break;
+        default: launch_instance_sums<7>(vec, nb, st, x, elems, w0, w1, w2, out4); break;
+    }
     return check_launch("carle_instance_sums_f32");
 }
