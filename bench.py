@@ -468,8 +468,10 @@ def run_rank(args):
     gc.freeze()
     barrier()
     t0 = time.perf_counter()
+    marks = [t0]
     for i in range(args.steps):
         one_step(i)
+        marks.append(time.perf_counter())
     join_rewards()
     stats.flush()
     torch.cuda.synchronize(dev)
@@ -484,6 +486,16 @@ def run_rank(args):
 
     # ---- roofline of the config's dominant kernel: back-to-back launches of that kernel alone
     warnings = []
+    # host-side stalls inside the timed region (enqueue time of a single step far above the median: a garbage
+    # collection, an allocator call, a page fault storm): reported, never hidden
+    host = sorted(b_ - a_ for a_, b_ in zip(marks, marks[1:]))
+    if host:
+        med = host[len(host) // 2]
+        slow = [(i, round((marks[i + 1] - marks[i]) * 1e3, 2)) for i in range(len(marks) - 1)
+                if marks[i + 1] - marks[i] > max(20 * med, 5e-3)]
+        if slow:
+            warnings.append(f"host stalls inside the timed region (step, ms): {slow[:8]}; median host time per step "
+                            f"{med * 1e6:.1f} us")
     cands = dominant_kernels(args, env, wenv, ring, hip, n, size, asize)
     timed = []
     for name, launch, alg, flop in cands:
@@ -560,6 +572,10 @@ def run_rank(args):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
+    # torch sizes its OpenMP pool by the visible cores (256 on a GPU box whose container may use 16): any CPU tensor
+    # op above the parallel grain then wakes 256 spinning workers, the cgroup quota runs out and the process is
+    # frozen for the rest of the 100 ms period (92 ms stalls inside the timed region, measured at N=65536)
+    torch.set_num_threads(max(1, _host_threads() // max(1, int(os.environ.get("WORLD_SIZE", "1")))))   # ranks share the node's quota
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         sys.exit(2)

@@ -17,6 +17,7 @@ What is different underneath:
 """
 import time
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -47,6 +48,15 @@ def _resolve_device(kwargs):
 # attributes rewritten every step: bypass nn.Module.__setattr__ (parameter/buffer/module
 # bookkeeping, ~3 us each) -- they are plain Python / tensor attributes
 _PLAIN_ATTRS = frozenset(("universe", "action", "_slot", "log", "_moments_merged"))
+
+
+def _done_zeros(n):
+    """The fresh CPU ``done`` tensor of a step, zeros (N,1) fp32 (env.py:237).  Built from a calloc'ed numpy array:
+    ``torch.zeros`` above 32768 elements is a parallel fill that wakes torch's whole OpenMP pool (one thread per
+    visible core -- 256 on a 16-CPU GPU box); the spinning workers exhaust the container's CPU quota and the kernel
+    freezes the process for the rest of the 100 ms period (measured: 92 ms stalls every few dozen steps at N=65536,
+    ``nr_throttled`` in /sys/fs/cgroup/cpu.stat; none with this form)."""
+    return torch.from_numpy(np.zeros((n, 1), dtype=np.float32))
 
 
 class CARLE(RLEMixin, nn.Module):
@@ -354,7 +364,7 @@ class CARLE(RLEMixin, nn.Module):
                 self._moments_merged = merge
                 self._slot = slot ^ 1
                 self.universe = out
-                return self.universe, reward, torch.zeros(self.instances, 1), [{}] * self.instances
+                return self.universe, reward, _done_zeros(self.instances), [{}] * self.instances
             action = action.materialize()
         act, cropped, full = self._device_action(action)
         publish = not cropped
@@ -372,7 +382,7 @@ class CARLE(RLEMixin, nn.Module):
             launch(u_in, act, out, reward, rule, self._status, slot, publish)
         self._slot = slot ^ 1
         self.universe = out
-        done = torch.zeros(self.instances, 1)
+        done = _done_zeros(self.instances)
         info = [{}] * self.instances
         return self.universe, reward, done, info
 
@@ -439,7 +449,7 @@ class CARLE(RLEMixin, nn.Module):
             if agent is not None and actions is None:
                 agent.calls += k
         self.action = None
-        return self.universe, reward, torch.zeros(self.instances, 1), [{}] * self.instances
+        return self.universe, reward, _done_zeros(self.instances), [{}] * self.instances
 
     def multistep(self, steps):
         """``steps`` generations with no action in ONE kernel launch: the state, counters and return
@@ -464,7 +474,7 @@ class CARLE(RLEMixin, nn.Module):
         self.action = None
         self._moments_merged = False
         reward = torch.zeros(self.instances, 1, dtype=torch.float32, device=self.my_device)
-        return self.get_observation(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
+        return self.get_observation(), reward, _done_zeros(self.instances), [{}] * self.instances
 
     # ------------------------------------------------------------------ cold helpers
     def render(self):
@@ -596,7 +606,7 @@ class CARLEPacked(CARLE):
                     self._moments_merged = merge
                     self._slot = slot ^ 1
                     d["_bits"], d["_f32"] = out, None
-                    return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
+                    return self._obs(), reward, _done_zeros(self.instances), [{}] * self.instances
                 action = action.materialize()
             a32, cropped, full = self._device_action(action)
             if self.exact_action_predicates:
@@ -616,7 +626,7 @@ class CARLEPacked(CARLE):
         self._slot = slot ^ 1
         d["_bits"] = out
         d["_f32"] = None
-        done = torch.zeros(self.instances, 1)
+        done = _done_zeros(self.instances)
         info = [{}] * self.instances
         return self._obs(), reward, done, info
 
@@ -636,7 +646,7 @@ class CARLEPacked(CARLE):
         self.action = None
         self._moments_merged = False
         reward = torch.zeros(self.instances, 1, dtype=torch.float32, device=self.my_device)
-        return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
+        return self._obs(), reward, _done_zeros(self.instances), [{}] * self.instances
 
 
 class CARLEBytes(CARLE):
@@ -717,7 +727,7 @@ class CARLEBytes(CARLE):
         self.action = None
         self._moments_merged = False
         reward = torch.zeros(self.instances, 1, dtype=torch.float32, device=self.my_device)
-        return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
+        return self._obs(), reward, _done_zeros(self.instances), [{}] * self.instances
 
     def step(self, action):
         hip.require_gpu()
@@ -742,7 +752,7 @@ class CARLEBytes(CARLE):
                 self._moments_merged = merge
                 self._slot = slot ^ 1
                 self.universe = out
-                return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
+                return self._obs(), reward, _done_zeros(self.instances), [{}] * self.instances
             action = action.materialize()
         if (isinstance(action, torch.Tensor) and action.dtype == torch.uint8 and action.is_cuda
                 and tuple(action.shape) == (self.instances, 1, self.action_width, self.action_height)):
@@ -764,7 +774,7 @@ class CARLEBytes(CARLE):
         self._moments_merged = merge
         self._slot = slot ^ 1
         self.universe = out
-        return self._obs(), reward, torch.zeros(self.instances, 1), [{}] * self.instances
+        return self._obs(), reward, _done_zeros(self.instances), [{}] * self.instances
 
 
 def _check_moore(module, incompatible_keys):
