@@ -46,4 +46,13 @@ inline int check_dims(int64_t n, int h, int w, bool has_action, int ah, int aw) 
     return 0;
 }
 
+// Hides a uniform pointer from loop-invariant code motion: the scalar loads behind it stay in the phase
+// that uses them (from the scalar cache) instead of being hoisted out of the grid / tile loop, where 124-140
+// uniform weights overflow the SGPR file and spill into VGPR lanes (v_writelane / v_readlane per use).
+typedef const float __attribute__((address_space(4))) kfloat;   // constant address space: s_load
+__device__ __forceinline__ kfloat *opaque_uniform(const float *p) {
+    asm volatile("" : "+s"(p));
+    return (kfloat *)p;
+}
+
 }  // namespace carle

@@ -213,6 +213,8 @@ struct AeBlockShared {
     float red[4];
 };
 
+// (kfloat / opaque_uniform: common.hpp)
+
 template <bool PACKED_OBS>
 __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
     const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
@@ -228,8 +230,7 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
     }
     __syncthreads();
     const float *prm = ws + kAeLutFloats;            // uniform parameter block
-    const float *w2 = prm, *b2 = prm + 72, *wt1 = prm + 74, *wt2 = prm + 107;
-    const float bt1 = prm[106], bt2 = prm[123];
+    // (the 124 uniform weights are scalar-loaded inside the phase that uses them: opaque_uniform)
 
     const int q = lane >> 4, k = lane & 15;          // load mapping: rows 16w+4i+q, columns 4k..4k+3
     const int py = tid >> 4, px = tid & 15;          // compute mapping
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
 
         // ---- conv2 (4->2, 3x3, zero pad) + relu + 2x2 pool -> A2 (py, px)
         {
+            kfloat *w2 = opaque_uniform(prm), *b2 = w2 + 72;
             float acc2[2][2][2];
 #pragma unroll
             for (int oc = 0; oc < 2; ++oc) { acc2[oc][0][0] = 0.f; acc2[oc][0][1] = 0.f; acc2[oc][1][0] = 0.f; acc2[oc][1][1] = 0.f; }
@@ -332,6 +334,8 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
 
         // ---- convT1 (2->1, k4 s2 p1) + relu -> A3 (2py+j, 2px+i), overlaying A1 plane 0
         {
+            kfloat *wt1 = opaque_uniform(prm) + 74;
+            const float bt1 = wt1[32];
             float r2[2][3][3];                        // A2 rows py-1..py+1, cols px-1..px+1 (padded)
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
@@ -366,6 +370,8 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
         // ---- convT2 (1->1) + sigmoid + squared error on the thread's own 4x4 cells
         float sq = 0.0f;
         {
+            kfloat *wt2 = opaque_uniform(prm) + 107;
+            const float bt2 = wt2[16];
             float t3[4][4];                           // A3 rows 2py-1..2py+2, cols 2px-1..2px+2 (padded)
             const float *pl = s.a1 + (2 * py) * kA1Stride + 2 * px;
 #pragma unroll
@@ -859,14 +865,6 @@ __device__ __forceinline__ float quad_class_sum(float v) {
 }
 
 
-// Hides a uniform pointer from loop-invariant code motion: the scalar loads behind it stay in the phase
-// that uses them (from the scalar cache) instead of being hoisted out of the grid loop, where 140
-// weights would overflow the SGPR file and spill into VGPR lanes.
-typedef const float __attribute__((address_space(4))) kfloat;   // constant address space: s_load
-__device__ __forceinline__ kfloat *opaque_uniform(const float *p) {
-    asm volatile("" : "+s"(p));
-    return (kfloat *)p;
-}
 
 template <bool PACKED_OBS>
 __global__ __launch_bounds__(256, 3) void ae_train_block64_kernel(

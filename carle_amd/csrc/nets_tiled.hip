@@ -499,8 +499,11 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
         for (int i = tid; i < 2 * kT2Plane; i += 256) s.a2[i] = 0.0f;       // the ring stays zero
     }
     const float *prm = ws + kAeLutFloatsT;             // conv2.w[72] b[2] | convT1.w[32] b[1] | convT2.w[16] b[1]
-    const float *w2 = prm, *b2 = prm + 72, *wt1 = prm + 74, *wt2 = prm + 107;
+    // the 122 uniform weights are re-derived from an opaque pointer behind every barrier of the tile loop (AE_W_HERE):
+    // their scalar loads stay inside the phase that uses them (common.hpp: opaque_uniform)
+    kfloat *w2 = opaque_uniform(prm), *b2 = w2 + 72, *wt1 = w2 + 74, *wt2 = w2 + 107;
     const float bt1 = prm[106], bt2 = prm[123];
+#define AE_W_HERE() do { w2 = opaque_uniform(prm); b2 = w2 + 72; wt1 = w2 + 74; wt2 = w2 + 107; } while (0)
     const int tps = size >> 6, tiles = tps * tps;
     const int h2 = size >> 1, h4 = size >> 2;
     const int64_t total = n * tiles;
@@ -556,6 +559,7 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
         }
         if (t + gridDim.x < total) issue(t + gridDim.x);          // the next tile travels during this one's layers
         __syncthreads();
+        AE_W_HERE();
 
         // ---- conv1 (table) + relu + 2x2 pool -> A1, positions (32ty-3+pl, 32tx-3+ql), pl, ql in [0, 38)
         for (int i = tid; i < kT1 * kT1; i += 256) {
@@ -586,6 +590,7 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
             s.a1[3 * kT1Plane + off] = m3;
         }
         __syncthreads();
+        AE_W_HERE();
 
         // ---- conv2 (4->2) + relu + 2x2 pool -> A2, positions (16ty-1+il, 16tx-1+jl), il, jl in [0, 18); the
         //      output channel is wave-uniform (scalar weights): passes (oc 0, first 256), (oc 1, first 256), and
@@ -628,6 +633,7 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
             if (rem < 18 * 18 - 256) conv2_item(256 + rem, ocw);
         }
         __syncthreads();                               // A1 reads done: A3 may overlay plane 0
+        AE_W_HERE();
 
         // ---- convT1 (2->1, k4 s2 p1) + relu -> A3 rows 32ty-1 .. 32ty+32: thread = the 2x2 outputs (2B, 2B+1) of
         //      A2 index B = 16ty-1+bl (as the 64x64 kernel: compile-time taps); outputs outside the range are dropped
@@ -663,6 +669,7 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
                 }
         }
         __syncthreads();
+        AE_W_HERE();
 
         // ---- convT2 + sigmoid + squared error on the thread's own 4x4 cells (as the 64x64 kernel)
         float sq = 0.0f;
@@ -705,6 +712,7 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
         for (int sft = 32; sft > 0; sft >>= 1) sq += __shfl_xor(sq, sft, 64);
         if (lane == 0) s.red[wv] = sq;
         __syncthreads();                               // also: rows / A3 reads done before the next tile
+        AE_W_HERE();
         if (tid == 0) partial[t] = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
     }
 }
@@ -750,8 +758,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
         for (int i = tid; i < 2 * 40 * 40; i += NT) (&s.dmap[0][0][0])[i] = 0.0f;
     }
     const float *prm = ws + kAeLutFloatsT;
-    const float *w2 = prm, *b2 = prm + 72, *wt1 = prm + 74, *wt2 = prm + 107;
+    // the 122 uniform weights are re-derived from an opaque pointer behind every barrier of the tile loop (AE_W_HERE):
+    // their scalar loads stay inside the phase that uses them (common.hpp: opaque_uniform)
+    kfloat *w2 = opaque_uniform(prm), *b2 = w2 + 72, *wt1 = w2 + 74, *wt2 = w2 + 107;
     const float bt1 = prm[106], bt2 = prm[123];
+#define AE_W_HERE() do { w2 = opaque_uniform(prm); b2 = w2 + 72; wt1 = w2 + 74; wt2 = w2 + 107; } while (0)
     const int tps = size >> 6, tiles = tps * tps;
     const int h2 = size >> 1, h4 = size >> 2;
     const int64_t total = n * tiles;
@@ -813,6 +824,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
             }
         }
         __syncthreads();
+        AE_W_HERE();
 
         // ---- P1: conv1 (table) + relu + 2x2 pool -> A1 with arg-max index and 4x4 cell neighbourhood
         for (int i = tid; i < kT1 * kT1; i += NT) {
@@ -848,6 +860,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
             s.am[i] = (uint8_t)(i0 | (i1 << 2) | (i2 << 4) | (i3 << 6));
         }
         __syncthreads();
+        AE_W_HERE();
 
         // ---- P2: conv2 (4->2) + relu + 2x2 pool -> A2 (zero ring) with the arg-max of the window
         auto conv2_item = [&](int pos, int oc) {
@@ -897,6 +910,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
             if (rem < 18 * 18 - 256) conv2_item(256 + rem, ocw);
         }
         __syncthreads();
+        AE_W_HERE();
 
         // ---- P3: convT1 + relu -> A3 (rows 32ty-1 .. 32ty+32), blocks of 2x2 outputs per A2 index
         for (int i = tid; i < 18 * 18; i += NT) {
@@ -931,6 +945,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
                 }
         }
         __syncthreads();
+        AE_W_HERE();
 
         // ---- P4: convT2 + sigmoid + loss on the thread's own 4x4 cells; d loss / d pre-sigmoid; convT2 gradients
         float sq = 0.0f;
@@ -986,6 +1001,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
         for (int sft = 32; sft > 0; sft >>= 1) sq += __shfl_xor(sq, sft, 64);
         if (lane == 0) s.red_sq[wv] = sq;
         __syncthreads();
+        AE_W_HERE();
         if (tid == 0)
             partial[t] = ((s.red_sq[0] + s.red_sq[1]) + (s.red_sq[2] + s.red_sq[3])) +
                          (NT == 512 ? ((s.red_sq[4] + s.red_sq[5]) + (s.red_sq[6] + s.red_sq[7])) : 0.0f);
@@ -1005,6 +1021,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
             *a = *a > 0.0f ? da : 0.0f;
         }
         __syncthreads();
+        AE_W_HERE();
 
         // ---- P6: convT1 weight gradients (2x2 blocks, compile-time taps) and d loss / d A2 (gather), relu gate
         for (int i = tid; i < 18 * 18; i += NT) {
@@ -1053,6 +1070,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
                 s.g2[cc * 324 + i] = s.a2[cc * kT2Plane + (bl + 1) * kT2S + cl + 1] > 0.0f ? d2[cc] : 0.0f;
         }
         __syncthreads();
+        AE_W_HERE();
 
         // ---- P7: conv2 weight gradients and the sparse conv2-output gradient map; thread = ((oc, cc) pair, 1 of 32 slots)
         for (int pos = tid >> 3; pos < 18 * 18; pos += NT / 8) {
@@ -1071,6 +1089,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
                 for (int kx = 0; kx < 3; ++kx) gw2[ky * 3 + kx] = fmaf(dd, pl[ky * kT1S + kx], gw2[ky * 3 + kx]);
         }
         __syncthreads();
+        AE_W_HERE();
 
         // ---- P8: conv1 weight / bias gradients; thread = A1 position, gradient gathered from the map
         for (int i = tid; i < kT1 * kT1; i += NT) {
@@ -1100,6 +1119,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
             }
         }
         __syncthreads();
+        AE_W_HERE();
     }
     // ---- one partial row per workgroup, blob order: conv1.w[36] b[4] | conv2.w[72] b[2] | convT1.w[32] b[1] | convT2.w[16] b[1]
     // (one loop over all 164 entries is not unrolled by the compiler: the accumulator arrays would be indexed
@@ -1126,6 +1146,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
     for (int i = 0; i < 16; ++i) put(147 + i, gwt2[i]);
     put(163, gbt2);
     __syncthreads();
+    AE_W_HERE();
     if (tid < 164)
         rows_out[(int64_t)blockIdx.x * 164 + tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) +
                                                     (NT == 512 ? ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid])) : 0.0f);
