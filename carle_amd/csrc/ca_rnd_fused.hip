@@ -256,8 +256,14 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
                   int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
                   bool tables_valid, hipStream_t s) {
     if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
-    int64_t blocks = (n + 3) / 4;                     // persistent: 4 grids per workgroup when the
-    if (blocks > 256 * CARLE_RND_WG_PER_CU) blocks = 256 * CARLE_RND_WG_PER_CU;   // batch allows; all resident
+    // Two grids per workgroup (the second one's loads travel during the first one's network phases); batches up to
+    // 1024 grids one workgroup each.  Four per CU are resident, the others start as those retire -- out of phase, so
+    // the memory system is not idle while every workgroup computes its last grid.  Kernel alone (tools/kbench_rnd.py,
+    // profiles/r02_rnd_blocks.txt): N=4096 1024 / 2048 / 4096 workgroups 37.3-38.7 / 36.9 / 40.0 us, N=16384 1024 /
+    // 8192 / 16384: 138 / 129.5 / 139 us, N=65536 1024 / 8192 / 32768 / 65536: 585 / 552 / 510 / 535 us (0.69 -> 0.79
+    // of 8 TB/s).  (Before the table set-up stopped waiting for each of its loads, fewer, longer workgroups won.)
+    int64_t blocks = n <= 1024 ? n : (n + 1) / 2;
+    if (blocks < 1024 && n > 1024) blocks = 1024;
     if (const char *e = getenv("CARLE_RND_BLOCKS")) {  // experiment knob (tools/kbench_rnd.py)
         const int64_t v = atoll(e);
         if (v > 0) blocks = v < n ? v : n;

@@ -55,4 +55,18 @@ __device__ __forceinline__ kfloat *opaque_uniform(const float *p) {
     return (kfloat *)p;
 }
 
+// Global -> LDS copy of N4 float4 by NT threads with every load in flight before the first store (a plain copy loop
+// compiles to load, s_waitcnt vmcnt(0), ds_write per iteration: one dependent memory round trip each).  N4 is a
+// multiple of NT: no tail, hence no branch the compiler could sink a load into.
+template <int N4, int NT>
+__device__ __forceinline__ void lds_copy_f4(float4 *dst, const float4 *__restrict__ src, int tid) {
+    static_assert(N4 % NT == 0, "no tail");
+    constexpr int K = N4 / NT;
+    float4 v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = src[tid + NT * k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) dst[tid + NT * k] = v[k];
+}
+
 }  // namespace carle

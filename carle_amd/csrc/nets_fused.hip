@@ -13,6 +13,7 @@
 // Workgroups are persistent: they stride over grids, so the 21 KiB table load is amortised, and 4
 // of them per CU (33 KB of LDS each) are in different phases.  The training kernels further down
 // (forward + backward) use the same workgroup-per-grid decomposition.
+#include <stdlib.h>
 #include "rnd_device.hpp"
 
 namespace carle {
@@ -73,8 +74,6 @@ __global__ __launch_bounds__(256, 4) void rnd_block64_kernel(const void *__restr
     __shared__ RndBlockShared s;
     __shared__ float s_feat[2][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    rnd_block_init(s, ws, tid);
-    __syncthreads();
 
     const int q = lane >> 4, k = lane & 15;
     const int64_t first = blockIdx.x, stride = gridDim.x;
@@ -89,7 +88,9 @@ __global__ __launch_bounds__(256, 4) void rnd_block64_kernel(const void *__restr
             for (int i = 0; i < 4; ++i) v[i] = gin[i * 64];
         }
     };
-    if (first < n) issue(first);
+    if (first < n) issue(first);                     // the first grid travels while the tables are laid down
+    rnd_block_init(s, ws, tid);
+    __syncthreads();
     for (int64_t g = first; g < n; g += stride) {
         if (PACKED_OBS) {
             if (tid < 64) s.rows[1 + tid] = word;
@@ -146,6 +147,7 @@ int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, con
                   float reward_scale, bool tables_valid, hipStream_t s) {
     if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
     int64_t blocks = n < 1024 ? n : 1024;             // persistent: 4 workgroups are resident per CU
+    if (const char *e = getenv("CARLE_NET_BLOCKS")) { const int64_t v = atoll(e); if (v > 0) blocks = v < n ? v : n; }   // experiment knob
     if (blocks < 1) blocks = 1;
     if (obs_mode == 1)
         hipLaunchKernelGGL(rnd_block64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
@@ -221,14 +223,6 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
     float *__restrict__ recon, float *__restrict__ reward, float reward_scale, int64_t n) {
     __shared__ AeBlockShared s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(ws);
-        for (int i = tid; i < 512; i += 256) s.lut[i] = src[i];
-        for (int i = tid; i < 4 * kA1Plane; i += 256) s.a1[i] = 0.0f;
-        for (int i = tid; i < 2 * kA2Plane; i += 256) s.a2[i] = 0.0f;
-        if (tid < 66) s.rows[tid] = 0ull;
-    }
-    __syncthreads();
     const float *prm = ws + kAeLutFloats;            // uniform parameter block
     // (the 124 uniform weights are scalar-loaded inside the phase that uses them: opaque_uniform)
 
@@ -246,7 +240,15 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
             for (int i = 0; i < 4; ++i) v[i] = gin[i * 64];
         }
     };
-    if (first < n) issue(first);
+    if (first < n) issue(first);                     // the first grid travels while the table is laid down
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(ws);
+        lds_copy_f4<512, 256>(s.lut, src, tid);
+        for (int i = tid; i < 4 * kA1Plane; i += 256) s.a1[i] = 0.0f;
+        for (int i = tid; i < 2 * kA2Plane; i += 256) s.a2[i] = 0.0f;
+        if (tid < 66) s.rows[tid] = 0ull;
+    }
+    __syncthreads();
     for (int64_t g = first; g < n; g += stride) {
         // ---- the grid as 64 row words in LDS
         if (PACKED_OBS) {
@@ -428,6 +430,7 @@ int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float
                  float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s) {
     if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
     int64_t blocks = n < 1280 ? n : 1280;             // persistent: 5 workgroups are resident per CU
+    if (const char *e = getenv("CARLE_NET_BLOCKS")) { const int64_t v = atoll(e); if (v > 0) blocks = v < n ? v : n; }   // experiment knob
     if (blocks < 1) blocks = 1;
     if (packed)
         hipLaunchKernelGGL(ae_block64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(256, 3) void ae_train_block64_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const float4 *src = reinterpret_cast<const float4 *>(ws);
-        for (int i = tid; i < 512; i += 256) s.lut[i] = src[i];
+        lds_copy_f4<512, 256>(s.lut, src, tid);
         for (int i = tid; i < 4 * kA1Plane; i += 256) s.a1[i] = 0.0f;
         for (int i = tid; i < 2 * kA2Plane; i += 256) s.a2[i] = 0.0f;
         for (int i = tid; i < 2 * kA1Plane; i += 256) s.u.map2[i] = 0.0f;       // A3's border with it

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const float4 *src = reinterpret_cast<const float4 *>(ws);
-        for (int i = tid; i < 512; i += 256) s.lut[i] = src[i];
+        lds_copy_f4<512, 256>(s.lut, src, tid);
         for (int i = tid; i < 2 * kT2Plane; i += 256) s.a2[i] = 0.0f;       // the ring stays zero
     }
     const float *prm = ws + kAeLutFloatsT;             // conv2.w[72] b[2] | convT1.w[32] b[1] | convT2.w[16] b[1]
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const float4 *src = reinterpret_cast<const float4 *>(ws);
-        for (int i = tid; i < 512; i += NT) s.lut[i] = src[i];
+        lds_copy_f4<512, NT>(s.lut, src, tid);
         for (int i = tid; i < 2 * kT2Plane; i += NT) s.a2[i] = 0.0f;
         for (int i = tid; i < 2 * 40 * 40; i += NT) (&s.dmap[0][0][0])[i] = 0.0f;
     }

@@ -44,25 +44,42 @@ struct RndBlockShared {
 
 // tables -> LDS (coalesced copies), zero the plane borders and the two padding rows once; the
 // caller synchronises
+// Every global load is requested BEFORE the first LDS store: written as copy loops, each load was followed by its
+// own s_waitcnt vmcnt(0) -- eight dependent round trips at the head of every workgroup (and the first of them also
+// waited for the first grid's loads, which the fused CA + RND2D kernel requests ahead of this): round 2, seen in the
+// disassembly.
 __device__ __forceinline__ void rnd_block_init(RndBlockShared &s, const float *__restrict__ ws, int tid) {
-    const float4 *src = reinterpret_cast<const float4 *>(ws);
-    for (int i = tid; i < 512; i += 256) s.lut_p[i] = src[i];
-    const float2 *src2 = reinterpret_cast<const float2 *>(ws + 2048);
-    for (int i = tid; i < 512; i += 256) s.lut_r[i] = src2[i];
     static_assert((2 * kLinFloats) % 4 == 0 && (6 * kPlaneFloats) % 4 == 0 && kLutFloats % 4 == 0, "float4 copies");
+    constexpr int kLin4 = 2 * kLinFloats / 4, kLinIt = (kLin4 + 255) / 256;
+    const float4 *src = reinterpret_cast<const float4 *>(ws);
+    const float2 *src2 = reinterpret_cast<const float2 *>(ws + 2048);
     const float4 *lsrc = reinterpret_cast<const float4 *>(ws + kLutFloats);
+    const float4 p0 = src[tid], p1 = src[tid + 256];
+    const float2 r0 = src2[tid], r1 = src2[tid + 256];
+    // tails without a branch (the compiler would sink the load into it and wait there): a thread beyond the end
+    // repeats its previous element, load and store -- a benign duplicate
+    float4 l[kLinIt];
+    int li[kLinIt];
+#pragma unroll
+    for (int k = 0; k < kLinIt; ++k) { const int i = tid + 256 * k; li[k] = i < kLin4 ? i : i - 256; l[k] = lsrc[li[k]]; }
+    // conv2 parameters (behind the tables in the workspace: pred w[36] b at +0, rand w[18] b at +40): every thread
+    // handles entry tid % 96 of w2 and entry tid % 4 of b2
+    const int e = tid % 96, net = e / 48, c = (e % 48) / 12, t = e % 12;
+    const bool w2_in = t < 9 && (net == 0 || c < 2);
+    const float w2v = ws[kFusedWsFloats + (w2_in ? (net == 0 ? 0 : 40) + c * 9 + t : 0)];
+    const int be = tid & 3;
+    const float b2v = ws[kFusedWsFloats + (be == 1 ? 58 : 36)];
+
+    s.lut_p[tid] = p0; s.lut_p[tid + 256] = p1;
+    s.lut_r[tid] = r0; s.lut_r[tid + 256] = r1;
     float4 *ldst = reinterpret_cast<float4 *>(s.lin);
-    for (int i = tid; i < 2 * kLinFloats / 4; i += 256) ldst[i] = lsrc[i];
+#pragma unroll
+    for (int k = 0; k < kLinIt; ++k) ldst[li[k]] = l[k];
     float4 *pl = reinterpret_cast<float4 *>(&s.planes[0][0]);
     for (int i = tid; i < 6 * kPlaneFloats / 4; i += 256) pl[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 66) s.rows[tid] = 0ull;
-    // conv2 parameters (behind the tables in the workspace: pred w[36] b at +0, rand w[18] b at +40)
-    if (tid < 96) {
-        const int net = tid / 48, c = (tid % 48) / 12, t = tid % 12;
-        const float *c2 = ws + kFusedWsFloats + (net == 0 ? 0 : 40);
-        (&s.w2[0][0][0])[tid] = (t < 9 && (net == 0 || c < 2)) ? c2[c * 9 + t] : 0.0f;
-    }
-    if (tid >= 96 && tid < 100) s.b2[tid - 96] = tid == 96 ? ws[kFusedWsFloats + 36] : tid == 97 ? ws[kFusedWsFloats + 58] : 0.0f;
+    (&s.w2[0][0][0])[e] = w2_in ? w2v : 0.0f;
+    s.b2[be] = be < 2 ? b2v : 0.0f;
 }
 
 // The 16 lanes of a DPP row hold the nibbles (columns 4k..4k+3, k = lane % 16) of ONE grid row:
