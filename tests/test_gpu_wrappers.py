@@ -204,3 +204,28 @@ def test_step_graph_refuses_what_it_cannot_replay():
         StepGraph(RND2D(env), a)                            # trains its predictor
     with pytest.raises(NotImplementedError):
         StepGraph(SpeedDetector(env), a)
+
+
+@pytest.mark.parametrize("n,shape", [(3, (1, 64, 64)), (16, (1, 256, 256)), (5, (1, 7, 9)), (2, (1, 130, 130)), (1, (4099,)),
+                                     (4, (1, 6, 6))])
+def test_instance_sums_every_plane_combination(n, shape):
+    """carle_instance_sums_f32 (the reduction behind CornerBonus / SpeedDetector / ParsimonyBonus): every combination
+    of present weight planes, vector (elems % 4 == 0) and scalar paths, small and large block sizes, unaligned
+    plane views -- against fp64 torch sums."""
+    from carle_amd import hip
+    g = torch.Generator(device="cuda").manual_seed(n * 31 + len(shape))
+    x = torch.randn(n, *shape, device="cuda", generator=g)
+    elems = x[0].numel()
+    planes = [torch.randn(elems + 1, device="cuda", generator=g) for _ in range(3)]
+    for mask in range(8):
+        for shift in (0, 1):                               # shift 1: planes start 4 bytes off a 16-byte boundary
+            ws = [planes[j][shift:shift + elems] if (mask >> j) & 1 else None for j in range(3)]
+            got = hip.instance_sums_f32(x, *ws).double().cpu()
+            xd = x.double().reshape(n, -1)
+            exp = torch.zeros(n, 4, dtype=torch.float64)
+            exp[:, 0] = xd.sum(1).cpu()
+            for j in range(3):
+                if ws[j] is not None:
+                    exp[:, 1 + j] = (xd * ws[j].double()).sum(1).cpu()
+            scale = xd.abs().sum(1).cpu().clamp_min(1.0).unsqueeze(1)
+            assert torch.all((got - exp).abs() <= 2e-6 * scale * 4), (mask, shift, (got - exp).abs().max())
