@@ -147,7 +147,7 @@ __device__ __forceinline__ uint32_t next_state(const Count4<uint32_t> &n, uint32
 
 // ---- coalesced strip traffic (WW >= 2, single-step kernel) --------------------------------------------------------
 // A 64-row strip is contiguous in memory (64 * 8 * WW bytes).  The wave moves it with fully coalesced 16-byte
-// accesses -- lane L of access j touches bytes 1024 j + 16 L, one contiguous KiB per instruction, non-temporal --
+// accesses -- lane L of access j touches bytes 1024 j + 16 L, one contiguous KiB per instruction --
 // and changes between that layout and lane = row through its own LDS image of the strip, which is simply the
 // memory image: write linear / read row-wise on the way in, the reverse on the way out (row-wise accesses of 64-byte
 // rows are 2-way bank conflicts: a few dozen cycles per strip).  One wave per workgroup: no barrier, the LDS
@@ -155,24 +155,37 @@ __device__ __forceinline__ uint32_t next_state(const Count4<uint32_t> &n, uint32
 // Before: every lane read its row as WW / 2 accesses of 16 bytes at a stride of 8 * WW bytes (a quarter of every
 // 64-byte sector per instruction, cached loads and stores only -- with the streaming hint 110 us instead of 48),
 // and the dirty lines of the whole output sat in the L2 until the end-of-kernel write-back.
-// Chosen per launch: state arrays of 96 MiB and more (beyond what the caches keep between steps).  Same-box A/B
-// (profiles/r02_kbench_b1_lds.txt): 512x512 N=4096 (128 MiB) no window 47.9 -> 45.9 us, window 50.7-52.2 -> 50.1-50.4;
-// N=8192 (256 MiB, beyond the Infinity Cache) 115 -> 92.9 / 123 -> 100.5 us (0.58 -> 0.72 / 0.55 -> 0.67 of 8 TB/s); a
-// cache-resident 32 MiB batch (256x256, N=4096) is faster on the cached row-per-lane path: 11.5 against 13.3 us.
-static bool b1_use_lds(int64_t n, int ww) {
-    int64_t min_bytes = 96ll << 20;
-    if (const char *e = getenv("CARLE_B1_LDS_MIN_BYTES")) min_bytes = atoll(e);      // experiment knob
-    // 512-column grids only: 256 columns (32-byte rows, half a sector per lane) run at 0.81 on the row-per-lane path
-    // without a window (41 against 49 us at N=16384), though 9 % slower with one
-    return ww == 8 && n * (int64_t)(64 * ww) * ww * 8 >= min_bytes;
+// Three strip modes, chosen per launch (tools/b1_strip_modes.sh, profiles/r02_kbench_b1_lds.txt; kernel alone, us without /
+// with the 64x64 window; rows = row-per-lane, lds = StripLds with default cache policy, nt = StripLds streaming):
+//   512x512  N=1024 (32 MiB)  rows 17.4 / 16.7   lds 12.5 / 13.8   nt 11.2 / 16.4
+//            N=2048           rows 27.6 / 27.3   lds 21.5 / 23.2   nt 23.5 / 26.4
+//            N=4096 (128 MiB) rows 48.0 / 51.8   lds 41.5 / 47.5   nt 47.3 / 51.7     (0.70 / 0.65 -> 0.81 / 0.71 of 8 TB/s)
+//            N=6144 (192 MiB) rows 91.3 / 97.2   lds 74.6 / 78.7   nt 71.3 / 77.2
+//            N=8192 (256 MiB) rows 120 / 129     lds 101 / 107     nt 96 / 104
+//   256x256  N=4096 (32 MiB)  rows 11.5 / 12.3   lds 12.0 / 12.1   nt 13.6 / 14.5
+//            N=16384          rows 40.9 / 58.6   lds 41.7 / 53.4   nt 49.0 / 52.6
+//            N=32768          rows 108 / 117     lds 101 / 107     nt 98.4 / 105.8
+// Up to the size of the Infinity Cache the output of step t is (partly) still cached when step t+1 reads it: no
+// streaming hint below 192 MiB per array.
+static int b1_strip_mode(int64_t n, int ww) {
+    int64_t lds_bytes = ww == 8 ? 0 : 64ll << 20, nt_bytes = 192ll << 20;
+    if (const char *e = getenv("CARLE_B1_LDS_MIN_BYTES")) lds_bytes = atoll(e);      // experiment knobs
+    if (const char *e = getenv("CARLE_B1_NT_MIN_BYTES")) nt_bytes = atoll(e);
+    const int64_t bytes = n * (int64_t)(64 * ww) * ww * 8;
+    if ((ww != 8 && ww != 4) || bytes < lds_bytes) return 0;
+    return bytes >= nt_bytes ? 2 : 1;
 }
-__device__ __forceinline__ uint4 ld16nt(const uint4 *p) {      // the four dword hints merge into one dwordx4 ... nt
+template <bool NT>
+__device__ __forceinline__ uint4 ld16s(const uint4 *p) {       // NT: the four dword hints merge into one dwordx4 ... nt
+    if (!NT) return *p;
     uint4 v;
     v.x = __builtin_nontemporal_load(&p->x); v.y = __builtin_nontemporal_load(&p->y);
     v.z = __builtin_nontemporal_load(&p->z); v.w = __builtin_nontemporal_load(&p->w);
     return v;
 }
-__device__ __forceinline__ void st16nt(uint4 *p, const uint4 &v) {
+template <bool NT>
+__device__ __forceinline__ void st16s(uint4 *p, const uint4 &v) {
+    if (!NT) { *p = v; return; }
     __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
     __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
 }
@@ -182,7 +195,7 @@ struct StripLds {
     uint4 halo[2][WW / 2 > 0 ? WW / 2 : 1];   // row above, row below
 };
 
-template <int WW>
+template <int WW, bool NT>
 __device__ __forceinline__ void load_strip(StripLds<WW> &l, const uint64_t *__restrict__ gstrip,
                                            const uint64_t *__restrict__ grow_top, const uint64_t *__restrict__ grow_bot,
                                            bool multi, int lane, uint64_t (&c)[WW], uint64_t (&hal)[WW]) {
@@ -190,7 +203,7 @@ __device__ __forceinline__ void load_strip(StripLds<WW> &l, const uint64_t *__re
     const uint4 *g4 = reinterpret_cast<const uint4 *>(gstrip);
     uint4 v[Q];
 #pragma unroll
-    for (int j = 0; j < Q; ++j) v[j] = ld16nt(g4 + j * 64 + lane);
+    for (int j = 0; j < Q; ++j) v[j] = ld16s<NT>(g4 + j * 64 + lane);
     // halo: lanes 0..Q-1 the row above, Q..2Q-1 the row below (default cache policy: the neighbouring strip owns them)
     const int hq = lane < Q ? lane : lane - Q;
     const uint4 *h4 = reinterpret_cast<const uint4 *>(lane < Q ? grow_top : grow_bot) + (lane < 2 * Q ? hq : 0);
@@ -213,7 +226,7 @@ __device__ __forceinline__ void load_strip(StripLds<WW> &l, const uint64_t *__re
     }
 }
 
-template <int WW>
+template <int WW, bool NT>
 __device__ __forceinline__ void store_strip(StripLds<WW> &l, uint64_t *__restrict__ gstrip, int lane,
                                             const uint64_t (&nx)[WW]) {
     constexpr int Q = WW / 2;
@@ -226,7 +239,7 @@ __device__ __forceinline__ void store_strip(StripLds<WW> &l, uint64_t *__restric
     }
     uint4 *g4 = reinterpret_cast<uint4 *>(gstrip);
 #pragma unroll
-    for (int j = 0; j < Q; ++j) st16nt(g4 + j * 64 + lane, l.img[j * 64 + lane]);
+    for (int j = 0; j < Q; ++j) st16s<NT>(g4 + j * 64 + lane, l.img[j * 64 + lane]);
 }
 
 // the fused device-side random agent (ACT == 1, RAND): the 64 toggles of an action row are drawn in
@@ -245,7 +258,7 @@ __device__ __forceinline__ uint64_t drawn_row64(int64_t g, int ay, const RandB1 
 }
 
 // ACT: 0 = no action, 1 = 64-column window (toggle_row64), 2 = any packed window (toggle_row)
-template <int WW, int ACT, int RULE_MODE, bool RAND = false, bool LDS = false>
+template <int WW, int ACT, int RULE_MODE, bool RAND = false, int LDS = 0>      // LDS: 0 row-per-lane, 1 StripLds cached, 2 StripLds streaming
 __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     const uint64_t *__restrict__ u_in, const uint64_t *__restrict__ act, uint64_t *__restrict__ u_out,
     int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot,
@@ -255,7 +268,8 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     // the others with the leaner ACT = 0 instantiation (half the registers)
     constexpr int H = 64 * WW;
     constexpr bool MULTI = WW > 1;                          // more than one 64-row strip per grid
-    constexpr bool LDS_T = MULTI && LDS;                    // coalesced strip traffic through LDS (see StripLds)
+    constexpr bool LDS_T = MULTI && LDS != 0;               // coalesced strip traffic through LDS (see StripLds)
+    constexpr bool LDS_NT = LDS == 2;
     __shared__ StripLds<LDS_T ? WW : 2> lds;
     const int lane = threadIdx.x;
     // Persistent waves: the launch has at most 32 waves per CU and every wave walks a list of work units
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
 
     uint64_t c[WW], hal[WW];
     if constexpr (LDS_T) {
-        load_strip<WW>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
+        load_strip<WW, LDS_NT>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
     } else {
         load_row<WW>(gin + (int64_t)r * WW, c);
 #pragma unroll
@@ -442,7 +456,7 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
 #pragma unroll
     for (int j = 0; j < WW; ++j) nx[j] = ((uint64_t)nx32[2 * j + 1] << 32) | nx32[2 * j];
     B1_STAMP(2);
-    if constexpr (LDS_T) store_strip<WW>(lds, u_out + (g * (int64_t)H + r0) * WW, lane, nx);
+    if constexpr (LDS_T) store_strip<WW, LDS_NT>(lds, u_out + (g * (int64_t)H + r0) * WW, lane, nx);
     else store_row<WW>(u_out + (g * (int64_t)H + r) * WW, nx);
     B1_STAMP(3);
     };
@@ -597,7 +611,7 @@ template <int WW, int RULE_MODE>
 static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
                           int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
     const int64_t n8 = (n + 7) / 8 * 8;         // the XCD-aware mapping walks the batch in groups of 8 grids
-    const bool lds = b1_use_lds(n, WW);
+    const int lds = b1_strip_mode(n, WW);
     // persistent: just under 32 one-wave workgroups per CU (8 per SIMD).  8 x 1021: a multiple of 8 (a
     // wave stays on "its" XCD's grids) whose per-XCD stride 1021 is prime, so a wave's successive work
     // items rotate through the strips -- with a stride that is a multiple of the strip count every wave
@@ -611,7 +625,8 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     if (const char *e = getenv("CARLE_B1_UNITS")) { const int64_t v = atoll(e); if (v >= 8) ucap = v / 8 * 8; }       // experiment knob
     const unsigned full = WW > 1 ? (unsigned)(n8 * 2 < ucap ? n8 * 2 : ucap) : blocks(n8 * WW);
     if (!act) {
-        { if (lds) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, true>), dim3(blocks(n8 * WW)), dim3(64), 0,
+        { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 2>), dim3(blocks(n8 * WW)), dim3(64), 0,
+                           s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 1>), dim3(blocks(n8 * WW)), dim3(64), 0,
                            s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW); } else { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE>), dim3(blocks(n8 * WW)), dim3(64), 0,
                            s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW); } }
         return check_launch("carle_ca_step_b1");
@@ -620,7 +635,8 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
         // the usual 64x64 window: its toggle fits the full-occupancy instantiation -> one launch
         int dbg = 0;
         if (const char *e = getenv("CARLE_B1_DBG")) dbg = atoi(e);       // experiment knob: 1 = window words fetched at their use
-        { if (lds) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, true>), dim3(full), dim3(64), 0,
+        { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 2>), dim3(full), dim3(64), 0,
+                           s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 1>), dim3(full), dim3(64), 0,
                            s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg); } else { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE>), dim3(full), dim3(64), 0,
                            s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg); } }
         return check_launch("carle_ca_step_b1");
@@ -634,11 +650,14 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     if (ah == H) { first = 0; last = WW - 1; }
     int count = ((last - first + WW) % WW) + 1;
     if (count > WW) count = WW;
-    { if (lds) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 2, RULE_MODE, false, true>), dim3(blocks(n8 * count)), dim3(64), 0, s,
+    { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 2, RULE_MODE, false, 2>), dim3(blocks(n8 * count)), dim3(64), 0, s,
+                       u_in, act, u_out, n, ah, aw, rule, status, slot, first, count); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 2, RULE_MODE, false, 1>), dim3(blocks(n8 * count)), dim3(64), 0, s,
                        u_in, act, u_out, n, ah, aw, rule, status, slot, first, count); } else { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 2, RULE_MODE>), dim3(blocks(n8 * count)), dim3(64), 0, s,
                        u_in, act, u_out, n, ah, aw, rule, status, slot, first, count); } }
     if (count < WW)
-        { if (lds) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, true>), dim3(blocks(n8 * (WW - count))),
+        { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 2>), dim3(blocks(n8 * (WW - count))),
+                           dim3(64), 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot,
+                           (first + count) % WW, WW - count); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 1>), dim3(blocks(n8 * (WW - count))),
                            dim3(64), 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot,
                            (first + count) % WW, WW - count); } else { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE>), dim3(blocks(n8 * (WW - count))),
                            dim3(64), 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot,
@@ -651,20 +670,23 @@ static int launch_b1_rand(const uint64_t *u_in, uint64_t *u_out, int64_t n, uint
                           int32_t *status, int slot, hipStream_t s) {
     const int64_t n8 = (n + 7) / 8 * 8;
     if (n8 * WW > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step_b1_rand: batch too large");
-    const bool lds = b1_use_lds(n, WW);
+    const int lds = b1_strip_mode(n, WW);
     const int64_t wg = WW > 1 ? n8 * 2 : n8, cap = WW > 1 ? 8192 : 8 * 1021;     // half-grid units (see the kernel)
     const dim3 grid((unsigned)(wg < cap ? wg : cap)), block(64);
     const uint64_t *none = nullptr;
     if (rule == kLifeMask)
-        { if (lds) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleLife, true, true>), grid, block, 0, s, u_in, none, u_out, n, 64, 64,
+        { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleLife, true, 2>), grid, block, 0, s, u_in, none, u_out, n, 64, 64,
+                           rule, status, slot, 0, WW, ra); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleLife, true, 1>), grid, block, 0, s, u_in, none, u_out, n, 64, 64,
                            rule, status, slot, 0, WW, ra); } else { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleLife, true>), grid, block, 0, s, u_in, none, u_out, n, 64, 64,
                            rule, status, slot, 0, WW, ra); } }
     else if (rule == kHighLifeMask)
-        { if (lds) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleHighLife, true, true>), grid, block, 0, s, u_in, none, u_out, n, 64,
+        { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleHighLife, true, 2>), grid, block, 0, s, u_in, none, u_out, n, 64,
+                           64, rule, status, slot, 0, WW, ra); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleHighLife, true, 1>), grid, block, 0, s, u_in, none, u_out, n, 64,
                            64, rule, status, slot, 0, WW, ra); } else { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleHighLife, true>), grid, block, 0, s, u_in, none, u_out, n, 64,
                            64, rule, status, slot, 0, WW, ra); } }
     else
-        { if (lds) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleGeneric, true, true>), grid, block, 0, s, u_in, none, u_out, n, 64, 64,
+        { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleGeneric, true, 2>), grid, block, 0, s, u_in, none, u_out, n, 64, 64,
+                           rule, status, slot, 0, WW, ra); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleGeneric, true, 1>), grid, block, 0, s, u_in, none, u_out, n, 64, 64,
                            rule, status, slot, 0, WW, ra); } else { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, kRuleGeneric, true>), grid, block, 0, s, u_in, none, u_out, n, 64, 64,
                            rule, status, slot, 0, WW, ra); } }
     return check_launch("carle_ca_step_b1_rand");

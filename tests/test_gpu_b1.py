@@ -44,15 +44,21 @@ def test_pack_unpack(n, size):
     (2, 256, 256, ([2], [0])), (1, 512, 64, ([3, 6], [2, 3])), (2, 512, 256, ([3], [2, 3])),
     (1, 512, 512, (list(range(9)), [])), (2, 512, 448, ([0, 3, 5, 7], [2, 4, 6, 8])),
 ])
-@pytest.mark.parametrize("strip_path", ["by size", "lds"])
+@pytest.mark.parametrize("strip_path", ["by size", "rows", "lds", "lds+nt"])
 def test_step_b1_against_oracle(n, size, asize, rule, strip_path, monkeypatch):
-    """`lds`: forces the coalesced-through-LDS strip traffic that launches of >= 96 MiB arrays at 512 columns take
-    (ca_step_b1.hip: StripLds) onto these small cases; the full-size run below takes it by itself."""
+    """The three strip modes of the kernel (ca_step_b1.hip: row-per-lane, StripLds cached, StripLds streaming) are
+    chosen by array size; `rows` / `lds` / `lds+nt` force each of them onto these small cases."""
     from carle_amd import hip
-    if strip_path == "lds":
-        if size != 512:
-            pytest.skip("the LDS strip path exists for 512 columns")
+    if strip_path != "by size" and size not in (256, 512):
+        pytest.skip("StripLds exists for 256 and 512 columns")
+    if strip_path == "rows":
+        monkeypatch.setenv("CARLE_B1_LDS_MIN_BYTES", str(1 << 60))
+    elif strip_path == "lds":
         monkeypatch.setenv("CARLE_B1_LDS_MIN_BYTES", "0")
+        monkeypatch.setenv("CARLE_B1_NT_MIN_BYTES", str(1 << 60))
+    elif strip_path == "lds+nt":
+        monkeypatch.setenv("CARLE_B1_LDS_MIN_BYTES", "0")
+        monkeypatch.setenv("CARLE_B1_NT_MIN_BYTES", "0")
     rng = np.random.default_rng(n * 7 + size + asize)
     mask = O.rule_mask(*rule)
     u = (rng.random((n, 1, size, size)) < 0.4).astype(np.float32)
