@@ -70,7 +70,7 @@ struct Quads { uint4 v[4], a[4]; };     // one grid's loads of a lane: 4 state +
 #define CARLE_RND_WG_PER_CU 4
 #endif
 
-template <bool HAS_ACT>
+template <bool HAS_ACT, bool NT_ST = true>          // NT_ST: streaming stores (state arrays beyond the Infinity Cache)
 __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel(
     const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out, int64_t n,
     int aw, uint32_t rule, int32_t *__restrict__ status, int slot, const float *__restrict__ ws,
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
                 o4.y = __float_as_uint((float)((by >> 8) & 0xFFu));
                 o4.z = __float_as_uint((float)((by >> 16) & 0xFFu));
                 o4.w = __float_as_uint((float)((by >> 24) & 0xFFu));
-                __builtin_amdgcn_raw_buffer_store_b128(o4, ro, voff + 1024u * i, 0, 2);      // aux 2 = nt
+                __builtin_amdgcn_raw_buffer_store_b128(o4, ro, voff + 1024u * i, 0, NT_ST ? 2 : 0);      // aux 2 = nt
             }
         }
 
@@ -268,12 +268,19 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
         const int64_t v = atoll(e);
         if (v > 0) blocks = v < n ? v : n;
     }
-    if (action)
-        hipLaunchKernelGGL(ca_step_rnd64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, u_in, action,
-                           u_out, n, aw, rule, status, slot, ws, bonus);
+    // store policy by the size of one state array (ca_step_cells.hip: stream_stores): write-back up to 256 MiB
+    int64_t lim = 256ll << 20;
+    if (const char *e = getenv("CARLE_STREAM_STORE_MIN_BYTES")) lim = atoll(e) - 1;     // experiment knob
+    const bool nt_st = n * 16384 > lim;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (action && nt_st)
+        hipLaunchKernelGGL((ca_step_rnd64_kernel<true, true>), grid, block, 0, s, u_in, action, u_out, n, aw, rule, status, slot, ws, bonus);
+    else if (action)
+        hipLaunchKernelGGL((ca_step_rnd64_kernel<true, false>), grid, block, 0, s, u_in, action, u_out, n, aw, rule, status, slot, ws, bonus);
+    else if (nt_st)
+        hipLaunchKernelGGL((ca_step_rnd64_kernel<false, true>), grid, block, 0, s, u_in, action, u_out, n, 64, rule, status, slot, ws, bonus);
     else
-        hipLaunchKernelGGL(ca_step_rnd64_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, u_in, action,
-                           u_out, n, 64, rule, status, slot, ws, bonus);
+        hipLaunchKernelGGL((ca_step_rnd64_kernel<false, false>), grid, block, 0, s, u_in, action, u_out, n, 64, rule, status, slot, ws, bonus);
     return check_launch("carle_env_step_f32_rnd(fused CA + RND2D)");
 }
 

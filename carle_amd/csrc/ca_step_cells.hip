@@ -43,6 +43,21 @@ struct RandAct {
 #endif
 static constexpr int kActEarly = CARLE_ACT_EARLY;     // action loads requested before the state is packed
 
+// Store policy of the step kernels, chosen per launch by the size of one state array: up to the 256 MiB of the Infinity
+// Cache the output of step t is (partly) still cached when step t+1 reads it back -- default write-back stores;
+// beyond, streaming stores.  Loads always carry the streaming hint (every byte is read once per step).  Same-box A/B,
+// 64x64 fp32 kernel alone, with action (tools/kbench_64.py, profiles/r02_store_policy.txt), streaming -> write-back:
+// N=4096 (64 MiB) 32.5 -> 31.7 us, N=8192 67.3 -> 61.0, N=16384 (256 MiB) 133.6 -> 119.8 (0.75 -> 0.84 of 8 TB/s),
+// N=65536 (1 GiB) 537.6 -> 557.5 (worse: stays streaming); uint8 N=65536 (256 MiB) 129.6 -> 118.6.
+// uint8 state keeps streaming stores (write-back measured within +-4 % either way: wide 256x256 N=1024 26.4 -> 27.6 us,
+// 64x64 N=8192 17.9 -> 18.5, N=65536 129.6 -> 118.6); fp32 wide kernels: 256x256 N=256 28.0 -> 25.7 us, 512x512 N=256
+// (256 MiB) 93.4 -> 79.1 us; fused CA + RND2D N=16384 129.5 -> 122.2 us.
+static bool stream_stores(int64_t state_bytes, size_t cell_bytes) {
+    int64_t lim = 256ll << 20;
+    if (const char *e = getenv("CARLE_STREAM_STORE_MIN_BYTES")) lim = atoll(e) - 1;     // experiment knob
+    return cell_bytes != 4 || state_bytes > lim;
+}
+
 template <class C, class A, bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256,
           bool RAND_ACT = false>
 __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
@@ -291,7 +306,7 @@ __device__ __forceinline__ void horiz_neighbours(uint64_t c, uint64_t cw, uint64
 #endif
 static constexpr int kWideWaves = CARLE_WIDE_WAVES;
 
-template <class C, class A, bool HAS_ACT, int NS, int RW, bool RAND_ACT = false>
+template <class C, class A, bool HAS_ACT, int NS, int RW, bool RAND_ACT = false, bool NT_ST = true>
 __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
     const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
     typename C::T *__restrict__ u_out, int64_t n, int ah, int aw, uint32_t rule,
@@ -549,7 +564,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
                                            c[s][m], rule);
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                C::template store<true>(gout + (int64_t)(r0 + 16 * m + i) * W + 256 * s + 4 * k,
+                C::template store<NT_ST>(gout + (int64_t)(r0 + 16 * m + i) * W + 256 * s + 4 * k,
                                         (uint32_t)(nx >> (4 * i)) & 0xFu);
         }
     }
@@ -573,12 +588,21 @@ static int launch_wide(const typename C::T *u_in, const typename A::T *action, t
                        hipStream_t s) {
     const int64_t wgs = n * (WideGeom<NS, RW>::kW / WideGeom<NS, RW>::kR / kWideWaves);
     if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step: batch too large");
-    if (action)
-        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW>), dim3(persistent_blocks(wgs)), dim3(64 * kWideWaves), 0,
-                           s, u_in, action, u_out, n, ah, aw, rule, status, slot);
+    constexpr int64_t kGridBytes = (int64_t)WideGeom<NS, RW>::kW * WideGeom<NS, RW>::kW * (int64_t)sizeof(typename C::T);
+    const bool nt_st = stream_stores(n * kGridBytes, sizeof(typename C::T));
+    const dim3 grid(persistent_blocks(wgs)), block(64 * kWideWaves);
+    if (action && nt_st)
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW, false, true>), grid, block, 0, s, u_in, action, u_out, n,
+                           ah, aw, rule, status, slot);
+    else if (action)
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW, false, false>), grid, block, 0, s, u_in, action, u_out, n,
+                           ah, aw, rule, status, slot);
+    else if (nt_st)
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, false, NS, RW, false, true>), grid, block, 0, s, u_in, action, u_out, n,
+                           0, 0, rule, status, slot);
     else
-        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, false, NS, RW>), dim3(persistent_blocks(wgs)), dim3(64 * kWideWaves), 0,
-                           s, u_in, action, u_out, n, 0, 0, rule, status, slot);
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, false, NS, RW, false, false>), grid, block, 0, s, u_in, action, u_out, n,
+                           0, 0, rule, status, slot);
     return check_launch("carle_ca_step(wide)");
 }
 
@@ -674,11 +698,18 @@ static int ca_step_cells(const typename C::T *u_in, const typename A::T *action,
         if (n > 0x7FFFFFFFll) return fail(CARLE_E_DIMS, "batch too large");
         const unsigned blocks = (unsigned)n;
         RandAct ra;
-        if (action)
+        const bool nt_st = stream_stores((int64_t)bytes, sizeof(typename C::T));
+        if (action && nt_st)
             hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, true, 64>), dim3(blocks), dim3(64), 0,
                                s, u_in, action, u_out, n, aw, rule, status, slot, ra);
-        else
+        else if (action)
+            hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, false, 64>), dim3(blocks), dim3(64), 0,
+                               s, u_in, action, u_out, n, aw, rule, status, slot, ra);
+        else if (nt_st)
             hipLaunchKernelGGL((ca_step_64_kernel<C, A, false, true, true, 64>), dim3(blocks), dim3(64), 0,
+                               s, u_in, action, u_out, n, 0, rule, status, slot, ra);
+        else
+            hipLaunchKernelGGL((ca_step_64_kernel<C, A, false, true, false, 64>), dim3(blocks), dim3(64), 0,
                                s, u_in, action, u_out, n, 0, rule, status, slot, ra);
         return check_launch(who);
     }
@@ -839,8 +870,12 @@ static int ca_step_cells_rand(const typename C::T *u_in, typename C::T *u_out, i
                                u_in, (const float *)nullptr, u_out, n, ah, aw, rule, status, slot, ra);
         return check_launch(who);
     }
-    hipLaunchKernelGGL((ca_step_64_kernel<C, F32Cells, true, true, true, 64, true>), dim3((unsigned)n), dim3(64), 0, s,
-                       u_in, (const float *)nullptr, u_out, n, aw, rule, status, slot, ra);
+    if (stream_stores(n * (int64_t)h * w * (int64_t)sizeof(typename C::T), sizeof(typename C::T)))
+        hipLaunchKernelGGL((ca_step_64_kernel<C, F32Cells, true, true, true, 64, true>), dim3((unsigned)n), dim3(64), 0, s,
+                           u_in, (const float *)nullptr, u_out, n, aw, rule, status, slot, ra);
+    else
+        hipLaunchKernelGGL((ca_step_64_kernel<C, F32Cells, true, true, false, 64, true>), dim3((unsigned)n), dim3(64), 0, s,
+                           u_in, (const float *)nullptr, u_out, n, aw, rule, status, slot, ra);
     return check_launch(who);
 }
 }  // namespace carle
