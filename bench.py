@@ -519,6 +519,13 @@ def run_rank(args):
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us": k_ms * 1e3, "launches_timed": reps,
                 "frac_of_measured_copy_ceiling": achieved / 6.29e12}
+        state_bytes = int(env.universe_bits.numel() * 8 if packed else env.universe.numel() * env.universe.element_size())
+        if state_bytes <= 256 << 20:
+            # the library keeps the output of step t cacheable below 256 MiB per state array (write-back stores / cached
+            # packed strips): part of what step t+1 reads comes out of the 256 MiB Infinity Cache, not HBM
+            roof["cache_note"] = ("state array of %d MiB <= 256 MiB Infinity Cache: `achieved` counts algorithmic bytes, part of "
+                                  "the re-read state is served by the cache; run --instances %d for the cache-free figure"
+                                  % (state_bytes >> 20, max(n * 16, 65536) if size == 64 else n * 8))
         if flop:
             roof["flop_per_launch"] = flop
             roof["flop_frac_fp32_valu"] = flop / (k_ms * 1e-3) / FP32_PEAK
