@@ -171,6 +171,9 @@ int env_step_small64(const float *u_in, const float *action, float *u_out, float
 int env_step_small64_rand(const float *u_in, float *u_out, float *reward, int64_t n, int h, int w, int ah, int aw,
                           uint32_t rule, float p, uint64_t seed, uint64_t offset, float *action_out,
                           int32_t *status, int slot, int step_flags, void *stream);
+int env_run_small64(const float *u_in, const float *actions, float *u_out, float *reward, int64_t n, int h, int w, int ah,
+                    int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset, int k, int32_t *status, int slot0,
+                    int step_flags, void *stream);
 }
 
 // step + epilogue in one call: the per-step host cost of the drop-in surface is dominated by
@@ -254,6 +257,12 @@ extern "C" int carle_env_run_f32(float *buf_a, float *buf_b, const float *action
     if (slot0 != 0 && slot0 != 1) return fail_arg(CARLE_E_DIMS, "carle_env_run_f32: slot0 must be 0 or 1");
     if (k > 0 && (!buf_a || !buf_b)) return fail_arg(CARLE_E_NULL, "carle_env_run_f32: buf_a/buf_b is NULL");
     const int64_t act_elems = n * (int64_t)ah * aw;
+    if (k > 0 && n >= 1 && n <= 16 && h == 64 && w == 64) {
+        // small batches: all k steps in ONE launch, the grids stay in registers (ca_env_run_small64_kernel)
+        const int e = env_run_small64(buf_a, actions, (k & 1) ? buf_b : buf_a, reward, n, h, w, ah, aw, rule, p, seed, offset, k,
+                                      status, slot0, step_flags, stream);
+        if (e != -1000) return e;
+    }
     for (int t = 0; t < k; ++t) {
         float *in = (t & 1) ? buf_b : buf_a, *out = (t & 1) ? buf_a : buf_b;
         const int slot = (slot0 + t) & 1;

@@ -270,6 +270,129 @@ __global__ __launch_bounds__(1024) void ca_env_step_small64_kernel(
     }
 }
 
+// k consecutive steps of a small batch in ONE launch (carle_env_run_f32, N <= 16): the grids stay in registers between
+// the steps, every step is complete inside the workgroup -- toggle, generation, whole-batch predicates through LDS (two
+// alternating flag arrays: one barrier per step), master reset, counters, reward moments -- exactly as k launches of
+// ca_env_step_small64_kernel would leave the state, the status block and the running moments (same arithmetic, same
+// order), without a dispatch per step (3.2 us each; BASELINE configs[0] is N = 1, 256 steps).  u_out may be u_in.
+template <bool HAS_ACT, bool RAND_ACT>
+__global__ __launch_bounds__(1024) void ca_env_run_small64_kernel(
+    const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out,
+    float *__restrict__ reward, int64_t n, int aw, uint32_t rule, int32_t *__restrict__ st, int slot0,
+    int merge_moments, RandAct ra, int steps) {
+    __shared__ uint32_t s_any[2][16], s_notone[2][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t g = wv;                                  // blockDim.x = 64 * n
+    const int q = lane >> 4, k = lane & 15;
+    uint64_t c = 0;
+    {
+        const float *gin = u_in + g * 4096 + 4 * lane;
+        uint4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = ld16<false>(reinterpret_cast<const uint4 *>(gin + i * 256));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c |= (uint64_t)nibble_of(v[i]) << (4 * i);
+    }
+    const uint4 *st4 = reinterpret_cast<const uint4 *>(st);
+    const uint4 w1 = st4[1], w2 = st4[2], w3 = st4[3];
+    int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z);
+    int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x);
+    int64_t resets = (int64_t)(((uint64_t)w2.w << 32) | w2.z);
+    double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
+    double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
+    const bool moments = merge_moments && reward && mom_out && mom_acc;
+    double na = 0.0, ma = 0.0, qa = 0.0;
+    if (moments && threadIdx.x == 0) { na = mom_acc[0]; ma = mom_acc[1]; qa = mom_acc[2]; }
+    const int o = (64 - aw) >> 1, ax = 4 * k - o;
+    const bool col_in = HAS_ACT && ax >= 0 && ax < aw;
+    bool reset = false, any = false, notone = false;
+    for (int t = 0; t < steps; ++t) {
+        ActionSeen seen;
+        if (HAS_ACT) {
+            uint64_t tog = 0;
+            if (RAND_ACT) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ay = 4 * i + q - o;
+                    if (col_in && ay >= 0 && ay < aw) {
+                        const uint64_t quad = (uint64_t)((g * aw + ay) * (int64_t)aw + ax) >> 2;
+                        const uint32_t nib = bernoulli_nibble(quad, ra.seed, ra.offset + (uint64_t)t, ra.p);
+                        uint4 a;
+                        a.x = (nib & 1u) ? kOneBits : 0u;
+                        a.y = (nib & 2u) ? kOneBits : 0u;
+                        a.z = (nib & 4u) ? kOneBits : 0u;
+                        a.w = (nib & 8u) ? kOneBits : 0u;
+                        seen.add(a);
+                        tog |= (uint64_t)nib << (4 * i);
+                    }
+                }
+            } else {
+                const float *abase0 = act + ((int64_t)t * n + g) * (int64_t)aw * aw;   // step t's action of this grid
+                const float *abase = abase0 + ax;
+                uint4 a[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {                                         // unconditional loads
+                    const int ay = 4 * i + q - o;
+                    const bool in = col_in && ay >= 0 && ay < aw;
+                    a[i] = ld16<false>(reinterpret_cast<const uint4 *>(in ? abase + (int64_t)ay * aw : abase0));
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ay = 4 * i + q - o;
+                    if (col_in && ay >= 0 && ay < aw) {
+                        seen.add(a[i]);
+                        tog |= (uint64_t)nibble_of(a[i]) << (4 * i);
+                    }
+                }
+            }
+            c ^= tog;                                      // toggle, env.py:182
+        }
+        const uint64_t nxt = patch_generation64(c, lane, rule);
+        const int fb = t & 1;
+        const bool w_any = HAS_ACT && __ballot(seen.any_nonzero<F32Cells>()) != 0ull;
+        const bool w_notone = HAS_ACT && __ballot(seen.not_all_ones<F32Cells>()) != 0ull;
+        if (lane == 0) { s_any[fb][wv] = w_any; s_notone[fb][wv] = w_notone; }
+        __syncthreads();
+        any = false; notone = false;
+        for (int i = 0; i < (int)n; ++i) { any |= s_any[fb][i] != 0u; notone |= s_notone[fb][i] != 0u; }
+        reset = HAS_ACT && !notone;                        // env.py:208: every element of the batch is 1.0
+        any = HAS_ACT && any;
+        c = reset ? 0ull : nxt;
+        if (threadIdx.x == 0) {                            // the arithmetic of finish_status / the moments merge, per step
+            if (!any) since += 1;
+            if (reset) { step_number = 0; since = 0; resets += 1; } else { step_number += 1; }
+            if (moments) {
+                const double nb = (double)n, tot = na + nb;
+                if (tot > 0.0) {
+                    const double ma_new = ma - ma * nb / tot, qa_new = qa + ma * ma * na * nb / tot;
+                    na = tot; ma = ma_new; qa = qa_new;
+                }
+            }
+        }
+    }
+    float *gout = u_out + g * 4096 + 4 * lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) F32Cells::store<false>(gout + i * 256, (uint32_t)(c >> (4 * i)) & 0xFu);
+    if (reward && threadIdx.x < n) reward[threadIdx.x] = 0.0f;          // env.py:238
+    if (threadIdx.x == 0 && steps > 0) {
+        if (moments) {
+            mom_out[0] = (double)n; mom_out[1] = 0.0; mom_out[2] = 0.0;
+            mom_acc[0] = na; mom_acc[1] = ma; mom_acc[2] = qa;
+        }
+        // the status block as the last step's kernel + epilogue leave it: its flags in its slot, the other slot recycled
+        const int slot = (slot0 + steps - 1) & 1;
+        uint4 o0 = {0u, 0u, 0u, 0u}, o1 = w1, o2;
+        const uint32_t f_any = (HAS_ACT && any) ? 1u : 0u, f_not = (HAS_ACT && notone) ? 1u : 0u;
+        if (slot) { o0.y = f_any; o0.w = f_not; } else { o0.x = f_any; o0.z = f_not; }
+        o1.x = reset ? 1u : 0u;
+        o1.z = (uint32_t)step_number; o1.w = (uint32_t)((uint64_t)step_number >> 32);
+        o2.x = (uint32_t)since; o2.y = (uint32_t)((uint64_t)since >> 32);
+        o2.z = (uint32_t)resets; o2.w = (uint32_t)((uint64_t)resets >> 32);
+        uint4 *so = reinterpret_cast<uint4 *>(st);
+        so[0] = o0; so[1] = o1; so[2] = o2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // wide fast path: W = 256 * NS (NS = 1, 2), one wavefront per strip of R = 16 * RW rows
 // ---------------------------------------------------------------------------------------------
@@ -755,6 +878,9 @@ int env_step_small64(const float *u_in, const float *action, float *u_out, float
                      const RandAct *rand, void *stream) {
     const bool has_act = action != nullptr || rand != nullptr;
     if (h != 64 || w != 64 || n < 1 || n > 16 || !status || (has_act && (aw % 8) != 0)) return -1000;
+    // in-kernel toggles are ~100 instructions per quad: more than four grids of them on ONE compute unit take longer
+    // than the two launches of the general path (N=16: 19.6 against ~10 us per step)
+    if (rand && n > 4) return -1000;
     if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_env_step_f32: u_in/u_out is NULL");
     if (int e = check_dims(n, h, w, has_act, ah, aw)) return e;
     if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_env_step_f32: rule mask exceeds 18 bits");
@@ -777,6 +903,38 @@ int env_step_small64(const float *u_in, const float *action, float *u_out, float
         hipLaunchKernelGGL((ca_env_step_small64_kernel<false, false>), grid, block, 0, s, u_in, action, u_out, reward,
                            n, 0, rule, status, slot, publish, merge, RandAct());
     return check_launch("carle_env_step_f32(small batch)");
+}
+
+// k steps of a small batch in one launch (ca_env_run_small64_kernel); -1000 when the geometry does not qualify.
+// `actions`: k stacked (N,1,AW,AW) tensors, or nullptr with rand (in-kernel toggles, Philox offset + t) or without.
+int env_run_small64(const float *u_in, const float *actions, float *u_out, float *reward, int64_t n, int h, int w, int ah,
+                    int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset, int k, int32_t *status, int slot0,
+                    int step_flags, void *stream) {
+    RandAct ra;
+    ra.p = p; ra.seed = seed; ra.offset = offset;
+    const RandAct *rand = (!actions && p >= 0.0f) ? &ra : nullptr;
+    const bool has_act = actions != nullptr || rand != nullptr;
+    if (!has_act) { ah = 0; aw = 0; }
+    if (h != 64 || w != 64 || n < 1 || n > 16 || k < 1 || !status || (has_act && (aw % 8) != 0)) return -1000;
+    if (rand && n > 4) return -1000;                       // as env_step_small64: the draws of many grids on one CU
+    if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_env_run_f32: buffer is NULL");
+    if (int e = check_dims(n, h, w, has_act, ah, aw)) return e;
+    if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_env_run_f32: rule mask exceeds 18 bits");
+    if (!aligned16(u_in) || !aligned16(u_out) || (actions && !aligned16(actions)) || !aligned16(status))
+        return fail_arg(CARLE_E_ALIGN, "carle_env_run_f32: pointers must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(1), block((unsigned)(64 * n));
+    const int merge = (step_flags & CARLE_STEP_MERGE_MOMENTS) ? 1 : 0;
+    if (rand)
+        hipLaunchKernelGGL((ca_env_run_small64_kernel<true, true>), grid, block, 0, s, u_in, actions, u_out, reward, n, aw,
+                           rule, status, slot0, merge, *rand, k);
+    else if (actions)
+        hipLaunchKernelGGL((ca_env_run_small64_kernel<true, false>), grid, block, 0, s, u_in, actions, u_out, reward, n,
+                           aw, rule, status, slot0, merge, RandAct(), k);
+    else
+        hipLaunchKernelGGL((ca_env_run_small64_kernel<false, false>), grid, block, 0, s, u_in, actions, u_out, reward, n,
+                           0, rule, status, slot0, merge, RandAct(), k);
+    return check_launch("carle_env_run_f32(small batch)");
 }
 
 int env_step_small64_rand(const float *u_in, float *u_out, float *reward, int64_t n, int h, int w, int ah, int aw,
