@@ -380,10 +380,12 @@ __global__ __launch_bounds__(1024) void ca_env_run_small64_kernel(
             mom_acc[0] = na; mom_acc[1] = ma; mom_acc[2] = qa;
         }
         // the status block as the last step's kernel + epilogue leave it: its flags in its slot, the other slot recycled
+        // (the predicates travel through LDS, the flag words are only recycled: step t clears the slot of steps t - 1 and
+        // t + 1, so after two or more steps both slots are clear)
         const int slot = (slot0 + steps - 1) & 1;
-        uint4 o0 = {0u, 0u, 0u, 0u}, o1 = w1, o2;
-        const uint32_t f_any = (HAS_ACT && any) ? 1u : 0u, f_not = (HAS_ACT && notone) ? 1u : 0u;
-        if (slot) { o0.y = f_any; o0.w = f_not; } else { o0.x = f_any; o0.z = f_not; }
+        uint4 o0 = st4[0], o1 = w1, o2;
+        if (slot) { o0.x = 0u; o0.z = 0u; } else { o0.y = 0u; o0.w = 0u; }
+        if (steps >= 2) { o0.x = 0u; o0.y = 0u; o0.z = 0u; o0.w = 0u; }
         o1.x = reset ? 1u : 0u;
         o1.z = (uint32_t)step_number; o1.w = (uint32_t)((uint64_t)step_number >> 32);
         o2.x = (uint32_t)since; o2.y = (uint32_t)((uint64_t)since >> 32);

@@ -177,3 +177,39 @@ def test_running_stats_flush_two_ranks_on_device():
     for r in res:
         np.testing.assert_allclose(r[1], [allx.size, allx.mean(), ((allx - allx.mean()) ** 2).sum()], rtol=1e-10)
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2]      # bit-identical on both ranks
+
+
+@pytest.mark.parametrize("n", [1, 7, 16, 40])
+def test_run_merges_reward_moments_like_the_step_loop(n):
+    """CARLE.run with attached statistics: the k steps of a small batch run in one launch (ca_env_run_small64_kernel)
+    and merge their reward moments per step in the kernel; the pending triple, the counters and the status block must
+    equal those of k separate steps (n = 40: the two-launch path).  A master reset sits in the middle of the run."""
+    from carle_amd import dist as cd
+    from carle_amd.env import CARLE
+    g = torch.Generator().manual_seed(n)
+    u0 = (torch.rand(n, 1, 64, 64, generator=g) < 0.4).float()
+    acts = (torch.rand(9, n, 1, 64, 64, generator=g) < 0.1).float()
+    acts[4] = 1.0                                            # master reset at step 5
+    acts[6] = 0.0                                            # a step without any toggle
+    res = []
+    for mode in ("loop", "run"):
+        env = CARLE(width=64, height=64, instances=n, device="cuda:0")
+        stats = cd.RunningRewardStats("cuda:0", sync_every=100)
+        assert stats.attach(env)
+        env.reset()
+        env.universe = u0.clone().cuda()
+        if mode == "loop":
+            for t in range(9):
+                obs, reward, done, info = env.step(acts[t].cuda())
+                assert env._moments_merged
+        else:
+            env.run(actions=acts[:4].cuda())
+            obs, reward, done, info = env.run(actions=acts[4:].cuda())
+            assert env._moments_merged
+        res.append((obs.cpu().numpy(), reward.cpu().numpy(), env._status.cpu().tolist()[:12], stats._pending.cpu().numpy(),
+                    env.step_number, env.steps_since_action, env.master_resets))
+    a, b = res
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2] == b[2], (a[2], b[2])
+    assert np.array_equal(a[3], b[3]) and a[3][0] == 9 * n
+    assert a[4:] == b[4:] == (4, 0, 1) or a[4:] == b[4:]
