@@ -174,6 +174,8 @@ int env_step_small64_rand(const float *u_in, float *u_out, float *reward, int64_
 int env_run_small64(const float *u_in, const float *actions, float *u_out, float *reward, int64_t n, int h, int w, int ah,
                     int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset, int k, int32_t *status, int slot0,
                     int step_flags, void *stream);
+int env_run_noaction64(const float *u_in, float *u_out, float *reward, int64_t n, int h, int w, uint32_t rule, int k,
+                       int32_t *status, int slot0, int step_flags, void *stream);
 }
 
 // step + epilogue in one call: the per-step host cost of the drop-in surface is dominated by
@@ -261,6 +263,11 @@ extern "C" int carle_env_run_f32(float *buf_a, float *buf_b, const float *action
         // small batches: all k steps in ONE launch, the grids stay in registers (ca_env_run_small64_kernel)
         const int e = env_run_small64(buf_a, actions, (k & 1) ? buf_b : buf_a, reward, n, h, w, ah, aw, rule, p, seed, offset, k,
                                       status, slot0, step_flags, stream);
+        if (e != -1000) return e;
+    }
+    if (k > 0 && !actions && p < 0.0f && h == 64 && w == 64 && n > 16) {
+        // no action source: no predicates, no master reset -- all k generations in one launch, grids in registers
+        const int e = env_run_noaction64(buf_a, (k & 1) ? buf_b : buf_a, reward, n, h, w, rule, k, status, slot0, step_flags, stream);
         if (e != -1000) return e;
     }
     for (int t = 0; t < k; ++t) {

@@ -395,6 +395,68 @@ __global__ __launch_bounds__(1024) void ca_env_run_small64_kernel(
     }
 }
 
+// k action-free steps of ANY number of 64x64 fp32 grids in one launch (carle_env_run_f32 without actions): one wave per
+// grid, the grid stays in the wave's 64-bit patch registers for all k generations (no predicates, no master reset
+// without an action: env.py:191,208), one load and one store per grid.  Block 0 advances the counters by k and merges
+// the k all-zero reward batches into the running moments exactly as k epilogues would.  VALU-bound: ~620 instructions
+// per grid and generation.  u_out may be u_in.
+__global__ __launch_bounds__(64) void ca_run_noaction64_kernel(const float *__restrict__ u_in, float *__restrict__ u_out,
+                                                              float *__restrict__ reward, int64_t n, uint32_t rule,
+                                                              int32_t *__restrict__ st, int slot0, int merge_moments,
+                                                              int steps, int nt_st) {
+    const int lane = threadIdx.x;
+    const int64_t g = blockIdx.x;
+    const float *gin = u_in + g * 4096 + 4 * lane;
+    uint4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = ld16<true>(reinterpret_cast<const uint4 *>(gin + i * 256));
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c |= (uint64_t)nibble_of(v[i]) << (4 * i);
+    for (int t = 0; t < steps; ++t) c = patch_generation64(c, lane, rule);
+    float *gout = u_out + g * 4096 + 4 * lane;
+    if (nt_st) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) F32Cells::store<true>(gout + i * 256, (uint32_t)(c >> (4 * i)) & 0xFu);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) F32Cells::store<false>(gout + i * 256, (uint32_t)(c >> (4 * i)) & 0xFu);
+    }
+    if (reward && lane == 0) reward[g] = 0.0f;             // env.py:238
+    if (g == 0 && lane == 0 && steps > 0) {
+        const uint4 *st4 = reinterpret_cast<const uint4 *>(st);
+        const uint4 w0 = st4[0], w1 = st4[1], w2 = st4[2], w3 = st4[3];
+        if (merge_moments && reward) {
+            double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
+            double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
+            if (mom_out && mom_acc) {
+                double na = mom_acc[0], ma = mom_acc[1], qa = mom_acc[2];
+                const double nb = (double)n;
+                for (int t = 0; t < steps; ++t) {          // k merges of (n, 0, 0), in the epilogue's arithmetic
+                    const double tot = na + nb;
+                    if (tot > 0.0) {
+                        const double ma_new = ma - ma * nb / tot, qa_new = qa + ma * ma * na * nb / tot;
+                        na = tot; ma = ma_new; qa = qa_new;
+                    }
+                }
+                mom_out[0] = nb; mom_out[1] = 0.0; mom_out[2] = 0.0;
+                mom_acc[0] = na; mom_acc[1] = ma; mom_acc[2] = qa;
+            }
+        }
+        int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z) + steps;
+        int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x) + steps;
+        const int slot = (slot0 + steps - 1) & 1;
+        uint4 o0 = w0, o1 = w1, o2 = w2;
+        if (slot) { o0.x = 0u; o0.z = 0u; } else { o0.y = 0u; o0.w = 0u; }     // flag words recycled as by k epilogues
+        if (steps >= 2) { o0.x = 0u; o0.y = 0u; o0.z = 0u; o0.w = 0u; }
+        o1.x = 0u;                                          // CARLE_ST_LAST_RESET
+        o1.z = (uint32_t)step_number; o1.w = (uint32_t)((uint64_t)step_number >> 32);
+        o2.x = (uint32_t)since; o2.y = (uint32_t)((uint64_t)since >> 32);
+        uint4 *so = reinterpret_cast<uint4 *>(st);
+        so[0] = o0; so[1] = o1; so[2] = o2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // wide fast path: W = 256 * NS (NS = 1, 2), one wavefront per strip of R = 16 * RW rows
 // ---------------------------------------------------------------------------------------------
@@ -937,6 +999,20 @@ int env_run_small64(const float *u_in, const float *actions, float *u_out, float
         hipLaunchKernelGGL((ca_env_run_small64_kernel<false, false>), grid, block, 0, s, u_in, actions, u_out, reward, n,
                            0, rule, status, slot0, merge, RandAct(), k);
     return check_launch("carle_env_run_f32(small batch)");
+}
+
+// k action-free steps of a 64x64 fp32 batch in one launch (ca_run_noaction64_kernel); -1000 when it does not apply.
+int env_run_noaction64(const float *u_in, float *u_out, float *reward, int64_t n, int h, int w, uint32_t rule, int k,
+                       int32_t *status, int slot0, int step_flags, void *stream) {
+    if (h != 64 || w != 64 || n < 1 || k < 1 || !status || n > 0x7FFFFFFFll) return -1000;
+    if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_env_run_f32: buffer is NULL");
+    if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_env_run_f32: rule mask exceeds 18 bits");
+    if (!aligned16(u_in) || !aligned16(u_out) || !aligned16(status))
+        return fail_arg(CARLE_E_ALIGN, "carle_env_run_f32: pointers must be 16-byte aligned");
+    const int merge = (step_flags & CARLE_STEP_MERGE_MOMENTS) ? 1 : 0;
+    hipLaunchKernelGGL(ca_run_noaction64_kernel, dim3((unsigned)n), dim3(64), 0, static_cast<hipStream_t>(stream), u_in, u_out,
+                       reward, n, rule, status, slot0, merge, k, stream_stores(n * 16384, 4) ? 1 : 0);
+    return check_launch("carle_env_run_f32(no action)");
 }
 
 int env_step_small64_rand(const float *u_in, float *u_out, float *reward, int64_t n, int h, int w, int ah, int aw,

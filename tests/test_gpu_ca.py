@@ -491,9 +491,12 @@ def test_run_with_fused_random_agent_equals_step_loop(n, size):
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:] == (9, 0)
 
 
-def test_run_without_action_equals_multistep():
-    env_a, env_b = _env(width=64, height=64, instances=5), _env(width=64, height=64, instances=5)
-    u = (torch.rand(5, 1, 64, 64) < 0.5).float()
+@pytest.mark.parametrize("n", [5, 40, 1030])
+def test_run_without_action_equals_multistep(n):
+    """run(steps=k) without an action source: all k generations in one launch (n <= 16: the small-batch kernel, above:
+    ca_run_noaction64_kernel, one wave per grid) against the step-by-step evolution; in place for even k."""
+    env_a, env_b = _env(width=64, height=64, instances=n), _env(width=64, height=64, instances=n)
+    u = (torch.rand(n, 1, 64, 64) < 0.5).float()
     for e in (env_a, env_b):
         e.reset()
         e.universe = u.clone().cuda()
@@ -501,6 +504,16 @@ def test_run_without_action_equals_multistep():
     ob = env_b.multistep(12)[0]
     assert torch.equal(oa, ob) and env_a.step_number == env_b.step_number == 12
     assert env_a.steps_since_action == env_b.steps_since_action == 12
+    oa = env_a.run(steps=7)[0]
+    for _ in range(7):
+        ob = env_b.step(torch.zeros(n, 1, 64, 64))[0]
+    assert torch.equal(oa, ob) and env_a.step_number == env_b.step_number == 19
+    assert env_a.steps_since_action == env_b.steps_since_action == 19
+    assert env_a._status.cpu().tolist()[4:12] == env_b._status.cpu().tolist()[4:12]      # counters, last-reset word
+    # and an action afterwards behaves as usual (flag slots / parity carried over)
+    a = (torch.rand(n, 1, 64, 64) < 0.2).float()
+    assert torch.equal(env_a.step(a)[0], env_b.step(a)[0])
+    assert env_a.steps_since_action == env_b.steps_since_action == 19 and env_a.step_number == env_b.step_number == 20
 
 
 def test_c_consumer_steps_on_the_gpu(tmp_path):

@@ -206,10 +206,17 @@ def test_run_merges_reward_moments_like_the_step_loop(n):
             env.run(actions=acts[:4].cuda())
             obs, reward, done, info = env.run(actions=acts[4:].cuda())
             assert env._moments_merged
-        res.append((obs.cpu().numpy(), reward.cpu().numpy(), env._status.cpu().tolist()[:12], stats._pending.cpu().numpy(),
+        # three action-free steps on top (n > 16: all generations in one launch of ca_run_noaction64_kernel)
+        if mode == "loop":
+            for t in range(3):
+                obs, reward, done, info = env.step(torch.zeros(n, 1, 64, 64, device="cuda"))
+        else:
+            obs, reward, done, info = env.run(steps=3)
+        # (words 0..3 are the transient action-flag slots: an explicit all-zero action leaves NOT_ALL_ONES behind, no action nothing)
+        res.append((obs.cpu().numpy(), reward.cpu().numpy(), env._status.cpu().tolist()[4:12], stats._pending.cpu().numpy(),
                     env.step_number, env.steps_since_action, env.master_resets))
     a, b = res
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert a[2] == b[2], (a[2], b[2])
-    assert np.array_equal(a[3], b[3]) and a[3][0] == 9 * n
+    assert np.array_equal(a[3], b[3]) and a[3][0] == 12 * n
     assert a[4:] == b[4:] == (4, 0, 1) or a[4:] == b[4:]
