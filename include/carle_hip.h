@@ -193,7 +193,11 @@ int carle_env_step_f32(const float *u_in, const float *action, float *u_out, flo
  *   slot0                  flag slot of the first step; step t uses (slot0 + t) & 1
  *   step_flags             CARLE_STEP_MERGE_MOMENTS or 0
  * Every step is complete (master reset, counters, flags) before the next one starts, exactly as k
- * separate calls of carle_env_step_f32* on the same stream.
+ * separate calls of carle_env_step_f32* on the same stream (grids, counters, reward moments and the
+ * reward of the last step are identical; the contents of the buffer that does not hold the final state
+ * and the transient action-flag words of the status block are unspecified).  64x64 grids: batches of up
+ * to 16 run all k steps in ONE launch with the grids in registers, and without an action source any
+ * batch does (no predicates, no master reset without an action).
  */
 int carle_env_run_f32(float *buf_a, float *buf_b, const float *actions, float *reward, int64_t n,
                       int h, int w, int ah, int aw, uint32_t rule, float p, uint64_t seed,
