@@ -71,9 +71,11 @@ def parse(argv=None):
                     help="reward nets in training mode: every step also accumulates the predictor "
                          "gradient (fused forward+backward kernels), Adam update every 64 steps "
                          "(carle/train_mcl.py's per-step work)")
-    ap.add_argument("--sync-reward", action="store_true",
-                    help="run the reward consumers (reward nets, reward statistics) on the CA "
-                         "stream instead of the reward stream")
+    ap.add_argument("--async-reward", action="store_true",
+                    help="run the reward consumers (a stacked AE2D / training kernels, reward statistics) on a second "
+                         "HIP stream beside the next CA step instead of on the CA stream (measured slower since the "
+                         "kernels got faster: the cross-stream events cost more than they hide)")
+    ap.add_argument("--sync-reward", action="store_true", help="(default since late round 2; kept for old command lines)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1")
     ap.add_argument("--share-gpus", action="store_true",
                     help="rehearsal only: let several ranks share a device when the node has fewer "
@@ -403,21 +405,21 @@ def run_rank(args):
     if args.rnd or args.ae:
         from carle_amd.mcl import RND2D, AE2D
         torch.manual_seed(0)                 # construction order predictor -> random (mcl.py:248)
-        # forward passes only.  RND2D alone is fused into the CA kernel (one stream); a stacked AE2D
-        # runs its kernels on the reward stream beside the next CA step unless --sync-reward
-        kw = dict(async_reward=(args.ae or args.train) and not args.sync_reward, train_predictor=args.train)
+        # RND2D alone is fused into the CA kernel (one stream); a stacked AE2D / the training kernels run on the same
+        # stream too unless --async-reward puts them on the reward stream beside the next CA step
+        use_rs = (args.ae or args.train) and args.async_reward and not args.sync_reward
+        kw = dict(async_reward=use_rs, train_predictor=args.train)
         if args.rnd:
             wenv = RND2D(env, **kw)
         if args.ae:
             wenv = AE2D(wenv, **kw)
         wenv.eval()
         wenv.to(dev)
-    # with a stacked AE2D the reward consumers (its kernels, the per-step moments kernel) run on the
-    # reward stream unless --sync-reward: they overlap the CA kernel of the next step.  Measured:
-    # with no reward nets, or with RND2D alone (fused into the CA kernel), the cross-stream events
-    # cost more than they hide (45.6 vs 39.1 and 52.8 vs 46.5 us/step): those stay on one stream
+    # Measured (late round 2, N=4096 64x64 / the reference's default 16 x 256x256): one stream 0.0767 / 0.0513 ms/step with
+    # RND2D + AE2D forward, 0.171 / 0.088 in training mode; reward stream 0.0810 / 0.098 and 0.169 / 0.111 -- the
+    # cross-stream events cost more than the overlap hides, most of all for small batches: one stream is the default
     rs = None
-    if (args.ae or args.train) and not args.sync_reward:
+    if (args.ae or args.train) and args.async_reward and not args.sync_reward:
         from carle_amd.streams import RewardStream
         rs = env.__dict__.get("reward_stream")
         if rs is None:

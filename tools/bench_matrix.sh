@@ -21,7 +21,9 @@ run "cfg2: N=4096 64x64 f32, action ring (headline)" --steps 256 --warmup 16
 run "cfg2 with fused device-side RandomAgent" --agent fused --no-cpu-baseline
 run "cfg2 at N=65536 (1 GiB per array: no Infinity Cache)" --instances 65536 --steps 64 --warmup 8 --no-cpu-baseline
 run "cfg4 (BASELINE configs[3]): + RND2D forward (fused kernel)" --rnd --no-cpu-baseline
-run "cfg4 + AE2D forward (reward stream)" --rnd --ae --no-cpu-baseline
+run "cfg4 + AE2D forward" --rnd --ae --no-cpu-baseline
+run "reference default geometry: N=16 256x256 + RND2D + AE2D forward" --size 256 --instances 16 --rnd --ae --steps 512 --no-cpu-baseline
+run "reference default geometry, training mode (RND2D + AE2D forward+backward)" --size 256 --instances 16 --rnd --ae --train --steps 512 --no-cpu-baseline
 run "cfg3 shape: N=4096 256x256 f32" --size 256 --steps 64 --warmup 8 --no-cpu-baseline
 run "N=1024 512x512 f32" --size 512 --instances 1024 --steps 64 --warmup 8 --no-cpu-baseline
 run "N=4096 256x256 uint8 (uint8 actions)" --format u8 --size 256 --steps 128 --warmup 8 --no-cpu-baseline
