@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 FP32_PEAK = 157.3e12       # FLOP/s, same guide, "Peak FP32 (vector)"
 MIN_TIMED_MS = 5.0         # below this the timed region is too short to quote (warned in the JSON)
+MIN_BLOCKS, MAX_BLOCKS, MIN_TOTAL_MS = 5, 201, 50.0      # repeats of the timed block (odd cap: a true median)
 
 
 def parse(argv=None):
@@ -88,6 +89,8 @@ def parse(argv=None):
     ap.add_argument("--separate-stats-kernel", action="store_true",
                     help="reduce the rewards with the stand-alone moments kernel every step instead of "
                          "inside the step epilogue (A/B switch)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="number of timed blocks of --steps steps (default: >= 5, until >= 50 ms are timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
@@ -122,6 +125,9 @@ def launch_ranks(args, argv):
     port = _free_port()
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver supports dmabuf IPC only; with the legacy mode RCCL's
+        # intra-node transport setup fails in hipIpcGetMemHandle ("invalid argument").  The image exports it already;
+        # the launcher keeps it for ranks started from a scrubbed environment (an explicit setting wins).
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -350,7 +356,29 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
     return cand
 
 
+def pin_rank_cpus():
+    """One process per GPU: give every rank of the node its own contiguous slice of the CPUs this job may use, so
+    that eight ranks' Python / HIP-runtime threads do not migrate over each other (the step costs ~14 us of host
+    time against ~35 us of GPU time: a descheduled rank is the scaling risk SURVEY 8(e) names).  No-op for one
+    rank, with CARLE_NO_PIN=1, or where the affinity call is refused.  Returns the CPU list or None."""
+    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if lw <= 1 or os.environ.get("CARLE_NO_PIN") or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // lw
+    if per < 1:
+        return None
+    mine = cpus[lr * per:(lr + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
+
+
 def run_rank(args):
+    pinned = pin_rank_cpus()
     from carle_amd import dist as cdist
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if env_world != args.gpus:               # checked BEFORE the rendezvous: a mismatch must not hang
@@ -459,8 +487,10 @@ def run_rank(args):
         # the first Adam step of a process loads torch's optimiser kernels (tens of milliseconds, once):
         # it must fall into the warm-up, i.e. the warm-up has to cover two update windows of 64 steps
         args.warmup = 136
-    for i in range(args.warmup):
-        one_step(i)
+    step_no = 0
+    for _ in range(args.warmup):
+        one_step(step_no)
+        step_no += 1
     join_rewards()
     stats.flush()                       # first collective (RCCL setup) stays out of the timing
     # a full collection of the cyclic garbage collector takes 40-90 ms with torch imported (measured:
@@ -468,21 +498,58 @@ def run_rank(args):
     # to the permanent generation, so that no such pause can fall into a short timed region
     gc.collect()
     gc.freeze()
+
+    # ---- timed region (median of >= 5 repeats).  One BLOCK = exactly --steps steps bracketed by
+    # barrier + synchronize on both sides; the blocks repeat until >= MIN_TOTAL_MS have been timed (at least
+    # MIN_BLOCKS, at most MAX_BLOCKS), `value` is the MEDIAN block (max over ranks per block).  The periodic
+    # all-gather of the reward moments (every --stats-every steps) stays inside the blocks it falls into; the
+    # final flush of whatever is pending is timed once, outside (flush_us).
+    marks_all = []
+
+    def timed_block():
+        nonlocal step_no
+        barrier()
+        t0 = time.perf_counter()
+        marks = [t0]
+        for _ in range(args.steps):
+            one_step(step_no)
+            step_no += 1
+            marks.append(time.perf_counter())
+        join_rewards()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        marks_all.append(marks)
+        return t1 - t0
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    block_dt = [timed_block()]
+    first = max_over_ranks(block_dt[0])            # every rank derives the same number of repeats from it
+    repeats = args.repeats if args.repeats > 0 else \
+        min(MAX_BLOCKS, max(MIN_BLOCKS, int(MIN_TOTAL_MS * 1e-3 / max(first, 1e-9)) + 1))
+    repeats |= 1                                   # odd: the median is a block that was actually timed
+    while len(block_dt) < repeats:
+        block_dt.append(timed_block())
     barrier()
     t0 = time.perf_counter()
-    marks = [t0]
-    for i in range(args.steps):
-        one_step(i)
-        marks.append(time.perf_counter())
-    join_rewards()
     stats.flush()
     torch.cuda.synchronize(dev)
+    flush_us = (time.perf_counter() - t0) * 1e6
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    per_rank = torch.tensor(block_dt, dtype=torch.float64).reshape(1, -1)
+    if dist is not None:                             # [world, repeats]: every rank's block times
+        mine = per_rank.to(dev if args.backend == "nccl" else "cpu")
+        rows = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        per_rank = torch.cat(rows).cpu()
+    per_block = per_rank.max(dim=0).values           # a block lasts as long as its slowest rank
+    dt = float(per_block.median())                   # torch.median: the lower middle element for even counts
+    rank_ms = (per_rank.median(dim=1).values / args.steps * 1e3).tolist()
     pop = float(env.universe.sum().item())      # keeps the result live / sanity
     reward_count = stats.count                  # rewards seen by ALL ranks (the collective's result)
 
@@ -490,11 +557,11 @@ def run_rank(args):
     warnings = []
     # host-side stalls inside the timed region (enqueue time of a single step far above the median: a garbage
     # collection, an allocator call, a page fault storm): reported, never hidden
-    host = sorted(b_ - a_ for a_, b_ in zip(marks, marks[1:]))
+    gaps = [(b, i, m[i + 1] - m[i]) for b, m in enumerate(marks_all) for i in range(len(m) - 1)]
+    host = sorted(g_[2] for g_ in gaps)
     if host:
         med = host[len(host) // 2]
-        slow = [(i, round((marks[i + 1] - marks[i]) * 1e3, 2)) for i in range(len(marks) - 1)
-                if marks[i + 1] - marks[i] > max(20 * med, 5e-3)]
+        slow = [(f"block {b} step {i}", round(d_ * 1e3, 2)) for b, i, d_ in gaps if d_ > max(20 * med, 5e-3)]
         if slow:
             warnings.append(f"host stalls inside the timed region (step, ms): {slow[:8]}; median host time per step "
                             f"{med * 1e6:.1f} us")
@@ -509,9 +576,9 @@ def run_rank(args):
         timed.append((k_ms, name, alg, flop, reps))
     k_ms, kname, alg_bytes, flop, reps = max(timed)
     achieved = alg_bytes / (k_ms * 1e-3)
-    if dt * 1e3 < MIN_TIMED_MS:
-        warnings.append(f"timed region is {dt * 1e3:.2f} ms (< {MIN_TIMED_MS} ms): value is launch-jitter "
-                        f"sensitive; use --steps >= {int(args.steps * MIN_TIMED_MS / (dt * 1e3)) + 1}")
+    total_ms = float(per_block.sum()) * 1e3
+    if total_ms < MIN_TIMED_MS:
+        warnings.append(f"timed blocks sum to {total_ms:.2f} ms (< {MIN_TIMED_MS} ms): value is launch-jitter sensitive")
 
     if rank == 0:
         roof = {"bound": "hbm", "kernel": kname,
@@ -543,6 +610,15 @@ def run_rank(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "timing": {"estimator": "median over `repeats` blocks of exactly `steps` steps, each bracketed by barrier + "
+                                    "synchronize; per block the max over ranks",
+                       "repeats": repeats, "block_ms_min": float(per_block.min()) * 1e3,
+                       "block_ms_median": dt * 1e3, "block_ms_max": float(per_block.max()) * 1e3,
+                       "ms_per_step_min": float(per_block.min()) / args.steps * 1e3,
+                       "ms_per_step_max": float(per_block.max()) / args.steps * 1e3,
+                       "rank_ms_per_step_min": min(rank_ms), "rank_ms_per_step_max": max(rank_ms),
+                       "final_stats_flush_us": flush_us, "steps_run": step_no,
+                       "rank0_cpus": (f"{pinned[0]}-{pinned[-1]}" if pinned else "unpinned")},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

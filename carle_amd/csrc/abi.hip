@@ -1,5 +1,6 @@
 // abi.hip -- library-level C-ABI entry points: version, error text, and the step epilogue
 // (master reset + counters, carle/env.py:208-216,142-145,200,230).
+#include <stdlib.h>
 #include "ca_cells.hpp"
 #include "common.hpp"
 
@@ -9,6 +10,31 @@ std::string &last_error() {
     thread_local std::string msg;
     return msg;
 }
+
+static int64_t env_i64(const char *name) {
+    const char *e = getenv(name);
+    return (e && *e) ? atoll(e) : -1;
+}
+static Knobs read_knobs() {
+    Knobs k;
+    k.stream_store_min_bytes = env_i64("CARLE_STREAM_STORE_MIN_BYTES");
+    k.b1_lds_min_bytes = env_i64("CARLE_B1_LDS_MIN_BYTES");
+    k.b1_nt_min_bytes = env_i64("CARLE_B1_NT_MIN_BYTES");
+    k.b1_blocks = env_i64("CARLE_B1_BLOCKS");
+    k.b1_units = env_i64("CARLE_B1_UNITS");
+    k.wide_blocks = env_i64("CARLE_WIDE_BLOCKS");
+    k.rnd_blocks = env_i64("CARLE_RND_BLOCKS");
+    k.rnd_cached_load_max_bytes = env_i64("CARLE_RND_CACHED_LOAD_MAX_BYTES");
+    k.net_blocks = env_i64("CARLE_NET_BLOCKS");
+    k.b1_dbg = env_i64("CARLE_B1_DBG");
+    k.two_launch_step = env_i64("CARLE_TWO_LAUNCH_STEP");
+    return k;
+}
+static Knobs &knobs_storage() {
+    static Knobs k = read_knobs();       // C++11: initialised once, thread-safe
+    return k;
+}
+const Knobs &knobs() { return knobs_storage(); }
 
 // Applies the whole-batch master reset decided by the flags the step kernel published, zeroes
 // the reward vector, maintains the counters and recycles the other flag slot.
@@ -117,6 +143,8 @@ using namespace carle;
 extern "C" int carle_abi_version(void) { return CARLE_ABI_VERSION; }
 
 extern "C" const char *carle_last_error(void) { return last_error().c_str(); }
+
+extern "C" void carle_reload_knobs(void) { knobs_storage() = read_knobs(); }
 
 extern "C" const char *carle_build_arch(void) {
 #ifdef CARLE_BUILD_ARCH

@@ -267,16 +267,14 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
     // of 8 TB/s).  (Before the table set-up stopped waiting for each of its loads, fewer, longer workgroups won.)
     int64_t blocks = n <= 1024 ? n : (n + 1) / 2;
     if (blocks < 1024 && n > 1024) blocks = 1024;
-    if (const char *e = getenv("CARLE_RND_BLOCKS")) {  // experiment knob (tools/kbench_rnd.py)
-        const int64_t v = atoll(e);
+    {                                                  // experiment knob (tools/kbench_rnd.py), read once
+        const int64_t v = knobs().rnd_blocks;
         if (v > 0) blocks = v < n ? v : n;
     }
     // store policy by the size of one state array (ca_step_cells.hip: stream_stores): write-back up to 256 MiB
-    int64_t lim = 256ll << 20;
-    if (const char *e = getenv("CARLE_STREAM_STORE_MIN_BYTES")) lim = atoll(e) - 1;     // experiment knob
+    const int64_t lim = knobs().stream_store_min_bytes >= 0 ? knobs().stream_store_min_bytes - 1 : 256ll << 20;
     const bool nt_st = n * 16384 > lim;
-    int64_t ld_lim = 128ll << 20;
-    if (const char *e = getenv("CARLE_RND_CACHED_LOAD_MAX_BYTES")) ld_lim = atoll(e);   // experiment knob
+    const int64_t ld_lim = knobs().rnd_cached_load_max_bytes >= 0 ? knobs().rnd_cached_load_max_bytes : 128ll << 20;
     const dim3 grid((unsigned)blocks), block(256);
     if (action && !nt_st && n * 16384 <= ld_lim)
         hipLaunchKernelGGL((ca_step_rnd64_kernel<true, false, false>), grid, block, 0, s, u_in, action, u_out, n, aw, rule, status, slot, ws, bonus);

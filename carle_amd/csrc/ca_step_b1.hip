@@ -169,8 +169,8 @@ __device__ __forceinline__ uint32_t next_state(const Count4<uint32_t> &n, uint32
 // streaming hint below 192 MiB per array.
 static int b1_strip_mode(int64_t n, int ww) {
     int64_t lds_bytes = ww == 8 ? 0 : 64ll << 20, nt_bytes = 192ll << 20;
-    if (const char *e = getenv("CARLE_B1_LDS_MIN_BYTES")) lds_bytes = atoll(e);      // experiment knobs
-    if (const char *e = getenv("CARLE_B1_NT_MIN_BYTES")) nt_bytes = atoll(e);
+    if (knobs().b1_lds_min_bytes >= 0) lds_bytes = knobs().b1_lds_min_bytes;      // experiment knobs, read once
+    if (knobs().b1_nt_min_bytes >= 0) nt_bytes = knobs().b1_nt_min_bytes;
     const int64_t bytes = n * (int64_t)(64 * ww) * ww * 8;
     if ((ww != 8 && ww != 4) || bytes < lds_bytes) return 0;
     return bytes >= nt_bytes ? 2 : 1;
@@ -617,12 +617,12 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     // items rotate through the strips -- with a stride that is a multiple of the strip count every wave
     // kept ONE strip index, and the waves of the two strips under the action window finished last
     int64_t cap = 8 * 1021;
-    if (const char *e = getenv("CARLE_B1_BLOCKS")) { const int64_t v = atoll(e); if (v >= 8) cap = v / 8 * 8; }   // experiment knob
+    if (const int64_t v = knobs().b1_blocks; v >= 8) cap = v / 8 * 8;   // experiment knob
     auto blocks = [&](int64_t wg) { return (unsigned)(wg < cap ? wg : cap); };
     // window launches of multi-strip grids walk half-grid units (see the kernel): 8192 waves = 32 per CU, all
     // resident at once, and the batch sizes of the BASELINE configs divide evenly over them
     int64_t ucap = 8192;
-    if (const char *e = getenv("CARLE_B1_UNITS")) { const int64_t v = atoll(e); if (v >= 8) ucap = v / 8 * 8; }       // experiment knob
+    if (const int64_t v = knobs().b1_units; v >= 8) ucap = v / 8 * 8;       // experiment knob
     const unsigned full = WW > 1 ? (unsigned)(n8 * 2 < ucap ? n8 * 2 : ucap) : blocks(n8 * WW);
     if (!act) {
         { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 2>), dim3(blocks(n8 * WW)), dim3(64), 0,
@@ -634,7 +634,7 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     if (aw == 64) {
         // the usual 64x64 window: its toggle fits the full-occupancy instantiation -> one launch
         int dbg = 0;
-        if (const char *e = getenv("CARLE_B1_DBG")) dbg = atoi(e);       // experiment knob: 1 = window words fetched at their use
+        if (knobs().b1_dbg >= 0) dbg = (int)knobs().b1_dbg;       // experiment knob: 1 = window words fetched at their use
         { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 2>), dim3(full), dim3(64), 0,
                            s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 1>), dim3(full), dim3(64), 0,
                            s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg); } else { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE>), dim3(full), dim3(64), 0,

@@ -53,8 +53,8 @@ static constexpr int kActEarly = CARLE_ACT_EARLY;     // action loads requested 
 // 64x64 N=8192 17.9 -> 18.5, N=65536 129.6 -> 118.6); fp32 wide kernels: 256x256 N=256 28.0 -> 25.7 us, 512x512 N=256
 // (256 MiB) 93.4 -> 79.1 us; fused CA + RND2D N=16384 129.5 -> 122.2 us.
 static bool stream_stores(int64_t state_bytes, size_t cell_bytes) {
-    int64_t lim = 256ll << 20;
-    if (const char *e = getenv("CARLE_STREAM_STORE_MIN_BYTES")) lim = atoll(e) - 1;     // experiment knob
+    const int64_t k = knobs().stream_store_min_bytes;       // experiment knob, read once (common.hpp)
+    const int64_t lim = k >= 0 ? k - 1 : 256ll << 20;
     return cell_bytes != 4 || state_bytes > lim;
 }
 
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
 // 6-20 % faster: profiles/r02_kbench_wide.txt.  CARLE_WIDE_BLOCKS caps the launch for experiments.)
 static unsigned persistent_blocks(int64_t work_items) {
     int64_t cap = work_items;
-    if (const char *e = getenv("CARLE_WIDE_BLOCKS")) { const int64_t v = atoll(e); if (v >= 8) cap = v / 8 * 8; }
+    if (const int64_t v = knobs().wide_blocks; v >= 8) cap = v / 8 * 8;
     return (unsigned)(work_items < cap ? work_items : cap);
 }
 

@@ -46,6 +46,24 @@ inline int check_dims(int64_t n, int h, int w, bool has_action, int ah, int aw) 
     return 0;
 }
 
+// Experiment knobs (environment variables CARLE_*): read ONCE, when the first entry point that needs them runs
+// (a function-local static in abi.hip), never per launch -- getenv() costs a linear scan of the environment on a path
+// whose problem is host time, and is not safe against a concurrent setenv().  carle_reload_knobs() re-reads them
+// (tests and the A/B tools that switch a knob inside one process); a value < 0 means "not set: library default".
+struct Knobs {
+    int64_t stream_store_min_bytes;      // CARLE_STREAM_STORE_MIN_BYTES: fp32 state arrays from this size use streaming stores
+    int64_t b1_lds_min_bytes;            // CARLE_B1_LDS_MIN_BYTES: packed strips go through the LDS image from this size
+    int64_t b1_nt_min_bytes;             // CARLE_B1_NT_MIN_BYTES: ... with streaming hints from this size
+    int64_t b1_blocks, b1_units;         // CARLE_B1_BLOCKS / CARLE_B1_UNITS: launch caps of the packed kernel
+    int64_t wide_blocks;                 // CARLE_WIDE_BLOCKS: launch cap of the wavefront-per-strip kernels
+    int64_t rnd_blocks;                  // CARLE_RND_BLOCKS: workgroups of the fused CA + RND2D kernel
+    int64_t rnd_cached_load_max_bytes;   // CARLE_RND_CACHED_LOAD_MAX_BYTES
+    int64_t net_blocks;                  // CARLE_NET_BLOCKS: workgroups of the 64x64 reward-net kernels
+    int64_t b1_dbg;                      // CARLE_B1_DBG
+    int64_t two_launch_step;             // CARLE_TWO_LAUNCH_STEP: 1 = step kernel + epilogue kernel everywhere (A/B)
+};
+const Knobs &knobs();
+
 // Hides a uniform pointer from loop-invariant code motion: the scalar loads behind it stay in the phase
 // that uses them (from the scalar cache) instead of being hoisted out of the grid / tile loop, where 124-140
 // uniform weights overflow the SGPR file and spill into VGPR lanes (v_writelane / v_readlane per use).

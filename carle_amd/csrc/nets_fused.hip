@@ -147,7 +147,7 @@ int rnd2d_fused64(const void *obs, int obs_mode, int64_t n, const float *pp, con
                   float reward_scale, bool tables_valid, hipStream_t s) {
     if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
     int64_t blocks = n < 1024 ? n : 1024;             // persistent: 4 workgroups are resident per CU
-    if (const char *e = getenv("CARLE_NET_BLOCKS")) { const int64_t v = atoll(e); if (v > 0) blocks = v < n ? v : n; }   // experiment knob
+    if (const int64_t v = knobs().net_blocks; v > 0) blocks = v < n ? v : n;   // experiment knob, read once
     if (blocks < 1) blocks = 1;
     if (obs_mode == 1)
         hipLaunchKernelGGL(rnd_block64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws,
@@ -430,7 +430,7 @@ int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float
                  float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s) {
     if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
     int64_t blocks = n < 1280 ? n : 1280;             // persistent: 5 workgroups are resident per CU
-    if (const char *e = getenv("CARLE_NET_BLOCKS")) { const int64_t v = atoll(e); if (v > 0) blocks = v < n ? v : n; }   // experiment knob
+    if (const int64_t v = knobs().net_blocks; v > 0) blocks = v < n ? v : n;   // experiment knob, read once
     if (blocks < 1) blocks = 1;
     if (packed)
         hipLaunchKernelGGL(ae_block64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,

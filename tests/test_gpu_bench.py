@@ -45,7 +45,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["sharding"] == "batch x2"
-    assert d["rewards_counted_all_ranks"] == 2 * 512 * (130 + 4)
+    assert d["rewards_counted_all_ranks"] == 2 * 512 * (130 * d["timing"]["repeats"] + 4)
     assert "cpu_baseline" not in d
 
 
