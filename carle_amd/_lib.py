@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcarle_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_i64, _c_int, _c_u32, _c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p
 
@@ -16,6 +16,8 @@ SIGNATURES = {
     "carle_abi_version": (_c_int, []),
     "carle_last_error": (ctypes.c_char_p, []),
     "carle_build_arch": (ctypes.c_char_p, []),
+    "carle_reload_knobs": (None, []),
+    "carle_env_settle": (_c_int, [_c_vp, _c_vp]),
     "carle_ca_step_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int,
                                    _c_u32, _c_vp, _c_int, _c_vp]),
     "carle_ca_step_b1": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int,

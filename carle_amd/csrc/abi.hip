@@ -204,6 +204,21 @@ int env_run_small64(const float *u_in, const float *actions, float *u_out, float
                     int step_flags, void *stream);
 int env_run_noaction64(const float *u_in, float *u_out, float *reward, int64_t n, int h, int w, uint32_t rule, int k,
                        int32_t *status, int slot0, int step_flags, void *stream);
+int env_step_one_launch_f32(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h,
+                            int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
+                            void *stream);
+int env_step_one_launch_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out, float *reward,
+                           int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
+                           int step_flags, void *stream);
+
+__global__ void env_settle_kernel(int32_t *st) { settle_status_in_place(st); }
+}
+
+extern "C" int carle_env_settle(int32_t *status, void *stream) {
+    if (!status) return fail_arg(CARLE_E_NULL, "carle_env_settle: status is NULL");
+    if (!aligned16(status)) return fail_arg(CARLE_E_ALIGN, "carle_env_settle: status must be 16-byte aligned");
+    hipLaunchKernelGGL(env_settle_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), status);
+    return check_launch("carle_env_settle");
 }
 
 // step + epilogue in one call: the per-step host cost of the drop-in surface is dominated by
@@ -217,6 +232,10 @@ extern "C" int carle_env_step_f32(const float *u_in, const float *action, float 
     if (const int e = env_step_small64(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
                                        publish_flags, nullptr, stream); e != -1000)
         return e;
+    if (publish_flags & CARLE_STEP_DEFERRED)
+        if (const int e = env_step_one_launch_f32(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
+                                                  publish_flags, stream); e != -1000)
+            return e;
     if (int e = carle_ca_step_f32(u_in, action, u_out, n, h, w, ah, aw, rule,
                                   (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream))
         return e;
@@ -249,6 +268,10 @@ extern "C" int carle_env_step_u8(const uint8_t *u_in, const void *action, int ac
                                  float *reward, int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                                  int32_t *status, int slot, int publish_flags, void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_u8: status is NULL");
+    if (publish_flags & CARLE_STEP_DEFERRED)
+        if (const int e = env_step_one_launch_u8(u_in, action, action_fmt, u_out, reward, n, h, w, ah, aw, rule, status,
+                                                 slot, publish_flags, stream); e != -1000)
+            return e;
     if (int e = carle_ca_step_u8(u_in, action, action_fmt, u_out, n, h, w, ah, aw, rule,
                                  (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream))
         return e;

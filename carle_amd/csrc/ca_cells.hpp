@@ -124,21 +124,58 @@ struct U8Cells {
 __device__ __forceinline__ void see(ActionSeen &s, const uint4 &a) { s.add(a); }
 __device__ __forceinline__ void see(ActionSeen &s, uint32_t a) { s.add(a); }
 
+// Returns (wave-uniform) whether some action element seen by this wavefront differs from one.
 template <class A>
-__device__ __forceinline__ void publish_flags(const ActionSeen &s, int32_t *status, int slot) {
-    if (status == nullptr) return;
+__device__ __forceinline__ bool publish_flags(const ActionSeen &s, int32_t *status, int slot) {
+    if (status == nullptr) return true;
     const bool any = __ballot(s.any_nonzero<A>()) != 0ull;
     const bool notone = __ballot(s.not_all_ones<A>()) != 0ull;
     if ((threadIdx.x & 63) == 0) {      // every writer stores the same value: benign
         if (any) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
         if (notone) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
     }
+    return notone;
+}
+
+// A CARLE_STEP_DEFERRED step (one launch: ca_step_64_kernel<..., ENV>) leaves its counter update pending in
+// word CARLE_ST_PENDING; whoever touches the counters next applies it first.  Works on the register copy of the
+// first three 16-byte words of the status block; returns true if something was pending.
+__device__ __forceinline__ bool settle_pending(uint4 &w0, uint4 &w1, uint4 &w2) {
+    const uint32_t pend = w1.y;                                           // CARLE_ST_PENDING (index 5)
+    if (!(pend & 1u)) return false;
+    const bool ps = (pend & 4u) != 0u, has_action = (pend & 2u) != 0u;
+    const bool any = has_action && (ps ? w0.y : w0.x) != 0u;
+    const bool reset = has_action && (ps ? w0.w : w0.z) == 0u;
+    int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z);
+    int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x);
+    int64_t resets = (int64_t)(((uint64_t)w2.w << 32) | w2.z);
+    if (!any) since += 1;                       // env.py:199-200
+    if (reset) { step_number = 0; since = 0; resets += 1; } else { step_number += 1; }   // env.py:216,142-145 / 230
+    if (ps) { w0.y = 0u; w0.w = 0u; } else { w0.x = 0u; w0.z = 0u; }      // its flags are consumed
+    w1.x = reset ? 1u : 0u;
+    w1.y = 0u;
+    w1.z = (uint32_t)step_number; w1.w = (uint32_t)((uint64_t)step_number >> 32);
+    w2.x = (uint32_t)since; w2.y = (uint32_t)((uint64_t)since >> 32);
+    w2.z = (uint32_t)resets; w2.w = (uint32_t)((uint64_t)resets >> 32);
+    return true;
+}
+
+// The same on the block in memory, by ONE thread (kernels that update the counters in place).
+__device__ __forceinline__ void settle_status_in_place(int32_t *st) {
+    uint4 *s4 = reinterpret_cast<uint4 *>(st);
+    uint4 w0 = s4[0], w1 = s4[1], w2 = s4[2];
+    if (settle_pending(w0, w1, w2)) {
+        s4[0] = w0; s4[1] = w1; s4[2] = w2;
+        s4[4] = make_uint4(0u, 0u, 0u, 0u);                               // SCAN_TICKET / SCAN_DONE
+    }
 }
 
 // Counter / flag bookkeeping at the end of a step (env.py:142-145, 199-200, 216, 230), by ONE thread:
-// w0..w2 = the first three 16-byte words of the status block as read at the start of the epilogue.
-__device__ __forceinline__ void finish_status(int32_t *st, const uint4 &w0, const uint4 &w1, const uint4 &w2,
+// w0..w2 = the first three 16-byte words of the status block as read at the start of the epilogue (a pending
+// deferred step is applied first).
+__device__ __forceinline__ void finish_status(int32_t *st, uint4 w0, uint4 w1, uint4 w2,
                                               int slot, bool reset, bool any) {
+    settle_pending(w0, w1, w2);
     int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z);       // int32 index 6..7
     int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x);             // index 8..9
     int64_t resets = (int64_t)(((uint64_t)w2.w << 32) | w2.z);            // index 10..11
@@ -153,11 +190,60 @@ __device__ __forceinline__ void finish_status(int32_t *st, const uint4 &w0, cons
     uint4 o0 = w0, o1 = w1, o2;
     if (slot) { o0.x = 0u; o0.z = 0u; } else { o0.y = 0u; o0.w = 0u; }   // recycle slot^1
     o1.x = reset ? 1u : 0u;                     // CARLE_ST_LAST_RESET (index 4)
+    o1.y = 0u;                                  // CARLE_ST_PENDING
     o1.z = (uint32_t)step_number; o1.w = (uint32_t)((uint64_t)step_number >> 32);
     o2.x = (uint32_t)since; o2.y = (uint32_t)((uint64_t)since >> 32);
     o2.z = (uint32_t)resets; o2.w = (uint32_t)((uint64_t)resets >> 32);
     uint4 *so = reinterpret_cast<uint4 *>(st);
     so[0] = o0; so[1] = o1; so[2] = o2;              // words 12..15 (moment pointers) stay
+    so[4] = make_uint4(0u, 0u, 0u, 0u);              // SCAN_TICKET / SCAN_DONE of both slots
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Whole-batch master reset decided INSIDE the step kernel (CARLE_STEP_DEFERRED): `torch.mean(action) == 1.0`
+// (env.py:208) depends on every action element of the batch, and every output cell depends on it.  A wavefront
+// whose own grid's action is NOT all ones knows the answer (no reset) -- that is every wavefront of every step an
+// agent drives.  A wavefront that finds its own action all ones calls this: the wavefronts in that situation verify
+// the N action grids together -- a ticket per grid from SCAN_TICKET, one count per all-ones grid in SCAN_DONE,
+// bit 31 of SCAN_DONE as soon as a grid is not -- with agent-scope atomics (coherent across the XCDs' L2s).  A
+// wavefront only ever waits for wavefronts that hold a ticket, i.e. that are running: nothing waits for a wavefront
+// that has not been dispatched (N may exceed the resident wavefronts).  The action tensor is read-only in the kernel.
+// Returns true iff every element of the batch's action equals one.  Cost when it does: the action is read twice.
+// ---------------------------------------------------------------------------------------------------------------
+template <class A>
+__device__ __noinline__ bool batch_action_all_ones(const typename A::T *act, int64_t n, int aw, int32_t *st, int slot) {
+    constexpr uint32_t kAbort = 0x80000000u;
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(st + CARLE_ST_SCAN_TICKET(slot));
+    uint32_t *done = reinterpret_cast<uint32_t *>(st + CARLE_ST_SCAN_DONE(slot));
+    const int lane = threadIdx.x & 63;
+    const int64_t grid_quads = (int64_t)aw * aw * (int64_t)sizeof(typename A::T) / 16;     // AW % 8 == 0: whole uint4s
+    for (;;) {
+        uint32_t h = 0;
+        if (lane == 0) h = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h = __builtin_amdgcn_readfirstlane(h);
+        if ((int64_t)h >= n) break;
+        const uint4 *p = reinterpret_cast<const uint4 *>(act) + (int64_t)h * grid_quads;
+        bool ones = true;
+        for (int64_t q = lane; q < grid_quads; q += 64) {
+            const uint4 a = p[q];
+            ones = ones && a.x == A::kOnes && a.y == A::kOnes && a.z == A::kOnes && a.w == A::kOnes;
+        }
+        const bool all = __ballot(!ones) == 0ull;
+        uint32_t d = 0;
+        if (lane == 0)
+            d = all ? __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u
+                    : __hip_atomic_fetch_or(done, kAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | kAbort;
+        d = __builtin_amdgcn_readfirstlane(d);
+        if (d & kAbort) return false;
+    }
+    for (;;) {                                   // every grid has a verifier; wait for those still reading
+        uint32_t d = 0;
+        if (lane == 0) d = __hip_atomic_fetch_or(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d = __builtin_amdgcn_readfirstlane(d);
+        if (d & kAbort) return false;
+        if ((int64_t)d >= n) return true;
+        __builtin_amdgcn_s_sleep(16);
+    }
 }
 
 // One generation of a 64x64 torus held as one 64-bit "patch" word per lane: lane (q = L/16,

@@ -10,7 +10,7 @@
 // wrap-around IS the y torus seam, taller grids load the two rows bordering the strip into lanes
 // 0 and 63.  Count = bit-sliced adders, rule = equality masks selected by the SGPR rule bits
 // (ca_bits.hpp).  No MFMA, no LDS.
-#include "ca_bits.hpp"
+#include "ca_cells.hpp"
 #include "common.hpp"
 #include "philox.hpp"
 #include <stdlib.h>
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(64 * WW) void ca_multistep_b1_kernel(
 
     // counters of k action-free steps (env.py:199-200, 230): step_number += k, steps_since_action += k
     if (status != nullptr && g == 0 && threadIdx.x == 0) {
+        settle_status_in_place(status);                   // a deferred one-launch step before this call
         int64_t *cnt = reinterpret_cast<int64_t *>(status);
         cnt[CARLE_ST_STEP_NUMBER / 2] += k;
         cnt[CARLE_ST_STEPS_SINCE_ACTION / 2] += k;

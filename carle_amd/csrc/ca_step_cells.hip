@@ -58,15 +58,30 @@ static bool stream_stores(int64_t state_bytes, size_t cell_bytes) {
     return cell_bytes != 4 || state_bytes > lim;
 }
 
+// ENV instantiation (CARLE_STEP_DEFERRED, carle_hip.h): the WHOLE CARLE.step in this one launch -- no epilogue kernel
+// behind it (a dependent dispatch costs ~2 us against a 32 us kernel at N=4096).  What carle_ca_finish does is split up:
+//   master reset    decided per wavefront: its own action not all ones -> no reset (always, for an agent's toggles);
+//                   else batch_action_all_ones() (ca_cells.hpp).  With pre-stored flags (publish == 0) every wave reads them.
+//   reward := 0     one store per wavefront
+//   reward moments  (n, 0, 0) merged by wavefront 0 (the reward of a bare step is all zero whatever the action was)
+//   counters        depend on the flags of THIS launch: left pending (CARLE_ST_PENDING), applied by the next launch on the
+//                   block -- here by wavefront 0, which settles the PREVIOUS step -- or by carle_env_settle
+struct EnvArgs {
+    float *reward = nullptr;       // N floats, zeroed (nullable)
+    int publish = 1;               // 0: the caller stored the action flags of `slot` beforehand
+    int merge_moments = 0;
+};
+
 template <class C, class A, bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256,
-          bool RAND_ACT = false>
+          bool RAND_ACT = false, bool ENV = false>
 __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
     const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
     typename C::T *__restrict__ u_out, int64_t n, int aw, uint32_t rule, int32_t *__restrict__ status,
-    int slot, RandAct ra = RandAct()) {
+    int slot, RandAct ra = RandAct(), EnvArgs ea = EnvArgs()) {
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (g >= n) return;                              // wave-uniform
+    static_assert(!(ENV && RAND_ACT), "the in-kernel random agent keeps the two-launch step");
     const int q = lane >> 4, k = lane & 15;
     const typename C::T *gin = u_in + g * 4096 + 4 * lane;   // 1024 quads per grid, 64 per load
 
@@ -79,6 +94,7 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
         for (int i = 0; i < 16; ++i) c |= (uint64_t)C::nibble(v[i]) << (4 * i);
     }
 
+    bool own_notone = true;                          // ENV: some action element of this grid differs from one
     if (HAS_ACT) {
         // window offset o = (64-aw)/2 is a multiple of 4 (host guarantees aw % 8 == 0), so a
         // lane's four columns are all inside or all outside the window
@@ -141,14 +157,73 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
             }
         }
         c ^= tog;                                    // toggle, env.py:182
-        publish_flags<A>(seen, status, slot);
+        if (!ENV) {
+            publish_flags<A>(seen, status, slot);
+        } else if (ea.publish) {
+            own_notone = publish_flags<A>(seen, status, slot);
+        }
     }
 
-    const uint64_t nxt = patch_generation64(c, lane, rule);
+    uint64_t nxt = patch_generation64(c, lane, rule);
+
+    if (ENV && HAS_ACT) {
+        // master reset (env.py:208-216): every action element of the WHOLE batch is one
+        bool reset;
+        if (!ea.publish) {
+            reset = __builtin_nontemporal_load(status + CARLE_ST_NOT_ALL_ONES(slot)) == 0;   // stored before the launch
+        } else {
+            reset = false;
+            if (__builtin_expect(!own_notone, 0)) reset = batch_action_all_ones<A>(act, n, aw, status, slot);
+        }
+        if (reset) nxt = 0ull;
+    }
 
     typename C::T *gout = u_out + g * 4096 + 4 * lane;
 #pragma unroll
     for (int i = 0; i < 16; ++i) C::template store<NT_ST>(gout + i * 256, (uint32_t)(nxt >> (4 * i)) & 0xFu);
+
+    if (ENV) {
+        if (ea.reward && lane == 0) ea.reward[g] = 0.0f;               // env.py:238
+        if (g == 0 && lane == 0) {
+            // bookkeeping by ONE thread of the launch: settle the previous step if it is still pending, recycle its flag
+            // slot (= the next step's), merge the moments of this step's all-zero reward, leave this step pending.
+            // The words of THIS step's slot are written by the other wavefronts meanwhile: they are not touched here
+            // (dword stores only where a 16-byte store would cover them).
+            uint4 *s4 = reinterpret_cast<uint4 *>(status);
+            uint4 w0 = s4[0], w1 = s4[1], w2 = s4[2];
+            const uint4 w3 = s4[3];
+            settle_pending(w0, w1, w2);
+            if (ea.merge_moments && ea.reward) {
+                double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
+                double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
+                if (mom_out && mom_acc) {
+                    const double nb = (double)n, na = mom_acc[0], ma = mom_acc[1], qa = mom_acc[2], tot = na + nb;
+                    mom_out[0] = nb; mom_out[1] = 0.0; mom_out[2] = 0.0;
+                    if (tot > 0.0) {
+                        mom_acc[0] = tot;
+                        mom_acc[1] = ma - ma * nb / tot;
+                        mom_acc[2] = qa + ma * ma * na * nb / tot;
+                    }
+                }
+            }
+            if (!HAS_ACT) {
+                // no action: no predicates, no reset (env.py:191,208) -- nothing to wait for, count the step now
+                int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z) + 1;
+                int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x) + 1;
+                w1.x = 0u;
+                w1.z = (uint32_t)step_number; w1.w = (uint32_t)((uint64_t)step_number >> 32);
+                w2.x = (uint32_t)since; w2.y = (uint32_t)((uint64_t)since >> 32);
+            } else {
+                w1.y = 1u | 2u | (slot ? 4u : 0u);                     // CARLE_ST_PENDING: this step
+            }
+            s4[1] = w1; s4[2] = w2;
+            const int other = slot ^ 1;
+            status[CARLE_ST_ANY_NONZERO(other)] = 0;
+            status[CARLE_ST_NOT_ALL_ONES(other)] = 0;
+            status[CARLE_ST_SCAN_TICKET(other)] = 0;
+            status[CARLE_ST_SCAN_DONE(other)] = 0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -294,7 +369,9 @@ __global__ __launch_bounds__(1024) void ca_env_run_small64_kernel(
         for (int i = 0; i < 16; ++i) c |= (uint64_t)nibble_of(v[i]) << (4 * i);
     }
     const uint4 *st4 = reinterpret_cast<const uint4 *>(st);
-    const uint4 w1 = st4[1], w2 = st4[2], w3 = st4[3];
+    uint4 w0s = st4[0], w1 = st4[1], w2 = st4[2];
+    const uint4 w3 = st4[3];
+    settle_pending(w0s, w1, w2);                           // a deferred one-launch step before this call
     int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z);
     int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x);
     int64_t resets = (int64_t)(((uint64_t)w2.w << 32) | w2.z);
@@ -392,6 +469,7 @@ __global__ __launch_bounds__(1024) void ca_env_run_small64_kernel(
         o2.z = (uint32_t)resets; o2.w = (uint32_t)((uint64_t)resets >> 32);
         uint4 *so = reinterpret_cast<uint4 *>(st);
         so[0] = o0; so[1] = o1; so[2] = o2;
+        so[4] = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -425,7 +503,9 @@ __global__ __launch_bounds__(64) void ca_run_noaction64_kernel(const float *__re
     if (reward && lane == 0) reward[g] = 0.0f;             // env.py:238
     if (g == 0 && lane == 0 && steps > 0) {
         const uint4 *st4 = reinterpret_cast<const uint4 *>(st);
-        const uint4 w0 = st4[0], w1 = st4[1], w2 = st4[2], w3 = st4[3];
+        uint4 w0 = st4[0], w1 = st4[1], w2 = st4[2];
+        const uint4 w3 = st4[3];
+        settle_pending(w0, w1, w2);                         // a deferred one-launch step before this call
         if (merge_moments && reward) {
             double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
             double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
@@ -454,6 +534,7 @@ __global__ __launch_bounds__(64) void ca_run_noaction64_kernel(const float *__re
         o2.x = (uint32_t)since; o2.y = (uint32_t)((uint64_t)since >> 32);
         uint4 *so = reinterpret_cast<uint4 *>(st);
         so[0] = o0; so[1] = o1; so[2] = o2;
+        so[4] = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -918,6 +999,50 @@ static int ca_step_cells(const typename C::T *u_in, const typename A::T *action,
     return check_launch(who);
 }
 
+// CARLE_STEP_DEFERRED: the whole step of a 64x64 batch in ONE launch (ca_step_64_kernel<..., ENV>); -1000 when the
+// geometry does not qualify (the caller then takes step kernel + epilogue kernel).
+template <class C, class A>
+static int env_step_one_launch(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
+                               float *reward, int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status,
+                               int slot, int step_flags, void *stream, const char *who) {
+    if (h != 64 || w != 64 || n < 1 || n > 0x7FFFFFFFll || !status || (action && (aw % 8) != 0)) return -1000;
+    if (knobs().two_launch_step > 0) return -1000;                     // A/B switch (CARLE_TWO_LAUNCH_STEP)
+    auto fail = [&](int code, const char *what) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "%s: %s", who, what);
+        return fail_arg(code, buf);
+    };
+    if (!u_in || !u_out) return fail(CARLE_E_NULL, "u_in/u_out is NULL");
+    if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
+    if (rule >> 18) return fail(CARLE_E_RULE, "rule mask exceeds 18 bits");
+    if (slot != 0 && slot != 1) return fail(CARLE_E_DIMS, "slot must be 0 or 1");
+    if (!aligned16(u_in) || !aligned16(u_out) || (action && !aligned16(action)) || !aligned16(status))
+        return fail(CARLE_E_ALIGN, "pointers must be 16-byte aligned");
+    const size_t bytes = (size_t)n * h * w * sizeof(typename C::T);
+    if (overlap(u_in, bytes, u_out, bytes)) return fail(CARLE_E_ALIAS, "u_in and u_out overlap");
+    EnvArgs ea;
+    ea.reward = reward;
+    ea.publish = (step_flags & CARLE_STEP_PUBLISH_FLAGS) ? 1 : 0;
+    ea.merge_moments = (step_flags & CARLE_STEP_MERGE_MOMENTS) ? 1 : 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)n), block(64);
+    const bool nt_st = stream_stores((int64_t)bytes, sizeof(typename C::T));
+    const RandAct ra;
+    if (action && nt_st)
+        hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, true, 64, false, true>), grid, block, 0, s, u_in, action,
+                           u_out, n, aw, rule, status, slot, ra, ea);
+    else if (action)
+        hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, false, 64, false, true>), grid, block, 0, s, u_in, action,
+                           u_out, n, aw, rule, status, slot, ra, ea);
+    else if (nt_st)
+        hipLaunchKernelGGL((ca_step_64_kernel<C, A, false, true, true, 64, false, true>), grid, block, 0, s, u_in, action,
+                           u_out, n, 0, rule, status, slot, ra, ea);
+    else
+        hipLaunchKernelGGL((ca_step_64_kernel<C, A, false, true, false, 64, false, true>), grid, block, 0, s, u_in, action,
+                           u_out, n, 0, rule, status, slot, ra, ea);
+    return check_launch(who);
+}
+
 template <class C, class A>
 static int ca_toggle_cells(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
                            int64_t n, int h, int w, int ah, int aw, void *stream, const char *who) {
@@ -1022,6 +1147,26 @@ int env_step_small64_rand(const float *u_in, float *u_out, float *reward, int64_
     ra.p = p; ra.seed = seed; ra.offset = offset; ra.action_out = action_out;
     if (action_out && !aligned16(action_out)) return -1000;
     return env_step_small64(u_in, nullptr, u_out, reward, n, h, w, ah, aw, rule, status, slot, step_flags, &ra, stream);
+}
+}  // namespace carle
+
+namespace carle {
+int env_step_one_launch_f32(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h,
+                            int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
+                            void *stream) {
+    return env_step_one_launch<F32Cells, F32Cells>(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
+                                                   step_flags, stream, "carle_env_step_f32");
+}
+int env_step_one_launch_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out, float *reward,
+                           int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
+                           int step_flags, void *stream) {
+    if (action_fmt == CARLE_FMT_U8)
+        return env_step_one_launch<U8Cells, U8Cells>(u_in, static_cast<const uint8_t *>(action), u_out, reward, n, h, w,
+                                                     ah, aw, rule, status, slot, step_flags, stream, "carle_env_step_u8");
+    if (action_fmt == CARLE_FMT_F32)
+        return env_step_one_launch<U8Cells, F32Cells>(u_in, static_cast<const float *>(action), u_out, reward, n, h, w,
+                                                      ah, aw, rule, status, slot, step_flags, stream, "carle_env_step_u8");
+    return -1000;
 }
 }  // namespace carle
 

@@ -112,7 +112,7 @@ class CARLE(RLEMixin, nn.Module):
         self.birth = [3]                                         # Conway's Life, env.py:58-59
         self.survive = [2, 3]
 
-        self._status = None          # device int32[16]: flags + counters (include/carle_hip.h)
+        self._status = None          # device int32[32]: flags + counters (include/carle_hip.h)
         self._slot = 0
         self._reward_stats = None    # dist.RunningRewardStats whose triples the step epilogue feeds
         self._moments_merged = False
@@ -193,15 +193,23 @@ class CARLE(RLEMixin, nn.Module):
         self._status[hip.ST_MOMENTS_OUT:hip.ST_MOMENTS_OUT + 4] = \
             ptrs.view(torch.int32).to(self._status.device, non_blocking=True)
 
+    def settled_status(self):
+        """The status block with every finished step applied to the counters: the one-launch step
+        (CARLE_STEP_DEFERRED, carle_hip.h) leaves its counter update pending until the next call on the block."""
+        if self._status is not None and self._status.is_cuda:
+            hip.env_settle(self._status)
+        return self._status
+
     def _read_counter(self, idx):
         if self._status is None:
             return 0
-        host = self._status.cpu()                 # lazy synchronisation point
+        host = self.settled_status().cpu()        # lazy synchronisation point
         return int(host[idx:idx + 2].view(torch.int64).item())
 
     def _write_counter(self, idx, value):
         if self._status is None:
             return
+        self.settled_status()                     # a pending step must not be applied on top of the new value
         v = torch.tensor([int(value)], dtype=torch.int64).view(torch.int32)
         self._status[idx:idx + 2] = v.to(self._status.device, non_blocking=True)
 

@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 
-STATUS_WORDS = 16
+STATUS_WORDS = 32
 ST_LAST_RESET, ST_STEP_NUMBER, ST_STEPS_SINCE_ACTION, ST_RESETS = 4, 6, 8, 10
 ST_MOMENTS_OUT, ST_MOMENTS_ACC = 12, 14      # two 64-bit device pointers (see carle_hip.h)
 
@@ -81,6 +81,21 @@ def rule_mask(birth, survive):
 def new_status(device):
     """Zeroed per-environment status block (layout: include/carle_hip.h CARLE_ST_*)."""
     return torch.zeros(STATUS_WORDS, dtype=torch.int32, device=device)
+
+
+def env_settle(status):
+    """Applies a pending one-launch (CARLE_STEP_DEFERRED) step to the counters of the status block; call before
+    reading them.  One tiny kernel on the current stream, no host synchronisation."""
+    lib = _lib.load()
+    with _on_device(status.device):
+        rc = lib.carle_env_settle(status.data_ptr(), _stream(status))
+    _lib.check(rc, "carle_env_settle")
+    return status
+
+
+def reload_knobs():
+    """Re-reads the CARLE_* experiment knobs from the environment (the library reads them once, at first use)."""
+    _lib.load().carle_reload_knobs()
 
 
 def ca_step_f32(u_in, action, u_out, rule, status=None, slot=0):
@@ -222,14 +237,17 @@ def normalize_f32(x, moments, eps=1e-8):
     return y
 
 
-def _step_flags(publish_flags, merge_moments):
+def _step_flags(publish_flags, merge_moments, deferred=False):
     """`publish_flags` argument of the carle_env_step_* entry points (CARLE_STEP_* bits)."""
-    return (1 if publish_flags else 0) | (2 if merge_moments else 0)
+    return (1 if publish_flags else 0) | (2 if merge_moments else 0) | (4 if deferred else 0)
 
 
-def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False):
-    """CARLE.step hot path: fused CA kernel + epilogue, one library call (shapes are validated by
-    the caller; pointers by the library)."""
+def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False,
+                 deferred=True):
+    """CARLE.step hot path, one library call (shapes are validated by the caller; pointers by the library).
+    deferred (default): ONE kernel launch where the library has a one-launch step (64x64 grids: master reset and
+    reward inside the step kernel, counters settled lazily -- read them through ``env_settle``); else step kernel +
+    epilogue kernel."""
     lib = _lib.load()
     n, _, h, w = u_in.shape
     if action is None:
@@ -239,13 +257,13 @@ def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=
     with _on_device(u_in.device):
         rc = lib.carle_env_step_f32(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h,
                                     w, ah, aw, rule, status.data_ptr(), slot,
-                                    _step_flags(publish_flags, merge_moments), _stream(u_in))
+                                    _step_flags(publish_flags, merge_moments, deferred), _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_step_f32")
 
 
 def env_run_f32(buf_a, buf_b, actions, reward, rule, status, slot0, k, ah=0, aw=0, p=-1.0, seed=0, offset=0,
-                merge_moments=False):
+                merge_moments=False, deferred=True):
     """k CARLE.step calls in one library call (carle_env_run_f32): state in buf_a on entry, in
     buf_a / buf_b for even / odd k on return.  actions: (k,N,1,AH,AW) fp32 or None (then p >= 0
     draws Bernoulli(p) toggles in the kernel, p < 0 means no action)."""
@@ -260,7 +278,7 @@ def env_run_f32(buf_a, buf_b, actions, reward, rule, status, slot0, k, ah=0, aw=
     with _on_device(buf_a.device):
         rc = lib.carle_env_run_f32(buf_a.data_ptr(), buf_b.data_ptr(), ap, reward.data_ptr(), n, h, w, ah, aw,
                                    rule, float(p), int(seed), int(offset), int(k), status.data_ptr(), slot0,
-                                   _step_flags(False, merge_moments), _stream(buf_a))
+                                   _step_flags(False, merge_moments, deferred), _stream(buf_a))
     if rc != 0:
         _lib.check(rc, "carle_env_run_f32")
 
@@ -389,8 +407,9 @@ def ca_step_u8(u_in, action, u_out, rule, status=None, slot=0):
     _lib.check(rc, "carle_ca_step_u8")
 
 
-def env_step_u8(u_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False):
-    """CARLE.step hot path on uint8 state: step kernel + epilogue, one library call."""
+def env_step_u8(u_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False,
+                deferred=True):
+    """CARLE.step hot path on uint8 state, one library call (``deferred`` as for env_step_f32)."""
     lib = _lib.load()
     n, _, h, w = u_in.shape
     if action is None:
@@ -400,7 +419,7 @@ def env_step_u8(u_in, action, u_out, reward, rule, status, slot, publish_flags=T
     with _on_device(u_in.device):
         rc = lib.carle_env_step_u8(u_in.data_ptr(), ap, fmt, u_out.data_ptr(), reward.data_ptr(), n, h,
                                    w, ah, aw, rule, status.data_ptr(), slot,
-                                   _step_flags(publish_flags, merge_moments), _stream(u_in))
+                                   _step_flags(publish_flags, merge_moments, deferred), _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_step_u8")
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CARLE_ABI_VERSION 1
+#define CARLE_ABI_VERSION 2
 
 /* argument error codes (positive return values) */
 #define CARLE_E_NULL      1   /* required pointer is NULL */
@@ -44,17 +44,25 @@ extern "C" {
 #define CARLE_FMT_B1  2   /* 1 bit per cell: W/64 little-endian uint64 words per row, bit j of
                              word i = column 64*i+j; requires W % 64 == 0                     */
 
-/* Layout of the per-environment device status block (int32[16], zero-initialised by the
- * caller once).  Two flag slots alternate between consecutive steps (slot = step parity). */
+/* Layout of the per-environment device status block (int32[CARLE_ST_WORDS] = 128 bytes, 16-byte aligned,
+ * zero-initialised by the caller once).  Two flag slots alternate between consecutive steps (slot = step
+ * parity): consecutive steps of one environment MUST use alternating slots. */
 #define CARLE_ST_ANY_NONZERO(slot)   (0 + (slot))   /* some action element != 0   (env.py:191) */
 #define CARLE_ST_NOT_ALL_ONES(slot)  (2 + (slot))   /* some action element != 1.0 (env.py:208) */
 #define CARLE_ST_LAST_RESET          4              /* 1 if the last finished step was a master reset */
+#define CARLE_ST_PENDING             5              /* bookkeeping of a CARLE_STEP_DEFERRED step not yet applied to the
+                                                       counters: bit 0 = pending, bit 1 = the step had an action,
+                                                       bit 2 = its flag slot.  Applied by the next step / finish /
+                                                       run / multistep call on this block, or by carle_env_settle */
 #define CARLE_ST_STEP_NUMBER         6              /* int64 at int32 index 6..7  (env.py:142,230) */
 #define CARLE_ST_STEPS_SINCE_ACTION  8              /* int64 at int32 index 8..9  (env.py:145,200) */
 #define CARLE_ST_RESETS              10             /* int64 at int32 index 10..11: number of master resets */
 #define CARLE_ST_MOMENTS_OUT         12             /* device pointer (64 bit) at index 12..13: double[3], see below */
 #define CARLE_ST_MOMENTS_ACC         14             /* device pointer (64 bit) at index 14..15: double[3], see below */
-#define CARLE_ST_WORDS               16
+#define CARLE_ST_SCAN_TICKET(slot)   (16 + (slot))  /* transient, in-kernel: next action grid to verify ...         */
+#define CARLE_ST_SCAN_DONE(slot)     (18 + (slot))  /* ... and number verified all-ones, bit 31 = one was not (see
+                                                       CARLE_STEP_DEFERRED); both are zero between steps              */
+#define CARLE_ST_WORDS               32             /* words 20..31 reserved, zero */
 
 /* `publish_flags` argument of the carle_env_step_* entry points (bit set) */
 #define CARLE_STEP_PUBLISH_FLAGS     1   /* the step kernel writes the action predicates into the status block */
@@ -64,10 +72,29 @@ extern "C" {
                                             of carle_batch_moments_f32 without a third launch.  Ignored while the
                                             two pointer slots of the status block are zero. */
 
+#define CARLE_STEP_DEFERRED          4   /* ONE kernel launch per step where the geometry allows it (64x64 fp32 /
+                                            uint8 grids, AW % 8 == 0, more than 16 instances, action tensor or
+                                            none): the step kernel applies the master reset itself, writes the zero
+                                            reward and (MERGE_MOMENTS) the moments of the all-zero reward, and leaves
+                                            the counter update of env.py:191-230 PENDING in the status block
+                                            (CARLE_ST_PENDING).  Grids, reward and moments are final when the kernel
+                                            ends; step_number / steps_since_action / resets / LAST_RESET are valid
+                                            after the next call on the block or after carle_env_settle().  Other
+                                            geometries ignore the bit (step kernel + carle_ca_finish).
+                                            How the kernel decides the WHOLE-BATCH reset without a second launch: a
+                                            wavefront that finds its own grid's action all ones (never the case for
+                                            an agent's toggles) verifies the other grids' actions together with the
+                                            other such wavefronts -- tickets from SCAN_TICKET, results in SCAN_DONE,
+                                            agent-scope atomics, no wavefront ever waits for one that has not
+                                            started -- and zeroes its grid iff all N were verified. */
+
 int         carle_abi_version(void);
 const char *carle_last_error(void);
 /* "gfx950" etc.: the offload architectures compiled into the library */
 const char *carle_build_arch(void);
+/* Experiment knobs (CARLE_* environment variables, DESIGN.md "Knobs") are read once, at first use; this re-reads
+ * them.  For tests and A/B tools; not safe while another thread is inside a carle_* call. */
+void        carle_reload_knobs(void);
 
 /*
  * One CA generation, fp32 drop-in format.  Replaces CARLE.apply_action + the update branch of
@@ -178,6 +205,10 @@ int carle_ca_finish(void *u_out, int64_t u_out_bytes, float *reward, int64_t n,
 int carle_env_step_f32(const float *u_in, const float *action, float *u_out, float *reward,
                        int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                        int32_t *status, int slot, int publish_flags, void *stream);
+
+/* Applies a pending CARLE_STEP_DEFERRED step to the counters of the status block (one tiny kernel; a no-op on the
+ * device when nothing is pending).  Call before copying the counters to the host (env.py:142-145,199-200,230). */
+int carle_env_settle(int32_t *status, void *stream);
 
 /*
  * k consecutive CARLE.step calls (carle/env.py:188-242) in one library call -- the inner loop of

@@ -21,7 +21,10 @@ int main(void) {
                              CARLE_STEP_PUBLISH_FLAGS | CARLE_STEP_MERGE_MOMENTS, NULL) == CARLE_E_NULL);
     CHECK(carle_ca_multistep_b1((const uint64_t *)grid, (uint64_t *)grid, 0, 64, 64, 0, 4, status, NULL) == 0);
     CHECK(carle_rnd2d_workspace_floats(16, 256, 256) > 0 && carle_ae2d_workspace_floats(16, 256, 256) > 0);
-    CHECK(CARLE_ST_MOMENTS_ACC + 2 == CARLE_ST_WORDS);
+    CHECK(CARLE_ST_SCAN_DONE(1) < CARLE_ST_WORDS && CARLE_ST_WORDS * 4 == 128);
+    CHECK(carle_env_settle(NULL, NULL) == CARLE_E_NULL);
+    CHECK(carle_env_settle(status + 1, NULL) == CARLE_E_ALIGN);
+    carle_reload_knobs();
     printf("abi ok\n");
     return 0;
 }

@@ -61,6 +61,38 @@ int main(void) {
     CHECK(memcmp(hout, href, cells * 4) == 0);
     HIPCHK(hipMemcpy(hst, dst, sizeof hst, hipMemcpyDeviceToHost));
     CHECK(hst[CARLE_ST_STEP_NUMBER] == 0 && hst[CARLE_ST_LAST_RESET] == 1 && hst[CARLE_ST_RESETS] == 1);
+    /* the same five steps + the reset as ONE launch each (CARLE_STEP_DEFERRED): grids final at once, counters after
+     * carle_env_settle (or the next call on the block) */
+    HIPCHK(hipMemset(dst, 0, CARLE_ST_WORDS * 4));
+    {
+        unsigned s2 = 777u;
+        for (size_t i = 0; i < cells; ++i) { s2 = s2 * 1664525u + 1013904223u; hu[i] = (s2 >> 24) < 96 ? 1.0f : 0.0f; }
+        HIPCHK(hipMemcpy(du, hu, cells * 4, hipMemcpyHostToDevice));
+        for (int t = 0; t < steps + 1; ++t) {
+            for (size_t i = 0; i < cells; ++i) { s2 = s2 * 1664525u + 1013904223u; ha[i] = (t == steps || (s2 >> 24) < 26) ? 1.0f : 0.0f; }
+            if (t == 2) memset(ha, 0, cells * 4);                       /* an all-zero action: steps_since_action */
+            HIPCHK(hipMemcpy(da, ha, cells * 4, hipMemcpyHostToDevice));
+            CHECK(carle_env_step_f32(du, da, dv, dr, n, h, w, 64, 64, life, dst, t & 1,
+                                     CARLE_STEP_PUBLISH_FLAGS | CARLE_STEP_DEFERRED, NULL) == 0);
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemcpy(hout, dv, cells * 4, hipMemcpyDeviceToHost));
+            CHECK(oracle_env_step(hu, ha, href, hscr, n, h, w, 64, 64, life, NULL) == (t == steps));
+            CHECK(memcmp(hout, href, cells * 4) == 0);
+            memcpy(hu, href, cells * 4);
+            float *tmp = du; du = dv; dv = tmp;
+            if (t == steps - 1) {
+                CHECK(carle_env_settle(dst, NULL) == 0);
+                HIPCHK(hipMemcpy(hst, dst, sizeof hst, hipMemcpyDeviceToHost));
+                CHECK(hst[CARLE_ST_STEP_NUMBER] == steps && hst[CARLE_ST_STEPS_SINCE_ACTION] == 1 && hst[CARLE_ST_PENDING] == 0);
+            }
+        }
+        HIPCHK(hipMemcpy(hst, dst, sizeof hst, hipMemcpyDeviceToHost));
+        CHECK(hst[CARLE_ST_PENDING] != 0);                              /* the reset step is still pending ... */
+        CHECK(carle_env_settle(dst, NULL) == 0);
+        HIPCHK(hipMemcpy(hst, dst, sizeof hst, hipMemcpyDeviceToHost));  /* ... and applied here */
+        CHECK(hst[CARLE_ST_STEP_NUMBER] == 0 && hst[CARLE_ST_LAST_RESET] == 1 && hst[CARLE_ST_RESETS] == 1 && hst[CARLE_ST_PENDING] == 0);
+        CHECK(hst[CARLE_ST_SCAN_TICKET(0)] == 0 && hst[CARLE_ST_SCAN_TICKET(1)] == 0 && hst[CARLE_ST_SCAN_DONE(0)] == 0 && hst[CARLE_ST_SCAN_DONE(1)] == 0);
+    }
     /* one generation on bit-packed state, no action */
     CHECK(carle_pack_f32_b1(du, dp, n, h, w, NULL, 0, NULL) == 0);
     CHECK(carle_ca_step_b1(dp, NULL, dq, n, h, w, 0, 0, life, NULL, 0, NULL) == 0);

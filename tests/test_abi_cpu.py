@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, nm), f"{nm} declared in carle_hip.h but not exported"
         assert nm in _lib.SIGNATURES, f"{nm} has no ctypes signature in carle_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.carle_abi_version() == 1
+    assert lib.carle_abi_version() == _lib.ABI_VERSION == 2
     assert lib.carle_build_arch() == b"gfx950"
 
 

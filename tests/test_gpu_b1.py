@@ -10,6 +10,13 @@ from oracle import ca as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _restore_knobs():
+    yield
+    from carle_amd import hip             # after monkeypatch has undone its setenv calls (fixtures unwind in reverse)
+    hip.reload_knobs()
+
+
 def np_pack(a):
     """(N,1,H,W) 0/1 -> (N,1,H,W/64) int64, bit j of word i = column 64*i+j."""
     n, _, h, w = a.shape
@@ -59,6 +66,7 @@ def test_step_b1_against_oracle(n, size, asize, rule, strip_path, monkeypatch):
     elif strip_path == "lds+nt":
         monkeypatch.setenv("CARLE_B1_LDS_MIN_BYTES", "0")
         monkeypatch.setenv("CARLE_B1_NT_MIN_BYTES", "0")
+    hip.reload_knobs()                    # the library reads its knobs once; the fixture below restores them
     rng = np.random.default_rng(n * 7 + size + asize)
     mask = O.rule_mask(*rule)
     u = (rng.random((n, 1, size, size)) < 0.4).astype(np.float32)

@@ -509,7 +509,7 @@ def test_run_without_action_equals_multistep(n):
         ob = env_b.step(torch.zeros(n, 1, 64, 64))[0]
     assert torch.equal(oa, ob) and env_a.step_number == env_b.step_number == 19
     assert env_a.steps_since_action == env_b.steps_since_action == 19
-    assert env_a._status.cpu().tolist()[4:12] == env_b._status.cpu().tolist()[4:12]      # counters, last-reset word
+    assert env_a.settled_status().cpu().tolist()[4:12] == env_b.settled_status().cpu().tolist()[4:12]      # counters, last-reset word
     # and an action afterwards behaves as usual (flag slots / parity carried over)
     a = (torch.rand(n, 1, 64, 64) < 0.2).float()
     assert torch.equal(env_a.step(a)[0], env_b.step(a)[0])

@@ -213,7 +213,7 @@ def test_run_merges_reward_moments_like_the_step_loop(n):
         else:
             obs, reward, done, info = env.run(steps=3)
         # (words 0..3 are the transient action-flag slots: an explicit all-zero action leaves NOT_ALL_ONES behind, no action nothing)
-        res.append((obs.cpu().numpy(), reward.cpu().numpy(), env._status.cpu().tolist()[4:12], stats._pending.cpu().numpy(),
+        res.append((obs.cpu().numpy(), reward.cpu().numpy(), env.settled_status().cpu().tolist()[4:12], stats._pending.cpu().numpy(),
                     env.step_number, env.steps_since_action, env.master_resets))
     a, b = res
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -1,0 +1,230 @@
+"""GPU parity tests of the ONE-LAUNCH step (CARLE_STEP_DEFERRED, include/carle_hip.h): 64x64 batches of more than 16
+instances run CARLE.step (carle/env.py:188-242) as a single kernel -- master reset decided inside the step kernel, zero
+reward and reward moments written by it, counters settled lazily.  Checked against
+  (1) the golden cases recorded from the genuine reference, replicated along the batch axis (every replica must follow
+      the recorded grids and counters, master reset included),
+  (2) the C oracle and the two-launch path (step kernel + carle_ca_finish) on crafted action sequences: all ones
+      everywhere, all ones but one element, all-ones grids among others, non-binary values, windows of 8 ... 64,
+  (3) batches larger than the resident wavefronts (the in-kernel verification must never wait for a wavefront that
+      has not started), uint8 state, mixtures with run() / multistep() / the epilogue paths.
+Bit-exact everywhere."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from oracle import ca as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(**kw):
+    from carle_amd.env import CARLE
+    return CARLE(device="cuda:0", **kw)
+
+
+def _cases64():
+    names = [nm for nm in G.ca_case_names() if G.ca_case(nm).size == 64 and G.ca_case(nm).meta["action_kind"] != "oversize"
+             and G.ca_case(nm).steps <= 64]
+    return names + ["pred:" + nm for nm in G.predicate_case_names() if G.predicate_case(nm).size == 64]
+
+
+@pytest.mark.parametrize("storage", ["f32", "u8"])
+@pytest.mark.parametrize("name", _cases64())
+def test_replicated_golden_case_through_one_launch_step(name, storage):
+    """Every recorded 64x64 case, tiled to more than 16 instances: each replica reproduces the reference's grids, the
+    counters follow the recording (an all-ones action is all ones in every replica: the master reset fires)."""
+    pred = name.startswith("pred:")
+    c = G.predicate_case(name[5:]) if pred else G.ca_case(name)
+    if pred and "cancel" not in name:
+        pytest.skip("mean == 1.0 without all ones: exact predicates only (test_gpu_ca.py)")
+    reps = 17 // c.n + 1
+    n = reps * c.n
+    env = _env(width=64, height=64, action_width=c.asize, action_height=c.asize, instances=n, storage=storage)
+    env.birth, env.survive = list(c.birth), list(c.survive)
+    env.reset()
+    env.universe = torch.from_numpy(np.tile(c.init, (reps, 1, 1, 1))).cuda()
+    rec = 0
+    for t in range(c.steps):
+        a = torch.from_numpy(np.tile(c.actions[t], (reps, 1, 1, 1))).cuda()
+        obs, reward, done, info = env.step(a)
+        if (t + 1) in c.record:
+            got = env.universe.float().cpu().numpy()
+            assert np.array_equal(got, np.tile(c.obs[rec], (reps, 1, 1, 1))), f"grid mismatch at step {t + 1}"
+            assert float(reward.abs().sum()) == 0.0
+            assert env.step_number == c.step_number[t]
+            if not pred:                      # cancelling values: the documented default-predicate deviation
+                assert env.steps_since_action == c.steps_since_action[t]
+            rec += 1
+    assert rec == len(c.record)
+
+
+def _oracle_loop(u, actions, rule):
+    """-> list of (grid, step_number, steps_since_action, resets) after every step (kernel predicates)."""
+    sn = ssa = rs = 0
+    out = []
+    for a in actions:
+        if a is None or not (a != 0).any():
+            ssa += 1
+        nxt, reset, _ = O.c_env_step(u, a, rule)
+        if reset:
+            sn, ssa, rs = 0, 0, rs + 1
+        else:
+            sn += 1
+        u = nxt
+        out.append((u, sn, ssa, rs))
+    return out
+
+
+def _crafted_actions(rng, n, aw):
+    ones = np.ones((n, 1, aw, aw), np.float32)
+    acts = []
+    acts.append((rng.random((n, 1, aw, aw)) < 0.1).astype(np.float32))
+    acts.append(np.zeros((n, 1, aw, aw), np.float32))
+    acts.append(ones.copy())                                             # master reset
+    a = ones.copy(); a[n - 1, 0, aw - 1, aw - 1] = 0.0; acts.append(a)    # all ones but the very last element
+    a = ones.copy(); a[0, 0, 0, 0] = 2.0; acts.append(a)                 # ... but the very first, and non-zero
+    a = (rng.random((n, 1, aw, aw)) < 0.5).astype(np.float32); a[1] = 1.0; a[n // 2] = 1.0; a[n - 1] = 1.0
+    acts.append(a)                                                       # all-ones grids among ordinary ones
+    a = ones.copy(); a[n // 3, 0, aw // 2, 3] = np.float32("nan"); acts.append(a)
+    acts.append(ones.copy())                                             # and a second reset
+    a = (rng.random((n, 1, aw, aw)) < 0.3).astype(np.float32)
+    a[a != 0] = rng.choice(np.array([1.0, 0.5, -1.0, np.inf], np.float32), int((a != 0).sum()))
+    acts.append(a)
+    acts.append(None)
+    a = ones.copy(); a[:, :, :, 0] = -0.0; acts.append(a)
+    return acts
+
+
+@pytest.mark.parametrize("storage", ["f32", "u8"])
+@pytest.mark.parametrize("n,aw", [(17, 64), (100, 64), (1030, 32), (64, 8), (333, 48)])
+def test_one_launch_step_against_oracle_and_two_launch_path(n, aw, storage):
+    from carle_amd import hip
+    rng = np.random.default_rng(n * 100 + aw)
+    rule = O.rule_mask([3, 6], [2, 3])
+    u0 = (rng.random((n, 1, 64, 64)) < 0.4).astype(np.float32)
+    acts = _crafted_actions(rng, n, aw)
+    ref = _oracle_loop(u0, acts, rule)
+    dt = torch.float32 if storage == "f32" else torch.uint8
+    for deferred in (True, False):
+        st = hip.new_status("cuda:0")
+        mom_out = torch.zeros(3, dtype=torch.float64, device="cuda")
+        mom_acc = torch.zeros(3, dtype=torch.float64, device="cuda")
+        st[12:16] = torch.tensor([mom_out.data_ptr(), mom_acc.data_ptr()], dtype=torch.int64).view(torch.int32).cuda()
+        cur = torch.from_numpy(u0).cuda().to(dt)
+        for t, a in enumerate(acts):
+            nxt = torch.full_like(cur, 7)
+            reward = torch.full((n, 1), 3.0, device="cuda")
+            d_a = None if a is None else torch.from_numpy(a).cuda()
+            if storage == "f32":
+                hip.env_step_f32(cur, d_a, nxt, reward, rule, st, t & 1, True, True, deferred=deferred)
+            else:
+                hip.env_step_u8(cur, d_a, nxt, reward, rule, st, t & 1, True, True, deferred=deferred)
+            exp, sn, ssa, rs = ref[t]
+            assert np.array_equal(nxt.float().cpu().numpy(), exp), (deferred, t)
+            assert float(reward.abs().sum()) == 0.0
+            raw = st.cpu()
+            if deferred:
+                assert raw[5].item() == (0 if a is None else 3 | (4 if t & 1 else 0)), (t, raw.tolist())
+            s = hip.env_settle(st).cpu()
+            assert s[5].item() == 0 and s[16:20].tolist() == [0, 0, 0, 0], s.tolist()
+            assert int(s[6:8].view(torch.int64)) == sn and int(s[8:10].view(torch.int64)) == ssa, (deferred, t)
+            assert int(s[10:12].view(torch.int64)) == rs and s[4].item() == int(rs > (ref[t - 1][3] if t else 0))
+            assert mom_acc.cpu().tolist() == [float(n * (t + 1)), 0.0, 0.0] and mom_out.cpu().tolist() == [float(n), 0.0, 0.0]
+            cur = nxt
+
+
+def test_counters_settle_through_the_next_step_without_an_explicit_settle():
+    """Unsettled steps chain: every launch applies its predecessor's bookkeeping (no carle_env_settle in between)."""
+    n = 40
+    env = _env(width=64, height=64, instances=n)
+    env.reset()
+    rng = np.random.default_rng(5)
+    u0 = (rng.random((n, 1, 64, 64)) < 0.3).astype(np.float32)
+    env.universe = torch.from_numpy(u0).cuda()
+    acts = _crafted_actions(rng, n, 64) * 2
+    ref = _oracle_loop(u0, acts, env.rule_mask())
+    for t, a in enumerate(acts):
+        obs = env.step(torch.zeros(n, 1, 64, 64, device="cuda") if a is None else torch.from_numpy(a).cuda())[0]
+        assert np.array_equal(obs.cpu().numpy(), ref[t][0]), t
+    exp_ssa = ref[-1][2]
+    assert (env.step_number, env.master_resets) == (ref[-1][1], ref[-1][3])
+    assert env.steps_since_action == exp_ssa
+
+
+@pytest.mark.parametrize("storage", ["f32", "u8"])
+def test_master_reset_of_a_batch_larger_than_the_resident_wavefronts(storage):
+    """20000 wavefronts (the chip holds 8192 at most): an all-ones action everywhere zeroes every grid, all ones but
+    the last element of the last grid steps normally -- the wavefronts that verify the batch never wait for one that
+    has not been dispatched."""
+    from carle_amd import hip
+    n = 20000
+    rule = O.rule_mask([3], [2, 3])
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dt = torch.float32 if storage == "f32" else torch.uint8
+    u = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.4).to(dt)
+    a = torch.ones(n, 1, 64, 64, device="cuda", dtype=dt)
+    out = torch.full_like(u, 5)
+    reward = torch.empty(n, 1, device="cuda")
+    st = hip.new_status("cuda:0")
+    step = hip.env_step_f32 if storage == "f32" else hip.env_step_u8
+    step(u, a, out, reward, rule, st, 0)
+    assert int(out.count_nonzero()) == 0
+    s = hip.env_settle(st).cpu()
+    assert s[4].item() == 1 and int(s[10:12].view(torch.int64)) == 1 and int(s[6:8].view(torch.int64)) == 0
+    for where in ((n - 1, 63, 63), (0, 0, 0), (n // 2, 31, 7)):
+        a2 = a.clone()
+        a2[where[0], 0, where[1], where[2]] = 0
+        out.fill_(5)
+        step(u, a2, out, reward, rule, st, 1)
+        idx = sorted({0, 1, where[0], n // 2, n - 1})
+        exp, reset, _ = O.c_env_step(u[idx].float().cpu().numpy(), a2[idx].float().cpu().numpy(), rule)
+        assert np.array_equal(out[idx].float().cpu().numpy(), exp)
+        # toggling every cell but one, then one generation: the same as the complement stepped
+        ref = torch.empty_like(u)
+        hip.ca_step_f32(u, a2, ref, rule, None, 0) if storage == "f32" else hip.ca_step_u8(u, a2, ref, rule, None, 0)
+        assert torch.equal(out, ref)
+        s = hip.env_settle(st).cpu()
+        assert s[4].item() == 0 and s[16:20].tolist() == [0, 0, 0, 0]
+        st[0:4] = 0
+
+
+def test_one_launch_steps_mixed_with_run_multistep_and_exact_predicates():
+    n = 48
+    rng = np.random.default_rng(11)
+    u0 = (rng.random((n, 1, 64, 64)) < 0.35).astype(np.float32)
+    a1 = (rng.random((n, 1, 64, 64)) < 0.1).astype(np.float32)
+    ones = np.ones((n, 1, 64, 64), np.float32)
+    env = _env(width=64, height=64, instances=n)
+    env.reset()
+    env.universe = torch.from_numpy(u0).cuda()
+    rule = env.rule_mask()
+    seq = [a1, None, None, None, a1, ones, a1, None, None, a1]
+    ref = _oracle_loop(u0, seq, rule)
+    env.step(torch.from_numpy(a1).cuda())                       # one launch, pending
+    env.multistep(3)                                            # settles, + 3
+    assert (env.step_number, env.steps_since_action) == (ref[3][1], ref[3][2])
+    env.run(actions=torch.from_numpy(np.stack([a1, ones, a1])).cuda())
+    assert np.array_equal(env.universe.cpu().numpy(), ref[6][0])
+    env.run(steps=2)
+    obs = env.step(torch.from_numpy(a1).cuda())[0]
+    assert np.array_equal(obs.cpu().numpy(), ref[9][0])
+    assert (env.step_number, env.steps_since_action, env.master_resets) == ref[9][1:]
+    # exact predicates (flags stored before the launch): the kernel reads them instead of deciding itself
+    env2 = _env(width=64, height=64, instances=n, exact_action_predicates=True)
+    env2.reset()
+    env2.universe = torch.from_numpy(u0).cuda()
+    half = np.full((n, 1, 64, 64), 0.5, np.float32); half[:, :, ::2] = 1.5      # mean exactly 1.0, not all ones
+    o = env2.step(torch.from_numpy(a1).cuda())[0]
+    assert np.array_equal(o.cpu().numpy(), ref[0][0])
+    o = env2.step(torch.from_numpy(half).cuda())[0]
+    assert int(o.count_nonzero()) == 0 and env2.step_number == 0 and env2.master_resets == 1
+
+
+def test_step_number_assignment_survives_a_pending_step():
+    env = _env(width=64, height=64, instances=20)
+    env.reset()
+    env.step(torch.ones(20, 1, 64, 64, device="cuda") * 0.5)
+    env.step_number = 100                                       # settles first: the pending step is not re-applied
+    env.step(torch.zeros(20, 1, 64, 64, device="cuda"))
+    assert env.step_number == 101 and env.steps_since_action == 1

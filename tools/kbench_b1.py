@@ -33,6 +33,7 @@ for rep in range(3 if len(gridmaps) > 1 else 2):
         os.environ.pop("CARLE_B1_BLOCKS", None)
     else:
         os.environ["CARLE_B1_BLOCKS"] = blk
+    hip.reload_knobs()                  # the library reads its knobs once
     for name, fn in cases.items():
         for i in range(6):
             fn(i)

@@ -26,6 +26,7 @@ for fmt, n, size in (("f32", 4096, 256), ("f32", 1024, 512), ("u8", 4096, 256), 
             os.environ.pop("CARLE_WIDE_BLOCKS", None)
         else:
             os.environ["CARLE_WIDE_BLOCKS"] = blk
+        hip.reload_knobs()                  # the library reads its knobs once
         for name, fn, alg in (("noact", lambda i: step(bufs[i & 1], None, bufs[(i & 1) ^ 1], rule, st, 0), n * size * size * 2 * es),
                               ("act", lambda i: step(bufs[i & 1], ring[i % 6], bufs[(i & 1) ^ 1], rule, st, 0),
                                n * (size * size * 2 + 4096) * es)):
