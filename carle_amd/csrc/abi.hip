@@ -301,28 +301,36 @@ extern "C" int carle_env_step_f32_rand(const float *u_in, float *u_out, float *r
 // k consecutive CARLE.step calls in ONE library call: the loop of carle/train_mcl.py:64-69 with the
 // actions already on the device (a stack of k action tensors) or drawn in the step kernel (the
 // device-side RandomAgent).  The host pays one ctypes round trip for k steps instead of k.
-extern "C" int carle_env_run_f32(float *buf_a, float *buf_b, const float *actions, float *reward, int64_t n,
-                                 int h, int w, int ah, int aw, uint32_t rule, float p, uint64_t seed,
+extern "C" int carle_env_run_f32(const float *u_in, float *buf_a, float *buf_b, const float *actions, float *reward,
+                                 int64_t n, int h, int w, int ah, int aw, uint32_t rule, float p, uint64_t seed,
                                  uint64_t offset, int k, int32_t *status, int slot0, int step_flags,
                                  void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_run_f32: status is NULL");
     if (k < 0) return fail_arg(CARLE_E_DIMS, "carle_env_run_f32: k must be >= 0");
     if (slot0 != 0 && slot0 != 1) return fail_arg(CARLE_E_DIMS, "carle_env_run_f32: slot0 must be 0 or 1");
-    if (k > 0 && (!buf_a || !buf_b)) return fail_arg(CARLE_E_NULL, "carle_env_run_f32: buf_a/buf_b is NULL");
+    if (k > 0 && (!u_in || !buf_a || (k > 1 && !buf_b)))
+        return fail_arg(CARLE_E_NULL, "carle_env_run_f32: u_in / buf_a / buf_b is NULL");
+    if (k > 1 && n > 0 && h > 0 && w > 0) {
+        const size_t bytes = (size_t)n * h * w * sizeof(float);
+        if (overlap(buf_a, bytes, buf_b, bytes) || overlap(u_in, bytes, buf_b, bytes))
+            return fail_arg(CARLE_E_ALIAS, "carle_env_run_f32: u_in / buf_a / buf_b overlap");
+    }
     const int64_t act_elems = n * (int64_t)ah * aw;
+    float *fin = (k & 1) ? buf_a : buf_b;                  // the buffer of the final state
     if (k > 0 && n >= 1 && n <= 16 && h == 64 && w == 64) {
         // small batches: all k steps in ONE launch, the grids stay in registers (ca_env_run_small64_kernel)
-        const int e = env_run_small64(buf_a, actions, (k & 1) ? buf_b : buf_a, reward, n, h, w, ah, aw, rule, p, seed, offset, k,
+        const int e = env_run_small64(u_in, actions, fin, reward, n, h, w, ah, aw, rule, p, seed, offset, k,
                                       status, slot0, step_flags, stream);
         if (e != -1000) return e;
     }
     if (k > 0 && !actions && p < 0.0f && h == 64 && w == 64 && n > 16) {
         // no action source: no predicates, no master reset -- all k generations in one launch, grids in registers
-        const int e = env_run_noaction64(buf_a, (k & 1) ? buf_b : buf_a, reward, n, h, w, rule, k, status, slot0, step_flags, stream);
+        const int e = env_run_noaction64(u_in, fin, reward, n, h, w, rule, k, status, slot0, step_flags, stream);
         if (e != -1000) return e;
     }
     for (int t = 0; t < k; ++t) {
-        float *in = (t & 1) ? buf_b : buf_a, *out = (t & 1) ? buf_a : buf_b;
+        const float *in = t == 0 ? u_in : ((t & 1) ? buf_a : buf_b);
+        float *out = (t & 1) ? buf_b : buf_a;
         const int slot = (slot0 + t) & 1;
         int e;
         if (actions)

@@ -406,7 +406,8 @@ class CARLE(RLEMixin, nn.Module):
             step kernel (the agent's call counter advances by ``steps``);
           * neither: ``steps`` steps without an action.
         One ctypes round trip instead of k: for small batches the per-step cost is the kernel launch
-        (N <= 16 at 64x64: one launch per step), not Python.  fp32 storage only."""
+        (N <= 16 at 64x64: one launch per step), not Python.  fp32 storage only.  The tensor that held the state on
+        entry (a previously returned observation) is never written."""
         hip.require_gpu()
         self._check_domain()
         self._ensure_status()
@@ -448,10 +449,14 @@ class CARLE(RLEMixin, nn.Module):
         merge = self.__dict__.get("_final_reward_stats") is not None
         self._moments_merged = False
         if k > 0:
-            other = torch.empty_like(u)
-            hip.env_run_f32(u, other, actions, reward, self.rule_mask(), self._status, self._slot, k, ah, aw,
+            # `u` may be a tensor an earlier step()/reset() returned as the observation: it is only read; the k
+            # generations ping-pong between two private buffers (the reference returns a fresh tensor per step,
+            # env.py:229 -- a caller still holding an older observation must keep seeing that generation)
+            buf_a = torch.empty_like(u)
+            buf_b = torch.empty_like(u) if k > 1 else None
+            hip.env_run_f32(u, buf_a, buf_b, actions, reward, self.rule_mask(), self._status, self._slot, k, ah, aw,
                             p, seed, offset, merge)
-            self.universe = other if k & 1 else u
+            self.universe = buf_a if k & 1 else buf_b
             self._slot = (self._slot + k) & 1
             self._moments_merged = merge
             if agent is not None and actions is None:

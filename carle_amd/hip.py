@@ -262,23 +262,24 @@ def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=
         _lib.check(rc, "carle_env_step_f32")
 
 
-def env_run_f32(buf_a, buf_b, actions, reward, rule, status, slot0, k, ah=0, aw=0, p=-1.0, seed=0, offset=0,
+def env_run_f32(u_in, buf_a, buf_b, actions, reward, rule, status, slot0, k, ah=0, aw=0, p=-1.0, seed=0, offset=0,
                 merge_moments=False, deferred=True):
-    """k CARLE.step calls in one library call (carle_env_run_f32): state in buf_a on entry, in
-    buf_a / buf_b for even / odd k on return.  actions: (k,N,1,AH,AW) fp32 or None (then p >= 0
-    draws Bernoulli(p) toggles in the kernel, p < 0 means no action)."""
+    """k CARLE.step calls in one library call (carle_env_run_f32): the state is READ from u_in and the steps
+    ping-pong between the scratch buffers buf_a / buf_b (final state in buf_a for odd k, buf_b for even k; buf_b may
+    be None for k == 1).  actions: (k,N,1,AH,AW) fp32 or None (then p >= 0 draws Bernoulli(p) toggles in the kernel,
+    p < 0 means no action)."""
     lib = _lib.load()
-    n, _, h, w = buf_a.shape
+    n, _, h, w = u_in.shape
     ap = None
     if actions is not None:
         _chk_grid(actions, "actions", torch.float32)
         if actions.dim() != 5 or actions.shape[0] != k or actions.shape[1] != n:
             raise ValueError(f"actions must have shape (k={k}, N={n}, 1, AH, AW), got {tuple(actions.shape)}")
         ah, aw, ap = actions.shape[3], actions.shape[4], actions.data_ptr()
-    with _on_device(buf_a.device):
-        rc = lib.carle_env_run_f32(buf_a.data_ptr(), buf_b.data_ptr(), ap, reward.data_ptr(), n, h, w, ah, aw,
+    with _on_device(u_in.device):
+        rc = lib.carle_env_run_f32(u_in.data_ptr(), _ptr(buf_a), _ptr(buf_b), ap, reward.data_ptr(), n, h, w, ah, aw,
                                    rule, float(p), int(seed), int(offset), int(k), status.data_ptr(), slot0,
-                                   _step_flags(False, merge_moments, deferred), _stream(buf_a))
+                                   _step_flags(False, merge_moments, deferred), _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_run_f32")
 

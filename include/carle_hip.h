@@ -214,24 +214,28 @@ int carle_env_settle(int32_t *status, void *stream);
  * k consecutive CARLE.step calls (carle/env.py:188-242) in one library call -- the inner loop of
  * carle/train_mcl.py:64-69 / evaluation/eval.py:63-70 when the actions do not depend on the
  * observations that the loop produces (a device-side RandomAgent, carle/agents.py:35-42, or a
- * recorded action sequence).  The state ping-pongs between buf_a and buf_b (N*H*W floats each, not
- * aliased): on entry it is in buf_a, on return in buf_a for even k and in buf_b for odd k.
+ * recorded action sequence).
+ *   u_in                   N*H*W floats, the state on entry; READ ONLY (it may be a tensor the caller has handed
+ *                          out as an observation: the reference returns a fresh tensor per step, env.py:229)
+ *   buf_a, buf_b           N*H*W floats each, caller-owned scratch, no overlap with each other or u_in: step t
+ *                          writes buf_a for even t and buf_b for odd t, so the final state is in buf_a for odd k
+ *                          and in buf_b for even k (k == 0: nothing is written; k == 1: buf_b may be NULL)
  *   actions != NULL        k contiguous (N,1,AH,AW) fp32 tensors; step t uses the t-th
  *   actions == NULL, p>=0  Bernoulli(p) toggles drawn in the step kernel, step t with Philox offset
  *                          `offset + t` (= k calls of carle_env_step_f32_rand)
  *   actions == NULL, p<0   no action (AH/AW ignored)
  *   reward                 N floats: the reward of the LAST step (zero for the bare environment)
  *   slot0                  flag slot of the first step; step t uses (slot0 + t) & 1
- *   step_flags             CARLE_STEP_MERGE_MOMENTS or 0
- * Every step is complete (master reset, counters, flags) before the next one starts, exactly as k
- * separate calls of carle_env_step_f32* on the same stream (grids, counters, reward moments and the
+ *   step_flags             CARLE_STEP_MERGE_MOMENTS, CARLE_STEP_DEFERRED or 0
+ * Every step is complete (master reset, flags; counters: see CARLE_STEP_DEFERRED) before the next one starts,
+ * exactly as k separate calls of carle_env_step_f32* on the same stream (grids, counters, reward moments and the
  * reward of the last step are identical; the contents of the buffer that does not hold the final state
  * and the transient action-flag words of the status block are unspecified).  64x64 grids: batches of up
  * to 16 run all k steps in ONE launch with the grids in registers, and without an action source any
- * batch does (no predicates, no master reset without an action).
+ * batch does (no predicates, no master reset without an action); these launches write the final buffer only.
  */
-int carle_env_run_f32(float *buf_a, float *buf_b, const float *actions, float *reward, int64_t n,
-                      int h, int w, int ah, int aw, uint32_t rule, float p, uint64_t seed,
+int carle_env_run_f32(const float *u_in, float *buf_a, float *buf_b, const float *actions, float *reward,
+                      int64_t n, int h, int w, int ah, int aw, uint32_t rule, float p, uint64_t seed,
                       uint64_t offset, int k, int32_t *status, int slot0, int step_flags, void *stream);
 
 /* The same on bit-packed state: carle_ca_step_b1 + carle_ca_finish. */

@@ -464,6 +464,38 @@ def test_run_replays_golden_case(name):
         rec += 1
 
 
+@pytest.mark.parametrize("n,size", [(1, 64), (16, 64), (40, 64), (2, 256), (3, 20)])
+@pytest.mark.parametrize("source", ["actions", "agent", "none"])
+def test_run_never_writes_an_observation_the_caller_holds(n, size, source):
+    """The reference returns a fresh tensor per step (env.py:229): an observation the caller kept from an earlier
+    step() / reset() / run() must still show ITS generation after run(k) for even and odd k (every launch form:
+    one-launch small batches, one-launch action-free runs, the per-step loop)."""
+    from carle_amd.agents import RandomAgent
+    asz = min(64, size)
+    if source == "agent" and size == 20:
+        pytest.skip("in-kernel toggles need an aligned window")
+    env = _env(width=size, height=size, action_width=asz, action_height=asz, instances=n)
+    env.reset()
+    g = torch.Generator().manual_seed(n + size)
+    env.universe = (torch.rand(n, 1, size, size, generator=g) < 0.4).float().cuda()
+    agent = RandomAgent(action_width=asz, action_height=asz, fused=True, seed=3)
+    held = []                                     # (tensor the caller holds, what it showed when it was returned)
+    obs = env.step((torch.rand(n, 1, asz, asz, generator=g) < 0.1).float())[0]
+    held.append((obs, obs.clone()))
+    for k in (2, 3, 1, 4):
+        if source == "actions":
+            obs = env.run(actions=(torch.rand(k, n, 1, asz, asz, generator=g) < 0.1).float())[0]
+        elif source == "agent":
+            obs = env.run(agent=agent, steps=k)[0]
+        else:
+            obs = env.run(steps=k)[0]
+        assert obs is env.universe
+        for t_, snap in held:
+            assert torch.equal(t_, snap), f"run({k}) wrote into an observation returned earlier"
+            assert t_.data_ptr() != obs.data_ptr()
+        held.append((obs, obs.clone()))
+
+
 @pytest.mark.parametrize("n,size", [(1, 64), (16, 64), (17, 64), (300, 64), (3, 256)])
 def test_run_with_fused_random_agent_equals_step_loop(n, size):
     """env.run(agent=RandomAgent, steps=k) == k x env.step(agent(obs)): same Philox draws, same
