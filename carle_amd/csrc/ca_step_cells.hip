@@ -341,7 +341,13 @@ __global__ __launch_bounds__(1024) void ca_env_step_small64_kernel(
                 }
             }
         }
-        finish_status(st, w0, w1, w2, slot, reset, any);
+        // the predicates travelled through LDS: leave them in the step's flag slot as the step kernel of the general
+        // path does (consumers after the step -- PufferDetector's "no action this step" -- read them there)
+        uint4 w0f = w0;
+        if (publish && HAS_ACT) {
+            if (slot) { w0f.y = any ? 1u : 0u; w0f.w = notone ? 1u : 0u; } else { w0f.x = any ? 1u : 0u; w0f.z = notone ? 1u : 0u; }
+        }
+        finish_status(st, w0f, w1, w2, slot, reset, any);
     }
 }
 
@@ -463,6 +469,9 @@ __global__ __launch_bounds__(1024) void ca_env_run_small64_kernel(
         uint4 o0 = st4[0], o1 = w1, o2;
         if (slot) { o0.x = 0u; o0.z = 0u; } else { o0.y = 0u; o0.w = 0u; }
         if (steps >= 2) { o0.x = 0u; o0.y = 0u; o0.z = 0u; o0.w = 0u; }
+        if (HAS_ACT) {                                     // the last step's predicates, in its slot
+            if (slot) { o0.y = any ? 1u : 0u; o0.w = notone ? 1u : 0u; } else { o0.x = any ? 1u : 0u; o0.z = notone ? 1u : 0u; }
+        }
         o1.x = reset ? 1u : 0u;
         o1.z = (uint32_t)step_number; o1.w = (uint32_t)((uint64_t)step_number >> 32);
         o2.x = (uint32_t)since; o2.y = (uint32_t)((uint64_t)since >> 32);

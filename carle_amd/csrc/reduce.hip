@@ -84,9 +84,115 @@ static void launch_instance_sums(bool vec, unsigned n, hipStream_t st, const flo
     else hipLaunchKernelGGL((instance_sums_kernel<WM, false>), dim3(n), dim3(nt), 0, st, x, elems, w0, w1, w2, out);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// SpeedDetector.step after the reduction (carle/mcl.py:769-797), one single-block launch instead of ~8 tensor ops:
+//   com_h = sum(obs * w_h) / (live + 1e-7), com_w likewise;  velocity = previous com - com;
+//   speed = sqrt(sum over BOTH axes and ALL instances of velocity^2)  (batch-coupled, mcl.py:789);  reward += speed
+// sums4 (n,4): [sum obs, sum obs*w_h, sum obs*w_w, -] of carle_instance_sums_f32; live4 (nullable): the sums of the
+// inner universe where it is not the observation.  state[0] = 1 once a centre of mass has been stored (device side:
+// the launch is identical every step, so a HIP graph can replay it).  fp32 quotients as the reference; the sum of
+// squares is accumulated in fp64 in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void speed_update_kernel(const float *__restrict__ sums4, const float *__restrict__ live4,
+                                                           int64_t n, float *__restrict__ com, int32_t *__restrict__ state,
+                                                           float *__restrict__ velocity, float *__restrict__ speed_out,
+                                                           float *__restrict__ live_out, float *__restrict__ reward) {
+    __shared__ double part[4];
+    __shared__ float s_speed;
+    const bool has_prev = state[0] != 0;
+    double sq = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float live = live4 ? live4[4 * i] : sums4[4 * i];
+        const float ch = sums4[4 * i + 1] / (live + 1e-7f), cw = sums4[4 * i + 2] / (live + 1e-7f);
+        if (has_prev) {
+            const float vh = com[i] - ch, vw = com[n + i] - cw;
+            velocity[i] = vh; velocity[n + i] = vw;
+            sq = fma((double)vh, (double)vh, fma((double)vw, (double)vw, sq));
+        }
+        com[i] = ch; com[n + i] = cw;
+        live_out[i] = live;
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) sq += __shfl_xor(sq, k, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float sp = (float)sqrt((part[0] + part[1]) + (part[2] + part[3]));
+        s_speed = sp;
+        if (has_prev) speed_out[0] = sp;
+        state[0] = 1;
+    }
+    __syncthreads();
+    if (has_prev && reward) {
+        const float sp = s_speed;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) reward[i] += sp;       // mcl.py:795
+    }
+}
+
+// PufferDetector.step after the reduction (carle/mcl.py:832-851) without its two host round trips: the history of
+// live-cell totals is a device ring (rstate = [head, count], cap = growth_threshold + 1 slots), the "no action this
+// step" predicate is the flag the step kernel left in the status block (any_flag; NULL = no action).
+__global__ __launch_bounds__(256) void puffer_update_kernel(const float *__restrict__ sums4, int64_t n,
+                                                            const int32_t *__restrict__ any_flag, float *__restrict__ ring,
+                                                            int32_t *__restrict__ rstate, int cap,
+                                                            float *__restrict__ live_total, float *__restrict__ reward) {
+    __shared__ double part[4];
+    __shared__ int s_bonus;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += (double)sums4[4 * i];
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = (float)((part[0] + part[1]) + (part[2] + part[3]));     // torch.sum(universe), mcl.py:832
+        live_total[0] = total;
+        int head = rstate[0], count = rstate[1], bonus = 0;
+        const bool any = any_flag != nullptr && any_flag[0] != 0;
+        if (!any) {
+            ring[(head + count) % cap] = total;                                      // cells.append
+            count += 1;
+            if (count > cap - 1) {                                                   // len(cells) > growth_threshold
+                const float slope = total - ring[head];                              // cells[-1] - cells[0]
+                head = (head + 1) % cap;                                             // cells.pop(0)
+                count -= 1;
+                bonus = slope > 0.01f ? 1 : 0;
+            }
+        } else {
+            head = 0; count = 0;                                                     // cells = []
+        }
+        rstate[0] = head; rstate[1] = count;
+        s_bonus = bonus;
+    }
+    __syncthreads();
+    if (s_bonus && reward)
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) reward[i] += 1.0f;     // mcl.py:843
+}
+
 }  // namespace carle
 
 using namespace carle;
+
+extern "C" int carle_speed_update_f32(const float *sums4, const float *live4, int64_t n, float *com, int32_t *state,
+                                      float *velocity, float *speed, float *live_out, float *reward, void *stream) {
+    if (!sums4 || !com || !state || !velocity || !speed || !live_out)
+        return fail_arg(CARLE_E_NULL, "carle_speed_update_f32: NULL pointer");
+    if (n < 0) return fail_arg(CARLE_E_DIMS, "carle_speed_update_f32: negative size");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(speed_update_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), sums4, live4, n, com,
+                       state, velocity, speed, live_out, reward);
+    return check_launch("carle_speed_update_f32");
+}
+
+extern "C" int carle_puffer_update_f32(const float *sums4, int64_t n, const int32_t *any_flag, float *ring,
+                                       int32_t *ring_state, int cap, float *live_total, float *reward, void *stream) {
+    if (!sums4 || !ring || !ring_state || !live_total)
+        return fail_arg(CARLE_E_NULL, "carle_puffer_update_f32: NULL pointer");
+    if (n < 0 || cap < 2) return fail_arg(CARLE_E_DIMS, "carle_puffer_update_f32: n >= 0 and cap >= 2 required");
+    hipLaunchKernelGGL(puffer_update_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), sums4, n, any_flag,
+                       ring, ring_state, cap, live_total, reward);
+    return check_launch("carle_puffer_update_f32");
+}
 
 extern "C" int carle_instance_sums_f32(const float *x, int64_t n, int64_t elems, const float *w0,
                                        const float *w1, const float *w2, float *out4, void *stream) {

@@ -16,13 +16,17 @@ Contract (the usual one of graph replay):
     returns a fresh tensor per step, env.py:229.)
   * Replay repeats the captured launches; Python-side bookkeeping of wrappers does not run.  Valid for ``CARLE``
     (all storages) and for reward wrappers that only enqueue kernels per step: RND2D / AE2D without predictor
-    updates (``train_predictor=False``), CornerBonus, ParsimonyBonus.  Wrappers that keep host-side history per step
-    (SpeedDetector, PufferDetector), predictor training and RLE logging are refused or not supported.
+    updates (``train_predictor=False``), CornerBonus, ParsimonyBonus, SpeedDetector and PufferDetector (their
+    per-step history lives in fixed device buffers) -- the whole evaluation stack of evaluation/eval.py:83-87.
+    Predictor training and RLE logging are refused.
   * Between calls the caller may assign ``env.universe`` (patterns), call ``env.reset()`` or take eager steps:
     the graph copies a foreign state into its buffer before replaying.  Changing the rules re-captures.
   * Build it after ``env.reset()``: construction takes two eager warm-up steps and two capture steps with the
-    action buffer's current contents, then restores the CA state, the status block and the step parity; reward
-    wrappers see those four extra bonus evaluations (immaterial without updates).
+    action buffer's current contents, then restores the CA state, the status block, the step parity, the device
+    state of the wrappers (``_graph_state()``: centre of mass, growth history) and the moment accumulators of an
+    attached ``RunningRewardStats``.
+  * The lookup tables of the reward nets are frozen into the capture ("tables valid"): when a predictor / random
+    network parameter changes afterwards (``load_state_dict``, an optimiser step) the next call re-captures.
 """
 import torch
 
@@ -30,6 +34,8 @@ from . import hip
 
 
 class StepGraph:
+    check_params = True        # compare the reward nets' parameter versions every call (a few us per wrapper)
+
     def __init__(self, env, action):
         hip.require_gpu()
         base = env if getattr(env, "inner_env", None) is None else env.inner_env
@@ -42,8 +48,6 @@ class StepGraph:
             raise NotImplementedError("RLE logging runs on the host every step; not capturable")
         w = env
         while w is not base:
-            if type(w).__name__ in ("SpeedDetector", "PufferDetector"):
-                raise NotImplementedError(f"{type(w).__name__} keeps host-side history per step")
             if getattr(w, "train_predictor", False):
                 raise NotImplementedError(f"{type(w).__name__} trains its predictor (window bookkeeping and Adam "
                                           "run on the host): set train_predictor=False to replay the forward pass")
@@ -55,11 +59,42 @@ class StepGraph:
         self._graphs = None
         self._capture()
 
+    def _wrappers(self):
+        w = self.env
+        while w is not self.base:
+            yield w
+            w = w.env
+
+    def _param_key(self):
+        """Versions of every reward-net parameter the captured kernels' tables were built from."""
+        key = []
+        for w in self._wrappers():
+            for name in ("_pred_blob", "_rand_blob"):
+                blob = getattr(w, name, None)
+                if blob is not None:
+                    ps = blob.params if blob.params is not None else list(blob.module.parameters())
+                    key.extend((p.data_ptr(), p._version) for p in ps)
+        return tuple(key)
+
+    def _side_state(self):
+        """Device tensors outside the CA state that the warm-up / capture steps modify."""
+        ts = []
+        for w in self._wrappers():
+            gs = getattr(w, "_graph_state", None)
+            if gs is not None:
+                ts.extend(gs())
+        stats = self.base.__dict__.get("_reward_stats")
+        if stats is not None:
+            ts.extend([stats._batch, stats._pending])
+        return ts
+
     # ------------------------------------------------------------------ capture
     def _capture(self):
         env, base = self.env, self.base
         state = base._raw_state()                      # raises before reset()
         keep_state, keep_status, keep_slot = state.clone(), base._status.clone(), base._slot
+        side_before = self._side_state()
+        side_keep = {id(t): t.clone() for t in side_before}
         self._bufs = [torch.empty_like(state), torch.empty_like(state)]
         self._rule = base.rule_mask()
         # warm-up on a side stream: lazy initialisation (tables, workspaces, parameter blobs) must not be captured
@@ -84,7 +119,14 @@ class StepGraph:
             pool = g.pool()
             graphs.append((g, result, base.__dict__.get("_moments_merged", False)))
         self._graphs = graphs
-        # back to where the caller was
+        self._params = self._param_key()
+        # back to where the caller was: wrapper state that existed before is restored, state the warm-up created
+        # (lazily allocated histories) starts empty
+        for t in self._side_state():
+            if id(t) in side_keep:
+                t.copy_(side_keep[id(t)])
+            else:
+                t.zero_()
         base._status.copy_(keep_status)
         base._slot = keep_slot
         self._bufs[keep_slot].copy_(keep_state)
@@ -95,7 +137,7 @@ class StepGraph:
         """One ``env.step(action)`` with the action buffer's current contents; returns the captured call's
         ``(obs, reward, done, info)`` objects."""
         base = self.base
-        if base.rule_mask() != self._rule:
+        if base.rule_mask() != self._rule or (self.check_params and self._param_key() != self._params):
             self._capture()
         p = base._slot
         buf = self._bufs[p]

@@ -578,6 +578,29 @@ def instance_sums_f32(x, w0=None, w1=None, w2=None):
     return out
 
 
+def speed_update_f32(sums4, live4, com, state, velocity, speed, live_out, reward):
+    """SpeedDetector tail (carle_speed_update_f32): centre of mass, velocity, batch speed, reward += speed."""
+    lib = _lib.load()
+    n = sums4.shape[0]
+    with _on_device(sums4.device):
+        rc = lib.carle_speed_update_f32(sums4.data_ptr(), _ptr(live4), n, com.data_ptr(), state.data_ptr(),
+                                        velocity.data_ptr(), speed.data_ptr(), live_out.data_ptr(), _ptr(reward),
+                                        _stream(sums4))
+    if rc != 0:
+        _lib.check(rc, "carle_speed_update_f32")
+
+
+def puffer_update_f32(sums4, any_flag_ptr, ring, ring_state, live_total, reward):
+    """PufferDetector tail (carle_puffer_update_f32); any_flag_ptr: raw device address of an int32 or None."""
+    lib = _lib.load()
+    with _on_device(sums4.device):
+        rc = lib.carle_puffer_update_f32(sums4.data_ptr(), sums4.shape[0], any_flag_ptr, ring.data_ptr(),
+                                         ring_state.data_ptr(), ring.numel(), live_total.data_ptr(), _ptr(reward),
+                                         _stream(sums4))
+    if rc != 0:
+        _lib.check(rc, "carle_puffer_update_f32")
+
+
 def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_flags, pred_params,
                      rand_params, workspace, bonus, reward_scale, tables_valid,
                      event_handle, stream_env, stream_reward, merge_moments=False):

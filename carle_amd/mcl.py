@@ -13,6 +13,8 @@ table: observations of the current window are retained and, when ``batch_size`` 
 accumulated, forward+backward is recomputed with PyTorch-ROCm autograd on the ``nn.Sequential``
 below (mathematically identical in eval mode: parameters are constant inside a window).
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -24,7 +26,7 @@ from . import hip
 _PLAIN_WRAPPER_ATTRS = frozenset((
     "_ws", "_tables_key", "_tables_key_next", "_bonus_buf", "_step_bonus", "buffer_length",
     "accumulate_loss", "_window", "_grad_used", "live_cells", "speed", "velocity", "center_of_mass",
-    "growing_steps", "cells"))
+    "growing_steps"))
 
 
 class Motivator(nn.Module):
@@ -707,8 +709,28 @@ class CornerBonus(Motivator):
         return obs, reward, done, info
 
 
+def _live_sums(inner, dev):
+    """(N,4) sums of the inner universe, column 0 = live cells per instance (mcl.py:769,832).  Cached on the inner
+    environment for the tensor object they were computed from: a fresh universe tensor per step (env.py:229), so
+    stacked wrappers (eval.py:86-87: SpeedDetector and PufferDetector) reduce the grid once, not once each."""
+    u = inner.universe
+    hit = inner.__dict__.get("_live_cache")
+    if hit is not None and hit[0]() is u and hit[1] == u._version:
+        return hit[2]
+    sums = hip.instance_sums_f32(_as_device_f32(u, dev))
+    inner.__dict__["_live_cache"] = (weakref.ref(u), u._version, sums)
+    return sums
+
+
 class SpeedDetector(Motivator):
-    """Rewards centre-of-mass motion outside the action window (mcl.py:730-799)."""
+    """Rewards centre-of-mass motion outside the action window (mcl.py:730-799).
+
+    Per step: ONE reduction pass over the observation (carle_instance_sums_f32 with the two masked weight planes) and
+    one single-block kernel (carle_speed_update_f32: centre of mass, velocity, the batch-coupled speed, reward +=
+    speed) -- no host synchronisation, no per-step tensor allocation (the previous centre of mass, velocity, speed and
+    live-cell vector live in fixed device buffers, so a StepGraph can replay the step).  ``center_of_mass`` /
+    ``velocity`` / ``speed`` / ``live_cells`` are views of those buffers, with the reference's first-step values
+    (``center_of_mass`` None before the first step, ``speed`` None before the second)."""
 
     def __init__(self, env, **kwargs):
         super().__init__(env, **kwargs)
@@ -727,61 +749,135 @@ class SpeedDetector(Motivator):
         self.speed = None
         self.velocity = torch.tensor([self.inner_env.instances, 1, 0., 0.])
         self.live_cells = None
+        self.__dict__["_dev_state"] = None      # (com (2,N), velocity (2,N), speed (1), live (N), has_prev int32[1])
+        self.__dict__["_steps_seen"] = 0
+
+    def _dev_buffers(self, n, dev):
+        st = self.__dict__["_dev_state"]
+        if st is None or st[0].shape[1] != n or st[0].device != dev:
+            st = (torch.zeros(2, n, dtype=torch.float32, device=dev), torch.zeros(2, n, dtype=torch.float32, device=dev),
+                  torch.zeros(1, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.float32, device=dev),
+                  torch.zeros(1, dtype=torch.int32, device=dev))
+            if self.center_of_mass is not None:             # a caller-assigned centre of mass carries over
+                st[0].copy_(torch.as_tensor(self.center_of_mass, dtype=torch.float32).reshape(2, n))
+                st[4].fill_(1)
+            self.__dict__["_dev_state"] = st
+        return st
+
+    def _graph_state(self):
+        """Device tensors a StepGraph capture must snapshot around its warm-up steps."""
+        st = self.__dict__["_dev_state"]
+        return list(st) if st is not None else []
 
     def step(self, action):
         obs, reward, done, info = self.env.step(action)
-        dev = self.inner_env.my_device
-        universe = self.inner_env.universe
+        inner = self.inner_env
+        dev = inner.my_device
+        o = _as_device_f32(obs, dev)
         # sum(obs * w) over the whole grid with the action window masked out of the weights;
-        # live cells are counted on the inner universe (= obs) as in the reference (mcl.py:769)
-        sums = hip.instance_sums_f32(_as_device_f32(obs, dev), _cached_device(self, "mass_weight_h", dev),
-                                     _cached_device(self, "mass_weight_w", dev))
-        live_cells = sums[:, 0] if universe is obs else hip.instance_sums_f32(_as_device_f32(universe, dev))[:, 0]
-        center_of_mass_h = sums[:, 1] / (live_cells + 1e-7)
-        center_of_mass_w = sums[:, 2] / (live_cells + 1e-7)
-        center_of_mass = torch.cat([center_of_mass_h.unsqueeze(0), center_of_mass_w.unsqueeze(0)])
-        if self.center_of_mass is None:
-            self.center_of_mass = center_of_mass
+        # live cells are counted on the inner universe (= obs for the fp32 storage) as in the reference (mcl.py:769)
+        sums = hip.instance_sums_f32(o, _cached_device(self, "mass_weight_h", dev), _cached_device(self, "mass_weight_w", dev))
+        same = inner.__dict__.get("universe") is obs
+        if same:
+            inner.__dict__["_live_cache"] = (weakref.ref(obs), obs._version, sums)
+        live4 = None if same else _live_sums(inner, dev)
+        com, vel, speed, live, has_prev = self._dev_buffers(sums.shape[0], dev)
+        if not reward.is_contiguous():                      # (never for the rewards this package produces)
+            raise ValueError("SpeedDetector needs a contiguous reward tensor")
+        hip.speed_update_f32(sums, live4, com, has_prev, vel, speed, live, reward.reshape(-1))
+        seen = self.__dict__["_steps_seen"]
+        if seen == 0 and self.center_of_mass is None:
+            self.center_of_mass = com                       # mcl.py:781-782: stored, nothing else
         else:
-            velocity = self.center_of_mass - center_of_mass
-            speed = torch.sqrt(torch.sum(torch.pow(velocity, 2)))
-            self.speed = speed
-            self.velocity = velocity
-            self.center_of_mass = center_of_mass
-            reward += speed
-        self.live_cells = live_cells
+            self.speed = speed[0]
+            self.velocity = vel
+            self.center_of_mass = com
+        self.__dict__["_steps_seen"] = seen + 1
+        self.live_cells = live
         return obs, reward, done, info
 
 
 class PufferDetector(Motivator):
-    """Rewards sustained growth in the absence of actions (mcl.py:804-853).  Host-synchronising
-    by construction, exactly like the reference (live-cell total and action sum are read on the
-    host every step to drive a Python list)."""
+    """Rewards sustained growth in the absence of actions (mcl.py:804-853).
+
+    The reference reads the live-cell total and ``torch.sum(action)`` on the host every step to drive a Python list;
+    here the history is a device ring of ``growth_threshold + 1`` totals and the "no action this step" predicate is the
+    flag the step kernel left in the status block (env.py:191; ``CARLE(exact_action_predicates=True)`` makes it the
+    reference's own ``torch.sum`` truthiness): one reduction pass (shared with a SpeedDetector below) + one
+    single-block kernel (carle_puffer_update_f32), no host synchronisation.  ``cells`` / ``live_cells`` read the
+    device state back lazily."""
 
     def __init__(self, env, **kwargs):
         super().__init__(env, **kwargs)
         self.my_name = "PufferDetector"
-        self.cells = []
-        self.live_cells = 0.0
         self.reward_scale = 1.0
+        # growth threshold is also the length of the history (mcl.py:822-823)
         self.growth_threshold = 512
         self.growing_steps = 0
+        self.__dict__["_ring"] = None           # (ring (cap,), ring_state int32[2] = [head, count], live_total (1,))
+        self.__dict__["_host_cells"] = []       # history assigned by the caller before the ring exists
+
+    def _ring_state(self, dev):
+        r = self.__dict__["_ring"]
+        cap = int(self.growth_threshold) + 1
+        if r is None or r[0].numel() != cap or r[0].device != dev:
+            carry = self.cells if r is not None else self.__dict__["_host_cells"]
+            carry = list(carry)[-(cap - 1):] if cap > 1 else []
+            ring = torch.zeros(max(cap, 2), dtype=torch.float32, device=dev)
+            state = torch.zeros(2, dtype=torch.int32, device=dev)
+            if carry:
+                ring[:len(carry)] = torch.tensor(carry, dtype=torch.float32)
+                state[1] = len(carry)
+            r = self.__dict__["_ring"] = (ring, state, torch.zeros(1, dtype=torch.float32, device=dev))
+        return r
+
+    def _graph_state(self):
+        r = self.__dict__["_ring"]
+        return list(r) if r is not None else []
+
+    @property
+    def cells(self):
+        """The history of live-cell totals (oldest first), read back from the device ring (synchronises)."""
+        r = self.__dict__.get("_ring")
+        if r is None:
+            return list(self.__dict__.get("_host_cells", []))
+        ring, (head, count) = r[0].cpu().tolist(), r[1].cpu().tolist()
+        return [ring[(head + i) % len(ring)] for i in range(count)]
+
+    @cells.setter
+    def cells(self, value):
+        self.__dict__["_host_cells"] = list(value)
+        self.__dict__["_ring"] = None
+
+    @property
+    def live_cells(self):
+        r = self.__dict__.get("_ring")
+        return 0.0 if r is None else float(r[2].item())
+
+    @live_cells.setter
+    def live_cells(self, value):
+        pass                                    # recomputed every step (mcl.py:832)
 
     def step(self, action):
         obs, reward, done, info = self.env.step(action)
-        self.live_cells = float(hip.instance_sums_f32(
-            _as_device_f32(self.inner_env.universe, self.inner_env.my_device))[:, 0].sum().item())
-        a = _as_device_f32(action, self.inner_env.my_device)
-        if not bool(torch.sum(a)):
-            self.cells.append(self.live_cells)
-            if len(self.cells) > self.growth_threshold:
-                slope = self.cells[-1] - self.cells[0]
-                self.cells.pop(0)
-                if slope > 0.01:
-                    reward += 1
-        else:
-            self.growing_steps = 0
-            self.cells = []
+        inner = self.inner_env
+        dev = inner.my_device
+        sums = _live_sums(inner, dev)
+        ring, state, total = self._ring_state(dev)
+        flag_ptr = None
+        if action is not None:
+            st = inner.__dict__.get("_status")
+            if st is None:
+                # no status block to ask (foreign inner environment): the reference's predicate as a device flag
+                flag = (torch.sum(_as_device_f32(action, dev)) != 0).to(torch.int32).reshape(1)
+                self.__dict__["_flag_keep"] = flag
+                flag_ptr = flag.data_ptr()
+            else:
+                # ANY_NONZERO of the slot the step just used (the flags stay until the next step recycles them)
+                flag_ptr = st.data_ptr() + 4 * (inner._slot ^ 1)
+        if not reward.is_contiguous():
+            raise ValueError("PufferDetector needs a contiguous reward tensor")
+        hip.puffer_update_f32(sums, flag_ptr, ring, state, total, reward.reshape(-1))
         return obs, reward, done, info
 
 

@@ -426,6 +426,22 @@ int carle_env_step_b1_rand(const uint64_t *u_in, uint64_t *u_out, float *reward,
 int carle_instance_sums_f32(const float *x, int64_t n, int64_t elems, const float *w0,
                             const float *w1, const float *w2, float *out4, void *stream);
 
+/* SpeedDetector.step behind the reduction (carle/mcl.py:769-797), no host round trip: from sums4 =
+ * carle_instance_sums_f32(obs, mass_weight_h, mass_weight_w) (and live4 = the sums of the inner universe where that is
+ * not the observation; NULL otherwise) computes the centre of mass per instance, velocity (2,N) = previous - new,
+ * speed = sqrt(sum of all 2N squares) (one scalar for the whole batch, mcl.py:789) and adds it to every reward.
+ * com (2,N) holds the previous centre of mass (in/out), state[0] says whether it is valid yet (0 on the first step:
+ * then only com / live_out are written, as mcl.py:781-782); velocity (2,N), speed (1), live_out (N) are outputs. */
+int carle_speed_update_f32(const float *sums4, const float *live4, int64_t n, float *com, int32_t *state,
+                           float *velocity, float *speed, float *live_out, float *reward, void *stream);
+/* PufferDetector.step behind the reduction (carle/mcl.py:832-851): live_total = sum_i sums4[4i]; if the step had no
+ * non-zero action element (any_flag: device int32, e.g. status + CARLE_ST_ANY_NONZERO(slot) of the step just taken;
+ * NULL = no action) the total is appended to the history and, once it holds more than cap - 1 = growth_threshold
+ * entries, the oldest is dropped and every reward grows by 1 if newest - oldest > 0.01; else the history is cleared.
+ * ring: cap floats, ring_state: int32[2] = {head, count}, both caller-owned and zero-initialised. */
+int carle_puffer_update_f32(const float *sums4, int64_t n, const int32_t *any_flag, float *ring,
+                            int32_t *ring_state, int cap, float *live_total, float *reward, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Reward statistics for batch-sharded runs (build-side feature required by the north star; the
  * reference has none).  out3 / moments3 = fp64 (count, mean, M2) on the device.  The triples of

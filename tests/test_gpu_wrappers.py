@@ -96,6 +96,119 @@ def test_eval_wrapper_stack():
     _replay("evalstack", stack, atol=2e-5)
 
 
+def _eval_stack(n, size, graphable=True):
+    """RND2D -> AE2D -> SpeedDetector -> PufferDetector as evaluation/eval.py:83-87 stacks them."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D, SpeedDetector, PufferDetector
+    torch.manual_seed(3)
+    env = CARLE(width=size, height=size, instances=n, device="cuda:0")
+    kw = {"train_predictor": False} if graphable else {}
+    w = PufferDetector(SpeedDetector(AE2D(RND2D(env, **kw), **kw)))
+    w.env.reward_scale, w.reward_scale = 1e-2, 1e-3
+    for node in (w.env.env, w.env.env.env):
+        node.batch_size = 10 ** 6                           # eval.py:45: no update inside the run
+    w.growth_threshold = 5
+    w.eval()
+    w.reset()
+    return env, w
+
+
+@pytest.mark.parametrize("n,size", [(16, 64), (16, 256), (40, 64)])
+def test_eval_stack_steps_without_host_synchronisation(n, size):
+    """the evaluation stack (eval.py:83-87) issues no host synchronisation per step -- the reference's
+    PufferDetector alone makes two (mcl.py:832,835).  torch's sync debug mode raises on any synchronising call."""
+    env, w = _eval_stack(n, size, graphable=False)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    env.universe = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+    acts = [(torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.05).float() if t % 3 == 0 else
+            torch.zeros(n, 1, 64, 64, device="cuda") for t in range(12)]
+    sums = []
+    for a in acts[:4]:                                      # lazy set-up: workspaces, tables, weight planes, rings
+        sums.append(w.step(a)[1].detach().sum())
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for a in acts[4:]:
+            obs, reward, done, info = w.step(a)
+            sums.append(reward.detach().sum())              # the harness's per-step reduction (eval.py:69-70), deferred
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    trace = torch.stack(sums).cpu()
+    assert torch.isfinite(trace).all() and len(w.cells) <= w.growth_threshold
+
+
+@pytest.mark.parametrize("n,size", [(3, 64), (16, 256)])
+def test_step_graph_replays_the_evaluation_stack(n, size):
+    """StepGraph accepts SpeedDetector / PufferDetector: graph replay == eager loop for the whole eval.py stack,
+    rewards, centre of mass, speed, growth history and counters."""
+    from carle_amd.graphs import StepGraph
+    g = torch.Generator(device="cuda").manual_seed(2)
+    u0 = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+    acts = [(torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.05).float() if t in (0, 1, 9) else
+            torch.zeros(n, 1, 64, 64, device="cuda") for t in range(14)]
+    res = []
+    for mode in ("eager", "graph"):
+        env, w = _eval_stack(n, size)
+        env.universe = u0.clone()
+        static = torch.zeros_like(acts[0])
+        graph = StepGraph(w, static) if mode == "graph" else None
+        out = []
+        for a in acts:
+            if graph is None:
+                o, r, d, i = w.step(a)
+            else:
+                static.copy_(a)
+                o, r, d, i = graph()
+            out.append((o.clone(), r.clone()))
+        res.append((out, w.cells, w.live_cells, w.env.center_of_mass.clone(), w.env.speed.clone(), env.step_number))
+    (oe, ce, le, come, spe, sne), (og, cg, lg, comg, spg, sng) = res
+    for t, ((o0, r0), (o1, r1)) in enumerate(zip(oe, og)):
+        assert torch.equal(o0, o1), t
+        assert torch.allclose(r0, r1, atol=1e-6, rtol=1e-6), (t, (r0 - r1).abs().max())
+    assert ce == cg and le == lg and torch.equal(come, comg) and torch.equal(spe, spg) and sne == sng
+    assert any(float(r.max()) > 0.9 for _, r in og[8:]) or size == 64     # the growth bonus fired somewhere (soups grow or not)
+
+
+def test_puffer_history_matches_a_host_restatement():
+    """The device ring of PufferDetector against a host restatement of mcl.py:832-851 (append / pop / clear / slope),
+    with the threshold changed mid-run and a history assigned by the caller."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import PufferDetector
+    env = CARLE(width=64, height=64, instances=3, device="cuda:0")
+    env.rules_from_string("B3/S012345678")                  # growing rule: slopes > 0
+    w = PufferDetector(env)
+    w.growth_threshold = 4
+    w.reset()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    env.universe = (torch.rand(3, 1, 64, 64, device="cuda", generator=g) < 0.05).float()
+    cells, bonus = [], []
+    for t in range(20):
+        a = torch.zeros(3, 1, 64, 64, device="cuda")
+        if t in (7, 8):
+            a[1, 0, 3, 3] = 1.0
+        if t == 12:
+            w.growth_threshold = 6
+        obs, reward, done, info = w.step(a)
+        live = float(obs.sum())
+        exp = 0.0
+        if not bool(a.sum()):
+            cells.append(live)
+            if len(cells) > w.growth_threshold:
+                slope = cells[-1] - cells[0]
+                cells.pop(0)
+                exp = 1.0 if slope > 0.01 else 0.0
+        else:
+            cells = []
+        assert w.cells == cells and w.live_cells == live, t
+        assert reward.cpu().reshape(-1).tolist() == [exp] * 3, t
+        bonus.append(exp)
+    assert sum(bonus) > 0
+    w.cells = [1.0, 2.0]
+    assert w.cells == [1.0, 2.0]
+    w.step(torch.zeros(3, 1, 64, 64, device="cuda"))
+    assert w.cells[:2] == [1.0, 2.0] and len(w.cells) == 3
+
+
 def test_instance_sums_kernel():
     from carle_amd import hip
     x = (torch.rand(7, 1, 96, 96, device="cuda") < 0.3).float()
@@ -202,8 +315,8 @@ def test_step_graph_refuses_what_it_cannot_replay():
         StepGraph(env, RandomAgent(instances=2, action_width=64, action_height=64, device="cuda:0", fused=True)(env.universe))
     with pytest.raises(NotImplementedError):
         StepGraph(RND2D(env), a)                            # trains its predictor
-    with pytest.raises(NotImplementedError):
-        StepGraph(SpeedDetector(env), a)
+    g = StepGraph(SpeedDetector(env), a)                    # device-side history: replayable since round 3
+    assert g()[1].shape == (2, 1)
 
 
 @pytest.mark.parametrize("n,shape", [(3, (1, 64, 64)), (16, (1, 256, 256)), (5, (1, 7, 9)), (2, (1, 130, 130)), (1, (4099,)),
