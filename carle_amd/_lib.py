@@ -59,6 +59,8 @@ SIGNATURES = {
                                       _c_vp, ctypes.c_float, ctypes.c_float, _c_int, _c_vp]),
     "carle_ae2d_train_b1": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                      _c_vp, ctypes.c_float, ctypes.c_float, _c_int, _c_vp]),
+    "carle_adam_update_f32": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_i64, _c_int, _c_vp]),
     "carle_ae2d_workspace_floats": (_c_i64, [_c_i64, _c_int, _c_int]),
     "carle_ae2d_bonus_f32": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
                                       _c_vp, ctypes.c_float, _c_int, _c_vp]),

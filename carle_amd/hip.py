@@ -578,6 +578,22 @@ def instance_sums_f32(x, w0=None, w1=None, w2=None):
     return out
 
 
+def adam_update_f32(params, blob, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, zero_grad=True, stream=None):
+    """torch.optim.Adam's step on the flat gradient, one launch (carle_adam_update_f32): ``params`` = the contiguous
+    fp32 parameter tensors in blob order (updated in place), ``blob`` the flat copy the bonus kernels read."""
+    import ctypes
+    lib = _lib.load()
+    k = len(params)
+    ptrs = (ctypes.c_void_p * k)(*[p.data_ptr() for p in params])
+    counts = (ctypes.c_int64 * k)(*[p.numel() for p in params])
+    with _on_device(grad.device):
+        rc = lib.carle_adam_update_f32(ptrs, counts, k, _ptr(blob), grad.data_ptr(), exp_avg.data_ptr(),
+                                       exp_avg_sq.data_ptr(), float(lr), float(beta1), float(beta2), float(eps),
+                                       int(step), 1 if zero_grad else 0, stream if stream is not None else _stream(grad))
+    if rc != 0:
+        _lib.check(rc, "carle_adam_update_f32")
+
+
 def speed_update_f32(sums4, live4, com, state, velocity, speed, live_out, reward):
     """SpeedDetector tail (carle_speed_update_f32): centre of mass, velocity, batch speed, reward += speed."""
     lib = _lib.load()

@@ -109,6 +109,14 @@ class _ParamBlob:
             self.version += 1
         return self.blob
 
+    def updated_in_place(self, device):
+        """A kernel rewrote the parameters AND this blob (carle_adam_update_f32): the blob is current, its users'
+        derived data (lookup tables) is not.  The parameters' autograd version counters are bumped so that other
+        observers of the tensors see the change too."""
+        torch._C._increment_version(list(self.params))
+        self.key = (device,) + tuple([(p.data_ptr(), p._version) for p in self.params])
+        self.version += 1
+
 
 class RND2D(Motivator):
     """Random network distillation bonus on (N,1,H,W) grids (mcl.py:233-421)."""
@@ -271,10 +279,13 @@ class RND2D(Motivator):
     # parameters are constant inside a window, so the sum is the same)
     window_bytes_cap = 256 << 20
 
-    def _retain(self, obs):
+    def _retain(self, obs, scale=None):
         """Keeps ``obs`` for the replay.  Binary observations (anything CARLE.step returned) are kept
         bit-packed (carle_pack_f32_b1: 1/32 of the fp32 bytes) and unpacked per replay chunk; nothing
-        is kept while no predictor parameter requires a gradient (``set_no_grad``)."""
+        is kept while no predictor parameter requires a gradient (``set_no_grad``).  ``scale``: the loss
+        scale of an EARLY replay when the retained bytes exceed ``window_bytes_cap`` (the window's own scale --
+        1 / batch_size for ``get_bonus_accumulate``); None = never replay early (``get_bonus_update`` replays the
+        one observation itself, with scale 1)."""
         if not any(p.requires_grad for p in self._pred_blob.params or self.predictor.parameters()):
             return
         o, binary = self._obs(obs)
@@ -282,8 +293,12 @@ class RND2D(Motivator):
             o = hip.pack_f32_b1(o)
         self._window.append(o)
         self.__dict__["_window_bytes"] = self.__dict__.get("_window_bytes", 0) + o.numel() * o.element_size()
-        if self.__dict__["_window_bytes"] > self.window_bytes_cap:
-            self.accumulate_loss = self.accumulate_loss + self._replay_window(1.0 / self.batch_size)
+        if scale is not None and self.__dict__["_window_bytes"] > self.window_bytes_cap:
+            self.accumulate_loss = self.accumulate_loss + self._replay_window(scale)
+
+    def _drop_window(self):
+        self._window = []
+        self.__dict__["_window_bytes"] = 0
 
     def update_predictor(self, loss):
         loss.backward()
@@ -333,13 +348,21 @@ class RND2D(Motivator):
         return total
 
     def get_bonus_update(self, obs):
-        """Bonus + immediate predictor update on this observation (mcl.py:354-366)."""
-        self.predictor.zero_grad()
-        bonus = self.get_bonus(obs)
-        self._window = []
-        self._retain(obs)
-        self._replay_window(1.0)
-        self.optimizer.step()
+        """Bonus + immediate predictor update on this observation (mcl.py:354-366): the gradient of
+        mean_n(loss_n) through the HIP training kernels (fused / tiled / staged, as ``get_bonus_accumulate``),
+        then one Adam step -- no autograd graph.  Geometries the kernels do not cover (H != W or not a multiple
+        of 8) replay the observation through autograd."""
+        self.predictor.zero_grad()                           # drops whatever a window had accumulated, as the reference
+        if self._grad is not None and self._grad_used:
+            self._grad.zero_()
+            self._grad_used = False
+        self._drop_window()
+        o = self._obs(obs, allow_packed=True)[0]
+        bonus = torch.empty(o.shape[0], dtype=torch.float32, device=o.device)
+        if not self._fused_train(obs, None, bonus, None, batch=1):
+            bonus = self.get_bonus(obs)
+            self._retain(obs)                                # never replayed early: scale 1 below
+        self._apply_update()
         self._after_update()
         return bonus
 
@@ -351,10 +374,9 @@ class RND2D(Motivator):
         if self.buffer_length == 0:
             self.predictor.zero_grad()
             self.accumulate_loss = 0.0
-            self._window = []
-            self.__dict__["_window_bytes"] = 0
+            self._drop_window()
         if not self._fused_train(obs, None, bonus, None):
-            self._retain(obs)
+            self._retain(obs, 1.0 / self.batch_size)
             bonus = self.get_bonus(obs)
         self.buffer_length += 1
         if self.buffer_length >= self.batch_size:
@@ -379,31 +401,89 @@ class RND2D(Motivator):
         if self.buffer_length == 0:
             self.predictor.zero_grad()
             self.accumulate_loss = 0.0
-            self._window = []
-            self.__dict__["_window_bytes"] = 0
+            self._drop_window()
         if not self._fused_train(obs, reward, self._bonus_buf, stream):
-            self._retain(obs)
+            self._retain(obs, 1.0 / self.batch_size)
             self._hip_forward(obs, False, reward, self._bonus_buf, stream)
         self.buffer_length += 1
         if self.buffer_length >= self.batch_size:
             self._finish_window()
 
     def _finish_window(self):
-        """End of an update window: replay retained observations (if any), add the gradient the
-        fused kernel accumulated, Adam step (mcl.py:380-384, 333-341)."""
+        """End of an update window (mcl.py:380-384, 333-341): one Adam step on the window's gradient."""
+        self._apply_update(1.0 / self.batch_size)
+        self._after_update()
+        self.buffer_length = 0
+
+    # ---- optimizer.step() ------------------------------------------------------------------------------------
+    def _apply_update(self, replay_scale=1.0):
+        """optimizer.step() on the gradient of the window: the flat gradient the HIP training kernels accumulated
+        goes through ``carle_adam_update_f32`` (torch.optim.Adam's arithmetic in one launch, parameters and the
+        kernels' parameter blob updated in place, Adam's moments shared with ``self.optimizer.state`` so that
+        ``optimizer.state_dict()`` keeps working).  Retained observations (geometries without gradient kernels) are
+        replayed through autograd first; whenever autograd gradients or a non-default optimiser are involved the
+        step is torch's own."""
         if self._window:
-            self.accumulate_loss = self.accumulate_loss + self._replay_window(1.0 / self.batch_size)
+            self.accumulate_loss = self.accumulate_loss + self._replay_window(replay_scale)
+        params = self._pred_blob.params or list(self.predictor.parameters())
+        if self._grad_used and self._hip_adam_applies(params):
+            self._hip_adam_step(params)
+            return
         if self._grad_used:
             off = 0
-            for p in self._pred_blob.params:
+            for p in params:
                 gslice = self._grad[off:off + p.numel()].view_as(p)
                 p.grad = gslice.clone() if p.grad is None else p.grad + gslice
                 off += p.numel()
             self._grad.zero_()
             self._grad_used = False
         self.optimizer.step()
-        self._after_update()
-        self.buffer_length = 0
+
+    def _hip_adam_applies(self, params):
+        opt = self.optimizer
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1 or len(params) > 8:
+            return False
+        g = opt.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("weight_decay", 0) != 0 or g.get("differentiable"):
+            return False
+        if len(g["params"]) != len(params) or any(a is not b for a, b in zip(g["params"], params)):
+            return False
+        dev = self._grad.device
+        return all(p.grad is None and p.requires_grad and p.device == dev and p.dtype == torch.float32
+                   and p.is_contiguous() for p in params)
+
+    def _hip_adam_step(self, params):
+        dev = self._grad.device
+        total = self._grad.numel()
+        st = self.__dict__.get("_adam")
+        if st is None or st[0].device != dev or st[0].numel() != total:
+            st = self.__dict__["_adam"] = [torch.zeros(total, dtype=torch.float32, device=dev),
+                                          torch.zeros(total, dtype=torch.float32, device=dev), 0]
+        m, v, step = st
+        # Adam's moments are shared with the torch optimiser: its per-parameter state tensors are views of the flat
+        # vectors.  A state somebody else installed (optimizer.load_state_dict, earlier torch steps) is adopted.
+        off = 0
+        for p in params:
+            k = p.numel()
+            ps = self.optimizer.state.get(p)
+            if ps and "exp_avg" in ps and ps["exp_avg"].data_ptr() != m.data_ptr() + 4 * off:
+                m[off:off + k].copy_(ps["exp_avg"].reshape(-1))
+                v[off:off + k].copy_(ps["exp_avg_sq"].reshape(-1))
+                step = int(float(ps["step"]))
+            if not ps or ps["exp_avg"].data_ptr() != m.data_ptr() + 4 * off:
+                self.optimizer.state[p] = {"step": torch.tensor(float(step)), "exp_avg": m[off:off + k].view_as(p),
+                                           "exp_avg_sq": v[off:off + k].view_as(p)}
+            off += k
+        step += 1
+        st[2] = step
+        g = self.optimizer.param_groups[0]
+        blob = self._pred_blob.get(dev)
+        hip.adam_update_f32([p.data for p in params], blob, self._grad, m, v, g["lr"], g["betas"][0], g["betas"][1],
+                            g["eps"], step, zero_grad=True)
+        for p in params:
+            self.optimizer.state[p]["step"].fill_(float(step))        # host tensors
+        self._pred_blob.updated_in_place(dev)
+        self._grad_used = False
 
     # bit-packed observations of any square size that is a multiple of 64 go to the kernels as they are
     # (tiled forward, nets_tiled.hip)
@@ -413,7 +493,7 @@ class RND2D(Motivator):
     # autograd (the round-1 path; kept for A/B tests) instead of the staged HIP backward kernels
     hip_backward_any_size = True
 
-    def _fused_train(self, obs, reward, bonus_out, stream):
+    def _fused_train(self, obs, reward, bonus_out, stream, batch=None):
         """Bonus + gradient in one library call (carle_rnd2d_train_* / carle_ae2d_train_*): the fused
         forward+backward kernel for 64x64 binary observations, staged forward + staged backward HIP
         kernels for every other square size that is a multiple of 8 (the reference's default 256x256).
@@ -458,11 +538,11 @@ class RND2D(Motivator):
         versions = (self._pred_blob.version,) if is_ae else (self._pred_blob.version, self._rand_blob.version)
         valid = uses_tables and self._tables_key == (id(self._ws), versions)
         if is_ae:
-            grad_scale = 2.0 / (size * size * n * self.batch_size)
+            grad_scale = 2.0 / (size * size * n * (self.batch_size if batch is None else batch))
             hip.ae2d_train(o, pb, self._ws, self._partial, self._grad, bonus_out, reward,
                            self.reward_scale, grad_scale, valid, stream, binary=uses_tables)
         else:
-            grad_scale = 2.0 / (self.rnd_dim * n * self.batch_size)
+            grad_scale = 2.0 / (self.rnd_dim * n * (self.batch_size if batch is None else batch))
             hip.rnd2d_train(o, pb, rb, self._ws, self._partial, self._grad, bonus_out, reward,
                             self.reward_scale, grad_scale, valid, stream, binary=uses_tables)
         self._tables_key = (id(self._ws), versions) if uses_tables else None

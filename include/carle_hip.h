@@ -321,6 +321,21 @@ int carle_ae2d_train_b1(const uint64_t *obs, int64_t n, int h, int w, const floa
                         float *reward_accum, float reward_scale, float grad_scale, int flags,
                         void *stream);
 
+/* optimizer.step() of the wrappers' Adam (RND2D / AE2D.update_predictor, carle/mcl.py:333-341, 498-502; Adam(lr=6e-2)
+ * with torch's defaults, mcl.py:243,278-279) on the flat gradient the carle_*_train_* kernels accumulated -- one launch,
+ * torch.optim.Adam's arithmetic operation by operation (no weight decay, no amsgrad).
+ *   param_ptrs / param_counts  HOST arrays of n_params (<= CARLE_ADAM_MAX_PARAMS) device pointers / element counts:
+ *                              the predictor's parameter tensors in state_dict order, updated in place
+ *   blob (nullable)            flat copy of the parameters in the same order (the *_params argument of the bonus
+ *                              kernels): receives the new values too
+ *   grad, exp_avg, exp_avg_sq  flat fp32 vectors of sum(param_counts) elements (Adam's state lives with the caller);
+ *                              zero_grad != 0 clears grad afterwards (optimizer.zero_grad(), mcl.py:339)
+ *   step                       1 for the first update (torch increments its step counter before using it) */
+#define CARLE_ADAM_MAX_PARAMS 8
+int carle_adam_update_f32(float *const *param_ptrs, const int64_t *param_counts, int n_params, float *blob,
+                          float *grad, float *exp_avg, float *exp_avg_sq, double lr, double beta1, double beta2,
+                          double eps, int64_t step, int zero_grad, void *stream);
+
 /* AE2D.get_bonus (carle/mcl.py:436-443,504-512): bonus[i] = mean_{h,w} (obs_i - decoder(obs_i))^2.
  * recon_out: optional (N,1,H,W) reconstruction, may be NULL. */
 int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w);

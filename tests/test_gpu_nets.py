@@ -826,3 +826,158 @@ def test_tiled_nets_on_byte_and_packed_environments(storage):
         r0 = ref_ae.step(a)[1]
         r1 = ae.step(a)[1]
         np.testing.assert_allclose(r1.detach().cpu().numpy(), r0.detach().cpu().numpy(), rtol=0, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# optimizer.step() on the HIP path (carle_adam_update_f32) and get_bonus_update without autograd
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shapes", [[(4, 1, 3, 3), (4,), (1, 4, 3, 3), (1,), (16, 64), (16,)],      # RND2D predictor at 64x64
+                                    [(4, 1, 3, 3), (4,), (2, 4, 3, 3), (2,), (2, 1, 4, 4), (1,), (1, 1, 4, 4), (1,)],  # AE2D
+                                    [(16, 1024), (16,)], [(3,)]])
+def test_adam_kernel_matches_torch_adam(shapes):
+    """carle_adam_update_f32 against torch.optim.Adam(lr=6e-2) (the reference's optimiser, mcl.py:243,278-279) over
+    10 steps with fresh gradients: parameters and both moment vectors to 1e-7 relative (the kernel performs torch's
+    operations one by one in fp32; what is left is the compiler's choice of fused multiply-adds)."""
+    from carle_amd import hip
+    g = torch.Generator(device="cuda").manual_seed(len(shapes))
+    ref = [torch.nn.Parameter(torch.randn(s, device="cuda", generator=g) * 0.3) for s in shapes]
+    mine = [p.detach().clone() for p in ref]
+    opt = torch.optim.Adam(ref, lr=6e-2)
+    total = sum(p.numel() for p in ref)
+    blob = torch.cat([p.reshape(-1) for p in mine])
+    m, v = torch.zeros(total, device="cuda"), torch.zeros(total, device="cuda")
+    worst = 0.0
+    for step in range(1, 11):
+        grads = [torch.randn(s, device="cuda", generator=g) * (10.0 ** -(step % 4)) for s in shapes]
+        for p, gr in zip(ref, grads):
+            p.grad = gr.clone()
+        opt.step()
+        flat = torch.cat([gr.reshape(-1) for gr in grads])
+        hip.adam_update_f32(mine, blob, flat, m, v, 6e-2, 0.9, 0.999, 1e-8, step, zero_grad=True)
+        assert float(flat.abs().max()) == 0.0                                   # optimizer.zero_grad()
+        off = 0
+        for p, q in zip(ref, mine):
+            k = p.numel()
+            st = opt.state[p]
+            for a, b in ((p.detach(), q), (st["exp_avg"], m[off:off + k].view_as(p)), (st["exp_avg_sq"], v[off:off + k].view_as(p))):
+                err = ((a - b).abs() / a.abs().clamp_min(1e-30)).max().item()
+                worst = max(worst, err)
+                assert torch.allclose(a, b, rtol=1e-7, atol=1e-12), (step, err)
+            assert torch.equal(blob[off:off + k].view_as(q), q)                # the kernels' blob follows the parameters
+            off += k
+    print(f"adam kernel vs torch.optim.Adam, worst relative difference over 10 steps: {worst:.2e}")
+
+
+@pytest.mark.parametrize("cls,size,n", [("RND2D", 64, 6), ("AE2D", 64, 5), ("RND2D", 256, 3), ("AE2D", 128, 2), ("RND2D", 40, 3)])
+def test_update_window_through_the_adam_kernel_equals_torch_adam(cls, size, n):
+    """A wrapper's update window ends in carle_adam_update_f32; the same window with torch's own optimizer.step() on
+    the same kernel gradient (the round-2 path) gives the same parameters, and optimizer.state_dict() of the HIP path
+    loads into a fresh torch Adam that then continues identically."""
+    from carle_amd.env import CARLE
+    import carle_amd.mcl as M
+    ws = []
+    for use_hip in (True, False):
+        torch.manual_seed(9)
+        env = CARLE(width=size, height=size, action_width=min(64, size), action_height=min(64, size), instances=n, device="cuda:0")
+        w = getattr(M, cls)(env)
+        w.eval(); w.reset()
+        w.batch_size = 2
+        w.assume_binary_obs = True
+        if not use_hip:
+            w._hip_adam_applies = lambda params: False
+        ws.append(w)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(6):                                                          # three updates
+        obs = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+        b0, b1 = ws[0].get_bonus_accumulate(obs), ws[1].get_bonus_accumulate(obs)
+        assert torch.allclose(b0, b1, rtol=1e-6, atol=1e-8), t
+    assert ws[0].__dict__.get("_adam") is not None and ws[1].__dict__.get("_adam") is None
+    for (k, a), (_, b) in zip(ws[0].state_dict().items(), ws[1].state_dict().items()):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (k, (a - b).abs().max())
+    sd0, sd1 = ws[0].optimizer.state_dict(), ws[1].optimizer.state_dict()
+    assert sd0["param_groups"] == sd1["param_groups"]
+    for i in sd1["state"]:
+        assert float(sd0["state"][i]["step"]) == float(sd1["state"][i]["step"]) == 3.0
+        assert torch.allclose(sd0["state"][i]["exp_avg"], sd1["state"][i]["exp_avg"], rtol=2e-6, atol=1e-9)
+        assert torch.allclose(sd0["state"][i]["exp_avg_sq"], sd1["state"][i]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+    # round trip: the HIP path's optimiser state into the torch path and back
+    import copy
+    ws[1].optimizer.load_state_dict(copy.deepcopy(sd0))      # (state_dict() hands out the live tensors, as torch's does)
+    ws[1].load_state_dict(ws[0].state_dict())
+    ws[0].optimizer.load_state_dict(copy.deepcopy(sd0))      # replaces the shared views: adopted again at the next update
+    for t in range(4):
+        obs = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+        ws[0].get_bonus_accumulate(obs); ws[1].get_bonus_accumulate(obs)
+    for (k, a), (_, b) in zip(ws[0].state_dict().items(), ws[1].state_dict().items()):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (k, (a - b).abs().max())
+    assert float(ws[0].optimizer.state_dict()["state"][0]["step"]) == 5.0
+
+
+@pytest.mark.parametrize("cls,size,n", [("RND2D", 64, 7), ("AE2D", 64, 4), ("RND2D", 256, 2), ("AE2D", 256, 2), ("AE2D", 24, 3)])
+def test_get_bonus_update_runs_on_the_hip_path(cls, size, n, monkeypatch):
+    """get_bonus_update (mcl.py:354-366): bonus + one Adam step on the gradient of mean_n(loss_n), through the training
+    kernels and the Adam kernel -- no autograd (loss.backward is never called) -- equal to autograd + torch Adam on the
+    same network, and to get_bonus_accumulate with batch_size 1."""
+    from carle_amd.env import CARLE
+    import carle_amd.mcl as M
+    made = []
+    for i in range(3):
+        torch.manual_seed(31)
+        env = CARLE(width=size, height=size, action_width=min(64, size), action_height=min(64, size), instances=n, device="cuda:0")
+        w = getattr(M, cls)(env)
+        w.eval(); w.reset()
+        w.assume_binary_obs = True
+        made.append(w)
+    hipw, accw, refw = made
+    accw.batch_size = 1
+    called = []
+    monkeypatch.setattr(torch.Tensor, "backward", lambda self, *a, **k: called.append(1) or torch.autograd.backward(self, *a, **k))
+    g = torch.Generator(device="cuda").manual_seed(6)
+    for t in range(3):
+        obs = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+        before = len(called)
+        b0 = hipw.get_bonus_update(obs)
+        b1 = accw.get_bonus_accumulate(obs)
+        assert len(called) == before, "get_bonus_update went through autograd"
+        assert torch.equal(b0, b1)
+        # the reference's own sequence on the nn.Sequential: zero_grad, loss, backward, Adam
+        refw.predictor.zero_grad()
+        loss = refw._torch_loss(obs)
+        torch.mean(loss).backward()
+        refw.optimizer.step()
+        assert torch.allclose(b0, loss.detach(), rtol=0, atol=2e-5), t
+    assert len(called) == 3
+    assert hipw.updates == (3 if cls == "RND2D" else 0) and hipw.buffer_length == 0
+    for (k, a), (_, b), (_, c) in zip(hipw.state_dict().items(), accw.state_dict().items(), refw.state_dict().items()):
+        assert torch.equal(a, b), k
+        assert torch.allclose(a, c, rtol=0, atol=2e-3), (k, (a - c).abs().max())     # Adam's +-lr first steps, DESIGN.md
+
+
+def test_early_window_replay_keeps_its_scale():
+    """the autograd replay window (geometries without gradient kernels: H != W) replayed early above
+    window_bytes_cap uses the window's own loss scale, get_bonus_update never replays early, and a discarded window
+    leaves no stale byte count behind."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D
+    outs = []
+    for cap in (1 << 40, 1):
+        torch.manual_seed(4)
+        env = CARLE(width=64, height=64, instances=3, device="cuda:0")
+        w = RND2D(env)
+        w.eval(); w.reset()
+        w.hip_backward_any_size = False                     # force retention + autograd replay (the round-1 path)
+        w._fused_train = lambda *a, **k: False
+        w.window_bytes_cap = cap
+        w.batch_size = 3
+        g = torch.Generator(device="cuda").manual_seed(8)
+        obs = [(torch.rand(3, 1, 64, 64, device="cuda", generator=g) < 0.3).float() for _ in range(5)]
+        w.get_bonus_accumulate(obs[0])                      # a window in progress ...
+        w.get_bonus_update(obs[1])                          # ... discarded by zero_grad; one update with scale 1
+        assert w.__dict__.get("_window_bytes", 0) == 0 and not w._window
+        for o in obs[2:]:
+            w.get_bonus_accumulate(o)
+        outs.append({k: v.detach().clone() for k, v in w.state_dict().items()})
+        assert w.updates == 2
+    for k in outs[0]:
+        assert torch.allclose(outs[0][k], outs[1][k], rtol=0, atol=1e-5), (k, (outs[0][k] - outs[1][k]).abs().max())
