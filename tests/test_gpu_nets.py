@@ -13,6 +13,10 @@ from oracle import nets as ON
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+# reference-recorded training trajectories (3 Adam updates; the reference ran fp32 autograd + torch Adam on the CPU):
+# measured differences (profiles/r03_trajectory_errors.txt): rewards <= 3e-8 (one ulp of 0.3), weights <= 4e-7
+TRAJ_REWARD_TOL = 5e-7
+TRAJ_WEIGHT_TOL = 2e-6
 
 
 def _stack(size, n, rnd_sd=None, ae_sd=None):
@@ -105,12 +109,12 @@ def test_predictor_update_trajectory():
     acts = G.unpack(z["upd_actions"], (6, 4, 1, 64, 64))
     for t in range(6):
         obs, reward, done, info = ae.step(torch.from_numpy(acts[t]))
-        np.testing.assert_allclose(reward.cpu().numpy(), z["upd_rewards"][t], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(reward.cpu().numpy(), z["upd_rewards"][t], rtol=0, atol=TRAJ_REWARD_TOL)
     assert [rnd.updates, ae.updates] == z["upd_updates"].tolist()
     for prefix, mod in (("upd_rnd_sd", rnd), ("upd_ae_sd", ae)):
         ref = G.load_sd(z, prefix)
         for k, v in mod.state_dict().items():
-            np.testing.assert_allclose(v.cpu().numpy(), ref[k], rtol=0, atol=2e-3, err_msg=k)
+            np.testing.assert_allclose(v.cpu().numpy(), ref[k], rtol=0, atol=TRAJ_WEIGHT_TOL, err_msg=k)
 
 
 def test_fused64_matches_reference_and_staged():
@@ -308,14 +312,7 @@ def test_fused_rnd_gradient_matches_autograd(n, packed):
         assert rnd._fused_train(obs, reward, bonus, None)
     np.testing.assert_allclose(bonus.cpu().numpy(), expected_bonus.cpu().numpy(), rtol=0, atol=1e-6)
     np.testing.assert_allclose(reward.cpu().numpy()[:, 0], 2 * expected_bonus.cpu().numpy(), rtol=1e-5, atol=1e-6)
-    rnd.predictor.zero_grad()
-    loss = torch.mean(rnd._torch_loss(g)) / rnd.batch_size * 2.0
-    loss.backward()
-    ref = torch.cat([p.grad.reshape(-1) for p in rnd.predictor.parameters()]).cpu().numpy()
-    got = rnd._grad.cpu().numpy()
-    scale = np.abs(ref).max()
-    assert scale > 0
-    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+    _grad_check(rnd, g, rnd._grad, factor=2.0, what="fused64")
 
 
 def test_fused_training_window_updates_like_autograd():
@@ -339,7 +336,7 @@ def test_fused_training_window_updates_like_autograd():
         np.testing.assert_allclose(bf.cpu().numpy(), br.cpu().numpy(), rtol=0, atol=2e-5)
     assert fused.updates == replay.updates == 2
     for (k, a), (_, b) in zip(fused.state_dict().items(), replay.state_dict().items()):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-3, err_msg=k)
+        _assert_updated_weights_close(a.cpu(), b.cpu(), k)
 
 
 @pytest.mark.parametrize("n,packed", [(1, False), (4, False), (19, True), (600, False)])
@@ -361,14 +358,7 @@ def test_fused_ae_gradient_matches_autograd(n, packed):
         assert ae._fused_train(obs, reward, bonus, None)
     np.testing.assert_allclose(bonus.cpu().numpy(), expected_bonus.cpu().numpy(), rtol=0, atol=1e-6)
     np.testing.assert_allclose(reward.cpu().numpy()[:, 0], 2 * expected_bonus.cpu().numpy(), rtol=1e-5, atol=1e-6)
-    ae.predictor.zero_grad()
-    loss = torch.mean(ae._torch_loss(g)) / ae.batch_size * 2.0
-    loss.backward()
-    ref = torch.cat([p.grad.reshape(-1) for p in ae.predictor.parameters()]).cpu().numpy()
-    got = ae._grad.cpu().numpy()
-    scale = np.abs(ref).max()
-    assert scale > 0
-    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+    _grad_check(ae, g, ae._grad, factor=2.0, what="fused64")
 
 
 @pytest.mark.parametrize("size,n,steps", [(64, 64, 20), (32, 8, 20)])
@@ -507,6 +497,50 @@ def test_cfg3_full_size_against_the_oracle():
 # ---------------------------------------------------------------------------------------------
 # staged backward kernels (any size that is a multiple of 8; the reference's default 256x256)
 # ---------------------------------------------------------------------------------------------
+# Gradient kernels vs fp64 autograd, per parameter tensor: profiles/r03_grad_error_table.txt measures <= 6.1e-7 of the
+# tensor's largest gradient component for every kernel family (fused 64x64, tiled, staged; fp32 autograd itself: up to
+# 9.8e-7) -- fp32 rounding of sums of a few thousand terms, no systematic term.  The bound asserted is 5x that.
+GRAD_TOL = 3e-6
+
+
+def _grad_check(w, g, got, factor=1.0, what=""):
+    """`got` (flat, blob order) against the fp64 autograd gradient of factor * mean_n(loss_n) / batch_size."""
+    import copy
+    pred = copy.deepcopy(w.predictor).double().eval()
+    o = g.double()
+    if w.my_name == "RND2D":
+        with torch.no_grad():
+            target = copy.deepcopy(w.random_network).double().eval()(o)
+        loss = torch.mean(torch.abs((target - pred(o)) ** 2), dim=[1])
+    else:
+        loss = torch.mean(torch.abs((o - pred(o).reshape(o.shape)) ** 2), dim=[1, 2, 3])
+    (torch.mean(loss) * (factor / w.batch_size)).backward()
+    got = torch.as_tensor(got, dtype=torch.float64).reshape(-1).cpu()
+    off, seen = 0, 0.0
+    for name, p in pred.named_parameters():
+        ref = p.grad.reshape(-1).cpu()
+        mine = got[off:off + ref.numel()]
+        off += ref.numel()
+        scale = ref.abs().max().item()
+        err = (mine - ref).abs().max().item()
+        seen = max(seen, scale)
+        assert err <= GRAD_TOL * scale + 1e-12, f"{what} {w.my_name} {name}: |d| {err:.3e} vs max |grad| {scale:.3e}"
+    assert seen > 0 and off == got.numel()
+
+
+
+def _assert_updated_weights_close(a, b, name):
+    """Two fp32 evaluations of the same Adam trajectory (HIP gradient kernels vs fp32 autograd): Adam divides by
+    sqrt(v) + 1e-8, so a gradient component that is itself of the order of its own fp32 noise (<= 1e-6 of the tensor's
+    largest component) moves by a visible fraction of lr = 6e-2 in the first updates (seen: 3 of the 16384 linear weights
+    at 256x256 by 2e-5 against the reference's CPU run); every other element agrees to rounding (<= 2e-6 measured).
+    Bound: at most 8 elements of a tensor beyond 1e-5, none beyond 1e-4."""
+    d = (torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs()
+    far = int((d > 1e-5).sum())
+    print(f"  updated {name}: max diff {d.max().item():.2e}, {far} / {d.numel()} elements beyond 1e-5")
+    assert d.max().item() <= 1e-4 and far <= 8, (name, d.max().item(), far, d.numel())
+
+
 def _autograd_grad(w, g):
     """flat gradient of mean_n(loss_n) / batch_size through the nn.Sequential (eval mode)."""
     w.predictor.zero_grad()
@@ -542,9 +576,7 @@ def test_staged_backward_matches_autograd(size, n, binary):
             np.testing.assert_allclose(bonus.cpu().numpy(), exp_bonus.cpu().numpy(), rtol=0, atol=1e-6)
             np.testing.assert_allclose(reward.cpu().numpy()[:, 0], 2 * exp_bonus.cpu().numpy(), rtol=1e-5, atol=1e-6)
         assert np.array_equal(runs[0], runs[1])                      # deterministic reductions
-        scale = np.abs(ref).max()
-        assert scale > 0
-        np.testing.assert_allclose(runs[0], 2 * ref, rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=w.my_name)
+        _grad_check(w, g, runs[0], factor=2.0, what="staged")
 
 
 @pytest.mark.parametrize("size", [32, 256])
@@ -574,7 +606,7 @@ def test_staged_backward_window_equals_autograd_replay(size):
                      {k: v.detach().cpu().numpy() for k, v in ae.state_dict().items()}))
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
     for k in outs[0][1]:
-        np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=0, atol=2e-3, err_msg=k)
+        _assert_updated_weights_close(outs[0][1][k], outs[1][1][k], k)
 
 
 def test_reference_training_trajectory_256():
@@ -598,13 +630,17 @@ def test_reference_training_trajectory_256():
     for t in range(6):
         obs, reward, done, info = ae.step(torch.from_numpy(acts[t]))
         assert not rnd._window and not ae._window
-        np.testing.assert_allclose(reward.cpu().numpy(), z["rewards"][t], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(reward.cpu().numpy(), z["rewards"][t], rtol=0, atol=TRAJ_REWARD_TOL)
     assert [rnd.updates, ae.updates] == z["updates"].tolist()
     assert np.array_equal(obs.cpu().numpy(), G.unpack(z["final_obs"], (n, 1, 256, 256)))
     for prefix, mod in (("final_rnd_sd", rnd), ("final_ae_sd", ae)):
         ref = G.load_sd(z, prefix)
         for k, v in mod.state_dict().items():
-            np.testing.assert_allclose(v.cpu().numpy(), ref[k], rtol=0, atol=2e-3, err_msg=k)
+            d = np.abs(v.cpu().numpy() - ref[k])
+            # Adam divides by sqrt(v) + 1e-8: where a gradient component is itself ~1e-8 (a handful of the 16384 linear
+            # weights at 256x256), fp32 noise of that component moves the update by a visible fraction of lr -- 3 elements
+            # differ by up to 2.1e-5 (tools/trajectory_errors.py), everything else by < 4e-7
+            assert (d > TRAJ_WEIGHT_TOL).sum() <= 8 and d.max() <= 1e-4, (k, d.max(), (d > TRAJ_WEIGHT_TOL).sum())
 
 
 def test_tiled_rnd_matches_reference_and_staged_256():
@@ -729,7 +765,7 @@ def test_tiled_stack_through_the_environment_256():
 @pytest.mark.parametrize("size,n,packed", [(128, 5, False), (256, 4, False), (256, 19, True), (192, 2, False)])
 def test_tiled_rnd_training_matches_autograd_and_staged(size, n, packed):
     """carle_rnd2d_train_* on binary grids with H = W a multiple of 64: tiled forward (features kept) + tiled conv
-    gradients + the staged linear gradient.  Bonus = the forward bonus, accumulated gradient = autograd's (2e-4)
+    gradients + the staged linear gradient.  Bonus = the forward bonus, accumulated gradient = fp64 autograd's (GRAD_TOL per tensor)
     and the staged backward's, accumulation over two calls, deterministic."""
     from carle_amd import hip
     torch.manual_seed(500 + size + n)
@@ -759,16 +795,14 @@ def test_tiled_rnd_training_matches_autograd_and_staged(size, n, packed):
         np.testing.assert_allclose(bonus.cpu().numpy(), exp_bonus.cpu().numpy(), rtol=0, atol=1e-6)
         np.testing.assert_allclose(reward.cpu().numpy()[:, 0], 2 * exp_bonus.cpu().numpy(), rtol=1e-5, atol=1e-6)
     assert np.array_equal(runs[0], runs[1])                 # deterministic reductions
-    scale = np.abs(ref).max()
-    assert scale > 0
-    np.testing.assert_allclose(runs[0], 2 * ref, rtol=2e-4, atol=2e-6 * scale + 1e-9)
-    np.testing.assert_allclose(runs[0], staged, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+    _grad_check(rnd, g, runs[0], factor=2.0, what="tiled")
+    _grad_check(rnd, g, staged, factor=2.0, what="staged")
 
 
 @pytest.mark.parametrize("size,n,packed", [(128, 5, False), (256, 4, False), (256, 9, True), (192, 2, False)])
 def test_tiled_ae_training_matches_autograd_and_staged(size, n, packed):
     """carle_ae2d_train_* on binary grids with H = W a multiple of 64: ONE tiled kernel (forward + backward per
-    tile) + finish + row reduction.  Bonus = the forward bonus, accumulated gradient = autograd's (2e-4) and the
+    tile) + finish + row reduction.  Bonus = the forward bonus, accumulated gradient = fp64 autograd's (GRAD_TOL per tensor) and the
     staged backward's, accumulation over two calls, deterministic."""
     from carle_amd import hip
     torch.manual_seed(600 + size + n)
@@ -798,10 +832,8 @@ def test_tiled_ae_training_matches_autograd_and_staged(size, n, packed):
         np.testing.assert_allclose(bonus.cpu().numpy(), exp_bonus.cpu().numpy(), rtol=0, atol=1e-6)
         np.testing.assert_allclose(reward.cpu().numpy()[:, 0], 2 * exp_bonus.cpu().numpy(), rtol=1e-5, atol=1e-6)
     assert np.array_equal(runs[0], runs[1])
-    scale = np.abs(ref).max()
-    assert scale > 0
-    np.testing.assert_allclose(runs[0], 2 * ref, rtol=2e-4, atol=2e-6 * scale + 1e-9)
-    np.testing.assert_allclose(runs[0], staged, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+    _grad_check(ae, g, runs[0], factor=2.0, what="tiled")
+    _grad_check(ae, g, staged, factor=2.0, what="staged")
 
 
 @pytest.mark.parametrize("storage", ["u8", "b1"])
@@ -951,7 +983,7 @@ def test_get_bonus_update_runs_on_the_hip_path(cls, size, n, monkeypatch):
     assert hipw.updates == (3 if cls == "RND2D" else 0) and hipw.buffer_length == 0
     for (k, a), (_, b), (_, c) in zip(hipw.state_dict().items(), accw.state_dict().items(), refw.state_dict().items()):
         assert torch.equal(a, b), k
-        assert torch.allclose(a, c, rtol=0, atol=2e-3), (k, (a - c).abs().max())     # Adam's +-lr first steps, DESIGN.md
+        _assert_updated_weights_close(a, c, k)
 
 
 def test_early_window_replay_keeps_its_scale():
