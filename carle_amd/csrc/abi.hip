@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256) void ca_finish_kernel(uint4 *__restrict__ out,
     double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
     double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
     const bool moments = merge_moments && reward && mom_out && mom_acc;
+    // reward moments a one-launch CA + RND2D step left pending are merged first (wavefront 0 of block 0: the same
+    // wavefront that merges this step's below)
+    if (blockIdx.x == 0 && threadIdx.x < 64) settle_moments_wave(st, threadIdx.x);
     const int32_t any_flag = slot ? (int32_t)w0.y : (int32_t)w0.x;
     const int32_t notone_flag = slot ? (int32_t)w0.w : (int32_t)w0.z;
     const bool reset = has_action && notone_flag == 0;
@@ -211,13 +214,16 @@ int env_step_one_launch_u8(const uint8_t *u_in, const void *action, int action_f
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
                            int step_flags, void *stream);
 
-__global__ void env_settle_kernel(int32_t *st) { settle_status_in_place(st); }
+__global__ __launch_bounds__(64) void env_settle_kernel(int32_t *st) {
+    settle_moments_wave(st, threadIdx.x);
+    if (threadIdx.x == 0) settle_status_in_place(st);
+}
 }
 
 extern "C" int carle_env_settle(int32_t *status, void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_settle: status is NULL");
     if (!aligned16(status)) return fail_arg(CARLE_E_ALIGN, "carle_env_settle: status must be 16-byte aligned");
-    hipLaunchKernelGGL(env_settle_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), status);
+    hipLaunchKernelGGL(env_settle_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), status);
     return check_launch("carle_env_settle");
 }
 
@@ -395,8 +401,13 @@ extern "C" int carle_rnd2d_bonus_f32(const float *, int64_t, int, int, const flo
 namespace carle {
 int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
                   int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
-                  bool tables_valid, hipStream_t s);
+                  bool tables_valid, hipStream_t s, const RndEnvArgs *env);
+int64_t rnd64_blocks(int64_t n);
 }
+
+// doubles of the `moment_partials` scratch of carle_env_step_f32_rnd: two buffers (one per flag slot) of one
+// (sum, sum of squares) pair per workgroup
+extern "C" int64_t carle_rnd_step_partials_doubles(int64_t n) { return n > 0 ? 4 * rnd64_blocks(n) : 4; }
 
 // argument checks of the fused 64x64 CA + RND2D kernel (shared by the two entry points below)
 static int rnd_step_checks(const char *who, const float *u_in, const float *action, float *u_out, int64_t n,
@@ -425,7 +436,7 @@ extern "C" int carle_ca_step_f32_rnd(const float *u_in, const float *action, flo
     if (int e = rnd_step_checks("carle_ca_step_f32_rnd", u_in, action, u_out, n, h, w, ah, aw, rule, slot, workspace))
         return e;
     return ca_step_rnd64(u_in, action, u_out, n, aw, rule, status, slot, pred_params, rand_params, workspace,
-                         bonus, (net_flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream));
+                         bonus, (net_flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream), nullptr);
 }
 
 extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out,
@@ -433,7 +444,7 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
                                       uint32_t rule, int32_t *status, int slot, int publish_flags,
                                       const float *pred_params, const float *rand_params,
                                       float *workspace, float *bonus, float reward_scale,
-                                      int net_flags, void *event, void *stream_env,
+                                      int net_flags, double *moment_partials, void *event, void *stream_env,
                                       void *stream_reward) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: status is NULL");
     if (!pred_params || !rand_params || !workspace || !bonus)
@@ -451,10 +462,25 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
                                     workspace))
             return e;
         const size_t bytes = (size_t)n * h * w * sizeof(float);
+        const bool merge = (publish_flags & CARLE_STEP_MERGE_MOMENTS) != 0;
+        if ((publish_flags & CARLE_STEP_DEFERRED) && n > 16 && knobs().two_launch_step <= 0 && aligned16(status) &&
+            (!merge || (moment_partials && aligned16(moment_partials)))) {
+            // ONE launch: master reset, reward and (as partial sums) the reward moments inside the fused kernel
+            RndEnvArgs ea;
+            ea.reward = reward;
+            ea.reward_scale = reward_scale;
+            ea.publish = (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? 1 : 0;
+            ea.merge_moments = merge ? 1 : 0;
+            ea.partials = merge ? moment_partials + (size_t)slot * 2 * (size_t)rnd64_blocks(n) : nullptr;
+            if (int e = ca_step_rnd64(u_in, action, u_out, n, aw, rule, status, slot, pred_params, rand_params, workspace,
+                                      bonus, tables_valid, static_cast<hipStream_t>(stream_env), &ea))
+                return e;
+            return fork ? carle_stream_fork(event, stream_env, stream_reward) : 0;
+        }
         if (int e = ca_step_rnd64(u_in, action, u_out, n, aw, rule,
                                   (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot,
                                   pred_params, rand_params, workspace, bonus, tables_valid,
-                                  static_cast<hipStream_t>(stream_env)))
+                                  static_cast<hipStream_t>(stream_env), nullptr))
             return e;
         if (int e = ca_finish_impl(u_out, (int64_t)bytes, reward, n, status, slot, action != nullptr, nullptr, 0,
                                    bonus, reward_scale, publish_flags & CARLE_STEP_MERGE_MOMENTS, stream_env))

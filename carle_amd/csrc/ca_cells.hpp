@@ -170,6 +170,51 @@ __device__ __forceinline__ void settle_status_in_place(int32_t *st) {
     }
 }
 
+// Reward moments of a one-launch CA + RND2D step (carle_env_step_f32_rnd with CARLE_STEP_DEFERRED | MERGE_MOMENTS): the
+// rewards only exist when the launch ends, so its workgroups leave (sum, sum of squares) pairs behind and the NEXT call on
+// the status block -- or carle_env_settle -- reduces them (fixed order: lane l adds pairs l, l + 64, ...; then a xor
+// tree) and Chan-merges the triple (count, mean, M2) exactly as the epilogue kernel does.  Called by all 64 lanes of ONE
+// wavefront of the launch, before anything else of the launch touches the moment accumulators.
+__device__ __forceinline__ void settle_moments_wave(int32_t *st, int lane) {
+    const uint4 w5 = reinterpret_cast<const uint4 *>(st)[5];             // words 20..23
+    const uint32_t npart = w5.z;
+    if (npart == 0u) return;                                             // wave-uniform
+    const uint4 w3 = reinterpret_cast<const uint4 *>(st)[3];
+    const double2 *part = reinterpret_cast<const double2 *>(((uint64_t)w5.y << 32) | w5.x);
+    double s = 0.0, q = 0.0;
+    for (uint32_t base = 0; base < npart; base += 256u) {               // four pairs per lane in flight
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = base + 64u * u + (uint32_t)lane;
+            v[u] = part[i < npart ? i : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + 64u * u + (uint32_t)lane < npart) { s += v[u].x; q += v[u].y; }
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) { s += __shfl_xor(s, k, 64); q += __shfl_xor(q, k, 64); }
+    if (lane == 0) {
+        double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
+        double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
+        if (mom_out && mom_acc) {
+            const double nb = (double)w5.w, mean = nb > 0.0 ? s / nb : 0.0;
+            double m2 = q - s * mean;
+            if (m2 < 0.0) m2 = 0.0;
+            const double na = mom_acc[0], ma = mom_acc[1], qa = mom_acc[2], tot = na + nb;
+            mom_out[0] = nb; mom_out[1] = mean; mom_out[2] = m2;
+            if (tot > 0.0) {
+                const double delta = mean - ma;
+                mom_acc[0] = tot;
+                mom_acc[1] = ma + delta * nb / tot;
+                mom_acc[2] = qa + m2 + delta * delta * na * nb / tot;
+            }
+        }
+        st[CARLE_ST_MOM_COUNT] = 0;
+    }
+}
+
 // Counter / flag bookkeeping at the end of a step (env.py:142-145, 199-200, 216, 230), by ONE thread:
 // w0..w2 = the first three 16-byte words of the status block as read at the start of the epilogue (a pending
 // deferred step is applied first).
@@ -210,8 +255,13 @@ __device__ __forceinline__ void finish_status(int32_t *st, uint4 w0, uint4 w1, u
 // that has not been dispatched (N may exceed the resident wavefronts).  The action tensor is read-only in the kernel.
 // Returns true iff every element of the batch's action equals one.  Cost when it does: the action is read twice.
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef CARLE_SCAN_INLINE
+#define CARLE_SCAN_ATTR __forceinline__
+#else
+#define CARLE_SCAN_ATTR __noinline__
+#endif
 template <class A>
-__device__ __noinline__ bool batch_action_all_ones(const typename A::T *act, int64_t n, int aw, int32_t *st, int slot) {
+__device__ CARLE_SCAN_ATTR bool batch_action_all_ones(const typename A::T *act, int64_t n, int aw, int32_t *st, int slot) {
     constexpr uint32_t kAbort = 0x80000000u;
     uint32_t *ticket = reinterpret_cast<uint32_t *>(st + CARLE_ST_SCAN_TICKET(slot));
     uint32_t *done = reinterpret_cast<uint32_t *>(st + CARLE_ST_SCAN_DONE(slot));

@@ -49,6 +49,8 @@ struct CaRndShared {
     RndBlockShared net;
     uint32_t rows_in[64][2];     // toggled state, one 64-bit word per row (lo, hi)
     float feat[2][64];           // conv2 + pool output of both nets (read one phase later, see E)
+    uint32_t notone[4];          // ENV: per wavefront, some action element of the current grid differs from one
+    double racc[2];              // ENV: sum / sum of squares of this workgroup's rewards (wave 1, lane 0)
 };
 
 // 1 if the fp32 bit pattern is a non-zero NUMBER (NaN counts, -0.0 does not; the truthiness of
@@ -66,6 +68,18 @@ __device__ __forceinline__ uint32_t nibble_fast(const uint4 &v) {
 
 struct Quads { uint4 v[4], a[4]; };     // one grid's loads of a lane: 4 state + 4 action quads
 
+// ENV instantiation (CARLE_STEP_DEFERRED): the whole RND2D.step -- CARLE.step + bonus + reward -- in this ONE launch, no
+// epilogue kernel behind it.  As ca_step_64_kernel<..., ENV> (ca_step_cells.hip), plus:
+//   master reset    per grid: the four wavefronts combine "some action element of this grid differs from one" through
+//                   LDS behind the barrier they share anyway; an all-ones grid asks batch_action_all_ones().  A reset
+//                   grid's new rows are zero, so phases C-E store zeros and evaluate the bonus of the all-dead grid by
+//                   themselves (mcl.py:403-405 on the observation of env.py:216).
+//   reward          reward[g] = reward_scale * bonus[g], written where the bonus is formed
+//   reward moments  the rewards exist only when the launch ends: every workgroup leaves (sum, sum of squares) of its
+//                   rewards in `partials`; the next launch on the status block (or carle_env_settle) merges them
+//                   (settle_moments_wave, ca_cells.hpp)
+// (struct RndEnvArgs: common.hpp)
+
 #ifndef CARLE_RND_WG_PER_CU
 #define CARLE_RND_WG_PER_CU 4
 #endif
@@ -73,13 +87,17 @@ struct Quads { uint4 v[4], a[4]; };     // one grid's loads of a lane: 4 state +
 // NT_ST: streaming stores (state arrays beyond the Infinity Cache); NT_LD: streaming hint on the STATE loads (the action
 // loads always carry it) -- up to 128 MiB per state array the re-read state comes out of the caches faster without it
 // (N=4096: 36.7 -> 36.0 us, N=8192: 65.2 -> 63.7; N=16384: 122 -> 134 us, so larger batches keep the hint)
-template <bool HAS_ACT, bool NT_ST = true, bool NT_LD = true>
+template <bool HAS_ACT, bool NT_ST = true, bool NT_LD = true, bool ENV = false>
 __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel(
     const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out, int64_t n,
     int aw, uint32_t rule, int32_t *__restrict__ status, int slot, const float *__restrict__ ws,
-    float *__restrict__ bonus) {
+    float *__restrict__ bonus, RndEnvArgs ea = RndEnvArgs()) {
     __shared__ CaRndShared s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // ENV with pre-stored action flags (publish == 0): the reset is known before the launch
+    const bool reset_all = ENV && HAS_ACT && !ea.publish && status[CARLE_ST_NOT_ALL_ONES(slot)] == 0;
+    bool any_acc = false, notone_acc = false;         // ENV: the wavefront's action predicates over all its grids (uniform)
+    if (ENV && tid == 64) { s.racc[0] = 0.0; s.racc[1] = 0.0; }
     const int q = lane >> 4, k = lane & 15;
     // action window: offset o = (64-aw)/2 is a multiple of 4 (aw % 8 == 0): a lane's four columns
     // are all inside or all outside; bit i of `rows_in_win` = row 16w+4i+q is inside
@@ -154,14 +172,21 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
         issue(g + stride, nxt, g + stride < n);
         // ---- A: nibbles of this lane's four rows, toggled; row words by OR over the 16 lanes
         uint32_t x[4];
-#pragma unroll
+        ActionSeen seen_g;                            // ENV: the predicates of THIS grid (folded into two scalars below,
+#pragma unroll                                        //      no per-lane accumulator lives across the grid loop)
         for (int i = 0; i < 4; ++i) {
             uint32_t nib = nibble_fast(cur.v[i]);
             if (HAS_ACT) {
-                if ((rows_in_win >> i) & 1u) seen.add(cur.a[i]);
+                if ((rows_in_win >> i) & 1u) { if (ENV) seen_g.add(cur.a[i]); else seen.add(cur.a[i]); }
                 nib ^= nibble_fast(cur.a[i]);         // toggle, env.py:182
             }
             x[i] = nib << (4 * (k & 7));
+        }
+        if (ENV && HAS_ACT && ea.publish) {
+            const bool w_notone = __ballot(seen_g.not_all_ones<F32Cells>()) != 0ull;
+            any_acc |= __ballot(seen_g.any_nonzero<F32Cells>()) != 0ull;
+            notone_acc |= w_notone;
+            if (lane == 0) s.notone[wv] = w_notone ? 1u : 0u;
         }
         RND_STAMP(1);
         // the four rows' DPP chains are independent: interleaved, they fill each other's wait states
@@ -188,10 +213,25 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
             row_sums(wst, c, est, h0, h1, p0, p1);
             const uint64_t a0 = dpp64_ror1(h0), a1 = dpp64_ror1(h1);        // row above (lane - 1, wraps)
             const uint64_t b0 = dpp64_rol1(h0), b1 = dpp64_rol1(h1);        // row below
-            s.net.rows[1 + lane] = apply_rule(neighbour_count(a0, a1, b0, b1, p0, p1), c, rule);
+            uint64_t nx = apply_rule(neighbour_count(a0, a1, b0, b1, p0, p1), c, rule);
+            if (ENV && HAS_ACT) {
+                // master reset (env.py:208-216): every action element of the WHOLE batch is one
+                bool reset = reset_all;
+                if (ea.publish) {
+                    const bool own_notone = (s.notone[0] | s.notone[1] | s.notone[2] | s.notone[3]) != 0u;
+                    if (__builtin_expect(!own_notone, 0)) reset = batch_action_all_ones<F32Cells>(act, n, aw, status, slot);
+                }
+                if (reset) nx = 0ull;
+            }
+            s.net.rows[1 + lane] = nx;
         } else if (wv == 1 && pending >= 0) {
             const float b = rnd_linear_bonus(s.feat, s.net.lin, lane, pending, nullptr, nullptr);
             if (lane == 0) bonus[pending] = b;
+            if (ENV && lane == 0) {
+                const float r = ea.reward_scale * b;              // reward = 0 + scale * bonus (mcl.py:403-405)
+                if (ea.reward) ea.reward[pending] = r;
+                s.racc[0] += (double)r; s.racc[1] = fma((double)r, (double)r, s.racc[1]);
+            }
         }
         RND_STAMP(4);
         __syncthreads();
@@ -247,17 +287,72 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
         if (wv == 1) {
             const float b = rnd_linear_bonus(s.feat, s.net.lin, lane, pending, nullptr, nullptr);
             if (lane == 0) bonus[pending] = b;
+            if (ENV && lane == 0) {
+                const float r = ea.reward_scale * b;
+                if (ea.reward) ea.reward[pending] = r;
+                s.racc[0] += (double)r; s.racc[1] = fma((double)r, (double)r, s.racc[1]);
+            }
         }
     }
-    if (HAS_ACT) publish_flags<F32Cells>(seen, status, slot);
+    if (HAS_ACT && !ENV) publish_flags<F32Cells>(seen, status, slot);
+    if (ENV) {
+        if (HAS_ACT && ea.publish && lane == 0) {            // every writer stores the same value: benign
+            if (any_acc) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
+            if (notone_acc) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
+        }
+        if (wv == 1 && lane == 0 && ea.merge_moments && ea.partials)
+            reinterpret_cast<double2 *>(ea.partials)[blockIdx.x] = make_double2(s.racc[0], s.racc[1]);
+        if (blockIdx.x == 0 && wv == 2) {
+            // bookkeeping by ONE wavefront of the launch (see ca_step_64_kernel<..., ENV>): the previous step's pending
+            // moments and counters are applied, its flag slot recycled, this step left pending
+            settle_moments_wave(status, lane);
+            if (lane == 0) {
+                uint4 *s4 = reinterpret_cast<uint4 *>(status);
+                uint4 w0 = s4[0], w1 = s4[1], w2 = s4[2];
+                settle_pending(w0, w1, w2);
+                if (!HAS_ACT) {
+                    int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z) + 1;
+                    int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x) + 1;
+                    w1.x = 0u;
+                    w1.z = (uint32_t)step_number; w1.w = (uint32_t)((uint64_t)step_number >> 32);
+                    w2.x = (uint32_t)since; w2.y = (uint32_t)((uint64_t)since >> 32);
+                } else {
+                    w1.y = 1u | 2u | (slot ? 4u : 0u);                 // CARLE_ST_PENDING: this step
+                }
+                s4[1] = w1; s4[2] = w2;
+                const int other = slot ^ 1;
+                status[CARLE_ST_ANY_NONZERO(other)] = 0;
+                status[CARLE_ST_NOT_ALL_ONES(other)] = 0;
+                status[CARLE_ST_SCAN_TICKET(other)] = 0;
+                status[CARLE_ST_SCAN_DONE(other)] = 0;
+                if (ea.merge_moments && ea.partials && ea.reward) {
+                    uint4 w5;
+                    w5.x = (uint32_t)reinterpret_cast<uint64_t>(ea.partials);
+                    w5.y = (uint32_t)(reinterpret_cast<uint64_t>(ea.partials) >> 32);
+                    w5.z = gridDim.x;
+                    w5.w = (uint32_t)n;
+                    s4[5] = w5;                                        // CARLE_ST_MOM_*: merged by the next call
+                }
+            }
+        }
+    }
 }
 
 void rnd2d_prepare_tables(const float *pp, const float *rp, float *ws, hipStream_t s);
 
-// validated by the caller (carle_env_step_f32_rnd); bonus has n + 1 elements
+// workgroups of the fused launch (= reward-moment partial pairs of the one-launch step)
+int64_t rnd64_blocks(int64_t n) {
+    int64_t blocks = n <= 1024 ? n : (n + 1) / 2;
+    if (blocks < 1024 && n > 1024) blocks = 1024;
+    const int64_t v = knobs().rnd_blocks;              // experiment knob (tools/kbench_rnd.py), read once
+    if (v > 0) blocks = v < n ? v : n;
+    return blocks < 1 ? 1 : blocks;
+}
+
+// validated by the caller (carle_env_step_f32_rnd); bonus has n + 1 elements.  env != nullptr: the one-launch step.
 int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
                   int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
-                  bool tables_valid, hipStream_t s) {
+                  bool tables_valid, hipStream_t s, const RndEnvArgs *env) {
     if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
     // Two grids per workgroup (the second one's loads travel during the first one's network phases); batches up to
     // 1024 grids one workgroup each.  Four per CU are resident, the others start as those retire -- out of phase, so
@@ -265,27 +360,30 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
     // profiles/r02_rnd_blocks.txt): N=4096 1024 / 2048 / 4096 workgroups 37.3-38.7 / 36.9 / 40.0 us, N=16384 1024 /
     // 8192 / 16384: 138 / 129.5 / 139 us, N=65536 1024 / 8192 / 32768 / 65536: 585 / 552 / 510 / 535 us (0.69 -> 0.79
     // of 8 TB/s).  (Before the table set-up stopped waiting for each of its loads, fewer, longer workgroups won.)
-    int64_t blocks = n <= 1024 ? n : (n + 1) / 2;
-    if (blocks < 1024 && n > 1024) blocks = 1024;
-    {                                                  // experiment knob (tools/kbench_rnd.py), read once
-        const int64_t v = knobs().rnd_blocks;
-        if (v > 0) blocks = v < n ? v : n;
-    }
+    const int64_t blocks = rnd64_blocks(n);
     // store policy by the size of one state array (ca_step_cells.hip: stream_stores): write-back up to 256 MiB
     const int64_t lim = knobs().stream_store_min_bytes >= 0 ? knobs().stream_store_min_bytes - 1 : 256ll << 20;
     const bool nt_st = n * 16384 > lim;
     const int64_t ld_lim = knobs().rnd_cached_load_max_bytes >= 0 ? knobs().rnd_cached_load_max_bytes : 128ll << 20;
+    const bool cached_ld = !nt_st && n * 16384 <= ld_lim;
     const dim3 grid((unsigned)blocks), block(256);
-    if (action && !nt_st && n * 16384 <= ld_lim)
-        hipLaunchKernelGGL((ca_step_rnd64_kernel<true, false, false>), grid, block, 0, s, u_in, action, u_out, n, aw, rule, status, slot, ws, bonus);
-    else if (action && nt_st)
-        hipLaunchKernelGGL((ca_step_rnd64_kernel<true, true>), grid, block, 0, s, u_in, action, u_out, n, aw, rule, status, slot, ws, bonus);
-    else if (action)
-        hipLaunchKernelGGL((ca_step_rnd64_kernel<true, false>), grid, block, 0, s, u_in, action, u_out, n, aw, rule, status, slot, ws, bonus);
-    else if (nt_st)
-        hipLaunchKernelGGL((ca_step_rnd64_kernel<false, true>), grid, block, 0, s, u_in, action, u_out, n, 64, rule, status, slot, ws, bonus);
-    else
-        hipLaunchKernelGGL((ca_step_rnd64_kernel<false, false>), grid, block, 0, s, u_in, action, u_out, n, 64, rule, status, slot, ws, bonus);
+    const RndEnvArgs ea = env ? *env : RndEnvArgs();
+    const int awk = action ? aw : 64;
+#define CARLE_RND_LAUNCH(ACT, NTS, NTL, ENVF) \
+    hipLaunchKernelGGL((ca_step_rnd64_kernel<ACT, NTS, NTL, ENVF>), grid, block, 0, s, u_in, action, u_out, n, awk, rule, \
+                       status, slot, ws, bonus, ea)
+#define CARLE_RND_PICK(ENVF) \
+    do { \
+        if (action && cached_ld) CARLE_RND_LAUNCH(true, false, false, ENVF); \
+        else if (action && nt_st) CARLE_RND_LAUNCH(true, true, true, ENVF); \
+        else if (action) CARLE_RND_LAUNCH(true, false, true, ENVF); \
+        else if (nt_st) CARLE_RND_LAUNCH(false, true, true, ENVF); \
+        else CARLE_RND_LAUNCH(false, false, true, ENVF); \
+    } while (0)
+    if (env) CARLE_RND_PICK(true);
+    else CARLE_RND_PICK(false);
+#undef CARLE_RND_PICK
+#undef CARLE_RND_LAUNCH
     return check_launch("carle_env_step_f32_rnd(fused CA + RND2D)");
 }
 

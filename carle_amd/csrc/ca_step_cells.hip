@@ -184,6 +184,7 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
 
     if (ENV) {
         if (ea.reward && lane == 0) ea.reward[g] = 0.0f;               // env.py:238
+        if (g == 0) settle_moments_wave(status, lane);                  // (a one-launch CA + RND2D step before this one)
         if (g == 0 && lane == 0) {
             // bookkeeping by ONE thread of the launch: settle the previous step if it is still pending, recycle its flag
             // slot (= the next step's), merge the moments of this step's all-zero reward, leave this step pending.

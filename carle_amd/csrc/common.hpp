@@ -64,6 +64,14 @@ struct Knobs {
 };
 const Knobs &knobs();
 
+// Arguments of the one-launch CA + RND2D step (ca_step_rnd64_kernel<..., ENV>, ca_rnd_fused.hip)
+struct RndEnvArgs {
+    float *reward = nullptr;             // N floats: reward_scale * bonus
+    float reward_scale = 1.0f;
+    int publish = 1, merge_moments = 0;
+    double *partials = nullptr;          // gridDim.x (sum, sum of squares) pairs, this step's buffer
+};
+
 // Hides a uniform pointer from loop-invariant code motion: the scalar loads behind it stay in the phase
 // that uses them (from the scalar cache) instead of being hoisted out of the grid / tile loop, where 124-140
 // uniform weights overflow the SGPR file and spill into VGPR lanes (v_writelane / v_readlane per use).

@@ -150,6 +150,7 @@ class RunningRewardStats:
                 return False
         inner._install_reward_stats(self)
         env.__dict__["_final_reward_stats"] = self
+        self._inner_env = inner
         return True
 
     def after_step(self, env, reward, stream=None):
@@ -167,6 +168,9 @@ class RunningRewardStats:
         if self._pending_steps == 0:
             return None
         self._pending_steps = 0
+        inner = self.__dict__.get("_inner_env")
+        if inner is not None and inner.__dict__.get("_moments_pending"):
+            inner.settled_status()               # moments a one-launch step left as partial sums: merged now
         if self.device.type != "cuda":           # CPU process groups (gloo tests): tensor ops
             local = self._pending.clone()
             self._pending.zero_()

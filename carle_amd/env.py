@@ -198,7 +198,14 @@ class CARLE(RLEMixin, nn.Module):
         (CARLE_STEP_DEFERRED, carle_hip.h) leaves its counter update pending until the next call on the block."""
         if self._status is not None and self._status.is_cuda:
             hip.env_settle(self._status)
+            self.__dict__["_moments_pending"] = False
         return self._status
+
+    def _settle_pending_moments(self):
+        """Reward moments a one-launch CA + RND2D step left as partial sums (mcl.RND2D._fused_step) are merged before
+        a call whose kernels update the moment accumulators on their own (small-batch / multi-step launches)."""
+        if self.__dict__.get("_moments_pending"):
+            self.settled_status()
 
     def _read_counter(self, idx):
         if self._status is None:
@@ -242,6 +249,7 @@ class CARLE(RLEMixin, nn.Module):
         self.universe = torch.zeros(self.instances, 1, self.height, self.width,
                                     dtype=torch.float32, device=self.my_device)
         self._ensure_status()
+        self._settle_pending_moments()            # reward moments of the last step must not vanish with the counters
         self._status.zero_()
         self._write_stats_pointers()
         self._slot = 0
@@ -411,6 +419,7 @@ class CARLE(RLEMixin, nn.Module):
         hip.require_gpu()
         self._check_domain()
         self._ensure_status()
+        self._settle_pending_moments()
         if self.storage != "f32" or self.logging or self.exact_action_predicates:
             raise NotImplementedError("run() covers storage='f32' without logging / exact predicates")
         u = self._device_universe()
@@ -472,6 +481,7 @@ class CARLE(RLEMixin, nn.Module):
         hip.require_gpu()
         self._check_domain()
         self._ensure_status()
+        self._settle_pending_moments()
         steps = int(steps)
         if steps < 0:
             raise ValueError("steps must be >= 0")
@@ -572,6 +582,7 @@ class CARLEPacked(CARLE):
                                              dtype=torch.int64, device=self.my_device)
         self.__dict__["_f32"] = None
         self._ensure_status()
+        self._settle_pending_moments()            # reward moments of the last step must not vanish with the counters
         self._status.zero_()
         self._write_stats_pointers()
         self._slot = 0
@@ -687,6 +698,7 @@ class CARLEBytes(CARLE):
         self.universe = torch.zeros(self.instances, 1, self.height, self.width, dtype=torch.uint8,
                                     device=self.my_device)
         self._ensure_status()
+        self._settle_pending_moments()            # reward moments of the last step must not vanish with the counters
         self._status.zero_()
         self._write_stats_pointers()
         self._slot = 0

@@ -601,6 +601,15 @@ class RND2D(Motivator):
         rs = self._reward_stream()
 
         merge = self.__dict__.get("_final_reward_stats") is not None     # this wrapper is outermost
+        # one launch per step (CARLE_STEP_DEFERRED): the reward moments of step t are merged by the next call on the
+        # status block from per-workgroup partial sums kept here (two buffers, one per flag slot)
+        partials = None
+        if merge:
+            pneed = _lib.load().carle_rnd_step_partials_doubles(n)
+            partials = self.__dict__.get("_mom_partials")
+            if partials is None or partials.numel() < pneed or partials.device != dev:
+                env.settled_status()                         # nothing may still point into the old buffer
+                partials = self.__dict__["_mom_partials"] = torch.zeros(pneed, dtype=torch.float64, device=dev)
 
         def launch(u_in, act, out, reward, rule, status, slot, publish):
             main_raw = hip._stream(u_in)
@@ -609,11 +618,13 @@ class RND2D(Motivator):
             else:
                 rs_raw = rs.raw
                 ev = rs.event_for_fork(main_raw, out, reward)
+            fusable = act.shape[3] % 8 == 0     # (the library fuses -- and can merge the moments -- only with an 8-aligned window)
             hip.env_step_f32_rnd(u_in, act, out, reward, rule, status, slot, publish, pb, rb, self._ws,
                                  self._step_bonus, self.reward_scale, valid, ev, main_raw, rs_raw,
-                                 merge and act.shape[3] % 8 == 0)
-            # (the library fuses -- and can merge the moments -- only with an 8-aligned window)
-            self.__dict__["_moments_merged"] = merge and act.shape[3] % 8 == 0
+                                 merge and fusable, deferred=True, partials=partials)
+            self.__dict__["_moments_merged"] = merge and fusable
+            if merge and fusable:
+                env.__dict__["_moments_pending"] = True
         self.__dict__["_moments_merged"] = False
         result = env._step(action, launch)
         self._tables_key = (id(self._ws), versions)

@@ -62,7 +62,12 @@ extern "C" {
 #define CARLE_ST_SCAN_TICKET(slot)   (16 + (slot))  /* transient, in-kernel: next action grid to verify ...         */
 #define CARLE_ST_SCAN_DONE(slot)     (18 + (slot))  /* ... and number verified all-ones, bit 31 = one was not (see
                                                        CARLE_STEP_DEFERRED); both are zero between steps              */
-#define CARLE_ST_WORDS               32             /* words 20..31 reserved, zero */
+#define CARLE_ST_MOM_PARTIALS        20             /* device pointer (64 bit) at 20..21: per-workgroup (sum, sum of squares) fp64
+                                                       pairs of the rewards of a CARLE_STEP_DEFERRED step whose reward
+                                                       moments are still to be merged (carle_env_step_f32_rnd) ...     */
+#define CARLE_ST_MOM_COUNT           22             /* ... number of pairs (0 = nothing pending) ...                   */
+#define CARLE_ST_MOM_N               23             /* ... and number of rewards they cover                            */
+#define CARLE_ST_WORDS               32             /* words 24..31 reserved, zero */
 
 /* `publish_flags` argument of the carle_env_step_* entry points (bit set) */
 #define CARLE_STEP_PUBLISH_FLAGS     1   /* the step kernel writes the action predicates into the status block */
@@ -357,12 +362,18 @@ int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const floa
  *   other geometries: step and epilogue on stream_env, the bonus kernels (reward += reward_scale *
  *   bonus fused in) on stream_reward behind `event` (or on stream_env when stream_reward is NULL).
  * bonus: N + 1 floats (element N receives the bonus of the all-dead grid).
- * net_flags: CARLE_NET_TABLES_VALID as for carle_rnd2d_bonus_f32. */
+ * net_flags: CARLE_NET_TABLES_VALID as for carle_rnd2d_bonus_f32.
+ * CARLE_STEP_DEFERRED in publish_flags (64x64, more than 16 instances): no epilogue kernel -- the fused kernel applies
+ * the master reset per grid, writes the reward, and with CARLE_STEP_MERGE_MOMENTS leaves per-workgroup partial sums of
+ * the rewards in `moment_partials` (caller-owned scratch of carle_rnd_step_partials_doubles(n) doubles, 16-byte
+ * aligned, alive until the NEXT call on the status block or carle_env_settle has merged them; NULL without
+ * MERGE_MOMENTS).  Counters as described at CARLE_STEP_DEFERRED. */
+int64_t carle_rnd_step_partials_doubles(int64_t n);
 int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out, float *reward,
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                            int32_t *status, int slot, int publish_flags,
                            const float *pred_params, const float *rand_params, float *workspace,
-                           float *bonus, float reward_scale, int net_flags,
+                           float *bonus, float reward_scale, int net_flags, double *moment_partials,
                            void *event, void *stream_env, void *stream_reward);
 
 /* The fused kernel of the 64x64 case alone, without the epilogue (as carle_ca_step_f32 is to

@@ -68,7 +68,7 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert lib.carle_pack_u8_b1(p8, q8, 1, 64, 65, None, 0, None) == 2
     assert lib.carle_unpack_b1_u8(p8, ctypes.c_void_p(q8.value + 4), 1, 64, 64, None) == 4    # alignment
     assert lib.carle_env_step_f32_rnd(p, None, q, p, 1, 64, 64, 0, 0, 0, None, 0, 1, p, p, p, p, 1.0, 0,
-                                      None, None, None) == 1                                 # status NULL
+                                      None, None, None, None) == 1                                 # status NULL
     # RandomNetworkAgent forward
     assert lib.carle_agent_rn_forward_f32(None, 1, 64, 64, p, p, p, 64, 0.1, p, None, p, None) == 1
     assert lib.carle_agent_rn_forward_f32(p, 1, 60, 64, p, p, p, 64, 0.1, p, None, p, None) == 2   # H % 8

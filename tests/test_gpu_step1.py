@@ -228,3 +228,113 @@ def test_step_number_assignment_survives_a_pending_step():
     env.step_number = 100                                       # settles first: the pending step is not re-applied
     env.step(torch.zeros(20, 1, 64, 64, device="cuda"))
     assert env.step_number == 101 and env.steps_since_action == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# RND2D.step on a 64x64 fp32 CARLE (BASELINE configs[3]): CA step + bonus + reward (+ reward moments) in ONE launch
+# ---------------------------------------------------------------------------------------------------------------
+
+def _rnd_env(n, aw, stats, two_launch, monkeypatch):
+    from carle_amd import hip, dist as cd
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D
+    if two_launch:
+        monkeypatch.setenv("CARLE_TWO_LAUNCH_STEP", "1")
+    else:
+        monkeypatch.delenv("CARLE_TWO_LAUNCH_STEP", raising=False)
+    hip.reload_knobs()
+    torch.manual_seed(12)
+    env = CARLE(width=64, height=64, action_width=aw, action_height=aw, instances=n, device="cuda:0")
+    w = RND2D(env, train_predictor=False)
+    w.reward_scale = 0.75
+    w.eval()
+    st = None
+    if stats:
+        st = cd.RunningRewardStats("cuda:0", sync_every=4)
+        assert st.attach(w)
+    w.reset()
+    return env, w, st
+
+
+@pytest.mark.parametrize("n,aw,stats", [(17, 64, True), (100, 64, False), (1030, 32, True), (2050, 64, True)])
+def test_one_launch_rnd_step_equals_two_launch_path_and_oracle(n, aw, stats, monkeypatch):
+    """carle_env_step_f32_rnd with CARLE_STEP_DEFERRED (default through RND2D.step) against the step kernel + epilogue
+    pair: observations (also against the C oracle), rewards, counters bit-identical; the reward statistics -- merged
+    one call later from per-workgroup partial sums -- equal to the epilogue's to fp64 rounding.  Crafted actions:
+    master resets (every reward becomes scale * bonus(all-dead grid)), all ones but one element, all-ones grids."""
+    from carle_amd import hip
+    rng = np.random.default_rng(n + aw)
+    u0 = (rng.random((n, 1, 64, 64)) < 0.4).astype(np.float32)
+    acts = [a for a in _crafted_actions(rng, n, aw) if a is not None]
+    res = []
+    try:
+        for two in (False, True):
+            env, w, st = _rnd_env(n, aw, stats, two, monkeypatch)
+            env.universe = torch.from_numpy(u0).cuda()
+            out = []
+            for t, a in enumerate(acts):
+                obs, reward, done, info = w.step(torch.from_numpy(a).cuda())
+                if st is not None:
+                    assert w._moments_merged
+                    st.after_step(w, reward)
+                out.append((obs.clone(), reward.clone()))
+                if not two and st is None:
+                    assert env._status[5].item() != 0            # pending: no epilogue ran
+            snap = None
+            if st is not None:
+                st.flush()
+                snap = (st.state.cpu().numpy().copy(), st.last_batch.cpu().numpy().copy())
+            res.append((out, env.step_number, env.steps_since_action, env.master_resets, snap))
+    finally:
+        monkeypatch.delenv("CARLE_TWO_LAUNCH_STEP", raising=False)
+        hip.reload_knobs()
+    ref = _oracle_loop(u0, acts, O.rule_mask([3], [2, 3]))
+    (o1, sn1, ssa1, r1, m1), (o2, sn2, ssa2, r2, m2) = res
+    dead = None
+    for t, ((oa, ra), (ob, rb)) in enumerate(zip(o1, o2)):
+        assert np.array_equal(oa.cpu().numpy(), ref[t][0]), t
+        assert torch.equal(oa, ob) and torch.equal(ra, rb), (t, (ra - rb).abs().max())
+        if int(oa.count_nonzero()) == 0:                         # a master reset: one reward value for every instance
+            assert float(ra.max()) == float(ra.min()) > 0
+            dead = float(ra[0])
+    assert dead is not None
+    assert (sn1, ssa1, r1) == (sn2, ssa2, r2) == ref[-1][1:]
+    if stats:
+        allr = torch.cat([r.reshape(-1) for _, r in o1]).double().cpu().numpy()
+        np.testing.assert_allclose(m1[0], m2[0], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(m1[1], m2[1], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(m1[0], [allr.size, allr.mean(), ((allr - allr.mean()) ** 2).sum()], rtol=1e-10)
+
+
+def test_pending_rnd_moments_are_merged_by_whatever_comes_next(monkeypatch):
+    """The partial sums a one-launch CA + RND2D step leaves behind are merged by the next launch on the status block:
+    another wrapper step, a bare step of the inner environment, run(), multistep(), a stats flush -- same totals."""
+    n = 64
+    totals = []
+    for follow in ("wrapper", "bare", "run", "multistep", "flush"):
+        env, w, st = _rnd_env(n, 64, True, False, monkeypatch)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        env.universe = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.3).float()
+        a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
+        rewards = []
+        for t in range(3):
+            rewards.append(w.step(a)[1].reshape(-1).double())
+        if follow == "wrapper":
+            rewards.append(w.step(a)[1].reshape(-1).double())
+        elif follow == "bare":
+            env.step(a)                                     # (the statistics are attached to the wrapper: not counted)
+        elif follow == "run":
+            env.run(steps=2)
+        elif follow == "multistep":
+            env.multistep(2)
+        if follow == "flush":
+            st._pending_steps = 3
+            st.flush()
+            got = st.state.cpu().numpy()
+        else:
+            env.settled_status()
+            got = st._pending.cpu().numpy()
+        allr = torch.cat(rewards).cpu().numpy()
+        assert got[0] == allr.size, (follow, got, allr.size)
+        np.testing.assert_allclose(got[1:], [allr.mean(), ((allr - allr.mean()) ** 2).sum()], rtol=1e-10, err_msg=follow)
+        totals.append(got)
