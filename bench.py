@@ -312,22 +312,40 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
         name = ("ca_step_64_kernel" if size == 64 else "ca_step_wide_kernel") + "<carle::F32Cells, carle::F32Cells, true, ...>"
         step_fn = hip.ca_step_f32
 
-    def ca(i):
-        step_fn(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], rule, env._status, 0)
+    reward = torch.empty(n, 1, dtype=torch.float32, device=state.device)
+    one_launch = args.format in ("f32", "u8") and size == 64 and n > 16      # CARLE_STEP_DEFERRED: the step IS one kernel
 
+    def ca(i):
+        if one_launch:        # the kernel CARLE.step launches: step + master reset + reward + moments, no epilogue kernel
+            (hip.env_step_f32 if args.format == "f32" else hip.env_step_u8)(
+                bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1, True, True)
+        else:
+            step_fn(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], rule, env._status, 0)
+
+    if one_launch:
+        name = name.replace("true, ...>", "true, ..., ENV>")
     nets = args.rnd or args.ae
     fused_rnd = args.rnd and not args.train and args.format == "f32" and size == 64
     if fused_rnd:
-        # BASELINE configs[3]: the CA step and the RND2D forward are ONE kernel
+        # BASELINE configs[3]: the CA step and the RND2D forward are ONE kernel -- and, for more than 16 instances, the
+        # whole RND2D.step is that one launch (reward and reward-moment partial sums included)
         rnd = wenv if not args.ae else wenv.env
         pb, rb = rnd._pred_blob.get(state.device), rnd._rand_blob.get(state.device)
         ws, bonus = rnd._ws, rnd._step_bonus
+        partials = rnd.__dict__.get("_mom_partials")
+        raw = hip._stream(state)
 
         def ca_rnd(i):
-            hip.ca_step_f32_rnd(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], rule, env._status, 0,
-                                pb, rb, ws, bonus, True)
+            if n > 16:
+                hip.env_step_f32_rnd(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1,
+                                     True, pb, rb, ws, bonus, 1.0, True, None, raw, None, partials is not None,
+                                     deferred=True, partials=partials)
+            else:
+                hip.ca_step_f32_rnd(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], rule, env._status, 0,
+                                    pb, rb, ws, bonus, True)
         rnd_flop = 2 * 9 * size * size * 6 + 2 * 9 * (size // 4) ** 2 * 6 + 2 * (size // 8) ** 2 * 16 * 2
-        cand.append(("ca_step_rnd64_kernel<true>", ca_rnd, alg + 4 * n, n * rnd_flop))
+        cand.append(("ca_step_rnd64_kernel<true, ..., ENV>" if n > 16 else "ca_step_rnd64_kernel<true>", ca_rnd,
+                     alg + 4 * n, n * rnd_flop))
     else:
         cand.append((name, ca, alg, None))
     if nets and size == 64 and args.format == "f32":

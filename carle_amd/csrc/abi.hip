@@ -213,6 +213,8 @@ int env_step_one_launch_f32(const float *u_in, const float *action, float *u_out
 int env_step_one_launch_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out, float *reward,
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
                            int step_flags, void *stream);
+int env_step_one_launch_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out, float *reward, int64_t n, int h,
+                           int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags, void *stream);
 
 __global__ __launch_bounds__(64) void env_settle_kernel(int32_t *st) {
     settle_moments_wave(st, threadIdx.x);
@@ -259,6 +261,10 @@ extern "C" int carle_env_step_b1(const uint64_t *u_in, const uint64_t *action, u
                                  uint32_t rule, int32_t *status, int slot, int publish_flags,
                                  void *stream) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_b1: status is NULL");
+    if (publish_flags & CARLE_STEP_DEFERRED)
+        if (const int e = env_step_one_launch_b1(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
+                                                 publish_flags, stream); e != -1000)
+            return e;
     if (int e = carle_ca_step_b1(u_in, action, u_out, n, h, w, ah, aw, rule,
                                  (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream))
         return e;

@@ -215,6 +215,51 @@ __device__ __forceinline__ void settle_moments_wave(int32_t *st, int lane) {
     }
 }
 
+// Bookkeeping of a one-launch step of the BARE environment (ENV instantiations of the step kernels), by all 64 lanes of ONE
+// wavefront of the launch, out of line (it runs once per launch, behind everything else of its wavefront): pending reward
+// moments and counters of the previous step are applied, the moments of this step's all-zero reward merged, its flag slot's
+// neighbour recycled, and this step's counter update left pending (has_action) or applied at once (no action: no
+// predicates, no reset, env.py:191,208).
+static __device__ __noinline__ void env_step_bookkeeping(int32_t *status, int slot, int64_t n, int has_action, int merge_moments) {
+    const int lane = threadIdx.x & 63;
+    settle_moments_wave(status, lane);
+    if (lane != 0) return;
+    uint4 *s4 = reinterpret_cast<uint4 *>(status);
+    uint4 w0 = s4[0], w1 = s4[1], w2 = s4[2];
+    const uint4 w3 = s4[3];
+    settle_pending(w0, w1, w2);
+    if (merge_moments) {
+        double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
+        double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
+        if (mom_out && mom_acc) {
+            const double nb = (double)n, na = mom_acc[0], ma = mom_acc[1], qa = mom_acc[2], tot = na + nb;
+            mom_out[0] = nb; mom_out[1] = 0.0; mom_out[2] = 0.0;
+            if (tot > 0.0) {
+                mom_acc[0] = tot;
+                mom_acc[1] = ma - ma * nb / tot;
+                mom_acc[2] = qa + ma * ma * na * nb / tot;
+            }
+        }
+    }
+    if (!has_action) {
+        int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z) + 1;
+        int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x) + 1;
+        w1.x = 0u;
+        w1.z = (uint32_t)step_number; w1.w = (uint32_t)((uint64_t)step_number >> 32);
+        w2.x = (uint32_t)since; w2.y = (uint32_t)((uint64_t)since >> 32);
+    } else {
+        w1.y = 1u | 2u | (slot ? 4u : 0u);                     // CARLE_ST_PENDING: this step
+    }
+    // the words of THIS step's slot are written by the other wavefronts meanwhile: dword stores where a 16-byte store
+    // would cover them
+    s4[1] = w1; s4[2] = w2;
+    const int other = slot ^ 1;
+    status[CARLE_ST_ANY_NONZERO(other)] = 0;
+    status[CARLE_ST_NOT_ALL_ONES(other)] = 0;
+    status[CARLE_ST_SCAN_TICKET(other)] = 0;
+    status[CARLE_ST_SCAN_DONE(other)] = 0;
+}
+
 // Counter / flag bookkeeping at the end of a step (env.py:142-145, 199-200, 216, 230), by ONE thread:
 // w0..w2 = the first three 16-byte words of the status block as read at the start of the epilogue (a pending
 // deferred step is applied first).
@@ -260,25 +305,25 @@ __device__ __forceinline__ void finish_status(int32_t *st, uint4 w0, uint4 w1, u
 #else
 #define CARLE_SCAN_ATTR __noinline__
 #endif
-template <class A>
-__device__ CARLE_SCAN_ATTR bool batch_action_all_ones(const typename A::T *act, int64_t n, int aw, int32_t *st, int slot) {
+// `grid_quads`: 16-byte quads of one grid's action; `ones`: the dword pattern of four / thirty-two all-one elements
+static __device__ __forceinline__ bool batch_action_all_ones_inline(const void *act, int64_t n, int64_t grid_quads,
+                                                                    uint32_t ones, int32_t *st, int slot) {
     constexpr uint32_t kAbort = 0x80000000u;
     uint32_t *ticket = reinterpret_cast<uint32_t *>(st + CARLE_ST_SCAN_TICKET(slot));
     uint32_t *done = reinterpret_cast<uint32_t *>(st + CARLE_ST_SCAN_DONE(slot));
     const int lane = threadIdx.x & 63;
-    const int64_t grid_quads = (int64_t)aw * aw * (int64_t)sizeof(typename A::T) / 16;     // AW % 8 == 0: whole uint4s
     for (;;) {
         uint32_t h = 0;
         if (lane == 0) h = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         h = __builtin_amdgcn_readfirstlane(h);
         if ((int64_t)h >= n) break;
         const uint4 *p = reinterpret_cast<const uint4 *>(act) + (int64_t)h * grid_quads;
-        bool ones = true;
+        bool all1 = true;
         for (int64_t q = lane; q < grid_quads; q += 64) {
             const uint4 a = p[q];
-            ones = ones && a.x == A::kOnes && a.y == A::kOnes && a.z == A::kOnes && a.w == A::kOnes;
+            all1 = all1 && a.x == ones && a.y == ones && a.z == ones && a.w == ones;
         }
-        const bool all = __ballot(!ones) == 0ull;
+        const bool all = __ballot(!all1) == 0ull;
         uint32_t d = 0;
         if (lane == 0)
             d = all ? __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u
@@ -294,6 +339,19 @@ __device__ CARLE_SCAN_ATTR bool batch_action_all_ones(const typename A::T *act, 
         if ((int64_t)d >= n) return true;
         __builtin_amdgcn_s_sleep(16);
     }
+}
+
+// Out of line for the kernels that call it where many registers are live (a call in a cold branch costs them nothing
+// on the hot path; inlined, its loop would take part in their register allocation): the fp32 / uint8 step kernels.
+static __device__ CARLE_SCAN_ATTR bool batch_action_all_ones_raw(const void *act, int64_t n, int64_t grid_quads, uint32_t ones,
+                                                          int32_t *st, int slot) {
+    return batch_action_all_ones_inline(act, n, grid_quads, ones, st, slot);
+}
+
+template <class A>
+__device__ __forceinline__ bool batch_action_all_ones(const typename A::T *act, int64_t n, int aw, int32_t *st, int slot) {
+    // AW % 8 == 0: a grid's action is a whole number of uint4s
+    return batch_action_all_ones_raw(act, n, (int64_t)aw * aw * (int64_t)sizeof(typename A::T) / 16, A::kOnes, st, slot);
 }
 
 // One generation of a 64x64 torus held as one 64-bit "patch" word per lane: lane (q = L/16,

@@ -257,12 +257,24 @@ __device__ __forceinline__ uint64_t drawn_row64(int64_t g, int ay, const RandB1 
     return wrd;
 }
 
+// ENV instantiation (CARLE_STEP_DEFERRED): the whole CARLE.step of the packed environment in this one launch (as
+// ca_step_64_kernel<..., ENV>, ca_step_cells.hip).  The master reset is decided per work unit: a unit walks its window
+// strip first and learns there whether its share of the grid's action window is all ones (never, under an agent) -- only
+// then does it ask batch_action_all_ones_raw(); a reset unit writes zero strips.  Block 0 does the bookkeeping.
+struct B1EnvArgs {
+    float *reward = nullptr;       // N floats, zeroed (nullable)
+    int publish = 1;               // 0: the caller stored the action flags of `slot` beforehand (fp32 actions packed by
+                                   //    carle_pack_f32_b1, which publishes the exact fp32 predicates)
+    int merge_moments = 0;
+};
+
 // ACT: 0 = no action, 1 = 64-column window (toggle_row64), 2 = any packed window (toggle_row)
-template <int WW, int ACT, int RULE_MODE, bool RAND = false, int LDS = 0>      // LDS: 0 row-per-lane, 1 StripLds cached, 2 StripLds streaming
+template <int WW, int ACT, int RULE_MODE, bool RAND = false, int LDS = 0, bool ENV = false>      // LDS: 0 row-per-lane, 1 StripLds cached, 2 StripLds streaming
 __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     const uint64_t *__restrict__ u_in, const uint64_t *__restrict__ act, uint64_t *__restrict__ u_out,
     int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot,
-    int strip_first, int strip_count, RandB1 ra = RandB1(), int dbg = 0) {
+    int strip_first, int strip_count, RandB1 ra = RandB1(), int dbg = 0, B1EnvArgs ea = B1EnvArgs()) {
+    static_assert(!ENV || (ACT != 2 && !RAND), "one-launch step: no action or the 64-column window from memory");
     // the launch covers strips [strip_first, strip_first + strip_count) (mod WW) of every grid:
     // wide windows: the host launches the strips that can meet the action window with ACT = 2 and
     // the others with the leaner ACT = 0 instantiation (half the registers)
@@ -291,6 +303,9 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     // hurt: consecutive instead of interleaved grids per XCD, L2 prefetch of the records by a few waves, the nt
     // hint on the state traffic (2.3x slower), the window strip later in the unit, peeling the first strip out
     // of the loop.  Launches without a window keep the single-strip walk (47.9 us; half-grid units: 48.7 us).
+    const bool reset_all = ENV && ACT == 1 && !ea.publish && status[CARLE_ST_NOT_ALL_ONES(slot)] == 0;
+    if (ENV && ea.reward)
+        for (int64_t i = (int64_t)blockIdx.x * 64 + lane; i < n; i += (int64_t)gridDim.x * 64) ea.reward[i] = 0.0f;   // env.py:238
     const int64_t n8 = ((n + 7) / 8) * 8;
     const bool halves = MULTI && strip_count == WW && ACT == 1;
     const int per_unit = halves ? WW / 2 : 1;
@@ -303,6 +318,7 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     // the window words of the unit's window strip (HS >= 2: exactly one strip of a unit meets the 64-row
     // window, the one at the middle of the grid) and of that strip's bordering row
     uint32_t pa_lo = 0u, pa_hi = 0u, ph_lo = 0u, ph_hi = 0u;
+    bool unit_reset = reset_all;                             // ENV: this unit's strips are zeroed (master reset)
     const bool preload = ACT == 1 && !RAND && halves && HS >= 2 && !(dbg & 1);
     if (preload) {
         const int r0w = ((j & 1) ? WW - HS : HS - 1) * 64, oyw = (H - ah) >> 1;
@@ -315,6 +331,21 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
         // ... and waited for: the records arrive while the memory system is still idle (measured faster than
         // letting them travel beside the first strip's state loads: 52.3 against 53.8-57.9 us)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa_lo), "+v"(pa_hi), "+v"(ph_lo), "+v"(ph_hi));
+    }
+    if (ENV && ACT == 1 && ea.publish) {
+        // master reset (env.py:208-216), decided HERE, before the unit's strips occupy the registers: the unit's first
+        // strip holds its share of the action window; only if that is all ones (never, under an agent) the batch is asked
+        const int r0w = halves ? ((j & 1) ? WW - HS : HS - 1) * 64 : ((strip_first + (int)(j % strip_count)) % WW) * 64;
+        const int oyw = (H - ah) >> 1, rw = r0w + lane;
+        const bool inw = rw >= oyw && rw < oyw + ah;
+        uint32_t w_lo = pa_lo, w_hi = pa_hi;
+        if (!preload) {
+            const uint32_t *a32 = reinterpret_cast<const uint32_t *>(act + g * (int64_t)ah + (inw ? rw - oyw : 0));
+            w_lo = a32[0]; w_hi = a32[1];
+        }
+        const bool notone_u = __ballot(inw && (w_lo & w_hi) != 0xFFFFFFFFu) != 0ull;
+        if (__builtin_expect(!notone_u, 0))
+            unit_reset = batch_action_all_ones_raw(act, n, (int64_t)ah * 8 / 16, 0xFFFFFFFFu, status, slot);
     }
     // one strip: `first` = the unit's first strip (its window strip when the window words were fetched above)
     auto strip = [&](const int sub, const bool first) __attribute__((always_inline)) {
@@ -371,7 +402,7 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
                 toggle_row64<WW>(hal, ga + (hin ? hr - oy : 0), hin, d0, d1);
             }
             }
-            if (status != nullptr) {
+            if (status != nullptr && (!ENV || ea.publish)) {
                 const bool any = __ballot(s_or != 0u) != 0ull;
                 const bool notone = __ballot(in && s_and != 0xFFFFFFFFu) != 0ull;
                 if (lane == 0) {
@@ -455,6 +486,10 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     uint64_t nx[WW];
 #pragma unroll
     for (int j = 0; j < WW; ++j) nx[j] = ((uint64_t)nx32[2 * j + 1] << 32) | nx32[2 * j];
+    if (ENV && ACT == 1 && unit_reset) {                     // master reset, env.py:208-216
+#pragma unroll
+        for (int j = 0; j < WW; ++j) nx[j] = 0ull;
+    }
     B1_STAMP(2);
     if constexpr (LDS_T) store_strip<WW, LDS_NT>(lds, u_out + (g * (int64_t)H + r0) * WW, lane, nx);
     else store_row<WW>(u_out + (g * (int64_t)H + r) * WW, nx);
@@ -462,6 +497,8 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     };
     for (int sub = 0; sub < per_unit; ++sub) strip(sub, sub == 0);
   }
+    if (ENV && blockIdx.x == 0)
+        env_step_bookkeeping(status, slot, n, ACT != 0, ea.merge_moments && ea.reward != nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -610,7 +647,7 @@ __global__ __launch_bounds__(256) void unpack_b1_f32_kernel(const uint64_t *__re
 
 template <int WW, int RULE_MODE>
 static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
-                          int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
+                          int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s, const B1EnvArgs *env = nullptr) {
     const int64_t n8 = (n + 7) / 8 * 8;         // the XCD-aware mapping walks the batch in groups of 8 grids
     const int lds = b1_strip_mode(n, WW);
     // persistent: just under 32 one-wave workgroups per CU (8 per SIMD).  8 x 1021: a multiple of 8 (a
@@ -625,6 +662,24 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     int64_t ucap = 8192;
     if (const int64_t v = knobs().b1_units; v >= 8) ucap = v / 8 * 8;       // experiment knob
     const unsigned full = WW > 1 ? (unsigned)(n8 * 2 < ucap ? n8 * 2 : ucap) : blocks(n8 * WW);
+    if (env && !act) {                            // one-launch step, no action
+        const B1EnvArgs ea = *env;
+        const dim3 grid(blocks(n8 * WW)), block(64);
+        if (lds == 2) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 2, true>), grid, block, 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW, RandB1(), 0, ea);
+        else if (lds == 1) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 1, true>), grid, block, 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW, RandB1(), 0, ea);
+        else hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 0, true>), grid, block, 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW, RandB1(), 0, ea);
+        return check_launch("carle_env_step_b1");
+    }
+    if (env && aw == 64) {                        // one-launch step, the 64-column window
+        const B1EnvArgs ea = *env;
+        const dim3 grid(full), block(64);
+        const int dbg = knobs().b1_dbg >= 0 ? (int)knobs().b1_dbg : 0;
+        if (lds == 2) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 2, true>), grid, block, 0, s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg, ea);
+        else if (lds == 1) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 1, true>), grid, block, 0, s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg, ea);
+        else hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 0, true>), grid, block, 0, s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg, ea);
+        return check_launch("carle_env_step_b1");
+    }
+    if (env) return -1000;                        // wider windows: step kernel(s) + epilogue
     if (!act) {
         { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 2>), dim3(blocks(n8 * WW)), dim3(64), 0,
                            s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 1>), dim3(blocks(n8 * WW)), dim3(64), 0,
@@ -695,21 +750,43 @@ static int launch_b1_rand(const uint64_t *u_in, uint64_t *u_out, int64_t n, uint
 
 template <int WW>
 static int launch_b1(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
-                     int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s) {
+                     int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s, const B1EnvArgs *env = nullptr) {
     if (rule == kLifeMask)
-        return launch_b1_mode<WW, kRuleLife>(u_in, act, u_out, n, ah, aw, rule, status, slot, s);
+        return launch_b1_mode<WW, kRuleLife>(u_in, act, u_out, n, ah, aw, rule, status, slot, s, env);
     if (rule == kHighLifeMask)
-        return launch_b1_mode<WW, kRuleHighLife>(u_in, act, u_out, n, ah, aw, rule, status, slot, s);
-    return launch_b1_mode<WW, kRuleGeneric>(u_in, act, u_out, n, ah, aw, rule, status, slot, s);
+        return launch_b1_mode<WW, kRuleHighLife>(u_in, act, u_out, n, ah, aw, rule, status, slot, s, env);
+    return launch_b1_mode<WW, kRuleGeneric>(u_in, act, u_out, n, ah, aw, rule, status, slot, s, env);
 }
 
 }  // namespace carle
 
 using namespace carle;
 
+namespace carle {
+static int step_b1_checked(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out, int64_t n, int h, int w, int ah,
+                           int aw, uint32_t rule, int32_t *status, int slot, void *stream, const B1EnvArgs *env);
+
+// CARLE_STEP_DEFERRED on packed state: the whole step in one launch; -1000 where that form does not exist
+int env_step_one_launch_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out, float *reward, int64_t n, int h,
+                           int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags, void *stream) {
+    if (n < 1 || !status || !aligned16(status) || (action && aw != 64) || knobs().two_launch_step > 0) return -1000;
+    B1EnvArgs ea;
+    ea.reward = reward;
+    ea.publish = (step_flags & CARLE_STEP_PUBLISH_FLAGS) ? 1 : 0;
+    ea.merge_moments = (step_flags & CARLE_STEP_MERGE_MOMENTS) ? 1 : 0;
+    return step_b1_checked(u_in, action, u_out, n, h, w, ah, aw, rule, status, slot, stream, &ea);
+}
+}  // namespace carle
+
 extern "C" int carle_ca_step_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out,
                                 int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                                 int32_t *status, int slot, void *stream) {
+    return step_b1_checked(u_in, action, u_out, n, h, w, ah, aw, rule, status, slot, stream, nullptr);
+}
+
+static int carle::step_b1_checked(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out, int64_t n, int h, int w,
+                                  int ah, int aw, uint32_t rule, int32_t *status, int slot, void *stream,
+                                  const B1EnvArgs *env) {
     if (n == 0) return 0;
     if (!u_in || !u_out) return fail_arg(CARLE_E_NULL, "carle_ca_step_b1: u_in/u_out is NULL");
     if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
@@ -727,10 +804,10 @@ extern "C" int carle_ca_step_b1(const uint64_t *u_in, const uint64_t *action, ui
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (w) {
-        case 64: return launch_b1<1>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
-        case 128: return launch_b1<2>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
-        case 256: return launch_b1<4>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
-        default: return launch_b1<8>(u_in, action, u_out, n, ah, aw, rule, status, slot, s);
+        case 64: return launch_b1<1>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, env);
+        case 128: return launch_b1<2>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, env);
+        case 256: return launch_b1<4>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, env);
+        default: return launch_b1<8>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, env);
     }
 }
 

@@ -184,46 +184,7 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
 
     if (ENV) {
         if (ea.reward && lane == 0) ea.reward[g] = 0.0f;               // env.py:238
-        if (g == 0) settle_moments_wave(status, lane);                  // (a one-launch CA + RND2D step before this one)
-        if (g == 0 && lane == 0) {
-            // bookkeeping by ONE thread of the launch: settle the previous step if it is still pending, recycle its flag
-            // slot (= the next step's), merge the moments of this step's all-zero reward, leave this step pending.
-            // The words of THIS step's slot are written by the other wavefronts meanwhile: they are not touched here
-            // (dword stores only where a 16-byte store would cover them).
-            uint4 *s4 = reinterpret_cast<uint4 *>(status);
-            uint4 w0 = s4[0], w1 = s4[1], w2 = s4[2];
-            const uint4 w3 = s4[3];
-            settle_pending(w0, w1, w2);
-            if (ea.merge_moments && ea.reward) {
-                double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
-                double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
-                if (mom_out && mom_acc) {
-                    const double nb = (double)n, na = mom_acc[0], ma = mom_acc[1], qa = mom_acc[2], tot = na + nb;
-                    mom_out[0] = nb; mom_out[1] = 0.0; mom_out[2] = 0.0;
-                    if (tot > 0.0) {
-                        mom_acc[0] = tot;
-                        mom_acc[1] = ma - ma * nb / tot;
-                        mom_acc[2] = qa + ma * ma * na * nb / tot;
-                    }
-                }
-            }
-            if (!HAS_ACT) {
-                // no action: no predicates, no reset (env.py:191,208) -- nothing to wait for, count the step now
-                int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z) + 1;
-                int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x) + 1;
-                w1.x = 0u;
-                w1.z = (uint32_t)step_number; w1.w = (uint32_t)((uint64_t)step_number >> 32);
-                w2.x = (uint32_t)since; w2.y = (uint32_t)((uint64_t)since >> 32);
-            } else {
-                w1.y = 1u | 2u | (slot ? 4u : 0u);                     // CARLE_ST_PENDING: this step
-            }
-            s4[1] = w1; s4[2] = w2;
-            const int other = slot ^ 1;
-            status[CARLE_ST_ANY_NONZERO(other)] = 0;
-            status[CARLE_ST_NOT_ALL_ONES(other)] = 0;
-            status[CARLE_ST_SCAN_TICKET(other)] = 0;
-            status[CARLE_ST_SCAN_DONE(other)] = 0;
-        }
+        if (g == 0) env_step_bookkeeping(status, slot, n, HAS_ACT, ea.merge_moments && ea.reward != nullptr);
     }
 }
 

@@ -355,8 +355,9 @@ def ca_multistep_b1(u_in, u_out, rule, k, status=None):
     _lib.check(rc, "carle_ca_multistep_b1")
 
 
-def env_step_b1(u_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False):
-    """CARLE.step hot path on packed state: packed step kernel + epilogue, one library call."""
+def env_step_b1(u_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False, deferred=True):
+    """CARLE.step hot path on packed state, one library call (``deferred`` as for env_step_f32: one launch for no
+    action / the 64-column window)."""
     lib = _lib.load()
     n, _, h, ww = u_in.shape
     if action is None:
@@ -366,7 +367,7 @@ def env_step_b1(u_in, action, u_out, reward, rule, status, slot, publish_flags=T
     with _on_device(u_in.device):
         rc = lib.carle_env_step_b1(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h,
                                    ww * 64, ah, aw, rule, status.data_ptr(), slot,
-                                   _step_flags(publish_flags, merge_moments), _stream(u_in))
+                                   _step_flags(publish_flags, merge_moments, deferred), _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_step_b1")
 

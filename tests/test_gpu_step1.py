@@ -29,7 +29,7 @@ def _cases64():
     return names + ["pred:" + nm for nm in G.predicate_case_names() if G.predicate_case(nm).size == 64]
 
 
-@pytest.mark.parametrize("storage", ["f32", "u8"])
+@pytest.mark.parametrize("storage", ["f32", "u8", "b1"])
 @pytest.mark.parametrize("name", _cases64())
 def test_replicated_golden_case_through_one_launch_step(name, storage):
     """Every recorded 64x64 case, tiled to more than 16 instances: each replica reproduces the reference's grids, the
@@ -40,6 +40,8 @@ def test_replicated_golden_case_through_one_launch_step(name, storage):
         pytest.skip("mean == 1.0 without all ones: exact predicates only (test_gpu_ca.py)")
     reps = 17 // c.n + 1
     n = reps * c.n
+    if storage == "b1" and c.asize != 64:
+        pytest.skip("packed state: 64-column windows")
     env = _env(width=64, height=64, action_width=c.asize, action_height=c.asize, instances=n, storage=storage)
     env.birth, env.survive = list(c.birth), list(c.survive)
     env.reset()
@@ -84,7 +86,9 @@ def _crafted_actions(rng, n, aw):
     acts.append(ones.copy())                                             # master reset
     a = ones.copy(); a[n - 1, 0, aw - 1, aw - 1] = 0.0; acts.append(a)    # all ones but the very last element
     a = ones.copy(); a[0, 0, 0, 0] = 2.0; acts.append(a)                 # ... but the very first, and non-zero
-    a = (rng.random((n, 1, aw, aw)) < 0.5).astype(np.float32); a[1] = 1.0; a[n // 2] = 1.0; a[n - 1] = 1.0
+    a = (rng.random((n, 1, aw, aw)) < 0.5).astype(np.float32); a[min(1, n - 1)] = 1.0; a[n // 2] = 1.0; a[n - 1] = 1.0
+    if n == 1:
+        a[0, 0, 5, 5] = 0.0
     acts.append(a)                                                       # all-ones grids among ordinary ones
     a = ones.copy(); a[n // 3, 0, aw // 2, 3] = np.float32("nan"); acts.append(a)
     acts.append(ones.copy())                                             # and a second reset
@@ -338,3 +342,81 @@ def test_pending_rnd_moments_are_merged_by_whatever_comes_next(monkeypatch):
         assert got[0] == allr.size, (follow, got, allr.size)
         np.testing.assert_allclose(got[1:], [allr.mean(), ((allr - allr.mean()) ** 2).sum()], rtol=1e-10, err_msg=follow)
         totals.append(got)
+
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bit-packed state (BASELINE configs[4]): the whole step in one launch for no action / the 64-column window
+# ---------------------------------------------------------------------------------------------------------------
+
+def _np_pack(a):
+    n, _, h, w = a.shape
+    bits = np.packbits((a != 0).reshape(n, 1, h, w // 64, 64), axis=-1, bitorder="little")
+    return bits.reshape(n, 1, h, w // 64, 8).copy().view("<u8").reshape(n, 1, h, w // 64).astype(np.int64)
+
+
+@pytest.mark.parametrize("n,size", [(1, 64), (9, 64), (40, 64), (3, 128), (5, 256), (2, 512), (33, 512)])
+@pytest.mark.parametrize("publish", [True, False])
+def test_one_launch_packed_step_against_oracle_and_two_launch_path(n, size, publish):
+    """carle_env_step_b1 with CARLE_STEP_DEFERRED against the oracle and the packed step kernel + epilogue: packed
+    64x64 action windows (flags derived from the bits by the kernel, or stored beforehand as carle_pack_f32_b1 does),
+    crafted all-ones / all-but-one-bit / all-ones-grid cases, no action; grids, reward, counters, moments."""
+    from carle_amd import hip
+    rng = np.random.default_rng(n * 10 + size)
+    rule = O.rule_mask([3, 6], [2, 3])
+    u0 = (rng.random((n, 1, size, size)) < 0.4).astype(np.float32)
+    acts = [a if a is None else (a != 0).astype(np.float32) for a in _crafted_actions(rng, n, 64)]
+    ref = _oracle_loop(u0, acts, rule)
+    for deferred in (True, False):
+        st = hip.new_status("cuda:0")
+        mom_out = torch.zeros(3, dtype=torch.float64, device="cuda")
+        mom_acc = torch.zeros(3, dtype=torch.float64, device="cuda")
+        st[12:16] = torch.tensor([mom_out.data_ptr(), mom_acc.data_ptr()], dtype=torch.int64).view(torch.int32).cuda()
+        cur = torch.from_numpy(_np_pack(u0)).cuda()
+        for t, a in enumerate(acts):
+            nxt = torch.full_like(cur, 7)
+            reward = torch.full((n, 1), 3.0, device="cuda")
+            slot = t & 1
+            if a is None:
+                d_a = None
+            elif publish:
+                d_a = torch.from_numpy(_np_pack(a)).cuda()
+            else:
+                d_a = hip.pack_f32_b1(torch.from_numpy(a).cuda(), st, slot)       # stores the flags of `slot`
+            hip.env_step_b1(cur, d_a, nxt, reward, rule, st, slot, publish, True, deferred=deferred)
+            exp, sn, ssa, rs = ref[t]
+            assert np.array_equal(nxt.cpu().numpy(), _np_pack(exp)), (deferred, t)
+            assert float(reward.abs().sum()) == 0.0
+            s = hip.env_settle(st).cpu()
+            assert s[5].item() == 0 and s[16:20].tolist() == [0, 0, 0, 0], s.tolist()
+            assert int(s[6:8].view(torch.int64)) == sn and int(s[8:10].view(torch.int64)) == ssa, (deferred, t)
+            assert int(s[10:12].view(torch.int64)) == rs and s[4].item() == int(rs > (ref[t - 1][3] if t else 0))
+            assert mom_acc.cpu().tolist() == [float(n * (t + 1)), 0.0, 0.0]
+            cur = nxt
+
+
+def test_packed_master_reset_of_a_batch_larger_than_the_resident_wavefronts():
+    from carle_amd import hip
+    n, size = 9000, 256                                    # 18000 half-grid units, 8192 wavefronts resident
+    rule = O.rule_mask([3], [2, 3])
+    g = torch.Generator(device="cuda").manual_seed(3)
+    u = hip.pack_f32_b1((torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.4).float())
+    a = torch.full((n, 1, 64, 1), -1, dtype=torch.int64, device="cuda")
+    out = torch.full_like(u, 5)
+    reward = torch.empty(n, 1, device="cuda")
+    st = hip.new_status("cuda:0")
+    hip.env_step_b1(u, a, out, reward, rule, st, 0)
+    assert int(out.count_nonzero()) == 0
+    s = hip.env_settle(st).cpu()
+    assert s[4].item() == 1 and int(s[10:12].view(torch.int64)) == 1
+    for where in ((n - 1, 63), (0, 0), (n // 2, 31)):
+        a2 = a.clone()
+        a2[where[0], 0, where[1], 0] = ~(1 << 17)
+        ref = torch.empty_like(u)
+        hip.ca_step_b1(u, a2, ref, rule, None, 0)
+        out.fill_(5)
+        hip.env_step_b1(u, a2, out, reward, rule, st, 1)
+        assert torch.equal(out, ref) and int(out.count_nonzero()) > 0
+        s = hip.env_settle(st).cpu()
+        assert s[4].item() == 0 and s[16:20].tolist() == [0, 0, 0, 0]
+        st[0:4] = 0
