@@ -193,15 +193,21 @@ template <int WW>
 struct StripLds {
     uint4 img[64 * WW / 2];          // the strip
     uint4 halo[2][WW / 2 > 0 ? WW / 2 : 1];   // row above, row below
+    uint4 act[32];                   // the grid's packed 64x64 action record (64 row words), see load_strip<.., ACTREC>
 };
 
-template <int WW, bool NT>
+// ACTREC: the grid's 512-byte action record (the 64 row words of the 64-column window) travels WITH the strip -- one more
+// coalesced 16-byte access on 32 lanes in the same batch of loads, laid down in LDS beside the strip image -- instead of
+// a separate, earlier round trip for two dwords per lane (the 4096 cold records of a launch cost ~5 us that way).
+template <int WW, bool NT, bool ACTREC = false>
 __device__ __forceinline__ void load_strip(StripLds<WW> &l, const uint64_t *__restrict__ gstrip,
                                            const uint64_t *__restrict__ grow_top, const uint64_t *__restrict__ grow_bot,
-                                           bool multi, int lane, uint64_t (&c)[WW], uint64_t (&hal)[WW]) {
+                                           bool multi, int lane, uint64_t (&c)[WW], uint64_t (&hal)[WW],
+                                           const uint64_t *__restrict__ act_rec = nullptr) {
     constexpr int Q = WW / 2;                                // 16-byte quads per row = accesses per strip
     const uint4 *g4 = reinterpret_cast<const uint4 *>(gstrip);
-    uint4 v[Q];
+    uint4 v[Q], av = make_uint4(0u, 0u, 0u, 0u);
+    if (ACTREC) av = reinterpret_cast<const uint4 *>(act_rec)[lane & 31];     // unconditional; lanes >= 32 repeat
 #pragma unroll
     for (int j = 0; j < Q; ++j) v[j] = ld16s<NT>(g4 + j * 64 + lane);
     // halo: lanes 0..Q-1 the row above, Q..2Q-1 the row below (default cache policy: the neighbouring strip owns them)
@@ -211,6 +217,7 @@ __device__ __forceinline__ void load_strip(StripLds<WW> &l, const uint64_t *__re
 #pragma unroll
     for (int j = 0; j < Q; ++j) l.img[j * 64 + lane] = v[j];
     if (lane < 2 * Q) l.halo[lane < Q ? 0 : 1][hq] = hv;
+    if (ACTREC && lane < 32) l.act[lane] = av;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const uint4 r = l.img[lane * Q + q];
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     if (ENV && ea.reward)
         for (int64_t i = (int64_t)blockIdx.x * 64 + lane; i < n; i += (int64_t)gridDim.x * 64) ea.reward[i] = 0.0f;   // env.py:238
     const int64_t n8 = ((n + 7) / 8) * 8;
-    const bool halves = MULTI && strip_count == WW && ACT == 1;
+    const bool halves = MULTI && strip_count == WW && ACT == 1 && !(dbg & 8);    // dbg bit 3: the single-strip walk
     const int per_unit = halves ? WW / 2 : 1;
     const int64_t total = halves ? n8 * 2 : n8 * strip_count;
     constexpr int HS = WW / 2 > 0 ? WW / 2 : 1;
@@ -319,7 +326,9 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     // window, the one at the middle of the grid) and of that strip's bordering row
     uint32_t pa_lo = 0u, pa_hi = 0u, ph_lo = 0u, ph_hi = 0u;
     bool unit_reset = reset_all;                             // ENV: this unit's strips are zeroed (master reset)
-    const bool preload = ACT == 1 && !RAND && halves && HS >= 2 && !(dbg & 1);
+    // dbg bit 1: the action record travels with the window strip through LDS (load_strip<.., ACTREC>) -- no earlier fetch
+    const bool act_lds = LDS_T && ACT == 1 && !RAND && (dbg & 2) && ((halves && HS >= 2) || (dbg & 8));
+    const bool preload = ACT == 1 && !RAND && halves && HS >= 2 && !(dbg & 1) && !act_lds;
     if (preload) {
         const int r0w = ((j & 1) ? WW - HS : HS - 1) * 64, oyw = (H - ah) >> 1;
         const int rw = r0w + lane;
@@ -363,8 +372,17 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     const int hr = lane == 0 ? rt : (lane == 63 ? rb : -1);
 
     uint64_t c[WW], hal[WW];
+    // does the strip (with its bordering rows) meet the action window at all?  (wave-uniform)
+    const int oy_ = (H - ah) >> 1;
+    const bool touches_ = ACT == 1 && ((r0 < oy_ + ah && r0 + 64 > oy_) ||
+                                       (MULTI && ((rt >= oy_ && rt < oy_ + ah) || (rb >= oy_ && rb < oy_ + ah))));
+    const bool use_rec = ACT == 1 && !RAND && act_lds && touches_ && first;
     if constexpr (LDS_T) {
-        load_strip<WW, LDS_NT>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
+        if (ACT == 1 && !RAND && use_rec)
+            load_strip<WW, LDS_NT, true>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane,
+                                         c, hal, act + g * (int64_t)ah);
+        else
+            load_strip<WW, LDS_NT>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
     } else {
         load_row<WW>(gin + (int64_t)r * WW, c);
 #pragma unroll
@@ -395,6 +413,13 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
                 toggle_words64<WW>(c, pa_lo, pa_hi, in, s_or, s_and);
                 const bool hin = hr >= oy && hr < oy + ah;
                 toggle_words64<WW>(hal, ph_lo, ph_hi, hin, d0, d1);
+            } else if (LDS_T && use_rec) {
+                // the record lies in LDS beside the strip (ah == 64 rows of one word)
+                const uint2 *a2 = reinterpret_cast<const uint2 *>(lds.act);
+                const bool hin = hr >= oy && hr < oy + ah;
+                const uint2 wr = a2[in ? r - oy : 0], wh = a2[hin ? hr - oy : 0];
+                toggle_words64<WW>(c, wr.x, wr.y, in, s_or, s_and);
+                toggle_words64<WW>(hal, wh.x, wh.y, hin, d0, d1);
             } else {
             toggle_row64<WW>(c, ga + (in ? r - oy : 0), in, s_or, s_and);
             if (MULTI) {
@@ -495,7 +520,13 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     else store_row<WW>(u_out + (g * (int64_t)H + r) * WW, nx);
     B1_STAMP(3);
     };
-    for (int sub = 0; sub < per_unit; ++sub) strip(sub, sub == 0);
+    // dbg bit 2 (with bit 1): the units start at different strips of their half -- at any moment the wavefronts of the
+    // launch read all strip positions, not all the same 4 KB of every 16 KB (the window strip comes when it comes)
+    const int rot = (act_lds && (dbg & 4)) ? (int)((g >> 3) & (HS - 1)) : 0;
+    for (int s_ = 0; s_ < per_unit; ++s_) {
+        const int sub = (s_ + rot) & (per_unit - 1);
+        strip(sub, sub == 0);
+    }
   }
     if (ENV && blockIdx.x == 0)
         env_step_bookkeeping(status, slot, n, ACT != 0, ea.merge_moments && ea.reward != nullptr);
@@ -691,9 +722,11 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
         // the usual 64x64 window: its toggle fits the full-occupancy instantiation -> one launch
         int dbg = 0;
         if (knobs().b1_dbg >= 0) dbg = (int)knobs().b1_dbg;       // experiment knob: 1 = window words fetched at their use
-        { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 2>), dim3(full), dim3(64), 0,
-                           s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 1>), dim3(full), dim3(64), 0,
-                           s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg); } else { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE>), dim3(full), dim3(64), 0,
+        const unsigned wl = (dbg & 8) && lds != 0 ? blocks(n8 * WW) : full;
+        if (!lds) dbg &= ~8;
+        { if (lds == 2) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 2>), dim3(wl), dim3(64), 0,
+                           s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg); } else if (lds == 1) { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 1>), dim3(wl), dim3(64), 0,
+                           s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg); } else { hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE>), dim3(wl), dim3(64), 0,
                            s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg); } }
         return check_launch("carle_ca_step_b1");
     }
