@@ -64,6 +64,14 @@ struct Knobs {
 };
 const Knobs &knobs();
 
+// reward += scale * bonus as torch evaluates it (carle/mcl.py:403-405): the product and the sum are rounded separately.
+// (HIP's __fmul_rn / __fadd_rn are plain operators and contract into an fma like any other; the pragma does not.)
+__device__ __forceinline__ float reward_accumulate(float reward, float scale, float bonus) {
+#pragma clang fp contract(off)
+    const float prod = scale * bonus;
+    return reward + prod;
+}
+
 // Arguments of the one-launch CA + RND2D step (ca_step_rnd64_kernel<..., ENV>, ca_rnd_fused.hip)
 struct RndEnvArgs {
     float *reward = nullptr;             // N floats: reward_scale * bonus

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void ae_mse_finish_kernel(const float *__restr
     for (int c = 0; c < chunks; ++c) s += partial[g * chunks + c];
     const float b = s * inv_pixels;
     bonus[g] = b;
-    if (reward) reward[g] += reward_scale * b;
+    if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);      // mcl.py:403-405: product, then sum
 }
 
 static inline int check_net_dims(int64_t n, int h, int w, const char *who) {
@@ -480,6 +480,33 @@ extern "C" int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w) {
     int64_t fused = rnd2d_fused_workspace_floats();
     if (rnd2d_tiled_applies(h, w)) fused = rnd2d_tiled_workspace_floats(n, h);
     return staged > fused ? staged : fused;
+}
+
+namespace carle {
+int rnd_ae_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws, float *rbonus,
+                 float rscale, bool rnd_tables_valid, const float *ap, float *aws, float *abonus, float ascale,
+                 bool ae_tables_valid, float *reward, hipStream_t s);
+}
+
+// RND2D.get_bonus AND AE2D.get_bonus of the same observations (carle/mcl.py:343-352, 504-512) + both wrappers' reward
+// updates (mcl.py:403-405, RND2D first) in two launches: binary observations, H == W a multiple of 64 above 64 (the tiled
+// kernels; the reference's default 256x256).  obs_fmt: CARLE_FMT_F32 (values exactly 0 / 1) or CARLE_FMT_B1.
+// Workspaces, parameter blobs, bonuses and TABLES_VALID flags exactly as for carle_rnd2d_bonus_* / carle_ae2d_bonus_*.
+extern "C" int carle_rnd_ae_bonus(const void *obs, int obs_fmt, int64_t n, int h, int w, const float *rnd_pred_params,
+                                  const float *rnd_rand_params, float *rnd_workspace, float *rnd_bonus, float rnd_scale,
+                                  int rnd_flags, const float *ae_params, float *ae_workspace, float *ae_bonus, float ae_scale,
+                                  int ae_flags, float *reward_accum, void *stream) {
+    if (!obs || !rnd_pred_params || !rnd_rand_params || !rnd_workspace || !rnd_bonus || !ae_params || !ae_workspace || !ae_bonus)
+        return fail_arg(CARLE_E_NULL, "carle_rnd_ae_bonus: NULL pointer");
+    if (obs_fmt != CARLE_FMT_F32 && obs_fmt != CARLE_FMT_B1)
+        return fail_arg(CARLE_E_FORMAT, "carle_rnd_ae_bonus: obs_fmt must be CARLE_FMT_F32 or CARLE_FMT_B1");
+    if (n < 0 || !rnd2d_tiled_applies(h, w))
+        return fail_arg(CARLE_E_DIMS, "carle_rnd_ae_bonus: binary grids with H == W a multiple of 64 above 64 (use the "
+                                      "per-net entry points otherwise)");
+    if (n == 0) return 0;
+    return rnd_ae_tiled(obs, obs_fmt == CARLE_FMT_B1, n, h, rnd_pred_params, rnd_rand_params, rnd_workspace, rnd_bonus,
+                        rnd_scale, (rnd_flags & CARLE_NET_TABLES_VALID) != 0, ae_params, ae_workspace, ae_bonus, ae_scale,
+                        (ae_flags & CARLE_NET_TABLES_VALID) != 0, reward_accum, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,

@@ -84,12 +84,13 @@ __device__ __forceinline__ float tile_wave_sum(float v) {
 }
 
 // PACKED: obs = bit-packed grids (H rows of W/64 words); else fp32 (N,1,H,W), any non-zero number = alive
+// (body as a device function: the stand-alone kernel below and the launch that runs the RND2D and AE2D tiles of a
+// wrapper stack side by side, rnd_ae_tile_kernel, call it with their own workgroup index / count)
 template <bool PACKED>
-__global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
-                                                          const float *__restrict__ pp, const float *__restrict__ rp,
-                                                          float *__restrict__ partial, float *__restrict__ featbuf,
-                                                          int64_t n, int size) {
-    __shared__ RndTileShared s;
+__device__ __forceinline__ void rnd_tile_body(RndTileShared &s, const void *__restrict__ obs_v, const float *__restrict__ ws,
+                                              const float *__restrict__ pp, const float *__restrict__ rp,
+                                              float *__restrict__ partial, float *__restrict__ featbuf,
+                                              int64_t n, int size, unsigned bid, unsigned nblk) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     rnd_block_init(s.net, ws, tid);
     const int tps = size >> 6, tiles = tps * tps;      // tiles per side / per grid
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict
             }
         }
     };
-    if ((int64_t)blockIdx.x < total) issue(blockIdx.x);
+    if ((int64_t)bid < total) issue(bid);
     __syncthreads();
-    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+    for (int64_t t = bid; t < total; t += nblk) {
         const int64_t g = t / tiles;
         const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
         // ---- the tile's kTileRows rows as bit words: from the registers the previous iteration (or the prologue) filled
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict
                 if (lane == 0 && r < kTileRows) { s.rows[r][0] = lo; s.rows[r][1] = hi; }
             }
         }
-        if (t + gridDim.x < total) issue(t + gridDim.x);          // the next tile travels during this one's layers
+        if (t + nblk < total) issue(t + nblk);          // the next tile travels during this one's layers
         // this tile's 8 weights per thread of the linear layers: requested now, used after conv2
         const int lfy = tid & 7, lk = (tid >> 3) & 15, lnet = tid >> 7;
         const float *wrow = (lnet == 0 ? pp + 77 : rp + 39) + (int64_t)lk * dfeat + (int64_t)(8 * ty + lfy) * d8 + 8 * tx;
@@ -183,6 +184,15 @@ __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict
     }
 }
 
+template <bool PACKED>
+__global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
+                                                          const float *__restrict__ pp, const float *__restrict__ rp,
+                                                          float *__restrict__ partial, float *__restrict__ featbuf,
+                                                          int64_t n, int size) {
+    __shared__ RndTileShared s;
+    rnd_tile_body<PACKED>(s, obs_v, ws, pp, rp, partial, featbuf, n, size, blockIdx.x, gridDim.x);
+}
+
 // 16 threads per grid: thread k adds the tiles' partial sums of output k of both nets in tile order
 __global__ __launch_bounds__(256) void rnd_tile_finish_kernel(const float *__restrict__ partial, const float *__restrict__ pp,
                                                               const float *__restrict__ rp, float *__restrict__ bonus,
@@ -211,7 +221,9 @@ __global__ __launch_bounds__(256) void rnd_tile_finish_kernel(const float *__res
     if (g < n && k == 0) {
         const float b = sq * (1.0f / 16.0f);
         bonus[g] = b;
-        if (reward) reward[g] += reward_scale * b;        // mcl.py:403-405
+        // mcl.py:403-405, as torch evaluates it: product and sum rounded separately (no contraction into an fma -- also
+        // what keeps the paired launch, rnd_ae_finish_kernel, bit-identical to the two wrappers one after the other)
+        if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);
     }
 }
 
@@ -488,10 +500,9 @@ __device__ __forceinline__ uint32_t row_seg4(uint64_t lo, uint64_t hi, int c) {
 __device__ __forceinline__ float tile_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }   // as nets_fused.hip
 
 template <bool PACKED>
-__global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
-                                                         float *__restrict__ partial, float *__restrict__ recon,
-                                                         int64_t n, int size) {
-    __shared__ AeTileShared s;
+__device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__restrict__ obs_v, const float *__restrict__ ws,
+                                             float *__restrict__ partial, float *__restrict__ recon,
+                                             int64_t n, int size, unsigned bid, unsigned nblk) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const float4 *src = reinterpret_cast<const float4 *>(ws);
@@ -540,9 +551,9 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
             }
         }
     };
-    if ((int64_t)blockIdx.x < total) issue(blockIdx.x);
+    if ((int64_t)bid < total) issue(bid);
     __syncthreads();
-    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+    for (int64_t t = bid; t < total; t += nblk) {
         const int64_t g = t / tiles;
         const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
         // ---- the tile's kAeRows rows as bit words: from the registers the previous iteration (or the prologue) filled
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
                 if (lane == 0 && r < kAeRows) { s.rows[r][0] = lo; s.rows[r][1] = hi; }
             }
         }
-        if (t + gridDim.x < total) issue(t + gridDim.x);          // the next tile travels during this one's layers
+        if (t + nblk < total) issue(t + nblk);          // the next tile travels during this one's layers
         __syncthreads();
         AE_W_HERE();
 
@@ -715,6 +726,101 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
         AE_W_HERE();
         if (tid == 0) partial[t] = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
     }
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
+                                                         float *__restrict__ partial, float *__restrict__ recon,
+                                                         int64_t n, int size) {
+    __shared__ AeTileShared s;
+    ae_tile_body<PACKED>(s, obs_v, ws, partial, recon, n, size, blockIdx.x, gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RND2D + AE2D forward of a wrapper stack (AE2D(RND2D(env)), carle/train_mcl.py:34-38, evaluation/eval.py:83-85) in
+// TWO launches instead of four: both nets read the same observation, so the tile workgroups of both run side by side
+// in one launch -- workgroups [0, rnd_blocks) walk the RND2D tiles, the others the AE2D tiles, each with its own
+// barriers and LDS image -- and one finish kernel forms both bonuses and adds them to the reward in the wrappers'
+// order (reward += s_rnd * b_rnd, then += s_ae * b_ae: mcl.py:403-405 twice).  At the reference's default batch
+// (16 x 256x256: 256 tiles per net, a tile per CU) a step is bound by its dependent dispatches, not by the kernels.
+// ---------------------------------------------------------------------------------------------------------------
+union RndAeTileShared {
+    RndTileShared r;
+    AeTileShared a;
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(256, 4) void rnd_ae_tile_kernel(const void *__restrict__ obs_v, const float *__restrict__ rws,
+                                                             const float *__restrict__ pp, const float *__restrict__ rp,
+                                                             float *__restrict__ rpartial, const float *__restrict__ aws,
+                                                             float *__restrict__ apartial, int64_t n, int size,
+                                                             unsigned rnd_blocks) {
+    __shared__ RndAeTileShared s;
+    if (blockIdx.x < rnd_blocks)
+        rnd_tile_body<PACKED>(s.r, obs_v, rws, pp, rp, rpartial, nullptr, n, size, blockIdx.x, rnd_blocks);
+    else
+        ae_tile_body<PACKED>(s.a, obs_v, aws, apartial, nullptr, n, size, blockIdx.x - rnd_blocks, gridDim.x - rnd_blocks);
+}
+
+// 16 threads per grid (as rnd_tile_finish_kernel); thread 0 of a grid also adds the AE2D tiles' squared errors
+__global__ __launch_bounds__(256) void rnd_ae_finish_kernel(const float *__restrict__ rpartial, const float *__restrict__ pp,
+                                                            const float *__restrict__ rp, float *__restrict__ rbonus,
+                                                            const float *__restrict__ apartial, float *__restrict__ abonus,
+                                                            float *__restrict__ reward, float rscale, float ascale, int64_t n,
+                                                            int tiles, int dfeat, float inv_pixels) {
+    const int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int k = threadIdx.x & 15;
+    float sq = 0.0f, ae = 0.0f;
+    if (g < n) {
+        float p = 0.0f, r = 0.0f;
+        for (int t = 0; t < tiles; ++t) {
+            p += rpartial[((g * tiles + t) * 2 + 0) * 16 + k];
+            r += rpartial[((g * tiles + t) * 2 + 1) * 16 + k];
+        }
+        p = tanhf(p + pp[77 + (int64_t)16 * dfeat + k]);
+        r = tanhf(r + rp[39 + (int64_t)16 * dfeat + k]);
+        sq = (r - p) * (r - p);
+        if (k == 0)
+            for (int t = 0; t < tiles; ++t) ae += apartial[g * tiles + t];       // ae_mse_finish_kernel's order
+    }
+    sq += dpp_quad_xor1(sq);
+    sq += dpp_quad_xor2(sq);
+    sq += dpp_row_ror(sq, 0x124);
+    sq += dpp_row_ror(sq, 0x128);
+    if (g < n && k == 0) {
+        const float br = sq * (1.0f / 16.0f), ba = ae * inv_pixels;
+        rbonus[g] = br;
+        abonus[g] = ba;
+        if (reward) {
+            float x = reward[g];
+            x = reward_accumulate(x, rscale, br);          // RND2D.step, then AE2D.step (mcl.py:403-405)
+            x = reward_accumulate(x, ascale, ba);
+            reward[g] = x;
+        }
+    }
+}
+
+void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
+
+// both wrappers' bonuses of one observation batch; workspaces as rnd2d_tiled / ae2d_tiled use them
+int rnd_ae_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws, float *rbonus,
+                 float rscale, bool rnd_tables_valid, const float *ap, float *aws, float *abonus, float ascale,
+                 bool ae_tables_valid, float *reward, hipStream_t s) {
+    if (!rnd_tables_valid) rnd2d_prepare_tables(pp, rp, rws, s);
+    if (!ae_tables_valid) ae2d_prepare_tables(ap, aws, s);
+    const int tiles = (size >> 6) * (size >> 6);
+    const int64_t total = n * tiles;
+    if ((n + 15) / 16 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_rnd_ae_bonus: batch too large");
+    const unsigned rb = (unsigned)(total < 1024 ? total : 1024), ab = (unsigned)(total < 16384 ? total : 16384);
+    float *rpartial = rws + kFusedWsTotal, *apartial = aws + kAeLutFloatsT + 128;
+    if (packed)
+        hipLaunchKernelGGL(rnd_ae_tile_kernel<true>, dim3(rb + ab), dim3(256), 0, s, obs, rws, pp, rp, rpartial, aws, apartial, n, size, rb);
+    else
+        hipLaunchKernelGGL(rnd_ae_tile_kernel<false>, dim3(rb + ab), dim3(256), 0, s, obs, rws, pp, rp, rpartial, aws, apartial, n, size, rb);
+    const int d8 = size >> 3;
+    hipLaunchKernelGGL(rnd_ae_finish_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, rpartial, pp, rp, rbonus, apartial,
+                       abonus, reward, rscale, ascale, n, tiles, d8 * d8, 1.0f / ((float)size * (float)size));
+    return check_launch("carle_rnd_ae_bonus(tiled)");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -703,6 +703,50 @@ class AE2D(RND2D):
         self._commit_tables()
         return res
 
+    # -- stacked on an RND2D, forward only, tiled sizes: both bonuses in two launches (carle_rnd_ae_bonus) ----------
+    def _can_pair_step(self):
+        rnd, env = self.env, self.inner_env
+        return (type(self) is AE2D and type(rnd) is RND2D and rnd.env is env and not self.train_predictor
+                and not rnd.train_predictor and not self.async_reward and not rnd.async_reward
+                and env.height == env.width and env.height > 64 and env.height % 64 == 0)
+
+    def step(self, action):
+        """AE2D(RND2D(CARLE)) -- the stack of train_mcl.py:34-38 / eval.py:83-85 -- at the reference's default geometry
+        (binary grids, H = W a multiple of 64 above 64) without predictor updates: the environment step, then BOTH
+        wrappers' bonuses and reward updates in two launches (the tile workgroups of the two nets side by side, one
+        finish kernel) instead of four -- a step there is bound by its dependent dispatches.  Bit-identical to the
+        two wrappers stepping one after the other."""
+        if not self._can_pair_step():
+            return super().step(action)
+        rnd, env = self.env, self.inner_env
+        if isinstance(action, torch.Tensor):
+            action = action.to(env.my_device)
+        rnd.__dict__["_moments_merged"] = False
+        self.__dict__["_moments_merged"] = False
+        obs, reward, done, info = env.step(action)
+        o, binary = self._obs(obs, allow_packed=True)
+        if not binary or o.dim() != 4:
+            rnd._bonus_into(obs, reward)
+            self._bonus_into(obs, reward)
+            return obs, reward, done, info
+        from . import _lib
+        lib = _lib.load()
+        dev, n, size = o.device, o.shape[0], o.shape[2]
+        for w, need in ((rnd, lib.carle_rnd2d_workspace_floats(n, size, size)), (self, lib.carle_ae2d_workspace_floats(n, size, size))):
+            if w._ws is None or w._ws.numel() < need or w._ws.device != dev:
+                w._ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
+                w._tables_key = None
+            if w._bonus_buf is None or w._bonus_buf.shape[0] != n or w._bonus_buf.device != dev:
+                w._bonus_buf = torch.empty(n, dtype=torch.float32, device=dev)
+        pb, rb, ab = rnd._pred_blob.get(dev), rnd._rand_blob.get(dev), self._pred_blob.get(dev)
+        rvalid = rnd._tables_valid(o, True, (rnd._pred_blob.version, rnd._rand_blob.version))
+        avalid = self._tables_valid(o, True, (self._pred_blob.version,))
+        hip.rnd_ae_bonus(o, pb, rb, rnd._ws, rnd._bonus_buf, rnd.reward_scale, rvalid, ab, self._ws, self._bonus_buf,
+                         self.reward_scale, avalid, reward)
+        rnd._commit_tables()
+        self._commit_tables()
+        return obs, reward, done, info
+
     def random_forward(self, obs):
         raise AttributeError("AE2D has no random network (mcl.py:433-434)")
 

@@ -352,6 +352,18 @@ int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const floa
                         float *workspace, float *bonus, float *recon_out,
                         float *reward_accum, float reward_scale, int flags, void *stream);
 
+/* RND2D.get_bonus and AE2D.get_bonus of the SAME observations (carle/mcl.py:343-352, 504-512) and both wrappers'
+ * `reward += reward_scale * bonus` (mcl.py:403-405, RND2D's first: the stack AE2D(RND2D(env)) of train_mcl.py:34-38 and
+ * eval.py:83-85) in TWO launches instead of four -- the tile workgroups of both nets run side by side in one launch, one
+ * finish kernel forms both bonuses.  Binary observations with H == W a multiple of 64 above 64 (the reference's default
+ * 256x256); obs_fmt CARLE_FMT_F32 (every value exactly 0.0f / 1.0f) or CARLE_FMT_B1.  Everything else -- parameter
+ * blobs, workspaces (carle_*_workspace_floats), bonus vectors, CARLE_NET_TABLES_VALID per net -- as for
+ * carle_rnd2d_bonus_* / carle_ae2d_bonus_*; results are bit-identical to calling those two. */
+int carle_rnd_ae_bonus(const void *obs, int obs_fmt, int64_t n, int h, int w, const float *rnd_pred_params,
+                       const float *rnd_rand_params, float *rnd_workspace, float *rnd_bonus, float rnd_scale,
+                       int rnd_flags, const float *ae_params, float *ae_workspace, float *ae_bonus, float ae_scale,
+                       int ae_flags, float *reward_accum, void *stream);
+
 /* CARLE.step + the RND2D wrapper's bonus on the fresh observation (carle/env.py:188-242 +
  * carle/mcl.py:398-407) in one call.
  *   64x64 grids with an aligned action window (AW % 8 == 0 or no action): ONE kernel steps the

@@ -1013,3 +1013,41 @@ def test_early_window_replay_keeps_its_scale():
         assert w.updates == 2
     for k in outs[0]:
         assert torch.allclose(outs[0][k], outs[1][k], rtol=0, atol=1e-5), (k, (outs[0][k] - outs[1][k]).abs().max())
+
+
+@pytest.mark.parametrize("storage,size,n", [("f32", 256, 16), ("f32", 128, 5), ("b1", 256, 7), ("u8", 192, 3), ("f32", 512, 2)])
+def test_paired_rnd_ae_step_equals_the_two_wrappers(storage, size, n):
+    """AE2D(RND2D(CARLE)) at tiled sizes, forward only: one carle_rnd_ae_bonus call (two launches) gives bit-identical
+    rewards and bonuses to the wrappers stepping one after the other (four launches), also after a parameter change
+    (tables rebuilt) and for packed / uint8 observations."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D
+    stacks = []
+    for paired in (True, False):
+        torch.manual_seed(21)
+        env = CARLE(width=size, height=size, instances=n, device="cuda:0", storage=storage)
+        w = AE2D(RND2D(env, train_predictor=False), train_predictor=False)
+        w.env.reward_scale, w.reward_scale = 0.7, 1.3
+        if not paired:
+            w._can_pair_step = lambda: False
+        w.eval(); w.reset()
+        stacks.append((env, w))
+    assert stacks[0][1]._can_pair_step()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    u0 = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+    for env, w in stacks:
+        env.universe = u0.clone()
+    for t in range(5):
+        a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
+        if t == 3:
+            for env, w in stacks:                               # new parameter values: both nets' tables are stale
+                with torch.no_grad():
+                    w.predictor[0].weight.mul_(1.01)
+                    w.env.predictor[11].bias.add_(0.05)
+        outs = [w.step(a) for env, w in stacks]
+        (o0, r0, _, _), (o1, r1, _, _) = outs
+        assert torch.equal(o0.float() if o0.dtype != torch.int64 else o0, o1.float() if o1.dtype != torch.int64 else o1)
+        assert torch.equal(stacks[0][1]._bonus_buf, stacks[1][1]._bonus_buf), "AE2D bonus"
+        assert torch.equal(stacks[0][1].env._bonus_buf, stacks[1][1].env._bonus_buf), "RND2D bonus"
+        assert torch.equal(r0, r1), (t, (r0 - r1).abs().max())
+        assert float(r0.min()) > 0
