@@ -545,11 +545,21 @@ __device__ __forceinline__ void horiz_neighbours(uint64_t c, uint64_t cw, uint64
 #endif
 static constexpr int kWideWaves = CARLE_WIDE_WAVES;
 
-template <class C, class A, bool HAS_ACT, int NS, int RW, bool RAND_ACT = false, bool NT_ST = true>
+// ENV instantiation (CARLE_STEP_DEFERRED): the whole CARLE.step in this one launch, as ca_step_64_kernel<..., ENV>.  A
+// workgroup owns four strips of ONE grid and most strips never see an action element, so the master reset is decided from
+// a sample every workgroup can afford: wavefront 0 loads the FIRST ROW of its grid's action window with its other first
+// loads (256 bytes, a cache hit for all but the first workgroup of the grid); an element there that is not one rules the
+// reset out (always, under an agent), otherwise batch_action_all_ones() verifies the batch.  The verdict reaches the
+// other wavefronts through the LDS exchange (and barrier) the edge rows use anyway.
+template <class C, class A, bool HAS_ACT, int NS, int RW, bool RAND_ACT = false, bool NT_ST = true, bool ENV = false>
 __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
     const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
     typename C::T *__restrict__ u_out, int64_t n, int ah, int aw, uint32_t rule,
-    int32_t *__restrict__ status, int slot, RandAct ra = RandAct()) {
+    int32_t *__restrict__ status, int slot, RandAct ra = RandAct(), EnvArgs ea = EnvArgs()) {
+    static_assert(!(ENV && RAND_ACT), "the in-kernel random agent keeps the two-launch step");
+    static_assert(!ENV || kWideWaves > 1, "the verdict travels with the edge rows");
+    __shared__ uint32_t s_reset;
+    const bool reset_all = ENV && HAS_ACT && !ea.publish && status[CARLE_ST_NOT_ALL_ONES(slot)] == 0;
     constexpr int W = WideGeom<NS, RW>::kW, H = W, R = WideGeom<NS, RW>::kR;
     constexpr int WV = kWideWaves;
     constexpr int kStrips = H / R, kGroups = kStrips / WV;
@@ -584,6 +594,9 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
     const bool compact = touches && !RAND_ACT && aw == 64;
     const typename A::T *ga = (HAS_ACT && !RAND_ACT) ? act + g * (int64_t)ah * aw : nullptr;
     typename A::Quad aq[RW][4], aht[NS], ahb[NS];
+    typename A::Quad achk = typename A::Quad{};      // ENV: a quad of the first window row (lanes beyond it repeat quad 0)
+    if (ENV && HAS_ACT && ea.publish && wv == 0)
+        achk = A::template load<false>(act + g * (int64_t)ah * aw + 4 * (k < (aw >> 2) ? k : 0));
     uint32_t arow_ok = 0;                            // bit 4m+j: this lane's row of load (m, j) is a window row
 #pragma unroll
     for (int m = 0; m < RW; ++m)
@@ -668,7 +681,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) halo[s] ^= A::nibble(aht[s]) | (A::nibble(ahb[s]) << 4);
-            publish_flags<A>(seen, status, slot);
+            if (!ENV || ea.publish) publish_flags<A>(seen, status, slot);      // (ENV, publish == 0: the caller stored them)
         } else if (touches) {
             // in-kernel random agent: the nibble of action quad (ay, ax) is a pure function of its
             // index, so halo rows draw the same toggles as the strip that owns the row
@@ -732,13 +745,23 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
                     halo[s] ^= (tin ? A::nibble(at) : 0u) | ((bin ? A::nibble(ab) : 0u) << 4);
                 }
             }
-            publish_flags<A>(seen, status, slot);
+            if (!ENV || ea.publish) publish_flags<A>(seen, status, slot);      // (ENV, publish == 0: the caller stored them)
         } else if (status != nullptr && k == 0) {
             // a strip outside the window sees no action element; the flags describe the whole
             // action, which the in-window strips publish.  Nothing to do.
         }
     }
 
+    if (ENV && HAS_ACT && wv == 0) {                 // master reset (env.py:208-216): see above
+        bool reset = reset_all;
+        if (ea.publish) {
+            ActionSeen sample;
+            see(sample, achk);
+            const bool notone = __ballot(sample.not_all_ones<A>()) != 0ull;
+            if (__builtin_expect(!notone, 0)) reset = batch_action_all_ones<A>(act, n, aw, status, slot);
+        }
+        if (k == 0) s_reset = reset ? 1u : 0u;
+    }
     if (WV > 1) {                                    // the inner halo rows: the neighbouring waves' edge rows, toggled
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -799,16 +822,20 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
                 ((m == RW - 1 ? (uint64_t)(hh0[s] >> 4) : (h0[s][m < RW - 1 ? m + 1 : 0] & 0xFull)) << 60);
             const uint64_t dn1 = (h1[s][m] >> 4) |
                 ((m == RW - 1 ? (uint64_t)(hh1[s] >> 4) : (h1[s][m < RW - 1 ? m + 1 : 0] & 0xFull)) << 60);
-            const uint64_t nx = apply_rule(neighbour_count(up0, up1, dn0, dn1, p0[s][m], p1[s][m]),
-                                           c[s][m], rule);
+            uint64_t nx = apply_rule(neighbour_count(up0, up1, dn0, dn1, p0[s][m], p1[s][m]),
+                                     c[s][m], rule);
+            if (ENV && HAS_ACT && s_reset != 0u) nx = 0ull;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 C::template store<NT_ST>(gout + (int64_t)(r0 + 16 * m + i) * W + 256 * s + 4 * k,
                                         (uint32_t)(nx >> (4 * i)) & 0xFu);
         }
     }
-    if (WV > 1 && b + gridDim.x < nwg) __syncthreads();      // capped launch only: `edge` is rewritten
+    if (ENV && ea.reward && wid % kGroups == 0 && threadIdx.x == 0) ea.reward[g] = 0.0f;      // env.py:238
+    if (WV > 1 && b + gridDim.x < nwg) __syncthreads();      // capped launch only: `edge` / s_reset are rewritten
   }
+    if (ENV && blockIdx.x == 0 && wv == 0)
+        env_step_bookkeeping(status, slot, n, HAS_ACT, ea.merge_moments && ea.reward != nullptr);
 }
 
 // Launch size of the wavefront-per-strip kernels: one workgroup per group of kWideWaves strips.  (The kernels can walk the
@@ -824,12 +851,29 @@ static unsigned persistent_blocks(int64_t work_items) {
 template <class C, class A, int NS, int RW>
 static int launch_wide(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
                        int64_t n, int ah, int aw, uint32_t rule, int32_t *status, int slot,
-                       hipStream_t s) {
+                       hipStream_t s, const EnvArgs *env = nullptr) {
     const int64_t wgs = n * (WideGeom<NS, RW>::kW / WideGeom<NS, RW>::kR / kWideWaves);
     if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step: batch too large");
     constexpr int64_t kGridBytes = (int64_t)WideGeom<NS, RW>::kW * WideGeom<NS, RW>::kW * (int64_t)sizeof(typename C::T);
     const bool nt_st = stream_stores(n * kGridBytes, sizeof(typename C::T));
     const dim3 grid(persistent_blocks(wgs)), block(64 * kWideWaves);
+    if (env) {                                       // the one-launch step (CARLE_STEP_DEFERRED)
+        const EnvArgs ea = *env;
+        const RandAct ra;
+        if (action && nt_st)
+            hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW, false, true, true>), grid, block, 0, s, u_in, action, u_out, n,
+                               ah, aw, rule, status, slot, ra, ea);
+        else if (action)
+            hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW, false, false, true>), grid, block, 0, s, u_in, action, u_out, n,
+                               ah, aw, rule, status, slot, ra, ea);
+        else if (nt_st)
+            hipLaunchKernelGGL((ca_step_wide_kernel<C, A, false, NS, RW, false, true, true>), grid, block, 0, s, u_in, action, u_out, n,
+                               0, 0, rule, status, slot, ra, ea);
+        else
+            hipLaunchKernelGGL((ca_step_wide_kernel<C, A, false, NS, RW, false, false, true>), grid, block, 0, s, u_in, action, u_out, n,
+                               0, 0, rule, status, slot, ra, ea);
+        return check_launch("carle_env_step(wide, one launch)");
+    }
     if (action && nt_st)
         hipLaunchKernelGGL((ca_step_wide_kernel<C, A, true, NS, RW, false, true>), grid, block, 0, s, u_in, action, u_out, n,
                            ah, aw, rule, status, slot);
@@ -976,7 +1020,9 @@ template <class C, class A>
 static int env_step_one_launch(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
                                float *reward, int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status,
                                int slot, int step_flags, void *stream, const char *who) {
-    if (h != 64 || w != 64 || n < 1 || n > 0x7FFFFFFFll || !status || (action && (aw % 8) != 0)) return -1000;
+    const bool fast64 = h == 64 && w == 64 && (!action || (aw % 8) == 0);
+    const bool wide = h == w && (w == 256 || w == 512) && (!action || ((aw % 4) == 0 && ((w - aw) % 8) == 0));
+    if ((!fast64 && !wide) || n < 1 || n > 0x7FFFFFFFll || !status) return -1000;
     if (knobs().two_launch_step > 0) return -1000;                     // A/B switch (CARLE_TWO_LAUNCH_STEP)
     auto fail = [&](int code, const char *what) {
         char buf[200];
@@ -996,6 +1042,10 @@ static int env_step_one_launch(const typename C::T *u_in, const typename A::T *a
     ea.publish = (step_flags & CARLE_STEP_PUBLISH_FLAGS) ? 1 : 0;
     ea.merge_moments = (step_flags & CARLE_STEP_MERGE_MOMENTS) ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (wide) {
+        if (w == 256) return launch_wide<C, A, 1, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, &ea);
+        return launch_wide<C, A, 2, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, &ea);
+    }
     const dim3 grid((unsigned)n), block(64);
     const bool nt_st = stream_stores((int64_t)bytes, sizeof(typename C::T));
     const RandAct ra;
