@@ -89,7 +89,14 @@ class RandomNetworkAgent(nn.Module):
         for param in self.network.parameters():
             param.requires_grad = False
 
+    def _kernel_domain(self, obs):
+        """What carle_agent_rn_forward_f32 covers: H, W multiples of 8, fp32 weights, at most 65535 instances."""
+        h, w = obs.shape[2], obs.shape[3]
+        return (h % 8 == 0 and w % 8 == 0 and obs.shape[0] <= 65535 and
+                all(self.network[i].weight.dtype == torch.float32 for i in (0, 3, 7)))
+
     def forward(self, obs, want_output=False):
+        hip.require_gpu()                    # no CPU path: a missing device / library raises, it is never worked around
         if not torch.is_tensor(obs):
             obs = torch.as_tensor(obs)
         if not obs.is_cuda:
@@ -100,6 +107,18 @@ class RandomNetworkAgent(nn.Module):
         instances = obs.shape[0]
         if next(self.network.parameters()).device != obs.device:
             self.network.to(obs.device)
+        if not self._kernel_domain(obs):
+            # geometries outside the kernels' domain that the reference's nn.Sequential accepts (e.g. 100x100 with a
+            # 625-input linear layer): the module itself on the device, announced once -- never silently
+            if not self.__dict__.get("_warned_fallback"):
+                import warnings
+                warnings.warn(f"RandomNetworkAgent: observation {tuple(obs.shape)} is outside the HIP kernels' domain "
+                              "(H, W multiples of 8, fp32, N <= 65535): evaluating the torch module on the device")
+                self.__dict__["_warned_fallback"] = True
+            with torch.no_grad():
+                output = self.network(obs)
+            action = (1.0 * (output <= self.toggle_rate)).reshape(instances, 1, self.action_width, self.action_height)
+            return (action, output) if want_output else action
         w1, w2, wl = (self.network[i].weight.detach().contiguous() for i in (0, 3, 7))
         action, output, self._ws = hip.agent_rn_forward(obs, w1, w2, wl, self.toggle_rate,
                                                         getattr(self, "_ws", None), want_output)

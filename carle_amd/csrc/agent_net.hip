@@ -163,13 +163,12 @@ __global__ __launch_bounds__(256) void rn_linear_kernel(const float *__restrict_
         if (i < m && j < out_nodes) {
             if (SPLIT) {
                 partial[((int64_t)blockIdx.z * m + i) * out_nodes + j] = acc[v];
-            } else if (output) {
-                const float sg = 1.0f / (1.0f + expf(-acc[v]));
-                output[i * out_nodes + j] = sg;
-                action[i * out_nodes + j] = sg <= toggle_rate ? 1.0f : 0.0f;
             } else {
-                // sigmoid is monotonic: sigmoid(x) <= rate  <=>  x <= logit(rate); saves ~30 instructions per output
-                // (the two forms can differ for logits within an ulp of the threshold)
+                // sigmoid is monotonic: sigmoid(x) <= rate  <=>  x <= logit(rate); saves ~30 instructions per output.
+                // ONE threshold form in every path (with or without the sigmoid values, split-K or not): the same
+                // observation gives the same action whatever the caller asked for (the reference's own form,
+                // fp32 sigmoid <= fp32 rate, can differ from it for logits within an ulp of the threshold)
+                if (output) output[i * out_nodes + j] = 1.0f / (1.0f + expf(-acc[v]));
                 action[i * out_nodes + j] = acc[v] <= logit_rate ? 1.0f : 0.0f;
             }
         }
@@ -183,13 +182,8 @@ __global__ __launch_bounds__(256) void rn_finish_kernel(const float *__restrict_
     if (i >= count) return;
     float x = 0.0f;
     for (int z = 0; z < splits; ++z) x += partial[(int64_t)z * count + i];
-    if (output) {
-        const float sg = 1.0f / (1.0f + expf(-x));
-        output[i] = sg;
-        action[i] = sg <= toggle_rate ? 1.0f : 0.0f;
-    } else {
-        action[i] = x <= logit_rate ? 1.0f : 0.0f;
-    }
+    if (output) output[i] = 1.0f / (1.0f + expf(-x));
+    action[i] = x <= logit_rate ? 1.0f : 0.0f;
 }
 
 // The same product for large batches: 128x128 output tile per workgroup, a 64x64 quadrant (four 32x32 MFMA
@@ -259,13 +253,8 @@ __global__ __launch_bounds__(256, 2) void rn_linear128_kernel(const float *__res
             for (int v = 0; v < 16; ++v) {
                 const int64_t i = row0 + 64 * wm + 32 * im + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
                 if (i < m && j < out_nodes) {
-                    if (output) {
-                        const float sg = 1.0f / (1.0f + expf(-acc[im][jn][v]));
-                        output[i * out_nodes + j] = sg;
-                        action[i * out_nodes + j] = sg <= toggle_rate ? 1.0f : 0.0f;
-                    } else {
-                        action[i * out_nodes + j] = acc[im][jn][v] <= logit_rate ? 1.0f : 0.0f;
-                    }
+                    if (output) output[i * out_nodes + j] = 1.0f / (1.0f + expf(-acc[im][jn][v]));
+                    action[i * out_nodes + j] = acc[im][jn][v] <= logit_rate ? 1.0f : 0.0f;
                 }
             }
         }

@@ -22,8 +22,23 @@ def _drain(sums):
     return torch.stack(sums).detach().cpu().numpy() if sums else np.zeros(0, np.float32)
 
 
+def _warn_if_sharded():
+    """Batch-sharded training (one process per GPU, carle_amd.dist): the reference's predictor loss is a mean over the
+    WHOLE batch (carle/mcl.py:362,376); here every rank trains its own predictor on its own shard -- no gradient
+    all-reduce (SURVEY 8(e) lists it as optional, the north star names the reward statistics as the only exchange).
+    The ranks' predictors therefore drift apart and a sharded run is not the unsharded one in training mode.  Said
+    once per process instead of silently."""
+    import os
+    import warnings
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        warnings.warn("carle_amd.harness.train under WORLD_SIZE > 1: every rank trains its own RND2D / AE2D predictor on "
+                      "its shard of the batch (no gradient all-reduce); rewards and saved weights differ per rank and "
+                      "from an unsharded run (DESIGN.md, multi-GPU)", stacklevel=3)
+
+
 def train(agent_fn, instances=16, steps=(64, 2048), rules=(((3,), (2, 3)),), mcl=(RND2D, AE2D),
           out_dir="./logs/mcl", verbose=True, **env_kwargs):
+    _warn_if_sharded()
     env_kwargs.setdefault("use_cuda", True)
     env = CARLE(instances=instances, **env_kwargs)
     for wrapper in mcl:

@@ -67,3 +67,19 @@ def test_param_blob_tracks_updates():
         lin.weight.add_(1.0)
     b = blob.get(torch.device("cpu"))
     assert b is not a and torch.equal(b[:6], lin.weight.detach().reshape(-1))
+
+
+def test_train_warns_under_sharding(monkeypatch):
+    """harness.train says so when WORLD_SIZE > 1 (per-rank predictors, no gradient all-reduce)."""
+    import warnings
+    from carle_amd import harness
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        harness._warn_if_sharded()
+    assert any("every rank trains its own" in str(w.message) for w in rec)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        harness._warn_if_sharded()
+    assert not rec
