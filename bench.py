@@ -313,7 +313,9 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
         step_fn = hip.ca_step_f32
 
     reward = torch.empty(n, 1, dtype=torch.float32, device=state.device)
-    one_launch = args.format in ("f32", "u8") and size == 64 and n > 16      # CARLE_STEP_DEFERRED: the step IS one kernel
+    # CARLE_STEP_DEFERRED: the step IS one kernel (64x64 beyond the small-batch kernel's 16 instances; 256 / 512: any batch)
+    one_launch = args.format in ("f32", "u8") and ((size == 64 and n > 16) or
+                                                   (size in (256, 512) and state.numel() * state.element_size() <= 32 << 20))
 
     def ca(i):
         if one_launch:        # the kernel CARLE.step launches: step + master reset + reward + moments, no epilogue kernel

@@ -182,11 +182,12 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
             }
             x[i] = nib << (4 * (k & 7));
         }
+        bool w_notone = true;                         // ENV: some action element of this wavefront's 16 rows differs from one
         if (ENV && HAS_ACT && ea.publish) {
-            const bool w_notone = __ballot(seen_g.not_all_ones<F32Cells>()) != 0ull;
+            w_notone = __ballot(seen_g.not_all_ones<F32Cells>()) != 0ull;
             any_acc |= __ballot(seen_g.any_nonzero<F32Cells>()) != 0ull;
             notone_acc |= w_notone;
-            if (lane == 0) s.notone[wv] = w_notone ? 1u : 0u;
+            if (lane == 0 && wv != 0) s.notone[wv] = w_notone ? 1u : 0u;
         }
         RND_STAMP(1);
         // the four rows' DPP chains are independent: interleaved, they fill each other's wait states
@@ -217,9 +218,11 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
             if (ENV && HAS_ACT) {
                 // master reset (env.py:208-216): every action element of the WHOLE batch is one
                 bool reset = reset_all;
-                if (ea.publish) {
-                    const bool own_notone = (s.notone[0] | s.notone[1] | s.notone[2] | s.notone[3]) != 0u;
-                    if (__builtin_expect(!own_notone, 0)) reset = batch_action_all_ones<F32Cells>(act, n, aw, status, slot);
+                // wavefront 0 knows its own 16 action rows: not all ones there (always, under an agent) -> no reset, and
+                // no LDS round trip on the generation's critical path; else the other wavefronts' verdicts, then the batch
+                if (ea.publish && __builtin_expect(!w_notone, 0)) {
+                    const bool own_notone = (s.notone[1] | s.notone[2] | s.notone[3]) != 0u;
+                    if (!own_notone) reset = batch_action_all_ones<F32Cells>(act, n, aw, status, slot);
                 }
                 if (reset) nx = 0ull;
             }

@@ -775,6 +775,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
             if (!bot_global) halo[s] |= edge[wv + 1][0][s][k] << 4;
         }
     }
+    const bool wg_reset = ENV && HAS_ACT && s_reset != 0u;      // read once, with the edge rows
 
     // horizontal sums of every row (strip words and the two halo rows)
     uint64_t h0[NS][RW], h1[NS][RW], p0[NS][RW], p1[NS][RW];
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
                 ((m == RW - 1 ? (uint64_t)(hh1[s] >> 4) : (h1[s][m < RW - 1 ? m + 1 : 0] & 0xFull)) << 60);
             uint64_t nx = apply_rule(neighbour_count(up0, up1, dn0, dn1, p0[s][m], p1[s][m]),
                                      c[s][m], rule);
-            if (ENV && HAS_ACT && s_reset != 0u) nx = 0ull;
+            if (ENV && HAS_ACT && wg_reset) nx = 0ull;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 C::template store<NT_ST>(gout + (int64_t)(r0 + 16 * m + i) * W + 256 * s + 4 * k,
@@ -1024,6 +1025,11 @@ static int env_step_one_launch(const typename C::T *u_in, const typename A::T *a
     const bool wide = h == w && (w == 256 || w == 512) && (!action || ((aw % 4) == 0 && ((w - aw) % 8) == 0));
     if ((!fast64 && !wide) || n < 1 || n > 0x7FFFFFFFll || !status) return -1000;
     if (knobs().two_launch_step > 0) return -1000;                     // A/B switch (CARLE_TWO_LAUNCH_STEP)
+    // 256 / 512 grids: the one-launch form pays where a step is bound by its dispatches (the reference's default 16
+    // instances: 16.6 -> 13.1 us per step); at N = 4096 x 256x256 the sample load and the verdict exchange cost the
+    // HBM-bound kernel 1.3 % (350.5 against 348.5 us for step kernel + epilogue) -- above 32 MiB per state array the
+    // step keeps its two launches
+    if (wide && (int64_t)n * h * w * (int64_t)sizeof(typename C::T) > (32ll << 20)) return -1000;
     auto fail = [&](int code, const char *what) {
         char buf[200];
         snprintf(buf, sizeof buf, "%s: %s", who, what);

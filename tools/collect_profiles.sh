@@ -5,9 +5,9 @@
 #   only) for the dominant kernels of cfg2 / cfg2 at N=65536 / cfg4 / cfg5.
 # Outputs land in gpurun_out/prof/ ; tools/pmc_summary.py folds the PMC passes into
 # profiles/pmc_latest.json (copied back through gpurun_out/prof/pmc_latest.json).
-# Usage: tools/collect_profiles.sh [round-tag]      (default r02)
+# Usage: tools/collect_profiles.sh [round-tag]      (default r03)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof
 mkdir -p $O
@@ -35,6 +35,7 @@ stats cfg4_rnd --rnd --steps 256 --warmup 16
 stats cfg5_b1 --format b1 --size 512 --instances 4096 --rule B36/S23 --steps 64 --warmup 8
 stats f32_256 --size 256 --steps 64 --warmup 8
 stats train_rnd_ae --rnd --ae --train --steps 256
+stats default_geom_rnd_ae --size 256 --instances 16 --rnd --ae --steps 64 --warmup 8
 python3 $R/tools/train_kernel_time.py > $O/${TAG}_train_kernel_time.txt 2>&1
 python3 $R/tools/agent_time.py > $O/${TAG}_agent_net.txt 2>&1
 : > $O/${TAG}_pmc.txt
