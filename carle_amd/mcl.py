@@ -8,10 +8,13 @@ names (so ``evaluation/RND2D_mcl.pt`` / ``AE2D_mcl.pt`` style state_dicts load s
 Underneath, every forward pass that produces a reward (``get_bonus``, ``get_bonus_only``,
 ``get_bonus_accumulate``, ``forward``, ``random_forward``) runs the hand-written HIP kernels
 ``carle_rnd2d_bonus_f32`` / ``carle_ae2d_bonus_f32`` (eval-mode semantics: Dropout = identity).
-The predictor UPDATE (backward + Adam, mcl.py:333-341, 368-386) is a "next" row of the scope
-table: observations of the current window are retained and, when ``batch_size`` steps have
-accumulated, forward+backward is recomputed with PyTorch-ROCm autograd on the ``nn.Sequential``
-below (mathematically identical in eval mode: parameters are constant inside a window).
+The predictor UPDATE (mcl.py:333-341, 354-386): the gradient of the update window is accumulated by
+the training kernels (``carle_rnd2d_train_*`` / ``carle_ae2d_train_*``: fused at 64x64, tiled at
+multiples of 64, staged otherwise) in the same pass that produces the bonus, and ``optimizer.step()``
+is ``carle_adam_update_f32`` (torch.optim.Adam's arithmetic in one launch).  PyTorch autograd is only
+used for geometries the kernels do not cover (H != W or not a multiple of 8): the observations of
+the window are then retained and replayed.  The hand-coded wrappers (Parsimony / Corner / Speed /
+Puffer) keep their per-step state on the device: no host synchronisation per step.
 """
 import weakref
 
