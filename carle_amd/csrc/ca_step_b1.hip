@@ -196,40 +196,72 @@ struct StripLds {
     uint4 act[32];                   // the grid's packed 64x64 action record (64 row words), see load_strip<.., ACTREC>
 };
 
-// ACTREC: the grid's 512-byte action record (the 64 row words of the 64-column window) travels WITH the strip -- one more
-// coalesced 16-byte access on 32 lanes in the same batch of loads, laid down in LDS beside the strip image -- instead of
-// a separate, earlier round trip for two dwords per lane (the 4096 cold records of a launch cost ~5 us that way).
-template <int WW, bool NT, bool ACTREC = false>
+// REC (kernels with the 64-column window), `with_rec` (wave-uniform): the grid's 512-byte action record (the 64 row words
+// of the window) is requested behind the strip's loads -- one more coalesced access, 8 bytes per lane -- and laid down in
+// l.act before `on_image` runs: the record travels WITH its window strip.  (Requesting it one strip early -- into two
+// registers, or as an LDS-DMA behind the first strip of the unit -- measured no better: 45.9 / 47.4 against 45.3 us at
+// N=4096 512x512.)
+// `on_image` runs between the two halves: the strip lies in LDS in memory layout, no row is in a register yet -- the
+// place where the window is toggled (toggle_strip_image).
+struct NoStripHook { __device__ __forceinline__ void operator()() const {} };
+// HALREG false: the two bordering rows stay in LDS (l.halo) -- the compute phase reads them chunk by chunk.
+template <int WW, bool NT, bool REC = false, bool HALREG = true, class Hook = NoStripHook>
 __device__ __forceinline__ void load_strip(StripLds<WW> &l, const uint64_t *__restrict__ gstrip,
                                            const uint64_t *__restrict__ grow_top, const uint64_t *__restrict__ grow_bot,
                                            bool multi, int lane, uint64_t (&c)[WW], uint64_t (&hal)[WW],
-                                           const uint64_t *__restrict__ act_rec = nullptr) {
+                                           const uint64_t *__restrict__ act_rec = nullptr, bool with_rec = false,
+                                           Hook on_image = Hook()) {
     constexpr int Q = WW / 2;                                // 16-byte quads per row = accesses per strip
     const uint4 *g4 = reinterpret_cast<const uint4 *>(gstrip);
-    uint4 v[Q], av = make_uint4(0u, 0u, 0u, 0u);
-    if (ACTREC) av = reinterpret_cast<const uint4 *>(act_rec)[lane & 31];     // unconditional; lanes >= 32 repeat
+    uint4 v[Q];
 #pragma unroll
     for (int j = 0; j < Q; ++j) v[j] = ld16s<NT>(g4 + j * 64 + lane);
-    // halo: lanes 0..Q-1 the row above, Q..2Q-1 the row below (default cache policy: the neighbouring strip owns them)
-    const int hq = lane < Q ? lane : lane - Q;
-    const uint4 *h4 = reinterpret_cast<const uint4 *>(lane < Q ? grow_top : grow_bot) + (lane < 2 * Q ? hq : 0);
-    uint4 hv = *h4;                                          // unconditional (lanes >= 2Q re-read quad 0 of the bottom row)
+    // halo: lanes 0..Q-1 the row above, Q..2Q-1 the row below (default cache policy: the neighbouring strip owns them);
+    // lanes >= 2Q repeat lane Q's access -- load AND store: with the store under `if (lane < 2Q)` the compiler sinks the
+    // load into the branch, behind the waits for the strip's loads: a second dependent round trip per strip (rounds 2-3)
+    const int hq = lane < Q ? lane : (lane < 2 * Q ? lane - Q : 0);
+    const uint4 *h4 = reinterpret_cast<const uint4 *>(lane < Q ? grow_top : grow_bot) + hq;
+    const uint4 hv = *h4;
+    uint2 av = make_uint2(0u, 0u);
+    if (REC && with_rec) av = reinterpret_cast<const uint2 *>(act_rec)[lane];
 #pragma unroll
     for (int j = 0; j < Q; ++j) l.img[j * 64 + lane] = v[j];
-    if (lane < 2 * Q) l.halo[lane < Q ? 0 : 1][hq] = hv;
-    if (ACTREC && lane < 32) l.act[lane] = av;
+    l.halo[lane < Q ? 0 : 1][hq] = hv;
+    if (REC && with_rec) reinterpret_cast<uint2 *>(l.act)[lane] = av;
+    on_image();
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const uint4 r = l.img[lane * Q + q];
         c[2 * q] = ((uint64_t)r.y << 32) | r.x;
         c[2 * q + 1] = ((uint64_t)r.w << 32) | r.z;
     }
+    if (HALREG) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const uint4 r = l.halo[lane == 63 ? 1 : 0][q];
-        const bool use = multi && (lane == 0 || lane == 63);
-        hal[2 * q] = use ? (((uint64_t)r.y << 32) | r.x) : 0ull;
-        hal[2 * q + 1] = use ? (((uint64_t)r.w << 32) | r.z) : 0ull;
+        for (int q = 0; q < Q; ++q) {
+            const uint4 r = l.halo[lane == 63 ? 1 : 0][q];
+            const bool use = multi && (lane == 0 || lane == 63);
+            hal[2 * q] = use ? (((uint64_t)r.y << 32) | r.x) : 0ull;
+            hal[2 * q + 1] = use ? (((uint64_t)r.w << 32) | r.z) : 0ull;
+        }
+    }
+}
+
+// The 64-column window applied to the strip IMAGE (and to the images of its two bordering rows) in LDS: the window's
+// 64 columns are dwords WW - 1 and WW of a row (bit offset 32 (WW - 1)), so a lane XORs the two dwords of its action row
+// into its image row -- two ds_xor_b32 without a result, no register beyond the record words.  (In registers the toggle
+// held both 64-bit row arrays and its selects live at once: 92 VGPRs, 5 waves per SIMD instead of 8.)
+// One wavefront per workgroup: the LDS pipeline keeps its accesses in order, the row reads behind this see the toggle.
+template <int WW>
+__device__ __forceinline__ void toggle_strip_image(StripLds<WW> &l, int lane, bool in, uint2 wr, bool hin, uint2 wh) {
+    uint32_t *img32 = reinterpret_cast<uint32_t *>(l.img);
+    if (in) {
+        __hip_atomic_fetch_xor(img32 + lane * 2 * WW + WW - 1, wr.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_xor(img32 + lane * 2 * WW + WW, wr.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    if (hin) {
+        uint32_t *h32 = reinterpret_cast<uint32_t *>(l.halo[lane == 63 ? 1 : 0]);
+        __hip_atomic_fetch_xor(h32 + WW - 1, wh.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_xor(h32 + WW, wh.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
 }
 
@@ -277,7 +309,7 @@ struct B1EnvArgs {
 
 // ACT: 0 = no action, 1 = 64-column window (toggle_row64), 2 = any packed window (toggle_row)
 template <int WW, int ACT, int RULE_MODE, bool RAND = false, int LDS = 0, bool ENV = false>      // LDS: 0 row-per-lane, 1 StripLds cached, 2 StripLds streaming
-__global__ __launch_bounds__(64) void ca_step_b1_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_step_b1_kernel(
     const uint64_t *__restrict__ u_in, const uint64_t *__restrict__ act, uint64_t *__restrict__ u_out,
     int64_t n, int ah, int aw, uint32_t rule, int32_t *__restrict__ status, int slot,
     int strip_first, int strip_count, RandB1 ra = RandB1(), int dbg = 0, B1EnvArgs ea = B1EnvArgs()) {
@@ -289,6 +321,10 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     constexpr bool MULTI = WW > 1;                          // more than one 64-row strip per grid
     constexpr bool LDS_T = MULTI && LDS != 0;               // coalesced strip traffic through LDS (see StripLds)
     constexpr bool LDS_NT = LDS == 2;
+    // the strip's two bordering rows stay in LDS and the compute phase reads them one 32-bit chunk at a time (a rolling
+    // window of three): 16 registers that only lanes 0 and 63 had a use for (window kernels: 76 -> <= 64 VGPRs, eight
+    // waves per SIMD instead of six).  Kernels that toggle the bordering rows in registers keep them there.
+    constexpr bool HROLL = LDS_T && (ACT == 0 || (ACT == 1 && !RAND));
     __shared__ StripLds<LDS_T ? WW : 2> lds;
     const int lane = threadIdx.x;
     // Persistent waves: the launch has at most 32 waves per CU and every wave walks a list of work units
@@ -326,8 +362,9 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     // window, the one at the middle of the grid) and of that strip's bordering row
     uint32_t pa_lo = 0u, pa_hi = 0u, ph_lo = 0u, ph_hi = 0u;
     bool unit_reset = reset_all;                             // ENV: this unit's strips are zeroed (master reset)
-    // dbg bit 1: the action record travels with the window strip through LDS (load_strip<.., ACTREC>) -- no earlier fetch
-    const bool act_lds = LDS_T && ACT == 1 && !RAND && (dbg & 2) && ((halves && HS >= 2) || (dbg & 8));
+    // LDS strip modes: the action record travels with the window strip through LDS (load_strip<.., ACTREC>) and the
+    // toggle happens there (toggle_strip_image) -- no earlier fetch, no toggle in registers
+    constexpr bool act_lds = LDS_T && ACT == 1 && !RAND;
     const bool preload = ACT == 1 && !RAND && halves && HS >= 2 && !(dbg & 1) && !act_lds;
     if (preload) {
         const int r0w = ((j & 1) ? WW - HS : HS - 1) * 64, oyw = (H - ah) >> 1;
@@ -341,21 +378,11 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
         // letting them travel beside the first strip's state loads: 52.3 against 53.8-57.9 us)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa_lo), "+v"(pa_hi), "+v"(ph_lo), "+v"(ph_hi));
     }
-    if (ENV && ACT == 1 && ea.publish) {
-        // master reset (env.py:208-216), decided HERE, before the unit's strips occupy the registers: the unit's first
-        // strip holds its share of the action window; only if that is all ones (never, under an agent) the batch is asked
-        const int r0w = halves ? ((j & 1) ? WW - HS : HS - 1) * 64 : ((strip_first + (int)(j % strip_count)) % WW) * 64;
-        const int oyw = (H - ah) >> 1, rw = r0w + lane;
-        const bool inw = rw >= oyw && rw < oyw + ah;
-        uint32_t w_lo = pa_lo, w_hi = pa_hi;
-        if (!preload) {
-            const uint32_t *a32 = reinterpret_cast<const uint32_t *>(act + g * (int64_t)ah + (inw ? rw - oyw : 0));
-            w_lo = a32[0]; w_hi = a32[1];
-        }
-        const bool notone_u = __ballot(inw && (w_lo & w_hi) != 0xFFFFFFFFu) != 0ull;
-        if (__builtin_expect(!notone_u, 0))
-            unit_reset = batch_action_all_ones_raw(act, n, (int64_t)ah * 8 / 16, 0xFFFFFFFFu, status, slot);
-    }
+    // ENV, master reset (env.py:208-216): the window strips of the unit note whether their share of the action window
+    // holds anything but ones; a unit that saw only ones (never, under an agent) asks the batch BEHIND its last strip and
+    // overwrites its strips with zeros if the answer is yes -- no call while rows are in registers, no fetch ahead of
+    // the strips, any strip order
+    bool unit_notone = false;
     // one strip: `first` = the unit's first strip (its window strip when the window words were fetched above)
     auto strip = [&](const int sub, const bool first) __attribute__((always_inline)) {
     const int64_t wid = halves ? unit * per_unit + sub : unit;          // stamp index
@@ -376,13 +403,38 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
     const int oy_ = (H - ah) >> 1;
     const bool touches_ = ACT == 1 && ((r0 < oy_ + ah && r0 + 64 > oy_) ||
                                        (MULTI && ((rt >= oy_ && rt < oy_ + ah) || (rb >= oy_ && rb < oy_ + ah))));
-    const bool use_rec = ACT == 1 && !RAND && act_lds && touches_ && first;
     if constexpr (LDS_T) {
-        if (ACT == 1 && !RAND && use_rec)
-            load_strip<WW, LDS_NT, true>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane,
-                                         c, hal, act + g * (int64_t)ah);
-        else
-            load_strip<WW, LDS_NT>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
+        if constexpr (act_lds) {
+            // a strip under the window: predicates and the toggle happen on the LDS image, before any row occupies a
+            // register.  64-row windows: the record arrives with this strip (StripLds::act holds its 64 row words);
+            // other heights read their words from memory here.
+            const bool rec = ah == 64;
+            auto on_image = [&]() __attribute__((always_inline)) {
+                if (!touches_) return;
+                const bool in = r >= oy_ && r < oy_ + ah, hin = hr >= oy_ && hr < oy_ + ah;
+                uint2 wr, wh;
+                if (rec) {
+                    const uint2 *a2 = reinterpret_cast<const uint2 *>(lds.act);
+                    wr = a2[in ? r - oy_ : 0]; wh = a2[hin ? hr - oy_ : 0];
+                } else {
+                    const uint2 *a2 = reinterpret_cast<const uint2 *>(act + g * (int64_t)ah);
+                    wr = a2[in ? r - oy_ : 0]; wh = a2[hin ? hr - oy_ : 0];
+                }
+                if (status != nullptr && (!ENV || ea.publish)) {
+                    const bool any = __ballot(in && (wr.x | wr.y) != 0u) != 0ull;
+                    const bool notone = __ballot(in && (wr.x & wr.y) != 0xFFFFFFFFu) != 0ull;
+                    if (lane == 0) {
+                        if (any) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
+                        if (notone) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
+                    }
+                    unit_notone |= notone;
+                }
+                toggle_strip_image<WW>(lds, lane, in, wr, hin, wh);
+            };
+            load_strip<WW, LDS_NT, true, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane,
+                                                 c, hal, act + g * (int64_t)ah, touches_ && rec, on_image);
+        } else
+            load_strip<WW, LDS_NT, false, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
     } else {
         load_row<WW>(gin + (int64_t)r * WW, c);
 #pragma unroll
@@ -394,7 +446,7 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
         const int oy = (H - ah) >> 1;
         const bool touches = (r0 < oy + ah && r0 + 64 > oy) ||
                              (MULTI && ((rt >= oy && rt < oy + ah) || (rb >= oy && rb < oy + ah)));
-        if (touches) {                          // wave-uniform
+        if (touches && !act_lds) {              // wave-uniform; the LDS modes toggle on the strip image (load_strip's hook)
             const uint64_t *ga = act + g * (int64_t)ah;
             uint32_t s_or = 0u, s_and = 0xFFFFFFFFu, d0 = 0u, d1 = 0xFFFFFFFFu;
             const bool in = r >= oy && r < oy + ah;
@@ -413,13 +465,6 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
                 toggle_words64<WW>(c, pa_lo, pa_hi, in, s_or, s_and);
                 const bool hin = hr >= oy && hr < oy + ah;
                 toggle_words64<WW>(hal, ph_lo, ph_hi, hin, d0, d1);
-            } else if (LDS_T && use_rec) {
-                // the record lies in LDS beside the strip (ah == 64 rows of one word)
-                const uint2 *a2 = reinterpret_cast<const uint2 *>(lds.act);
-                const bool hin = hr >= oy && hr < oy + ah;
-                const uint2 wr = a2[in ? r - oy : 0], wh = a2[hin ? hr - oy : 0];
-                toggle_words64<WW>(c, wr.x, wr.y, in, s_or, s_and);
-                toggle_words64<WW>(hal, wh.x, wh.y, hin, d0, d1);
             } else {
             toggle_row64<WW>(c, ga + (in ? r - oy : 0), in, s_or, s_and);
             if (MULTI) {
@@ -434,6 +479,7 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
                     if (any) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
                     if (notone) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
                 }
+                unit_notone |= notone;
             }
         }
     }
@@ -479,7 +525,15 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
 #pragma unroll
     for (int j = 0; j < WW; ++j) {
         cc[2 * j] = (uint32_t)c[j]; cc[2 * j + 1] = (uint32_t)(c[j] >> 32);
-        hc[2 * j] = (uint32_t)hal[j]; hc[2 * j + 1] = (uint32_t)(hal[j] >> 32);
+        hc[2 * j] = HROLL ? 0u : (uint32_t)hal[j]; hc[2 * j + 1] = HROLL ? 0u : (uint32_t)(hal[j] >> 32);
+    }
+    // HROLL: chunks k - 1 .. k + 1 of the lane's bordering row (lane 63: the row below, every other lane the row above --
+    // only lanes 0 and 63 have a use for theirs), read from the LDS image one chunk ahead of their use
+    const uint32_t *hrow32 = reinterpret_cast<const uint32_t *>(&lds.halo[0][0]);
+    uint32_t hidx = lane == 63 ? NC : 0;
+    uint32_t hw0 = 0u, hw1 = 0u, hw2 = 0u;
+    if constexpr (HROLL) {
+        hw0 = hrow32[hidx + NC - 1]; hw1 = hrow32[hidx]; hw2 = hrow32[hidx + 1];
     }
     uint32_t nx32[NC];
 #pragma unroll
@@ -491,10 +545,11 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
         row_sums(wst, cc[k], est, h0, h1, p0, p1);
         uint32_t a0, a1, b0, b1;
         if (MULTI) {
-            const uint32_t hprev = hc[(k + NC - 1) % NC], hnext = hc[(k + 1) % NC];
-            const uint32_t hw = __builtin_amdgcn_alignbit(hc[k], hprev, 31);
-            const uint32_t he = __builtin_amdgcn_alignbit(hnext, hc[k], 1);
-            const uint32_t g0 = bop3<kXor3>(hw, hc[k], he), g1 = bop3<kMaj>(hw, hc[k], he);
+            const uint32_t hprev = HROLL ? hw0 : hc[(k + NC - 1) % NC], hk = HROLL ? hw1 : hc[k],
+                           hnext = HROLL ? hw2 : hc[(k + 1) % NC];
+            const uint32_t hw = __builtin_amdgcn_alignbit(hk, hprev, 31);
+            const uint32_t he = __builtin_amdgcn_alignbit(hnext, hk, 1);
+            const uint32_t g0 = bop3<kXor3>(hw, hk, he), g1 = bop3<kMaj>(hw, hk, he);
             // lanes with no source keep `old` = the sums of the halo row they loaded themselves
             a0 = __builtin_amdgcn_update_dpp(g0, h0, 0x138, 0xF, 0xF, false);   // wave_shr:1, row above
             a1 = __builtin_amdgcn_update_dpp(g1, h1, 0x138, 0xF, 0xF, false);
@@ -507,6 +562,18 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
             b1 = __builtin_amdgcn_update_dpp(0u, h1, 0x134, 0xF, 0xF, false);
         }
         nx32[k] = next_state<RULE_MODE>(neighbour_count(a0, a1, b0, b1, p0, p1), cc[k], rule);
+        // chunk after chunk: left alone, the scheduler of the window kernels computes the row sums of ALL chunks first
+        // (its maximum-ILP order once some other region has cost it the occupancy it aimed for): 145 VGPRs instead of 65.
+        // An empty asm ties chunk k + 1's centre word (and the index of the next bordering-row read) to chunk k's result.
+        if ((HROLL || (ACT == 1 && !RAND)) && k + 1 < NC) {
+            if constexpr (HROLL) {
+                asm volatile("" : "+v"(cc[k + 1]), "+v"(hidx) : "v"(nx32[k]));
+                hw0 = hw1; hw1 = hw2;
+                hw2 = hrow32[hidx + (k + 2) % NC];
+            } else {
+                asm volatile("" : "+v"(cc[k + 1]) : "v"(nx32[k]));
+            }
+        }
     }
     uint64_t nx[WW];
 #pragma unroll
@@ -516,16 +583,30 @@ __global__ __launch_bounds__(64) void ca_step_b1_kernel(
         for (int j = 0; j < WW; ++j) nx[j] = 0ull;
     }
     B1_STAMP(2);
-    if constexpr (LDS_T) store_strip<WW, LDS_NT>(lds, u_out + (g * (int64_t)H + r0) * WW, lane, nx);
-    else store_row<WW>(u_out + (g * (int64_t)H + r) * WW, nx);
+    if constexpr (LDS_T) {
+        store_strip<WW, LDS_NT>(lds, u_out + (g * (int64_t)H + r0) * WW, lane, nx);
+    } else store_row<WW>(u_out + (g * (int64_t)H + r) * WW, nx);
     B1_STAMP(3);
     };
-    // dbg bit 2 (with bit 1): the units start at different strips of their half -- at any moment the wavefronts of the
-    // launch read all strip positions, not all the same 4 KB of every 16 KB (the window strip comes when it comes)
+    // dbg bit 2: the units start at different strips of their half -- at any moment the wavefronts of the launch read
+    // all strip positions, not all the same 4 KB of every 16 KB (the window strip comes when it comes)
     const int rot = (act_lds && (dbg & 4)) ? (int)((g >> 3) & (HS - 1)) : 0;
+#pragma nounroll
     for (int s_ = 0; s_ < per_unit; ++s_) {
         const int sub = (s_ + rot) & (per_unit - 1);
         strip(sub, sub == 0);
+    }
+    if (ENV && ACT == 1 && ea.publish && __builtin_expect(!unit_notone && !unit_reset, 0)) {
+        // this unit's share of the window was all ones: ask the batch; a master reset zeroes the unit's strips
+        if (batch_action_all_ones_raw(act, n, (int64_t)ah * 8 / 16, 0xFFFFFFFFu, status, slot)) {
+            for (int s_ = 0; s_ < per_unit; ++s_) {
+                const int li = HS - 1 - s_;
+                const int r0 = halves ? ((j & 1) ? WW - 1 - li : li) * 64 : ((strip_first + (int)(j % strip_count)) % WW) * 64;
+                uint64_t *dst = u_out + (g * (int64_t)H + r0 + lane) * WW;
+#pragma unroll
+                for (int q = 0; q < WW; ++q) dst[q] = 0ull;
+            }
+        }
     }
   }
     if (ENV && blockIdx.x == 0)
@@ -704,7 +785,7 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     if (env && aw == 64) {                        // one-launch step, the 64-column window
         const B1EnvArgs ea = *env;
         const dim3 grid(full), block(64);
-        const int dbg = knobs().b1_dbg >= 0 ? (int)knobs().b1_dbg : 0;
+        const int dbg = knobs().b1_dbg >= 0 ? (int)knobs().b1_dbg & ~8 : 0;            // half-grid units
         if (lds == 2) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 2, true>), grid, block, 0, s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg, ea);
         else if (lds == 1) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 1, true>), grid, block, 0, s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg, ea);
         else hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 0, true>), grid, block, 0, s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg, ea);

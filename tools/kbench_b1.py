@@ -15,12 +15,13 @@ rule = (1 << 12) | (1 << 15) | 0xC              # B36/S23
 g = torch.Generator(device="cuda").manual_seed(1)
 a = torch.randint(-2 ** 63, 2 ** 63 - 1, (n, 1, size, size // 64), device="cuda", generator=g, dtype=torch.int64)
 b = torch.empty_like(a)
-ring = [hip.pack_f32_b1((torch.rand(n, 1, 64, 64, device="cuda", generator=g) <= 0.1).float()) for _ in range(6)]
+RING = int(os.environ.get("KB_RING", "6"))         # action tensors in rotation (6 = bench.py's ring)
+ring = [hip.pack_f32_b1((torch.rand(n, 1, 64, 64, device="cuda", generator=g) <= 0.1).float()) for _ in range(RING)]
 st = hip.new_status(a.device)
 bufs = [a, b]
 cases = {"noact": lambda i: hip.ca_step_b1(bufs[i & 1], None, bufs[(i & 1) ^ 1], rule, st, 0),
-         "act": lambda i: hip.ca_step_b1(bufs[i & 1], ring[i % 6], bufs[(i & 1) ^ 1], rule, st, 0),
-         "act_nostatus": lambda i: hip.ca_step_b1(bufs[i & 1], ring[i % 6], bufs[(i & 1) ^ 1], rule, None, 0)}
+         "act": lambda i: hip.ca_step_b1(bufs[i & 1], ring[i % RING], bufs[(i & 1) ^ 1], rule, st, 0),
+         "act_nostatus": lambda i: hip.ca_step_b1(bufs[i & 1], ring[i % RING], bufs[(i & 1) ^ 1], rule, None, 0)}
 alg = {"noact": n * size * size // 4, "act": n * (size * size // 4 + 512), "act_nostatus": n * (size * size // 4 + 512)}
 blocks = sys.argv[3].split(",") if len(sys.argv) > 3 else ["0"]
 gridmaps = sys.argv[4].split(",") if len(sys.argv) > 4 else [os.environ.get("CARLE_B1_DBG", "")]
@@ -37,12 +38,16 @@ for rep in range(3 if len(gridmaps) > 1 else 2):
     for name, fn in cases.items():
         for i in range(6):
             fn(i)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for i in range(100):
-            fn(i)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 10
-        print(f"N={n} {size}x{size} gridmap={gmap:>5} blocks={blk:>6} {name:13s}: {us:7.2f} us  {alg[name] / us / 1e6:5.2f} TB/s  frac {alg[name] / us / 8e6:.3f}", flush=True)
+        reps = []
+        for _ in range(int(os.environ.get("KB_REPS", "5"))):      # median and minimum of several blocks of 200 launches
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(200):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            reps.append(e0.elapsed_time(e1) * 5)
+        reps.sort()
+        us, us_min = reps[len(reps) // 2], reps[0]
+        print(f"N={n} {size}x{size} gridmap={gmap:>5} blocks={blk:>6} {name:13s}: {us:7.2f} us (min {us_min:6.2f})  {alg[name] / us / 1e6:5.2f} TB/s  frac {alg[name] / us / 8e6:.3f}", flush=True)
