@@ -406,20 +406,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
     if constexpr (LDS_T) {
         if constexpr (act_lds) {
             // a strip under the window: predicates and the toggle happen on the LDS image, before any row occupies a
-            // register.  64-row windows: the record arrives with this strip (StripLds::act holds its 64 row words);
-            // other heights read their words from memory here.
-            const bool rec = ah == 64;
+            // register.  The record arrives with this strip (StripLds::act holds its 64 row words: the window is square,
+            // check_dims, so AW == 64 means AH == 64).
             auto on_image = [&]() __attribute__((always_inline)) {
                 if (!touches_) return;
                 const bool in = r >= oy_ && r < oy_ + ah, hin = hr >= oy_ && hr < oy_ + ah;
-                uint2 wr, wh;
-                if (rec) {
-                    const uint2 *a2 = reinterpret_cast<const uint2 *>(lds.act);
-                    wr = a2[in ? r - oy_ : 0]; wh = a2[hin ? hr - oy_ : 0];
-                } else {
-                    const uint2 *a2 = reinterpret_cast<const uint2 *>(act + g * (int64_t)ah);
-                    wr = a2[in ? r - oy_ : 0]; wh = a2[hin ? hr - oy_ : 0];
-                }
+                const uint2 *a2 = reinterpret_cast<const uint2 *>(lds.act);
+                const uint2 wr = a2[in ? r - oy_ : 0], wh = a2[hin ? hr - oy_ : 0];
                 if (status != nullptr && (!ENV || ea.publish)) {
                     const bool any = __ballot(in && (wr.x | wr.y) != 0u) != 0ull;
                     const bool notone = __ballot(in && (wr.x & wr.y) != 0xFFFFFFFFu) != 0ull;
@@ -432,7 +425,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
                 toggle_strip_image<WW>(lds, lane, in, wr, hin, wh);
             };
             load_strip<WW, LDS_NT, true, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane,
-                                                 c, hal, act + g * (int64_t)ah, touches_ && rec, on_image);
+                                                 c, hal, act + g * (int64_t)ah, touches_, on_image);
         } else
             load_strip<WW, LDS_NT, false, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
     } else {

@@ -51,7 +51,7 @@ def test_pack_unpack(n, size):
     (2, 256, 256, ([2], [0])), (1, 512, 64, ([3, 6], [2, 3])), (2, 512, 256, ([3], [2, 3])),
     (1, 512, 512, (list(range(9)), [])), (2, 512, 448, ([0, 3, 5, 7], [2, 4, 6, 8])),
 ])
-@pytest.mark.parametrize("strip_path", ["by size", "rows", "lds", "lds+nt", "lds+record", "lds+record+rotate", "lds+record+single"])
+@pytest.mark.parametrize("strip_path", ["by size", "rows", "lds", "lds+nt", "lds+rotate", "lds+single", "lds+nt+single"])
 def test_step_b1_against_oracle(n, size, asize, rule, strip_path, monkeypatch):
     """The three strip modes of the kernel (ca_step_b1.hip: row-per-lane, StripLds cached, StripLds streaming) are
     chosen by array size; `rows` / `lds` / `lds+nt` force each of them onto these small cases."""
@@ -66,12 +66,12 @@ def test_step_b1_against_oracle(n, size, asize, rule, strip_path, monkeypatch):
     elif strip_path == "lds+nt":
         monkeypatch.setenv("CARLE_B1_LDS_MIN_BYTES", "0")
         monkeypatch.setenv("CARLE_B1_NT_MIN_BYTES", "0")
-    elif strip_path.startswith("lds+record"):
-        # experiment knob CARLE_B1_DBG (ca_step_b1.hip): bit 1 = the action record travels with the window strip through
-        # LDS, bit 2 = the units of a launch start at different strips, bit 3 = single-strip walk instead of half grids
+    else:
+        # experiment knob CARLE_B1_DBG (ca_step_b1.hip): bit 2 = the half-grid units of a window launch start at different
+        # strips, bit 3 = single-strip walk instead of half grids
         monkeypatch.setenv("CARLE_B1_LDS_MIN_BYTES", "0")
-        monkeypatch.setenv("CARLE_B1_NT_MIN_BYTES", str(1 << 60))
-        monkeypatch.setenv("CARLE_B1_DBG", {"lds+record": "2", "lds+record+rotate": "6", "lds+record+single": "10"}[strip_path])
+        monkeypatch.setenv("CARLE_B1_NT_MIN_BYTES", "0" if "+nt" in strip_path else str(1 << 60))
+        monkeypatch.setenv("CARLE_B1_DBG", "4" if "rotate" in strip_path else "8")
     hip.reload_knobs()                    # the library reads its knobs once; the fixture below restores them
     rng = np.random.default_rng(n * 7 + size + asize)
     mask = O.rule_mask(*rule)
