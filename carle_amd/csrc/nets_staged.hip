@@ -19,6 +19,7 @@
 //   AE predictor : conv1.w[4][1][3][3] b[4] conv2.w[2][4][3][3] b[2] convT1.w[2][1][4][4] b[1]
 //                  convT2.w[1][1][4][4] b[1]                                          (164 floats)
 #include "common.hpp"
+#include "train_bodies.hpp"
 
 namespace carle {
 // A padded read: zero outside the plane.  The load is UNCONDITIONAL (index 0 of the plane when outside): behind a
@@ -415,13 +416,8 @@ __global__ __launch_bounds__(256) void ae_mse_finish_kernel(const float *__restr
                                                             float *__restrict__ bonus,
                                                             float *__restrict__ reward, float reward_scale,
                                                             int64_t n, int chunks, float inv_pixels) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n) return;
-    float s = 0.0f;
-    for (int c = 0; c < chunks; ++c) s += partial[g * chunks + c];
-    const float b = s * inv_pixels;
-    bonus[g] = b;
-    if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);      // mcl.py:403-405: product, then sum
+    ae_mse_finish_body(partial, bonus, reward, reward_scale, n, chunks, inv_pixels,
+                       (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 static inline int check_net_dims(int64_t n, int h, int w, const char *who) {
@@ -486,6 +482,10 @@ namespace carle {
 int rnd_ae_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws, float *rbonus,
                  float rscale, bool rnd_tables_valid, const float *ap, float *aws, float *abonus, float ascale,
                  bool ae_tables_valid, float *reward, hipStream_t s);
+int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws,
+                       float *rscratch, float *rgrad, float *rbonus, float rscale, float rgrad_scale, bool rvalid,
+                       const float *ap, float *aws, float *arows, float *agrad, float *abonus, float ascale, float agrad_scale,
+                       bool avalid, float *reward, hipStream_t s);
 }
 
 // RND2D.get_bonus AND AE2D.get_bonus of the same observations (carle/mcl.py:343-352, 504-512) + both wrappers' reward
@@ -507,6 +507,31 @@ extern "C" int carle_rnd_ae_bonus(const void *obs, int obs_fmt, int64_t n, int h
     return rnd_ae_tiled(obs, obs_fmt == CARLE_FMT_B1, n, h, rnd_pred_params, rnd_rand_params, rnd_workspace, rnd_bonus,
                         rnd_scale, (rnd_flags & CARLE_NET_TABLES_VALID) != 0, ae_params, ae_workspace, ae_bonus, ae_scale,
                         (ae_flags & CARLE_NET_TABLES_VALID) != 0, reward_accum, static_cast<hipStream_t>(stream));
+}
+
+// The same stack in TRAINING mode (carle/train_mcl.py:34-38, 64-69): both wrappers' bonuses, reward updates and the
+// accumulation of both predictors' gradients of one step -- what carle_rnd2d_train_* followed by carle_ae2d_train_* do --
+// in five launches instead of nine.  Scratch and gradient buffers exactly as for those two entry points
+// (carle_rnd2d_train_scratch_floats / carle_ae2d_train_scratch_floats); bit-identical results.
+extern "C" int carle_rnd_ae_train(const void *obs, int obs_fmt, int64_t n, int h, int w, const float *rnd_pred_params,
+                                  const float *rnd_rand_params, float *rnd_workspace, float *rnd_scratch, float *rnd_grad,
+                                  float *rnd_bonus, float rnd_scale, float rnd_grad_scale, int rnd_flags,
+                                  const float *ae_params, float *ae_workspace, float *ae_scratch, float *ae_grad,
+                                  float *ae_bonus, float ae_scale, float ae_grad_scale, int ae_flags, float *reward_accum,
+                                  void *stream) {
+    if (!obs || !rnd_pred_params || !rnd_rand_params || !rnd_workspace || !rnd_scratch || !rnd_grad || !rnd_bonus ||
+        !ae_params || !ae_workspace || !ae_scratch || !ae_grad || !ae_bonus)
+        return fail_arg(CARLE_E_NULL, "carle_rnd_ae_train: NULL pointer");
+    if (obs_fmt != CARLE_FMT_F32 && obs_fmt != CARLE_FMT_B1)
+        return fail_arg(CARLE_E_FORMAT, "carle_rnd_ae_train: obs_fmt must be CARLE_FMT_F32 or CARLE_FMT_B1");
+    if (n < 0 || !rnd2d_tiled_applies(h, w))
+        return fail_arg(CARLE_E_DIMS, "carle_rnd_ae_train: binary grids with H == W a multiple of 64 above 64 (use the "
+                                      "per-net entry points otherwise)");
+    if (n == 0) return 0;
+    return rnd_ae_tiled_train(obs, obs_fmt == CARLE_FMT_B1, n, h, rnd_pred_params, rnd_rand_params, rnd_workspace, rnd_scratch,
+                              rnd_grad, rnd_bonus, rnd_scale, rnd_grad_scale, (rnd_flags & CARLE_NET_TABLES_VALID) != 0,
+                              ae_params, ae_workspace, ae_scratch, ae_grad, ae_bonus, ae_scale, ae_grad_scale,
+                              (ae_flags & CARLE_NET_TABLES_VALID) != 0, reward_accum, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,

@@ -21,6 +21,7 @@
 //     shuffles + a fixed-order LDS combine into ONE partial row, and rnd_grad_reduce_kernel adds
 //     the rows in a fixed order: deterministic.
 #pragma once
+#include "train_bodies.hpp"
 
 namespace carle {
 
@@ -29,25 +30,7 @@ namespace carle {
 __global__ __launch_bounds__(1024) void staged_grad_reduce_kernel(const float *__restrict__ partial, int rows,
                                                                  float *__restrict__ grad, int nparams) {
     __shared__ float part[32][33];
-    const int pl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int p = blockIdx.x * 32 + pl;
-    float s0 = 0.0f, s1 = 0.0f;
-    if (p < nparams) {
-        int r = rl;
-        for (; r + 32 < rows; r += 64) {
-            s0 += partial[(int64_t)r * nparams + p];
-            s1 += partial[(int64_t)(r + 32) * nparams + p];
-        }
-        if (r < rows) s0 += partial[(int64_t)r * nparams + p];
-    }
-    part[rl][pl] = s0 + s1;
-    __syncthreads();
-    if (rl == 0 && p < nparams) {
-        float t = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) t += part[i][pl];
-        grad[p] += t;
-    }
+    staged_grad_reduce_body(part, partial, rows, grad, nparams, (int)blockIdx.x);
 }
 
 static inline unsigned blocks256(int64_t total) { return (unsigned)((total + 255) / 256); }
@@ -88,30 +71,10 @@ __device__ __forceinline__ int first_max4(float a, float b, float c, float d) {
 // RND2D predictor:  conv1(1->4) relu pool2 pool2 conv2(4->1) relu pool2 flatten linear(D->16) tanh
 // blob: conv1.w[36] conv1.b[4] conv2.w[36] conv2.b[1] lin.w[16][D] lin.b[16]
 // =============================================================================================
-static constexpr int kRndK = kRndDim;
-
-__device__ __forceinline__ float rnd_dz(const float *__restrict__ pred, const float *__restrict__ targ,
-                                        int64_t n, int k, float gs) {
-    const float p = pred[n * kRndK + k], t = targ[n * kRndK + k];
-    return gs * (p - t) * (1.0f - p * p);                 // d/dz of gs/2 (t - tanh z)^2
-}
-
-// linear layer: grad[77 + k*D + f] += sum_n dz[n][k] * feat[n][f];  grad[77 + 16 D + k] += sum_n dz[n][k]
 __global__ __launch_bounds__(256) void rnd_bwd_linear_kernel(
     const float *__restrict__ ws2, const float *__restrict__ pred, const float *__restrict__ targ,
     float *__restrict__ grad, float gs, int64_t n, int d) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nw = (int64_t)kRndK * d;
-    if (idx >= nw + kRndK) return;
-    const bool bias = idx >= nw;
-    const int k = bias ? (int)(idx - nw) : (int)(idx / d);
-    const int f = bias ? 0 : (int)(idx % d);
-    float acc = 0.0f;
-    for (int64_t i = 0; i < n; ++i) {
-        const float dz = rnd_dz(pred, targ, i, k, gs);
-        acc = fmaf(dz, bias ? 1.0f : ws2[(i * 2) * (int64_t)d + f], acc);
-    }
-    grad[77 + idx] += acc;
+    rnd_bwd_linear_body(ws2, pred, targ, grad, gs, n, d, (int64_t)blockIdx.x);
 }
 
 // pooled conv2 output f of grid n: gradient through the linear layer, relu gate, arg-max of the 2x2

@@ -12,6 +12,7 @@
 // Two launches instead of the staged path's three, and nothing but the observation is read from HBM
 // (staged: 6 pooled planes + 2 feature planes written and re-read).
 #include "rnd_device.hpp"
+#include "train_bodies.hpp"
 #include <type_traits>
 
 namespace carle {
@@ -245,12 +246,13 @@ struct RndTileBwdShared {
     float red[4][80];
 };
 
+// (body as a device function: the stand-alone kernel and rnd_bwd_pair_kernel -- the tile gradients and the linear layer's
+// gradient of a training step side by side in one launch -- call it with their own workgroup index / count)
 template <bool PACKED>
-__global__ __launch_bounds__(256, 2) void rnd_tile_bwd_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
-                                                              const float *__restrict__ pp, const float *__restrict__ pred,
-                                                              const float *__restrict__ targ, float *__restrict__ rows_out,
-                                                              float gs, int64_t n, int size) {
-    __shared__ RndTileBwdShared s;
+__device__ __forceinline__ void rnd_tile_bwd_body(RndTileBwdShared &s, const void *__restrict__ obs_v, const float *__restrict__ ws,
+                                                  const float *__restrict__ pp, const float *__restrict__ pred,
+                                                  const float *__restrict__ targ, float *__restrict__ rows_out,
+                                                  float gs, int64_t n, int size, const int bidx, const int bcount) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     rnd_block_init(s.f.net, ws, tid);
     for (int i = tid; i < 400; i += 256) (&s.dmap[0][0])[i] = 0.0f;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void rnd_tile_bwd_kernel(const void *__rest
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc2[i] = 0.0f;
     __syncthreads();
-    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+    for (int64_t t = bidx; t < total; t += bcount) {
         const int64_t g = t / tiles;
         const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
         const int y0 = 64 * ty - 5, x0 = 64 * tx - 5;
@@ -433,7 +435,31 @@ __global__ __launch_bounds__(256, 2) void rnd_tile_bwd_kernel(const void *__rest
         if (lane == 0) s.red[wv][i] = x;
     }
     __syncthreads();
-    if (tid < 77) rows_out[(int64_t)blockIdx.x * 77 + tid] = (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
+    if (tid < 77) rows_out[(int64_t)bidx * 77 + tid] = (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256, 2) void rnd_tile_bwd_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
+                                                              const float *__restrict__ pp, const float *__restrict__ pred,
+                                                              const float *__restrict__ targ, float *__restrict__ rows_out,
+                                                              float gs, int64_t n, int size) {
+    __shared__ RndTileBwdShared s;
+    rnd_tile_bwd_body<PACKED>(s, obs_v, ws, pp, pred, targ, rows_out, gs, n, size, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// workgroups [0, brows): the tile gradients; [brows, brows + lin_blocks): the linear layer's gradient from the stored
+// features (nets_staged_bwd.hpp) -- independent of each other, both behind rnd_tile_finish_kernel
+template <bool PACKED>
+__global__ __launch_bounds__(256, 2) void rnd_bwd_pair_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
+                                                              const float *__restrict__ pp, const float *__restrict__ pred,
+                                                              const float *__restrict__ targ, float *__restrict__ rows_out,
+                                                              const float *__restrict__ featbuf, float *__restrict__ grad,
+                                                              float gs, int64_t n, int size, int brows) {
+    __shared__ RndTileBwdShared s;
+    if ((int)blockIdx.x < brows)
+        rnd_tile_bwd_body<PACKED>(s, obs_v, ws, pp, pred, targ, rows_out, gs, n, size, (int)blockIdx.x, brows);
+    else
+        rnd_bwd_linear_body(featbuf, pred, targ, grad, gs, n, (size >> 3) * (size >> 3), (int64_t)blockIdx.x - brows);
 }
 
 // number of partial rows (= workgroups) of the tiled backward kernel
@@ -1284,6 +1310,63 @@ int ae2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const fl
             hipLaunchKernelGGL((ae_tile_train_kernel<false, 256>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size);
     }
     return check_launch("carle_ae2d_train(tiled)");
+}
+
+// ---------------------------------------------------------------------------------------------
+// AE2D(RND2D(env)) in training mode at tiled sizes -- the stack of carle/train_mcl.py:34-38 at the reference's default
+// geometry: both wrappers' bonuses, reward updates and predictor gradients of one step in FIVE launches instead of nine
+// (a step there is a chain of dependent dispatches of 4-7 us each, whatever their size):
+//   rnd_tile_kernel (features kept) -> rnd_tile_finish_kernel -> rnd_bwd_pair_kernel (tile gradients | linear-layer gradient)
+//   -> ae_tile_train_kernel -> rnd_ae_train_tail_kernel (row reduction RND2D | row reduction AE2D | AE2D bonus + reward).
+// Same device bodies, same order of every sum as the two wrappers stepping one after the other: bit-identical.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rnd_ae_train_tail_kernel(const float *__restrict__ rrows, int rrow_count,
+                                                                float *__restrict__ rgrad, const float *__restrict__ arows,
+                                                                int arow_count, float *__restrict__ agrad,
+                                                                const float *__restrict__ apartial, float *__restrict__ abonus,
+                                                                float *__restrict__ reward, float ascale, int64_t n, int tiles,
+                                                                float inv_pixels) {
+    __shared__ float part[32][33];
+    const int b = (int)blockIdx.x;
+    if (b < 3) staged_grad_reduce_body(part, rrows, rrow_count, rgrad, 77, b);                 // workgroup-uniform branches
+    else if (b < 9) staged_grad_reduce_body(part, arows, arow_count, agrad, 164, b - 3);
+    else ae_mse_finish_body(apartial, abonus, reward, ascale, n, tiles, inv_pixels, (int64_t)(b - 9) * 1024 + threadIdx.x);
+}
+
+// rscratch: pred (n x 16) | targ (n x 16) | features (n x 2 x D) | rows, as carle_rnd2d_train_scratch_floats lays it out;
+// arows: the AE2D gradient rows (carle_ae2d_train_scratch_floats)
+int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws,
+                       float *rscratch, float *rgrad, float *rbonus, float rscale, float rgrad_scale, bool rvalid,
+                       const float *ap, float *aws, float *arows, float *agrad, float *abonus, float ascale, float agrad_scale,
+                       bool avalid, float *reward, hipStream_t s) {
+    if (!rvalid) rnd2d_prepare_tables(pp, rp, rws, s);
+    const int tiles = (size >> 6) * (size >> 6);
+    const int64_t total = n * tiles;
+    if ((n + 15) / 16 > 0x7FFFFFFFll || (n + 1023) / 1024 > 0x7FFFFF00ll)
+        return fail_arg(CARLE_E_DIMS, "carle_rnd_ae_train: batch too large");
+    const int d8 = size >> 3, d = d8 * d8;
+    float *pred = rscratch, *targ = pred + n * kRndK, *featbuf = targ + n * kRndK, *rrows = featbuf + n * 2 * (int64_t)d;
+    const unsigned blocks = (unsigned)(total < 1024 ? total : 1024);
+    float *rpartial = rws + kFusedWsTotal;
+    if (packed)
+        hipLaunchKernelGGL(rnd_tile_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, rws, pp, rp, rpartial, featbuf, n, size);
+    else
+        hipLaunchKernelGGL(rnd_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, rws, pp, rp, rpartial, featbuf, n, size);
+    hipLaunchKernelGGL(rnd_tile_finish_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, rpartial, pp, rp, rbonus,
+                       pred, targ, reward, rscale, n, tiles, d);
+    const int brows = rnd2d_tiled_bwd_rows(n, size);
+    const unsigned lin = (unsigned)(((int64_t)kRndK * d + kRndK + 255) / 256);
+    if (packed)
+        hipLaunchKernelGGL(rnd_bwd_pair_kernel<true>, dim3((unsigned)brows + lin), dim3(256), 0, s, obs, rws, pp, pred, targ,
+                           rrows, featbuf, rgrad, rgrad_scale, n, size, brows);
+    else
+        hipLaunchKernelGGL(rnd_bwd_pair_kernel<false>, dim3((unsigned)brows + lin), dim3(256), 0, s, obs, rws, pp, pred, targ,
+                           rrows, featbuf, rgrad, rgrad_scale, n, size, brows);
+    if (int e = ae2d_tiled_train(obs, packed, n, size, ap, aws, arows, agrad_scale, avalid, s)) return e;
+    hipLaunchKernelGGL(rnd_ae_train_tail_kernel, dim3(9u + (unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, rrows, brows, rgrad,
+                       arows, ae2d_tiled_train_rows(n, size), agrad, aws + kAeLutFloatsT + 128, abonus, reward, ascale, n, tiles,
+                       1.0f / ((float)size * (float)size));
+    return check_launch("carle_rnd_ae_train(tiled)");
 }
 
 int64_t ae2d_tiled_workspace_floats(int64_t n, int size) {

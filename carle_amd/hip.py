@@ -223,6 +223,27 @@ def rnd_ae_bonus(obs, rnd_pred, rnd_rand, rnd_ws, rnd_bonus, rnd_scale, rnd_vali
         _lib.check(rc, "carle_rnd_ae_bonus")
 
 
+def rnd_ae_train(obs, rnd_pred, rnd_rand, rnd_ws, rnd_scratch, rnd_grad, rnd_bonus, rnd_scale, rnd_grad_scale, rnd_valid,
+                 ae_params, ae_ws, ae_scratch, ae_grad, ae_bonus, ae_scale, ae_grad_scale, ae_valid, reward, stream=None):
+    """Bonuses, reward updates and gradient accumulation of a stacked RND2D + AE2D pair in training mode, five launches
+    (carle_rnd_ae_train): binary obs, fp32 (N,1,H,W) or int64 bit-packed, H == W a multiple of 64 above 64.  Workspaces,
+    scratch and gradient buffers must already have their full size."""
+    lib = _lib.load()
+    packed = obs.dtype == torch.int64
+    n, _, h, w = obs.shape
+    if packed:
+        w *= 64
+    with _on_device(obs.device):
+        rc = lib.carle_rnd_ae_train(obs.data_ptr(), FMT_B1 if packed else FMT_F32, n, h, w, rnd_pred.data_ptr(),
+                                    rnd_rand.data_ptr(), rnd_ws.data_ptr(), rnd_scratch.data_ptr(), rnd_grad.data_ptr(),
+                                    rnd_bonus.data_ptr(), float(rnd_scale), float(rnd_grad_scale), 2 if rnd_valid else 0,
+                                    ae_params.data_ptr(), ae_ws.data_ptr(), ae_scratch.data_ptr(), ae_grad.data_ptr(),
+                                    ae_bonus.data_ptr(), float(ae_scale), float(ae_grad_scale), 2 if ae_valid else 0,
+                                    _ptr(reward), stream if stream is not None else _stream(obs))
+    if rc != 0:
+        _lib.check(rc, "carle_rnd_ae_train")
+
+
 def stream_fork(event_handle, from_stream, to_stream):
     """to_stream waits for everything enqueued so far on from_stream (raw handles)."""
     rc = _lib.load().carle_stream_fork(event_handle, from_stream, to_stream)

@@ -496,6 +496,35 @@ class RND2D(Motivator):
     # autograd (the round-1 path; kept for A/B tests) instead of the staged HIP backward kernels
     hip_backward_any_size = True
 
+    def _tiled_train_buffers(self, o):
+        """Workspace, scratch and gradient buffers of the tiled training kernels for the binary observations ``o``
+        (as ``_fused_train`` sets them up); returns (predictor blob, random-network blob or None, tables valid,
+        table key to commit, gradient scale of one step)."""
+        from . import _lib
+        lib = _lib.load()
+        is_ae = type(self) is AE2D
+        dev, n, size = o.device, o.shape[0], o.shape[2]
+        pb = self._pred_blob.get(dev)
+        rb = None if is_ae else self._rand_blob.get(dev)
+        need = (lib.carle_ae2d_workspace_floats if is_ae else lib.carle_rnd2d_workspace_floats)(n, size, size)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.float32, device=dev)
+            self._tables_key = None
+        pneed = (lib.carle_ae2d_train_scratch_floats if is_ae else lib.carle_rnd2d_train_scratch_floats)(n, size, size)
+        if self._partial is None or self._partial.numel() < pneed or self._partial.device != dev:
+            self._partial = torch.empty(pneed, dtype=torch.float32, device=dev)
+        if self._grad is None or self._grad.device != dev or self._grad.numel() != pb.numel():
+            self._grad = torch.zeros(pb.numel(), dtype=torch.float32, device=dev)
+        if self._bonus_buf is None or self._bonus_buf.shape[0] != n or self._bonus_buf.device != dev:
+            self._bonus_buf = torch.empty(n, dtype=torch.float32, device=dev)
+        versions = (self._pred_blob.version,) if is_ae else (self._pred_blob.version, self._rand_blob.version)
+        key = (id(self._ws), versions)
+        if is_ae:
+            grad_scale = 2.0 / (size * size * n * self.batch_size)
+        else:
+            grad_scale = 2.0 / (self.rnd_dim * n * self.batch_size)
+        return pb, rb, self._tables_key == key, key, grad_scale
+
     def _fused_train(self, obs, reward, bonus_out, stream, batch=None):
         """Bonus + gradient in one library call (carle_rnd2d_train_* / carle_ae2d_train_*): the fused
         forward+backward kernel for 64x64 binary observations, staged forward + staged backward HIP
@@ -708,10 +737,17 @@ class AE2D(RND2D):
 
     # -- stacked on an RND2D, forward only, tiled sizes: both bonuses in two launches (carle_rnd_ae_bonus) ----------
     def _can_pair_step(self):
+        """0: the wrappers step one after the other; 1: paired forward (both without predictor updates); 2: paired
+        training step (both with predictor updates through the HIP gradient kernels)."""
         rnd, env = self.env, self.inner_env
-        return (type(self) is AE2D and type(rnd) is RND2D and rnd.env is env and not self.train_predictor
-                and not rnd.train_predictor and not self.async_reward and not rnd.async_reward
-                and env.height == env.width and env.height > 64 and env.height % 64 == 0)
+        if not (type(self) is AE2D and type(rnd) is RND2D and rnd.env is env and not self.async_reward
+                and not rnd.async_reward and env.height == env.width and env.height > 64 and env.height % 64 == 0):
+            return 0
+        if not self.train_predictor and not rnd.train_predictor:
+            return 1
+        if self.train_predictor and rnd.train_predictor and self.hip_backward_any_size and rnd.hip_backward_any_size:
+            return 2
+        return 0
 
     def step(self, action):
         """AE2D(RND2D(CARLE)) -- the stack of train_mcl.py:34-38 / eval.py:83-85 -- at the reference's default geometry
@@ -719,7 +755,8 @@ class AE2D(RND2D):
         wrappers' bonuses and reward updates in two launches (the tile workgroups of the two nets side by side, one
         finish kernel) instead of four -- a step there is bound by its dependent dispatches.  Bit-identical to the
         two wrappers stepping one after the other."""
-        if not self._can_pair_step():
+        mode = self._can_pair_step()
+        if not mode:
             return super().step(action)
         rnd, env = self.env, self.inner_env
         if isinstance(action, torch.Tensor):
@@ -732,6 +769,8 @@ class AE2D(RND2D):
             rnd._bonus_into(obs, reward)
             self._bonus_into(obs, reward)
             return obs, reward, done, info
+        if mode == 2:
+            return self._paired_train_step(o, obs, reward, done, info)
         from . import _lib
         lib = _lib.load()
         dev, n, size = o.device, o.shape[0], o.shape[2]
@@ -748,6 +787,28 @@ class AE2D(RND2D):
                          self.reward_scale, avalid, reward)
         rnd._commit_tables()
         self._commit_tables()
+        return obs, reward, done, info
+
+    def _paired_train_step(self, o, obs, reward, done, info):
+        """Training mode of the pair (train_mcl.py:64-69): what ``RND2D._bonus_into`` followed by ``AE2D._bonus_into``
+        do -- window bookkeeping, bonus + reward + gradient accumulation, Adam at the end of each wrapper's window --
+        with the kernels of both wrappers in five launches (carle_rnd_ae_train) instead of nine.  Bit-identical."""
+        rnd = self.env
+        for w in (rnd, self):
+            if w.buffer_length == 0:
+                w.predictor.zero_grad()
+                w.accumulate_loss = 0.0
+                w._drop_window()
+        pb, rb, rvalid, rkey, rgs = rnd._tiled_train_buffers(o)
+        ab, _, avalid, akey, ags = self._tiled_train_buffers(o)
+        hip.rnd_ae_train(o, pb, rb, rnd._ws, rnd._partial, rnd._grad, rnd._bonus_buf, rnd.reward_scale, rgs, rvalid,
+                         ab, self._ws, self._partial, self._grad, self._bonus_buf, self.reward_scale, ags, avalid, reward)
+        rnd._tables_key, self._tables_key = rkey, akey
+        for w in (rnd, self):
+            w._grad_used = True
+            w.buffer_length += 1
+            if w.buffer_length >= w.batch_size:
+                w._finish_window()
         return obs, reward, done, info
 
     def random_forward(self, obs):

@@ -364,6 +364,19 @@ int carle_rnd_ae_bonus(const void *obs, int obs_fmt, int64_t n, int h, int w, co
                        int rnd_flags, const float *ae_params, float *ae_workspace, float *ae_bonus, float ae_scale,
                        int ae_flags, float *reward_accum, void *stream);
 
+/* The same stack in TRAINING mode (carle/train_mcl.py:34-38, 64-69; mcl.py:368-386, 521-547): both wrappers' bonuses, both
+ * `reward += reward_scale * bonus` and the accumulation of both predictors' gradients for one step -- what
+ * carle_rnd2d_train_* followed by carle_ae2d_train_* do -- in FIVE launches instead of nine (at the reference's default
+ * geometry a step is a chain of dependent dispatches of 4-7 us each, whatever their size).  Binary observations, H == W a
+ * multiple of 64 above 64; rnd_scratch / ae_scratch: carle_rnd2d_train_scratch_floats / carle_ae2d_train_scratch_floats
+ * floats; gradients are ADDED to rnd_grad / ae_grad (blob order); everything else as for the two per-net entry points,
+ * results bit-identical to calling them one after the other. */
+int carle_rnd_ae_train(const void *obs, int obs_fmt, int64_t n, int h, int w, const float *rnd_pred_params,
+                       const float *rnd_rand_params, float *rnd_workspace, float *rnd_scratch, float *rnd_grad,
+                       float *rnd_bonus, float rnd_scale, float rnd_grad_scale, int rnd_flags, const float *ae_params,
+                       float *ae_workspace, float *ae_scratch, float *ae_grad, float *ae_bonus, float ae_scale,
+                       float ae_grad_scale, int ae_flags, float *reward_accum, void *stream);
+
 /* CARLE.step + the RND2D wrapper's bonus on the fresh observation (carle/env.py:188-242 +
  * carle/mcl.py:398-407) in one call.
  *   64x64 grids with an aligned action window (AW % 8 == 0 or no action): ONE kernel steps the

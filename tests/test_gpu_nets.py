@@ -1029,10 +1029,10 @@ def test_paired_rnd_ae_step_equals_the_two_wrappers(storage, size, n):
         w = AE2D(RND2D(env, train_predictor=False), train_predictor=False)
         w.env.reward_scale, w.reward_scale = 0.7, 1.3
         if not paired:
-            w._can_pair_step = lambda: False
+            w._can_pair_step = lambda: 0
         w.eval(); w.reset()
         stacks.append((env, w))
-    assert stacks[0][1]._can_pair_step()
+    assert stacks[0][1]._can_pair_step() == 1
     g = torch.Generator(device="cuda").manual_seed(9)
     u0 = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
     for env, w in stacks:
@@ -1051,3 +1051,42 @@ def test_paired_rnd_ae_step_equals_the_two_wrappers(storage, size, n):
         assert torch.equal(stacks[0][1].env._bonus_buf, stacks[1][1].env._bonus_buf), "RND2D bonus"
         assert torch.equal(r0, r1), (t, (r0 - r1).abs().max())
         assert float(r0.min()) > 0
+
+
+@pytest.mark.parametrize("storage,size,n,batch", [("f32", 256, 16, 3), ("f32", 128, 5, 2), ("b1", 256, 7, 3), ("f32", 512, 2, 4)])
+def test_paired_rnd_ae_training_step_equals_the_two_wrappers(storage, size, n, batch):
+    """AE2D(RND2D(CARLE)) at tiled sizes WITH predictor updates (train_mcl.py:34-38, 64-69): one carle_rnd_ae_train call
+    (five launches) leaves bit-identical rewards, bonuses, gradient buffers and -- after the Adam steps at the end of the
+    update windows -- parameters as the two wrappers stepping one after the other (nine launches)."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D
+    stacks = []
+    for paired in (True, False):
+        torch.manual_seed(23)
+        env = CARLE(width=size, height=size, instances=n, device="cuda:0", storage=storage)
+        w = AE2D(RND2D(env))
+        w.env.reward_scale, w.reward_scale = 0.7, 1.3
+        w.env.batch_size, w.batch_size = batch, batch + 1        # the two windows end at different steps
+        if not paired:
+            w._can_pair_step = lambda: 0
+        w.eval(); w.reset()
+        stacks.append((env, w))
+    assert stacks[0][1]._can_pair_step() == 2
+    g = torch.Generator(device="cuda").manual_seed(10)
+    u0 = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+    for env, w in stacks:
+        env.universe = u0.clone()
+    for t in range(2 * (batch + 1) + 1):
+        a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
+        (o0, r0, _, _), (o1, r1, _, _) = [w.step(a) for env, w in stacks]
+        assert torch.equal(r0, r1), (t, (r0 - r1).abs().max())
+        assert torch.equal(stacks[0][1]._bonus_buf, stacks[1][1]._bonus_buf), "AE2D bonus"
+        assert torch.equal(stacks[0][1].env._bonus_buf, stacks[1][1].env._bonus_buf), "RND2D bonus"
+        for name, a_, b_ in (("AE2D", stacks[0][1], stacks[1][1]), ("RND2D", stacks[0][1].env, stacks[1][1].env)):
+            assert a_.buffer_length == b_.buffer_length and a_.updates == b_.updates
+            assert torch.equal(a_._grad, b_._grad), (name, t, (a_._grad - b_._grad).abs().max())
+    (e0, w0), (e1, w1) = stacks
+    assert w0.env.updates >= 2 and w0.buffer_length == 1          # both wrappers went through two update windows
+    sd0, sd1 = w0.state_dict(), w1.state_dict()
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
