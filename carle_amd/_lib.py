@@ -42,10 +42,11 @@ SIGNATURES = {
     "carle_rnd2d_bonus_b1": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
                                       _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_vp]),
     "carle_rnd_ae_bonus": (_c_int, [_c_vp, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int,
-                                    _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp]),
+                                    _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "carle_rnd_ae_partials_doubles": (_c_i64, [_c_i64]),
     "carle_rnd_ae_train": (_c_int, [_c_vp, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                     ctypes.c_float, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
-                                    ctypes.c_float, ctypes.c_float, _c_int, _c_vp, _c_vp]),
+                                    ctypes.c_float, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "carle_stream_fork": (_c_int, [_c_vp, _c_vp, _c_vp]),
     "carle_env_step_f32_rnd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
                                         _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp,

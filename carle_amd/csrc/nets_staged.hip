@@ -481,11 +481,11 @@ extern "C" int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w) {
 namespace carle {
 int rnd_ae_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws, float *rbonus,
                  float rscale, bool rnd_tables_valid, const float *ap, float *aws, float *abonus, float ascale,
-                 bool ae_tables_valid, float *reward, hipStream_t s);
+                 bool ae_tables_valid, float *reward, double *mom_partials, int32_t *status, hipStream_t s);
 int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws,
                        float *rscratch, float *rgrad, float *rbonus, float rscale, float rgrad_scale, bool rvalid,
                        const float *ap, float *aws, float *arows, float *agrad, float *abonus, float ascale, float agrad_scale,
-                       bool avalid, float *reward, hipStream_t s);
+                       bool avalid, float *reward, double *mom_partials, int32_t *status, hipStream_t s);
 }
 
 // RND2D.get_bonus AND AE2D.get_bonus of the same observations (carle/mcl.py:343-352, 504-512) + both wrappers' reward
@@ -495,7 +495,8 @@ int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const 
 extern "C" int carle_rnd_ae_bonus(const void *obs, int obs_fmt, int64_t n, int h, int w, const float *rnd_pred_params,
                                   const float *rnd_rand_params, float *rnd_workspace, float *rnd_bonus, float rnd_scale,
                                   int rnd_flags, const float *ae_params, float *ae_workspace, float *ae_bonus, float ae_scale,
-                                  int ae_flags, float *reward_accum, void *stream) {
+                                  int ae_flags, float *reward_accum, double *moment_partials, int32_t *status,
+                                  void *stream) {
     if (!obs || !rnd_pred_params || !rnd_rand_params || !rnd_workspace || !rnd_bonus || !ae_params || !ae_workspace || !ae_bonus)
         return fail_arg(CARLE_E_NULL, "carle_rnd_ae_bonus: NULL pointer");
     if (obs_fmt != CARLE_FMT_F32 && obs_fmt != CARLE_FMT_B1)
@@ -503,22 +504,29 @@ extern "C" int carle_rnd_ae_bonus(const void *obs, int obs_fmt, int64_t n, int h
     if (n < 0 || !rnd2d_tiled_applies(h, w))
         return fail_arg(CARLE_E_DIMS, "carle_rnd_ae_bonus: binary grids with H == W a multiple of 64 above 64 (use the "
                                       "per-net entry points otherwise)");
+    if ((moment_partials != nullptr) != (status != nullptr) || (status && (!reward_accum || !aligned16(status))))
+        return fail_arg(CARLE_E_NULL, "carle_rnd_ae_bonus: moment_partials, status (16-byte aligned) and reward_accum go together");
     if (n == 0) return 0;
     return rnd_ae_tiled(obs, obs_fmt == CARLE_FMT_B1, n, h, rnd_pred_params, rnd_rand_params, rnd_workspace, rnd_bonus,
                         rnd_scale, (rnd_flags & CARLE_NET_TABLES_VALID) != 0, ae_params, ae_workspace, ae_bonus, ae_scale,
-                        (ae_flags & CARLE_NET_TABLES_VALID) != 0, reward_accum, static_cast<hipStream_t>(stream));
+                        (ae_flags & CARLE_NET_TABLES_VALID) != 0, reward_accum, moment_partials, status,
+                        static_cast<hipStream_t>(stream));
 }
+
+// fp64 values behind `moment_partials` of the two entry points around this one (one (sum, sum of squares) pair per
+// workgroup of their finish kernels)
+extern "C" int64_t carle_rnd_ae_partials_doubles(int64_t n) { return n < 0 ? 0 : 2 * ((n + 15) / 16); }
 
 // The same stack in TRAINING mode (carle/train_mcl.py:34-38, 64-69): both wrappers' bonuses, reward updates and the
 // accumulation of both predictors' gradients of one step -- what carle_rnd2d_train_* followed by carle_ae2d_train_* do --
-// in five launches instead of nine.  Scratch and gradient buffers exactly as for those two entry points
+// in four launches instead of nine.  Scratch and gradient buffers exactly as for those two entry points
 // (carle_rnd2d_train_scratch_floats / carle_ae2d_train_scratch_floats); bit-identical results.
 extern "C" int carle_rnd_ae_train(const void *obs, int obs_fmt, int64_t n, int h, int w, const float *rnd_pred_params,
                                   const float *rnd_rand_params, float *rnd_workspace, float *rnd_scratch, float *rnd_grad,
                                   float *rnd_bonus, float rnd_scale, float rnd_grad_scale, int rnd_flags,
                                   const float *ae_params, float *ae_workspace, float *ae_scratch, float *ae_grad,
                                   float *ae_bonus, float ae_scale, float ae_grad_scale, int ae_flags, float *reward_accum,
-                                  void *stream) {
+                                  double *moment_partials, int32_t *status, void *stream) {
     if (!obs || !rnd_pred_params || !rnd_rand_params || !rnd_workspace || !rnd_scratch || !rnd_grad || !rnd_bonus ||
         !ae_params || !ae_workspace || !ae_scratch || !ae_grad || !ae_bonus)
         return fail_arg(CARLE_E_NULL, "carle_rnd_ae_train: NULL pointer");
@@ -527,11 +535,14 @@ extern "C" int carle_rnd_ae_train(const void *obs, int obs_fmt, int64_t n, int h
     if (n < 0 || !rnd2d_tiled_applies(h, w))
         return fail_arg(CARLE_E_DIMS, "carle_rnd_ae_train: binary grids with H == W a multiple of 64 above 64 (use the "
                                       "per-net entry points otherwise)");
+    if ((moment_partials != nullptr) != (status != nullptr) || (status && (!reward_accum || !aligned16(status))))
+        return fail_arg(CARLE_E_NULL, "carle_rnd_ae_train: moment_partials, status (16-byte aligned) and reward_accum go together");
     if (n == 0) return 0;
     return rnd_ae_tiled_train(obs, obs_fmt == CARLE_FMT_B1, n, h, rnd_pred_params, rnd_rand_params, rnd_workspace, rnd_scratch,
                               rnd_grad, rnd_bonus, rnd_scale, rnd_grad_scale, (rnd_flags & CARLE_NET_TABLES_VALID) != 0,
                               ae_params, ae_workspace, ae_scratch, ae_grad, ae_bonus, ae_scale, ae_grad_scale,
-                              (ae_flags & CARLE_NET_TABLES_VALID) != 0, reward_accum, static_cast<hipStream_t>(stream));
+                              (ae_flags & CARLE_NET_TABLES_VALID) != 0, reward_accum, moment_partials, status,
+                              static_cast<hipStream_t>(stream));
 }
 
 extern "C" int carle_rnd2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,

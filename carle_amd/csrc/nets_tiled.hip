@@ -26,6 +26,7 @@ struct RndTileShared {
     RndBlockShared net;                                // tables, planes, conv2 parameters (lin / rows unused)
     uint64_t rows[kTileRows + 2][2];                   // [r][0] = columns x0 .. x0+63, [r][1] = x0+64 .. x0+73
     float feat[2][64];
+    int last;                                          // RndTileFinish: this workgroup delivered the last tile of its grid
 };
 
 // 6 bits of a 74-bit row starting at local column c (0 <= c <= 68)
@@ -85,13 +86,74 @@ __device__ __forceinline__ float tile_wave_sum(float v) {
 }
 
 // PACKED: obs = bit-packed grids (H rows of W/64 words); else fp32 (N,1,H,W), any non-zero number = alive
+// the finish of one grid by the 16 lanes of a DPP row: lane k adds the tiles' partial sums of output k of both nets in tile
+// order, tanh, squared difference, mean over the 16 outputs; bonus, outputs and reward += scale * bonus (mcl.py:343-352, 403-405)
+template <bool COHERENT = false>
+__device__ __forceinline__ void rnd_finish_grid(const float *__restrict__ partial, const float *__restrict__ pp,
+                                                const float *__restrict__ rp, float *__restrict__ bonus,
+                                                float *__restrict__ pred_out, float *__restrict__ target_out,
+                                                float *__restrict__ reward, float reward_scale, int64_t g, bool valid, int k,
+                                                int tiles, int dfeat) {
+    // no contraction: whether (r - p)^2 and the first DPP add become one fma depends on the code around this function, and
+    // its three users (finish kernel, finish by the last tile, rnd_ae_finish_kernel) must agree to the bit
+#pragma clang fp contract(off)
+    float sq = 0.0f;
+    if (valid) {
+        float p = 0.0f, r = 0.0f;
+        // COHERENT: the sums were stored by workgroups on other XCDs (finish by the last tile): agent-scope loads, which
+        // read past this XCD's L2 (a fence would invalidate all of it under the other workgroups' feet)
+        auto ld = [&](const float *q) {
+            return COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+        };
+        // sixteen tiles' sums requested at once, added in tile order (one round trip per sixteen tiles, not per tile)
+        for (int t0 = 0; t0 < tiles; t0 += 16) {
+            float a[16], b[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int t = t0 + i < tiles ? t0 + i : tiles - 1;
+                a[i] = ld(partial + ((g * tiles + t) * 2 + 0) * 16 + k);
+                b[i] = ld(partial + ((g * tiles + t) * 2 + 1) * 16 + k);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (t0 + i < tiles) { p += a[i]; r += b[i]; }
+        }
+        p = tanhf(p + pp[77 + (int64_t)16 * dfeat + k]);
+        r = tanhf(r + rp[39 + (int64_t)16 * dfeat + k]);
+        if (pred_out) pred_out[g * 16 + k] = p;
+        if (target_out) target_out[g * 16 + k] = r;
+        sq = (r - p) * (r - p);
+    }
+    sq += dpp_quad_xor1(sq);
+    sq += dpp_quad_xor2(sq);
+    sq += dpp_row_ror(sq, 0x124);
+    sq += dpp_row_ror(sq, 0x128);
+    if (valid && k == 0) {
+        const float b = sq * (1.0f / 16.0f);
+        bonus[g] = b;
+        // mcl.py:403-405, as torch evaluates it: product and sum rounded separately (no contraction into an fma -- also
+        // what keeps the paired launch, rnd_ae_finish_kernel, bit-identical to the two wrappers one after the other)
+        if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);
+    }
+}
+
+// Finish WITHOUT a finish launch: the workgroup that delivers the LAST tile of a grid (a counter per grid, agent scope)
+// finishes that grid itself -- the same sums in the same (tile) order, whoever comes last.  counters: n ints, zero before
+// the launch and zero again behind it.
+struct RndTileFinish {
+    int32_t *counters = nullptr;
+    float *bonus = nullptr, *pred = nullptr, *targ = nullptr, *reward = nullptr;
+    float reward_scale = 0.0f;
+};
+
 // (body as a device function: the stand-alone kernel below and the launch that runs the RND2D and AE2D tiles of a
 // wrapper stack side by side, rnd_ae_tile_kernel, call it with their own workgroup index / count)
 template <bool PACKED>
 __device__ __forceinline__ void rnd_tile_body(RndTileShared &s, const void *__restrict__ obs_v, const float *__restrict__ ws,
                                               const float *__restrict__ pp, const float *__restrict__ rp,
                                               float *__restrict__ partial, float *__restrict__ featbuf,
-                                              int64_t n, int size, unsigned bid, unsigned nblk) {
+                                              int64_t n, int size, unsigned bid, unsigned nblk,
+                                              const RndTileFinish fin = RndTileFinish()) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     rnd_block_init(s.net, ws, tid);
     const int tps = size >> 6, tiles = tps * tps;      // tiles per side / per grid
@@ -179,7 +241,26 @@ __device__ __forceinline__ void rnd_tile_body(RndTileShared &s, const void *__re
             acc += dpp_quad_xor1(acc);
             acc += dpp_quad_xor2(acc);
             acc += __shfl_xor(acc, 4, 64);
-            if (fy == 0) partial[(t * 2 + net) * 16 + k] = acc;
+            if (fy == 0) {
+                if (fin.counters) __hip_atomic_store(partial + (t * 2 + net) * 16 + k, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else partial[(t * 2 + net) * 16 + k] = acc;
+            }
+        }
+        if (fin.counters) {                             // kernel argument: the same for every workgroup
+            // The tile's partial sums went out as agent-scope stores (written through to where every XCD reads them);
+            // once they are acknowledged the workgroup takes its ticket.  No fences: an agent-scope fence writes back and
+            // invalidates the XCD's WHOLE L2 -- 25 us per step at 16 x 256x256 with 256 workgroups doing it.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                s.last = __hip_atomic_fetch_add(fin.counters + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tiles - 1;
+            __syncthreads();
+            if (s.last) {                               // workgroup-uniform
+                if (tid < 16)
+                    rnd_finish_grid<true>(partial, pp, rp, fin.bonus, fin.pred, fin.targ, fin.reward, fin.reward_scale, g, true,
+                                          tid, tiles, dfeat);
+                if (tid == 0) __hip_atomic_store(fin.counters + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         // rows / planes / feat are rewritten behind the next iteration's barriers
     }
@@ -189,9 +270,9 @@ template <bool PACKED>
 __global__ __launch_bounds__(256, 4) void rnd_tile_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
                                                           const float *__restrict__ pp, const float *__restrict__ rp,
                                                           float *__restrict__ partial, float *__restrict__ featbuf,
-                                                          int64_t n, int size) {
+                                                          int64_t n, int size, const RndTileFinish fin = RndTileFinish()) {
     __shared__ RndTileShared s;
-    rnd_tile_body<PACKED>(s, obs_v, ws, pp, rp, partial, featbuf, n, size, blockIdx.x, gridDim.x);
+    rnd_tile_body<PACKED>(s, obs_v, ws, pp, rp, partial, featbuf, n, size, blockIdx.x, gridDim.x, fin);
 }
 
 // 16 threads per grid: thread k adds the tiles' partial sums of output k of both nets in tile order
@@ -201,31 +282,7 @@ __global__ __launch_bounds__(256) void rnd_tile_finish_kernel(const float *__res
                                                               float *__restrict__ reward, float reward_scale, int64_t n,
                                                               int tiles, int dfeat) {
     const int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int k = threadIdx.x & 15;
-    float sq = 0.0f;
-    if (g < n) {
-        float p = 0.0f, r = 0.0f;
-        for (int t = 0; t < tiles; ++t) {
-            p += partial[((g * tiles + t) * 2 + 0) * 16 + k];
-            r += partial[((g * tiles + t) * 2 + 1) * 16 + k];
-        }
-        p = tanhf(p + pp[77 + (int64_t)16 * dfeat + k]);
-        r = tanhf(r + rp[39 + (int64_t)16 * dfeat + k]);
-        if (pred_out) pred_out[g * 16 + k] = p;
-        if (target_out) target_out[g * 16 + k] = r;
-        sq = (r - p) * (r - p);
-    }
-    sq += dpp_quad_xor1(sq);
-    sq += dpp_quad_xor2(sq);
-    sq += dpp_row_ror(sq, 0x124);
-    sq += dpp_row_ror(sq, 0x128);
-    if (g < n && k == 0) {
-        const float b = sq * (1.0f / 16.0f);
-        bonus[g] = b;
-        // mcl.py:403-405, as torch evaluates it: product and sum rounded separately (no contraction into an fma -- also
-        // what keeps the paired launch, rnd_ae_finish_kernel, bit-identical to the two wrappers one after the other)
-        if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);
-    }
+    rnd_finish_grid(partial, pp, rp, bonus, pred_out, target_out, reward, reward_scale, g, g < n, threadIdx.x & 15, tiles, dfeat);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -793,10 +850,13 @@ __global__ __launch_bounds__(256) void rnd_ae_finish_kernel(const float *__restr
                                                             const float *__restrict__ rp, float *__restrict__ rbonus,
                                                             const float *__restrict__ apartial, float *__restrict__ abonus,
                                                             float *__restrict__ reward, float rscale, float ascale, int64_t n,
-                                                            int tiles, int dfeat, float inv_pixels) {
+                                                            int tiles, int dfeat, float inv_pixels,
+                                                            double *__restrict__ mom_partials, int32_t *__restrict__ status) {
+#pragma clang fp contract(off)                          // as rnd_finish_grid
+    __shared__ double2 mpart[16];
     const int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int k = threadIdx.x & 15;
-    float sq = 0.0f, ae = 0.0f;
+    float sq = 0.0f, ae = 0.0f, final_reward = 0.0f;
     if (g < n) {
         float p = 0.0f, r = 0.0f;
         for (int t = 0; t < tiles; ++t) {
@@ -822,8 +882,11 @@ __global__ __launch_bounds__(256) void rnd_ae_finish_kernel(const float *__restr
             x = reward_accumulate(x, rscale, br);          // RND2D.step, then AE2D.step (mcl.py:403-405)
             x = reward_accumulate(x, ascale, ba);
             reward[g] = x;
+            final_reward = x;
         }
     }
+    if (mom_partials && status && reward)             // kernel arguments: the same for every workgroup
+        reward_moment_partials(mpart, g < n && k == 0, final_reward, mom_partials, status, (int)blockIdx.x, (int)gridDim.x, n);
 }
 
 void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
@@ -831,7 +894,7 @@ void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
 // both wrappers' bonuses of one observation batch; workspaces as rnd2d_tiled / ae2d_tiled use them
 int rnd_ae_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws, float *rbonus,
                  float rscale, bool rnd_tables_valid, const float *ap, float *aws, float *abonus, float ascale,
-                 bool ae_tables_valid, float *reward, hipStream_t s) {
+                 bool ae_tables_valid, float *reward, double *mom_partials, int32_t *status, hipStream_t s) {
     if (!rnd_tables_valid) rnd2d_prepare_tables(pp, rp, rws, s);
     if (!ae_tables_valid) ae2d_prepare_tables(ap, aws, s);
     const int tiles = (size >> 6) * (size >> 6);
@@ -845,7 +908,7 @@ int rnd_ae_tiled(const void *obs, bool packed, int64_t n, int size, const float 
         hipLaunchKernelGGL(rnd_ae_tile_kernel<false>, dim3(rb + ab), dim3(256), 0, s, obs, rws, pp, rp, rpartial, aws, apartial, n, size, rb);
     const int d8 = size >> 3;
     hipLaunchKernelGGL(rnd_ae_finish_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, rpartial, pp, rp, rbonus, apartial,
-                       abonus, reward, rscale, ascale, n, tiles, d8 * d8, 1.0f / ((float)size * (float)size));
+                       abonus, reward, rscale, ascale, n, tiles, d8 * d8, 1.0f / ((float)size * (float)size), mom_partials, status);
     return check_launch("carle_rnd_ae_bonus(tiled)");
 }
 
@@ -1314,9 +1377,9 @@ int ae2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const fl
 
 // ---------------------------------------------------------------------------------------------
 // AE2D(RND2D(env)) in training mode at tiled sizes -- the stack of carle/train_mcl.py:34-38 at the reference's default
-// geometry: both wrappers' bonuses, reward updates and predictor gradients of one step in FIVE launches instead of nine
+// geometry: both wrappers' bonuses, reward updates and predictor gradients of one step in FOUR launches instead of nine
 // (a step there is a chain of dependent dispatches of 4-7 us each, whatever their size):
-//   rnd_tile_kernel (features kept) -> rnd_tile_finish_kernel -> rnd_bwd_pair_kernel (tile gradients | linear-layer gradient)
+//   rnd_tile_kernel (features kept; the last tile of a grid finishes it) -> rnd_bwd_pair_kernel (tile gradients | linear-layer gradient)
 //   -> ae_tile_train_kernel -> rnd_ae_train_tail_kernel (row reduction RND2D | row reduction AE2D | AE2D bonus + reward).
 // Same device bodies, same order of every sum as the two wrappers stepping one after the other: bit-identical.
 // ---------------------------------------------------------------------------------------------
@@ -1325,12 +1388,19 @@ __global__ __launch_bounds__(1024) void rnd_ae_train_tail_kernel(const float *__
                                                                 int arow_count, float *__restrict__ agrad,
                                                                 const float *__restrict__ apartial, float *__restrict__ abonus,
                                                                 float *__restrict__ reward, float ascale, int64_t n, int tiles,
-                                                                float inv_pixels) {
+                                                                float inv_pixels, double *__restrict__ mom_partials,
+                                                                int32_t *__restrict__ status) {
     __shared__ float part[32][33];
+    __shared__ double2 mpart[16];
     const int b = (int)blockIdx.x;
     if (b < 3) staged_grad_reduce_body(part, rrows, rrow_count, rgrad, 77, b);                 // workgroup-uniform branches
     else if (b < 9) staged_grad_reduce_body(part, arows, arow_count, agrad, 164, b - 3);
-    else ae_mse_finish_body(apartial, abonus, reward, ascale, n, tiles, inv_pixels, (int64_t)(b - 9) * 1024 + threadIdx.x);
+    else {
+        const int64_t g = (int64_t)(b - 9) * 1024 + threadIdx.x;
+        const float r = ae_mse_finish_body(apartial, abonus, reward, ascale, n, tiles, inv_pixels, g);
+        if (mom_partials && status && reward)
+            reward_moment_partials(mpart, g < n, r, mom_partials, status, b - 9, (int)gridDim.x - 9, n);
+    }
 }
 
 // rscratch: pred (n x 16) | targ (n x 16) | features (n x 2 x D) | rows, as carle_rnd2d_train_scratch_floats lays it out;
@@ -1338,7 +1408,7 @@ __global__ __launch_bounds__(1024) void rnd_ae_train_tail_kernel(const float *__
 int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws,
                        float *rscratch, float *rgrad, float *rbonus, float rscale, float rgrad_scale, bool rvalid,
                        const float *ap, float *aws, float *arows, float *agrad, float *abonus, float ascale, float agrad_scale,
-                       bool avalid, float *reward, hipStream_t s) {
+                       bool avalid, float *reward, double *mom_partials, int32_t *status, hipStream_t s) {
     if (!rvalid) rnd2d_prepare_tables(pp, rp, rws, s);
     const int tiles = (size >> 6) * (size >> 6);
     const int64_t total = n * tiles;
@@ -1348,12 +1418,20 @@ int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const 
     float *pred = rscratch, *targ = pred + n * kRndK, *featbuf = targ + n * kRndK, *rrows = featbuf + n * 2 * (int64_t)d;
     const unsigned blocks = (unsigned)(total < 1024 ? total : 1024);
     float *rpartial = rws + kFusedWsTotal;
+    // the workgroup that delivers a grid's last tile finishes the grid (bonus, outputs, reward): no finish launch.  The
+    // arrival counters live behind the partial sums; zero whenever the tables are (re)built -- TABLES_VALID promises the
+    // workspace of a finished call with the same parameters AND the same (n, size) -- and zero again behind every launch.
+    RndTileFinish fin;
+    fin.counters = reinterpret_cast<int32_t *>(rpartial + total * 32);
+    fin.bonus = rbonus; fin.pred = pred; fin.targ = targ; fin.reward = reward; fin.reward_scale = rscale;
+    if (!rvalid) {
+        if (hipError_t e = hipMemsetAsync(fin.counters, 0, (size_t)n * sizeof(int32_t), s); e != hipSuccess)
+            return fail_hip(e, "carle_rnd_ae_train: hipMemsetAsync");
+    }
     if (packed)
-        hipLaunchKernelGGL(rnd_tile_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, rws, pp, rp, rpartial, featbuf, n, size);
+        hipLaunchKernelGGL(rnd_tile_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, rws, pp, rp, rpartial, featbuf, n, size, fin);
     else
-        hipLaunchKernelGGL(rnd_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, rws, pp, rp, rpartial, featbuf, n, size);
-    hipLaunchKernelGGL(rnd_tile_finish_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, rpartial, pp, rp, rbonus,
-                       pred, targ, reward, rscale, n, tiles, d);
+        hipLaunchKernelGGL(rnd_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, rws, pp, rp, rpartial, featbuf, n, size, fin);
     const int brows = rnd2d_tiled_bwd_rows(n, size);
     const unsigned lin = (unsigned)(((int64_t)kRndK * d + kRndK + 255) / 256);
     if (packed)
@@ -1365,7 +1443,7 @@ int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const 
     if (int e = ae2d_tiled_train(obs, packed, n, size, ap, aws, arows, agrad_scale, avalid, s)) return e;
     hipLaunchKernelGGL(rnd_ae_train_tail_kernel, dim3(9u + (unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, rrows, brows, rgrad,
                        arows, ae2d_tiled_train_rows(n, size), agrad, aws + kAeLutFloatsT + 128, abonus, reward, ascale, n, tiles,
-                       1.0f / ((float)size * (float)size));
+                       1.0f / ((float)size * (float)size), mom_partials, status);
     return check_launch("carle_rnd_ae_train(tiled)");
 }
 
@@ -1397,7 +1475,7 @@ bool rnd2d_tiled_applies(int h, int w) { return h == w && h > 64 && (h & 63) == 
 // workspace: the fused tables (kFusedWsTotal floats) + 32 partial sums per tile
 int64_t rnd2d_tiled_workspace_floats(int64_t n, int size) {
     const int64_t tiles = (int64_t)(size >> 6) * (size >> 6);
-    return kFusedWsTotal + n * tiles * 32;
+    return kFusedWsTotal + n * tiles * 32 + n;            // + one arrival counter per grid (RndTileFinish)
 }
 
 int rnd2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *ws,

@@ -59,15 +59,47 @@ __device__ __forceinline__ void rnd_bwd_linear_body(
 }
 
 // AE2D: bonus of grid g from its squared-error partials (fixed order), reward += scale * bonus (mcl.py:403-405, 504-512)
-__device__ __forceinline__ void ae_mse_finish_body(const float *__restrict__ partial, float *__restrict__ bonus,
-                                                   float *__restrict__ reward, float reward_scale, int64_t n, int chunks,
-                                                   float inv_pixels, int64_t g) {
-    if (g >= n) return;
+// (returns the reward it left, 0 without a reward vector or beyond the batch)
+__device__ __forceinline__ float ae_mse_finish_body(const float *__restrict__ partial, float *__restrict__ bonus,
+                                                    float *__restrict__ reward, float reward_scale, int64_t n, int chunks,
+                                                    float inv_pixels, int64_t g) {
+    if (g >= n) return 0.0f;
     float s = 0.0f;
     for (int c = 0; c < chunks; ++c) s += partial[g * chunks + c];
     const float b = s * inv_pixels;
     bonus[g] = b;
-    if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);      // mcl.py:403-405: product, then sum
+    if (!reward) return 0.0f;
+    const float r = reward_accumulate(reward[g], reward_scale, b);              // mcl.py:403-405: product, then sum
+    reward[g] = r;
+    return r;
+}
+
+// Reward moments of a step whose rewards are final only in a finish kernel (wrapper stacks): every workgroup of that kernel
+// leaves (sum, sum of squares) of the rewards it wrote, in fp64, in `partials[bidx]`, and workgroup 0 registers the pairs
+// in the status block (words CARLE_ST_MOM_*): the next launch on the status block -- the environment step of the next
+// step -- or carle_env_settle merges them into the running triple (settle_moments_wave, ca_cells.hpp), exactly as for
+// the one-launch RND2D step.  `part` = 16 pairs of LDS; every thread of the workgroup calls (has = it holds a reward).
+__device__ __forceinline__ void reward_moment_partials(double2 (&part)[16], bool has, float value, double *__restrict__ partials,
+                                                       int32_t *__restrict__ status, int bidx, int bcount, int64_t n) {
+    double sm = has ? (double)value : 0.0, q = sm * sm;
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) { sm += __shfl_xor(sm, k, 64); q += __shfl_xor(q, k, 64); }
+    const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) part[wv] = make_double2(sm, q);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < nw; ++i) { a += part[i].x; b += part[i].y; }
+        reinterpret_cast<double2 *>(partials)[bidx] = make_double2(a, b);
+        if (bidx == 0) {
+            uint4 w5;
+            w5.x = (uint32_t)reinterpret_cast<uint64_t>(partials);
+            w5.y = (uint32_t)(reinterpret_cast<uint64_t>(partials) >> 32);
+            w5.z = (uint32_t)bcount;
+            w5.w = (uint32_t)n;
+            reinterpret_cast<uint4 *>(status)[5] = w5;                  // CARLE_ST_MOM_PARTIALS / _COUNT / _N
+        }
+    }
 }
 
 }  // namespace carle

@@ -137,16 +137,19 @@ class RunningRewardStats:
         """Let the step epilogue of ``env`` feed these statistics: the kernel that finishes a step
         (master reset, counters, reward vector) also reduces the step's rewards and merges them
         into the pending triple, so ``after_step`` has nothing to launch.  ``env`` must be the
-        OUTERMOST environment the caller steps -- a bare ``CARLE`` (any storage), or an ``RND2D``
-        sitting directly on one (its bonus is part of the fused step) -- because the epilogue only
+        OUTERMOST environment the caller steps -- a bare ``CARLE`` (any storage), an ``RND2D``
+        sitting directly on one (its bonus is part of the fused step), or the pair ``AE2D(RND2D(CARLE))``
+        at tiled sizes (the pair's finish kernel leaves the partial sums) -- because the epilogue only
         sees the rewards that exist when it runs.  Returns False (and changes nothing) otherwise;
         ``after_step`` then falls back to the stand-alone moments kernel."""
         inner = getattr(env, "inner_env", None) or env
         if not hasattr(inner, "_install_reward_stats") or self.device.type != "cuda":
             return False
         if env is not inner:
-            from .mcl import RND2D
-            if type(env) is not RND2D or env.env is not inner or env.train_predictor:
+            from .mcl import RND2D, AE2D
+            # ... or the pair AE2D(RND2D(CARLE)) at tiled sizes, whose rewards are final in the pair's finish kernel
+            pair = type(env) is AE2D and env._can_pair_step() != 0
+            if not pair and (type(env) is not RND2D or env.env is not inner or env.train_predictor):
                 return False
         inner._install_reward_stats(self)
         env.__dict__["_final_reward_stats"] = self

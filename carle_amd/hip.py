@@ -205,7 +205,7 @@ def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False,
 
 
 def rnd_ae_bonus(obs, rnd_pred, rnd_rand, rnd_ws, rnd_bonus, rnd_scale, rnd_valid, ae_params, ae_ws, ae_bonus, ae_scale,
-                 ae_valid, reward, stream=None):
+                 ae_valid, reward, stream=None, partials=None, status=None):
     """Both bonuses of a stacked RND2D + AE2D pair in two launches (carle_rnd_ae_bonus): binary obs, fp32 (N,1,H,W) or
     int64 bit-packed, H == W a multiple of 64 above 64.  Workspaces must already have their full size."""
     lib = _lib.load()
@@ -217,15 +217,16 @@ def rnd_ae_bonus(obs, rnd_pred, rnd_rand, rnd_ws, rnd_bonus, rnd_scale, rnd_vali
         rc = lib.carle_rnd_ae_bonus(obs.data_ptr(), FMT_B1 if packed else FMT_F32, n, h, w, rnd_pred.data_ptr(),
                                     rnd_rand.data_ptr(), rnd_ws.data_ptr(), rnd_bonus.data_ptr(), float(rnd_scale),
                                     2 if rnd_valid else 0, ae_params.data_ptr(), ae_ws.data_ptr(), ae_bonus.data_ptr(),
-                                    float(ae_scale), 2 if ae_valid else 0, _ptr(reward),
+                                    float(ae_scale), 2 if ae_valid else 0, _ptr(reward), _ptr(partials), _ptr(status),
                                     stream if stream is not None else _stream(obs))
     if rc != 0:
         _lib.check(rc, "carle_rnd_ae_bonus")
 
 
 def rnd_ae_train(obs, rnd_pred, rnd_rand, rnd_ws, rnd_scratch, rnd_grad, rnd_bonus, rnd_scale, rnd_grad_scale, rnd_valid,
-                 ae_params, ae_ws, ae_scratch, ae_grad, ae_bonus, ae_scale, ae_grad_scale, ae_valid, reward, stream=None):
-    """Bonuses, reward updates and gradient accumulation of a stacked RND2D + AE2D pair in training mode, five launches
+                 ae_params, ae_ws, ae_scratch, ae_grad, ae_bonus, ae_scale, ae_grad_scale, ae_valid, reward, stream=None,
+                 partials=None, status=None):
+    """Bonuses, reward updates and gradient accumulation of a stacked RND2D + AE2D pair in training mode, four launches
     (carle_rnd_ae_train): binary obs, fp32 (N,1,H,W) or int64 bit-packed, H == W a multiple of 64 above 64.  Workspaces,
     scratch and gradient buffers must already have their full size."""
     lib = _lib.load()
@@ -239,7 +240,8 @@ def rnd_ae_train(obs, rnd_pred, rnd_rand, rnd_ws, rnd_scratch, rnd_grad, rnd_bon
                                     rnd_bonus.data_ptr(), float(rnd_scale), float(rnd_grad_scale), 2 if rnd_valid else 0,
                                     ae_params.data_ptr(), ae_ws.data_ptr(), ae_scratch.data_ptr(), ae_grad.data_ptr(),
                                     ae_bonus.data_ptr(), float(ae_scale), float(ae_grad_scale), 2 if ae_valid else 0,
-                                    _ptr(reward), stream if stream is not None else _stream(obs))
+                                    _ptr(reward), _ptr(partials), _ptr(status),
+                                    stream if stream is not None else _stream(obs))
     if rc != 0:
         _lib.check(rc, "carle_rnd_ae_train")
 

@@ -518,7 +518,9 @@ class RND2D(Motivator):
         if self._bonus_buf is None or self._bonus_buf.shape[0] != n or self._bonus_buf.device != dev:
             self._bonus_buf = torch.empty(n, dtype=torch.float32, device=dev)
         versions = (self._pred_blob.version,) if is_ae else (self._pred_blob.version, self._rand_blob.version)
-        key = (id(self._ws), versions)
+        # (n, size) belong to the key: the workspace of the paired training call also holds per-grid arrival counters,
+        # laid out by the batch geometry and zeroed whenever the tables are rebuilt (carle_rnd_ae_train)
+        key = (id(self._ws), versions, n, size)
         if is_ae:
             grad_scale = 2.0 / (size * size * n * self.batch_size)
         else:
@@ -769,8 +771,9 @@ class AE2D(RND2D):
             rnd._bonus_into(obs, reward)
             self._bonus_into(obs, reward)
             return obs, reward, done, info
+        partials, status = self._pair_moment_buffers(o.shape[0], o.device)
         if mode == 2:
-            return self._paired_train_step(o, obs, reward, done, info)
+            return self._paired_train_step(o, obs, reward, done, info, partials, status)
         from . import _lib
         lib = _lib.load()
         dev, n, size = o.device, o.shape[0], o.shape[2]
@@ -784,15 +787,36 @@ class AE2D(RND2D):
         rvalid = rnd._tables_valid(o, True, (rnd._pred_blob.version, rnd._rand_blob.version))
         avalid = self._tables_valid(o, True, (self._pred_blob.version,))
         hip.rnd_ae_bonus(o, pb, rb, rnd._ws, rnd._bonus_buf, rnd.reward_scale, rvalid, ab, self._ws, self._bonus_buf,
-                         self.reward_scale, avalid, reward)
+                         self.reward_scale, avalid, reward, partials=partials, status=status)
         rnd._commit_tables()
         self._commit_tables()
+        self._pair_moments_left(partials)
         return obs, reward, done, info
 
-    def _paired_train_step(self, o, obs, reward, done, info):
+    def _pair_moment_buffers(self, n, dev):
+        """RunningRewardStats attached to this pair (``attach``): the pair's finish kernel leaves per-workgroup partial sums
+        of the step's final rewards and registers them in the environment's status block; the next environment step (or
+        ``settled_status``) merges them -- no moments launch per step."""
+        if self.__dict__.get("_final_reward_stats") is None:
+            return None, None
+        from . import _lib
+        env = self.inner_env
+        need = _lib.load().carle_rnd_ae_partials_doubles(n)
+        partials = self.__dict__.get("_mom_partials")
+        if partials is None or partials.numel() < need or partials.device != dev:
+            env.settled_status()                             # nothing may still point into the old buffer
+            partials = self.__dict__["_mom_partials"] = torch.zeros(need, dtype=torch.float64, device=dev)
+        return partials, env._status
+
+    def _pair_moments_left(self, partials):
+        if partials is not None:
+            self.__dict__["_moments_merged"] = True
+            self.inner_env.__dict__["_moments_pending"] = True
+
+    def _paired_train_step(self, o, obs, reward, done, info, partials=None, status=None):
         """Training mode of the pair (train_mcl.py:64-69): what ``RND2D._bonus_into`` followed by ``AE2D._bonus_into``
         do -- window bookkeeping, bonus + reward + gradient accumulation, Adam at the end of each wrapper's window --
-        with the kernels of both wrappers in five launches (carle_rnd_ae_train) instead of nine.  Bit-identical."""
+        with the kernels of both wrappers in four launches (carle_rnd_ae_train) instead of nine.  Bit-identical."""
         rnd = self.env
         for w in (rnd, self):
             if w.buffer_length == 0:
@@ -802,8 +826,10 @@ class AE2D(RND2D):
         pb, rb, rvalid, rkey, rgs = rnd._tiled_train_buffers(o)
         ab, _, avalid, akey, ags = self._tiled_train_buffers(o)
         hip.rnd_ae_train(o, pb, rb, rnd._ws, rnd._partial, rnd._grad, rnd._bonus_buf, rnd.reward_scale, rgs, rvalid,
-                         ab, self._ws, self._partial, self._grad, self._bonus_buf, self.reward_scale, ags, avalid, reward)
+                         ab, self._ws, self._partial, self._grad, self._bonus_buf, self.reward_scale, ags, avalid, reward,
+                         partials=partials, status=status)
         rnd._tables_key, self._tables_key = rkey, akey
+        self._pair_moments_left(partials)
         for w in (rnd, self):
             w._grad_used = True
             w.buffer_length += 1

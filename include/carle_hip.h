@@ -362,12 +362,21 @@ int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const floa
 int carle_rnd_ae_bonus(const void *obs, int obs_fmt, int64_t n, int h, int w, const float *rnd_pred_params,
                        const float *rnd_rand_params, float *rnd_workspace, float *rnd_bonus, float rnd_scale,
                        int rnd_flags, const float *ae_params, float *ae_workspace, float *ae_bonus, float ae_scale,
-                       int ae_flags, float *reward_accum, void *stream);
+                       int ae_flags, float *reward_accum, double *moment_partials, int32_t *status, void *stream);
+/* moment_partials + status (both or neither; reward_accum required): the rewards are final in the finish kernel of these
+ * calls, so that kernel leaves per-workgroup (sum, sum of squares) pairs in moment_partials
+ * (carle_rnd_ae_partials_doubles(n) fp64 values) and registers them in the status block of the environment
+ * (CARLE_ST_MOM_*): the next launch on that block -- the next environment step -- or carle_env_settle merges them into the
+ * running reward moments (CARLE_ST_MOMENTS_*), as for the one-launch RND2D step.  The block's previous pairs must have
+ * been merged (any environment step or carle_env_settle since). */
+int64_t carle_rnd_ae_partials_doubles(int64_t n);
 
 /* The same stack in TRAINING mode (carle/train_mcl.py:34-38, 64-69; mcl.py:368-386, 521-547): both wrappers' bonuses, both
  * `reward += reward_scale * bonus` and the accumulation of both predictors' gradients for one step -- what
- * carle_rnd2d_train_* followed by carle_ae2d_train_* do -- in FIVE launches instead of nine (at the reference's default
- * geometry a step is a chain of dependent dispatches of 4-7 us each, whatever their size).  Binary observations, H == W a
+ * carle_rnd2d_train_* followed by carle_ae2d_train_* do -- in FOUR launches instead of nine (at the reference's default
+ * geometry a step is a chain of dependent dispatches of 4-7 us each, whatever their size; the workgroup that delivers the
+ * last tile of a grid finishes the grid).  CARLE_NET_TABLES_VALID in rnd_flags additionally promises that the previous
+ * call on rnd_workspace had the same (n, h, w): the workspace keeps per-grid arrival counters behind the tables.  Binary observations, H == W a
  * multiple of 64 above 64; rnd_scratch / ae_scratch: carle_rnd2d_train_scratch_floats / carle_ae2d_train_scratch_floats
  * floats; gradients are ADDED to rnd_grad / ae_grad (blob order); everything else as for the two per-net entry points,
  * results bit-identical to calling them one after the other. */
@@ -375,7 +384,8 @@ int carle_rnd_ae_train(const void *obs, int obs_fmt, int64_t n, int h, int w, co
                        const float *rnd_rand_params, float *rnd_workspace, float *rnd_scratch, float *rnd_grad,
                        float *rnd_bonus, float rnd_scale, float rnd_grad_scale, int rnd_flags, const float *ae_params,
                        float *ae_workspace, float *ae_scratch, float *ae_grad, float *ae_bonus, float ae_scale,
-                       float ae_grad_scale, int ae_flags, float *reward_accum, void *stream);
+                       float ae_grad_scale, int ae_flags, float *reward_accum, double *moment_partials, int32_t *status,
+                       void *stream);
 
 /* CARLE.step + the RND2D wrapper's bonus on the fresh observation (carle/env.py:188-242 +
  * carle/mcl.py:398-407) in one call.

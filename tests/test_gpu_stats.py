@@ -89,6 +89,50 @@ def test_step_epilogue_merges_reward_moments(kind):
     np.testing.assert_allclose(other.mean, float(reward.double().mean()), rtol=1e-9)
 
 
+@pytest.mark.parametrize("train,storage,size,n", [(False, "f32", 256, 16), (True, "f32", 256, 16), (False, "b1", 128, 37),
+                                                  (True, "f32", 128, 1030)])
+def test_pair_finish_kernel_leaves_the_reward_moments(train, storage, size, n):
+    """AE2D(RND2D(CARLE)) at tiled sizes: the rewards are final in the pair's finish kernel, which leaves their partial
+    sums for the next environment step to merge (carle_rnd_ae_bonus / carle_rnd_ae_train with moment_partials) -- the
+    statistics equal those of explicit update() calls, across reset() and a change of mode."""
+    from carle_amd import dist as cd
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D
+    torch.manual_seed(5)
+    env = CARLE(width=size, height=size, instances=n, device="cuda:0", storage=storage)
+    w = AE2D(RND2D(env, train_predictor=train), train_predictor=train)
+    w.env.batch_size = w.batch_size = 3
+    w.eval(); w.reset()
+    attached = cd.RunningRewardStats("cuda:0", sync_every=3)
+    explicit = cd.RunningRewardStats("cuda:0", sync_every=3)
+    assert attached.attach(w)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    env.universe = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+    rewards = []
+    for t in range(8):
+        if t == 5:
+            w.reset()
+        a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.2).float()
+        obs, reward, done, info = w.step(a)
+        assert w._moments_merged
+        attached.after_step(w, reward)
+        explicit.update(reward)
+        rewards.append(reward.detach().clone())
+    attached.flush(); explicit.flush()
+    allr = torch.cat(rewards).double().cpu().numpy().reshape(-1)
+    np.testing.assert_allclose([attached.count, attached.mean, attached.var],
+                               [allr.size, allr.mean(), allr.var()], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(attached.state.cpu().numpy(), explicit.state.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(attached.last_batch.cpu().numpy(), explicit.last_batch.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    # a step the pair cannot take (one wrapper training, the other not): the stand-alone moments kernel counts it
+    w.train_predictor = not train
+    obs, reward, done, info = w.step(torch.zeros(n, 1, 64, 64, device="cuda"))
+    assert not w._moments_merged
+    before = attached.count
+    attached.after_step(w, reward); attached.flush()
+    assert attached.count == before + n
+
+
 def test_attached_stats_with_fused_random_agent():
     """The in-kernel random-toggle step merges the moments too; a wrapper the epilogue cannot cover
     (here: logging, which falls back to the materialised action) still counts every step once."""
