@@ -774,10 +774,14 @@ class AE2D(RND2D):
         partials, status = self._pair_moment_buffers(o.shape[0], o.device)
         if mode == 2:
             return self._paired_train_step(o, obs, reward, done, info, partials, status)
-        from . import _lib
-        lib = _lib.load()
         dev, n, size = o.device, o.shape[0], o.shape[2]
-        for w, need in ((rnd, lib.carle_rnd2d_workspace_floats(n, size, size)), (self, lib.carle_ae2d_workspace_floats(n, size, size))):
+        needs = self.__dict__.get("_pair_needs")             # (n, size) -> workspace floats of both nets: one library
+        if needs is None or needs[0] != (n, size):           # call each per geometry, not per step (the step is host-bound)
+            from . import _lib
+            lib = _lib.load()
+            needs = self.__dict__["_pair_needs"] = ((n, size), lib.carle_rnd2d_workspace_floats(n, size, size),
+                                                    lib.carle_ae2d_workspace_floats(n, size, size))
+        for w, need in ((rnd, needs[1]), (self, needs[2])):
             if w._ws is None or w._ws.numel() < need or w._ws.device != dev:
                 w._ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
                 w._tables_key = None
@@ -799,9 +803,8 @@ class AE2D(RND2D):
         ``settled_status``) merges them -- no moments launch per step."""
         if self.__dict__.get("_final_reward_stats") is None:
             return None, None
-        from . import _lib
         env = self.inner_env
-        need = _lib.load().carle_rnd_ae_partials_doubles(n)
+        need = 2 * ((n + 15) // 16)                          # = carle_rnd_ae_partials_doubles(n)
         partials = self.__dict__.get("_mom_partials")
         if partials is None or partials.numel() < need or partials.device != dev:
             env.settled_status()                             # nothing may still point into the old buffer

@@ -1053,7 +1053,8 @@ def test_paired_rnd_ae_step_equals_the_two_wrappers(storage, size, n):
         assert float(r0.min()) > 0
 
 
-@pytest.mark.parametrize("storage,size,n,batch", [("f32", 256, 16, 3), ("f32", 128, 5, 2), ("b1", 256, 7, 3), ("f32", 512, 2, 4)])
+@pytest.mark.parametrize("storage,size,n,batch", [("f32", 256, 16, 3), ("f32", 128, 5, 2), ("b1", 256, 7, 3), ("f32", 512, 2, 4),
+                                                   ("f32", 128, 300, 2)])      # 1200 tiles on 1024 persistent workgroups
 def test_paired_rnd_ae_training_step_equals_the_two_wrappers(storage, size, n, batch):
     """AE2D(RND2D(CARLE)) at tiled sizes WITH predictor updates (train_mcl.py:34-38, 64-69): one carle_rnd_ae_train call
     (four launches) leaves bit-identical rewards, bonuses, gradient buffers and -- after the Adam steps at the end of the
