@@ -36,8 +36,12 @@ stats cfg5_b1 --format b1 --size 512 --instances 4096 --rule B36/S23 --steps 64 
 stats f32_256 --size 256 --steps 64 --warmup 8
 stats train_rnd_ae --rnd --ae --train --steps 256
 stats default_geom_rnd_ae --size 256 --instances 16 --rnd --ae --steps 64 --warmup 8
+stats default_geom_rnd_ae_train --size 256 --instances 16 --rnd --ae --train --steps 64 --warmup 8
 python3 $R/tools/train_kernel_time.py > $O/${TAG}_train_kernel_time.txt 2>&1
 python3 $R/tools/agent_time.py > $O/${TAG}_agent_net.txt 2>&1
+{ python3 $R/tools/kbench_b1.py 4096 512 0 0; python3 $R/tools/kbench_b1.py 8192 512 0 0; python3 $R/tools/kbench_b1.py 16384 256 0 0; } 2>&1 | grep -v amdgpu.ids > $O/${TAG}_kbench_b1_final.txt
+python3 $R/tools/profile_host.py --stack rnd+ae --size 256 --instances 16 --burst 200 2>&1 | grep -v amdgpu.ids > $O/${TAG}_host_default_geom.txt
+for i in 1 2 3; do python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{'; done > $O/${TAG}_driver_style_bench.json
 : > $O/${TAG}_pmc.txt
 pmc cfg2 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 4096 64 f32
 pmc cfg2_n65536 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 65536 64 f32 --instances 65536
