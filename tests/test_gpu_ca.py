@@ -569,5 +569,7 @@ def test_c_consumer_steps_on_the_gpu(tmp_path):
                     "-L", libdir, "-lcarle_hip", "-L", odir, "-lca_oracle", "-L", "/opt/rocm/lib", "-lamdhip64",
                     "-Wl,-rpath," + libdir, "-Wl,-rpath," + odir, "-Wl,-rpath,/opt/rocm/lib"],
                    check=True, capture_output=True, text=True)
-    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    # the consumer checks the default (one-launch, deferred) form of the step: no experiment knobs in its environment
+    child_env = {k: v for k, v in os.environ.items() if not k.startswith("CARLE_")}
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, env=child_env)
     assert out.returncode == 0 and "abi gpu ok" in out.stdout, out.stdout + out.stderr

@@ -18,6 +18,22 @@ from oracle import ca as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _one_launch_form(monkeypatch):
+    """These tests are about the one-launch step: an experiment knob that forces the two-launch form everywhere
+    (tools/test_all_paths.sh runs the suite under CARLE_TWO_LAUNCH_STEP=1) is lifted for their duration."""
+    import os
+    from carle_amd import hip
+    forced = os.environ.get("CARLE_TWO_LAUNCH_STEP")
+    if forced is not None:
+        monkeypatch.delenv("CARLE_TWO_LAUNCH_STEP")
+        hip.reload_knobs()
+    yield
+    if forced is not None:
+        monkeypatch.setenv("CARLE_TWO_LAUNCH_STEP", forced)
+        hip.reload_knobs()
+
+
 def _env(**kw):
     from carle_amd.env import CARLE
     return CARLE(device="cuda:0", **kw)
