@@ -89,6 +89,10 @@ def parse(argv=None):
     ap.add_argument("--separate-stats-kernel", action="store_true",
                     help="reduce the rewards with the stand-alone moments kernel every step instead of "
                          "inside the step epilogue (A/B switch)")
+    ap.add_argument("--replay", default="none", choices=["none", "calls", "graph"],
+                    help="replay the step instead of calling env.step: 'calls' = the recorded library calls of a step "
+                         "issued again (carle_amd.graphs.StepGraph backend='calls'), 'graph' = a HIP graph; both for "
+                         "forward-only stacks under the action ring.  Off by default: the headline is the eager surface")
     ap.add_argument("--repeats", type=int, default=0,
                     help="number of timed blocks of --steps steps (default: >= 5, until >= 50 ms are timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -485,8 +489,24 @@ def run_rank(args):
     if not args.separate_stats_kernel:
         stats.attach(wenv)
 
+    plan = None
+    if args.replay != "none":
+        if agent is not None or args.train or rs is not None:
+            raise SystemExit("--replay needs the action ring, no predictor updates and one stream")
+        from carle_amd.graphs import StepGraph
+        static = ring[0].clone()
+        plan = StepGraph(wenv, static, backend=args.replay)
+
     def one_step(i):
         action = ring[i % len(ring)] if agent is None else agent(env.universe)
+        if plan is not None:
+            if args.replay == "calls":
+                obs, reward, done, info = plan(action)
+            else:
+                static.copy_(action)
+                obs, reward, done, info = plan()
+            stats.after_step(wenv, reward)
+            return
         obs, reward, done, info = wenv.step(action)
         if rs is None:
             stats.after_step(wenv, reward)
@@ -650,6 +670,8 @@ def run_rank(args):
                        "instances_per_gpu": n, "height": size, "width": size,
                        "action": asize, "rule": args.rule, "sharding": f"batch x{world}",
                        "action_source": args.agent,
+                       "step_surface": {"none": "env.step (eager)", "calls": "recorded library calls of env.step, replayed",
+                                        "graph": "HIP graph of env.step"}[args.replay],
                        "reward_nets": ("RND2D" if args.rnd else "") + ("+AE2D" if args.ae else "") +
                                       ((" forward+backward, Adam every 64 steps" if args.train else " forward")
                                        if (args.rnd or args.ae) else ""),

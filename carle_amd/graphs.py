@@ -27,17 +27,64 @@ Contract (the usual one of graph replay):
     attached ``RunningRewardStats``.
   * The lookup tables of the reward nets are frozen into the capture ("tables valid"): when a predictor / random
     network parameter changes afterwards (``load_state_dict``, an optimiser step) the next call re-captures.
+
+``backend="calls"`` replays the step WITHOUT a HIP graph: the library calls one ``env.step`` makes (their ctypes
+functions and argument tuples) are recorded once per step parity and issued again -- a handful of ctypes calls per step,
+none of the Python of the wrappers.  hipGraphLaunch costs ~10 us per replay on this stack and loses against eager steps
+for most stacks (tools/graph_time.py); a recorded call list costs ~2 us per library call.  Same contract as above, plus:
+a step may only reach the device through the library (the capture verifies it: the replayed step must reproduce the
+eager step's observation and reward bit for bit, else the constructor raises), and the replays are enqueued on the
+stream that was current at capture.  ``plan(action)`` may pass a different action tensor of the captured shape per call
+(its pointer replaces the captured one): no copy into a static buffer.
 """
 import torch
 
 from . import hip
+from . import _lib
+
+# entry points that launch nothing (sizes, versions, errors): called during a step, not part of its replay
+_QUERIES = ("_floats", "_doubles", "carle_abi_version", "carle_last_error", "carle_build_arch", "carle_reload_knobs")
+
+
+# wrappers whose step reaches the device through the library only (backend="calls"; the capture also verifies it)
+_LIBRARY_ONLY_WRAPPERS = ("RND2D", "AE2D", "SpeedDetector", "PufferDetector")
+
+
+class _CallRecorder:
+    """While active, every launching entry point of the library records (function, arguments) before it runs."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __enter__(self):
+        lib = self._lib = _lib.load()
+        self._saved = {}
+        for name in _lib.SIGNATURES:
+            fn = getattr(lib, name)
+            self._saved[name] = fn
+            if name.endswith(_QUERIES[:2]) or name in _QUERIES:
+                continue
+
+            def proxy(*args, _fn=fn):
+                self.calls.append((_fn, args))
+                return _fn(*args)
+            lib.__dict__[name] = proxy
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved.items():
+            self._lib.__dict__[name] = fn
+        return False
 
 
 class StepGraph:
     check_params = True        # compare the reward nets' parameter versions every call (a few us per wrapper)
 
-    def __init__(self, env, action):
+    def __init__(self, env, action, backend="graph"):
         hip.require_gpu()
+        if backend not in ("graph", "calls"):
+            raise ValueError("backend must be 'graph' or 'calls'")
+        self.backend = backend
         base = env if getattr(env, "inner_env", None) is None else env.inner_env
         if getattr(action, "materialize", None) is not None:
             raise TypeError("a fused RandomAgent action cannot be captured (its Philox offset is a kernel "
@@ -54,6 +101,9 @@ class StepGraph:
             if getattr(w, "async_reward", False):
                 raise NotImplementedError("async_reward=True forks to a second stream per step; capture the "
                                           "same-stream form")
+            if backend == "calls" and type(w).__name__ not in _LIBRARY_ONLY_WRAPPERS:
+                raise NotImplementedError(f"{type(w).__name__}.step also launches torch kernels: its step is not made of "
+                                          "library calls alone -- use backend='graph'")
             w = w.env
         self.env, self.base, self.action = env, base, action
         self._graphs = None
@@ -96,6 +146,7 @@ class StepGraph:
         side_before = self._side_state()
         side_keep = {id(t): t.clone() for t in side_before}
         self._bufs = [torch.empty_like(state), torch.empty_like(state)]
+        self.__dict__["_mem_pools"] = []                # (a re-capture releases the previous recording's pools)
         self._rule = base.rule_mask()
         # warm-up on a side stream: lazy initialisation (tables, workspaces, parameter blobs) must not be captured
         side = torch.cuda.Stream(device=state.device)
@@ -111,14 +162,26 @@ class StepGraph:
             base._set_raw_state(self._bufs[p])
             base._slot = p
             base.__dict__["_out_override"] = self._bufs[p ^ 1]
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                result = env.step(self.action)
+            if self.backend == "graph":
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    result = env.step(self.action)
+                pool = g.pool()
+            else:
+                # every tensor the step allocates (bonus vectors, sums, the reward) comes from a private memory pool that
+                # lives as long as the recording: the recorded pointers stay valid and nobody else is handed the blocks
+                mpool = torch.cuda.MemPool()
+                self.__dict__.setdefault("_mem_pools", []).append(mpool)
+                with torch.cuda.use_mem_pool(mpool, device=state.device), _CallRecorder() as rec:
+                    result = env.step(self.action)
+                aptr = self.action.data_ptr()          # (function, arguments, positions of the action pointer)
+                g = [(fn, args, tuple(i for i, a in enumerate(args) if a == aptr)) for fn, args in rec.calls]
             if base.__dict__.pop("_out_override", None) is not None or base._raw_state() is not self._bufs[p ^ 1]:
                 raise RuntimeError("the captured step did not write the graph's state buffer")
-            pool = g.pool()
-            graphs.append((g, result, base.__dict__.get("_moments_merged", False)))
+            graphs.append((g, result, base.__dict__.get("_moments_merged", False),
+                           env.__dict__.get("_moments_merged", False), base.__dict__.get("_moments_pending", False)))
         self._graphs = graphs
+        self._action_ptr = self.action.data_ptr()
         self._params = self._param_key()
         # back to where the caller was: wrapper state that existed before is restored, state the warm-up created
         # (lazily allocated histories) starts empty
@@ -131,11 +194,48 @@ class StepGraph:
         base._slot = keep_slot
         self._bufs[keep_slot].copy_(keep_state)
         base._set_raw_state(self._bufs[keep_slot])
+        if self.backend == "calls":
+            self._verify_calls(keep_state, keep_status, keep_slot, side_keep)
+
+    def _verify_calls(self, keep_state, keep_status, keep_slot, side_keep):
+        """The recorded calls must BE the step: an eager step and a replayed one from the same state agree bit for bit in
+        observation and reward (a wrapper that also launches torch kernels in its step would not)."""
+        env, base = self.env, self.base
+
+        def restore():
+            for t in self._side_state():
+                if id(t) in side_keep:
+                    t.copy_(side_keep[id(t)])
+                else:
+                    t.zero_()
+            base._status.copy_(keep_status)
+            base._slot = keep_slot
+            self._bufs[keep_slot].copy_(keep_state)
+            base._set_raw_state(self._bufs[keep_slot])
+
+        # ... with an action that toggles something: the action must reach the library as it is (a storage whose step
+        # converts the action with torch operations first would replay the conversion's stale result)
+        keep_action = self.action.clone()
+        gen = torch.Generator(device=self.action.device).manual_seed(7)
+        self.action.copy_((torch.rand(self.action.shape, device=self.action.device, generator=gen) < 0.3).to(self.action.dtype))
+        base.__dict__["_out_override"] = self._bufs[keep_slot ^ 1]
+        obs, reward = env.step(self.action)[:2]
+        base.__dict__.pop("_out_override", None)
+        want = (obs.clone(), reward.clone())
+        restore()
+        obs, reward = self._replay(keep_slot, self._action_ptr)[:2]
+        same = torch.equal(obs, want[0]) and torch.equal(reward, want[1])
+        restore()
+        self.action.copy_(keep_action)
+        if not same:
+            raise NotImplementedError("this step is not made of library calls alone (a wrapper or the action / observation "
+                                      "conversion of this storage launches torch kernels per step): use backend='graph'")
 
     # ------------------------------------------------------------------ replay
-    def __call__(self):
+    def __call__(self, action=None):
         """One ``env.step(action)`` with the action buffer's current contents; returns the captured call's
-        ``(obs, reward, done, info)`` objects."""
+        ``(obs, reward, done, info)`` objects.  backend="calls": ``action`` may be another device tensor of the captured
+        shape and dtype (used in place, no copy)."""
         base = self.base
         if base.rule_mask() != self._rule or (self.check_params and self._param_key() != self._params):
             self._capture()
@@ -144,12 +244,41 @@ class StepGraph:
         state = base._raw_state()
         if state is not buf:                            # reset(), an assigned pattern, eager steps in between
             buf.copy_(state)
-        g, result, merged = self._graphs[p]
-        g.replay()
+        if action is None or action is self.action:
+            act, ptr = self.action, self._action_ptr
+        else:
+            if self.backend != "calls":
+                raise TypeError("a HIP graph replays its static action buffer: copy the action into it")
+            if action.shape != self.action.shape or action.dtype != self.action.dtype or action.device != self.action.device \
+                    or not action.is_contiguous():
+                raise ValueError("action must match the captured action tensor (shape, dtype, device, contiguous)")
+            act, ptr = action, action.data_ptr()
+        result = self._replay(p, ptr)
+        base.action = act
+        return result
+
+    def _replay(self, p, action_ptr):
+        base = self.base
+        g, result, merged, outer_merged, pending = self._graphs[p]
+        if self.backend == "graph":
+            g.replay()
+        else:
+            swap = action_ptr != self._action_ptr
+            for fn, args, where in g:
+                if swap and where:
+                    args = list(args)
+                    for i in where:
+                        args[i] = action_ptr
+                rc = fn(*args)
+                if rc:
+                    _lib.check(rc, getattr(fn, "__name__", "library call"))
         base._set_raw_state(self._bufs[p ^ 1])
         base._slot = p ^ 1
-        base.action = self.action
         base._moments_merged = merged
+        if self.env is not base:
+            self.env.__dict__["_moments_merged"] = outer_merged
+        if pending:
+            base.__dict__["_moments_pending"] = True
         return result
 
     step = __call__

@@ -137,8 +137,9 @@ def test_eval_stack_steps_without_host_synchronisation(n, size):
     assert torch.isfinite(trace).all() and len(w.cells) <= w.growth_threshold
 
 
+@pytest.mark.parametrize("backend", ["graph", "calls"])
 @pytest.mark.parametrize("n,size", [(3, 64), (16, 256)])
-def test_step_graph_replays_the_evaluation_stack(n, size):
+def test_step_graph_replays_the_evaluation_stack(n, size, backend):
     """StepGraph accepts SpeedDetector / PufferDetector: graph replay == eager loop for the whole eval.py stack,
     rewards, centre of mass, speed, growth history and counters."""
     from carle_amd.graphs import StepGraph
@@ -151,11 +152,13 @@ def test_step_graph_replays_the_evaluation_stack(n, size):
         env, w = _eval_stack(n, size)
         env.universe = u0.clone()
         static = torch.zeros_like(acts[0])
-        graph = StepGraph(w, static) if mode == "graph" else None
+        graph = StepGraph(w, static, backend=backend) if mode == "graph" else None
         out = []
         for a in acts:
             if graph is None:
                 o, r, d, i = w.step(a)
+            elif backend == "calls":
+                o, r, d, i = graph(a)                       # the recorded calls take the action tensor as it is
             else:
                 static.copy_(a)
                 o, r, d, i = graph()
@@ -246,7 +249,8 @@ def test_train_and_evaluate_loops(tmp_path):
     ("f32", 3, 64, False), ("f32", 1, 64, False), ("f32", 16, 256, True), ("f32", 5, 64, True),
     ("u8", 3, 64, False), ("b1", 2, 128, False), ("u8", 2, 256, True),
 ])
-def test_step_graph_replays_eager_steps(storage, n, size, stack):
+@pytest.mark.parametrize("backend", ["graph", "calls"])
+def test_step_graph_replays_eager_steps(storage, n, size, stack, backend):
     """carle_amd.graphs.StepGraph: a HIP graph of env.step(action) gives the eager loop's observations, rewards and
     counters -- bare CARLE in every storage, and the RND2D + AE2D + CornerBonus stack (forward only); survives
     reset(), an assigned universe, an eager step in between, a master reset and a rule change."""
@@ -291,8 +295,22 @@ def test_step_graph_replays_eager_steps(storage, n, size, stack):
     ref = drive(ref_env, ref_env.step, None)
     env = make()
     static = torch.zeros_like(acts[0])
-    graph = StepGraph(env, static)
-    got = drive(env, lambda a: graph(), static)
+    if backend == "calls" and storage == "u8":
+        # uint8 state with fp32 actions / observations: the conversions are torch kernels, not library calls
+        with pytest.raises(NotImplementedError):
+            StepGraph(env if not stack else env.env, static, backend="calls")
+        return
+    if backend == "calls" and stack:
+        # CornerBonus adds its terms with torch operations: not a step made of library calls alone -- refused at
+        # construction (the replayed step would not reproduce the eager one); without it the stack replays
+        with pytest.raises(NotImplementedError):
+            StepGraph(env, static, backend="calls")
+        env = env.env
+    graph = StepGraph(env, static, backend=backend)
+    if backend == "calls" and stack:
+        ref_env = make().env
+        ref = drive(ref_env, ref_env.step, None)
+    got = drive(env, (lambda a: graph(a)) if backend == "calls" else (lambda a: graph()), None if backend == "calls" else static)
     for t, ((o0, r0, s0, a0), (o1, r1, s1, a1)) in enumerate(zip(ref, got)):
         assert torch.equal(o0, o1), t
         assert torch.allclose(r0, r1, atol=1e-6, rtol=0), (t, (r0 - r1).abs().max())

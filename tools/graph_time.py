@@ -37,7 +37,8 @@ for name, n, size, stack, storage in (("configs[0]: N=1 64x64", 1, 64, False, "f
                                       ("N=4096 64x64 uint8", 4096, 64, False, "u8"),
                                       ("reference default: N=16 256x256", 16, 256, False, "f32"),
                                       ("N=16 256x256 + RND2D + AE2D (forward)", 16, 256, True, "f32"),
-                                      ("N=16 64x64 + RND2D + AE2D (forward)", 16, 64, True, "f32")):
+                                      ("N=16 64x64 + RND2D + AE2D (forward)", 16, 64, True, "f32"),
+                                      ("configs[1]: N=4096 64x64", 4096, 64, False, "f32")):
     torch.manual_seed(0)
     env = CARLE(instances=n, width=size, height=size, device="cuda:0", storage=storage)
     if stack:
@@ -65,5 +66,18 @@ for name, n, size, stack, storage in (("configs[0]: N=1 64x64", 1, 64, False, "f
 
     t_g = timed(replay, 2000)
     t_i = timed(replay_inplace, 2000)
+    # the recorded library calls of a step issued again (backend="calls"): a fresh action tensor per call, no copy
+    t_c = float("nan")
+    try:
+        env.reset()
+        plan = StepGraph(env, static, backend="calls")
+
+        def replay_calls():
+            i[0] += 1
+            plan(ring[i[0] % 6])
+
+        t_c = timed(replay_calls, 2000)
+    except NotImplementedError:
+        pass
     print(f"{name:45s} eager {t_e * 1e6:7.1f} us/step ({n / t_e:9.3e} env-steps/s) | graph + action copy {t_g * 1e6:7.1f} us "
-          f"| graph {t_i * 1e6:7.1f} us ({n / t_i:9.3e} env-steps/s)", flush=True)
+          f"| graph {t_i * 1e6:7.1f} us | recorded calls {t_c * 1e6:7.1f} us ({n / t_c:9.3e} env-steps/s)", flush=True)
