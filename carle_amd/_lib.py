@@ -43,7 +43,7 @@ SIGNATURES = {
                                       _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_vp]),
     "carle_rnd_ae_bonus": (_c_int, [_c_vp, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int,
                                     _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
-    "carle_rnd_ae_partials_doubles": (_c_i64, [_c_i64]),
+    "carle_rnd_ae_partials_doubles": (_c_i64, [_c_i64, _c_int, _c_int]),
     "carle_rnd_ae_train": (_c_int, [_c_vp, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                     ctypes.c_float, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                     ctypes.c_float, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),

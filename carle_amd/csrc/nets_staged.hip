@@ -482,6 +482,7 @@ namespace carle {
 int rnd_ae_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws, float *rbonus,
                  float rscale, bool rnd_tables_valid, const float *ap, float *aws, float *abonus, float ascale,
                  bool ae_tables_valid, float *reward, double *mom_partials, int32_t *status, hipStream_t s);
+int64_t rnd_ae_tiled_blocks(int64_t n, int size);
 int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws,
                        float *rscratch, float *rgrad, float *rbonus, float rscale, float rgrad_scale, bool rvalid,
                        const float *ap, float *aws, float *arows, float *agrad, float *abonus, float ascale, float agrad_scale,
@@ -489,7 +490,7 @@ int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const 
 }
 
 // RND2D.get_bonus AND AE2D.get_bonus of the same observations (carle/mcl.py:343-352, 504-512) + both wrappers' reward
-// updates (mcl.py:403-405, RND2D first) in two launches: binary observations, H == W a multiple of 64 above 64 (the tiled
+// updates (mcl.py:403-405, RND2D first) in one launch: binary observations, H == W a multiple of 64 above 64 (the tiled
 // kernels; the reference's default 256x256).  obs_fmt: CARLE_FMT_F32 (values exactly 0 / 1) or CARLE_FMT_B1.
 // Workspaces, parameter blobs, bonuses and TABLES_VALID flags exactly as for carle_rnd2d_bonus_* / carle_ae2d_bonus_*.
 extern "C" int carle_rnd_ae_bonus(const void *obs, int obs_fmt, int64_t n, int h, int w, const float *rnd_pred_params,
@@ -515,7 +516,11 @@ extern "C" int carle_rnd_ae_bonus(const void *obs, int obs_fmt, int64_t n, int h
 
 // fp64 values behind `moment_partials` of the two entry points around this one (one (sum, sum of squares) pair per
 // workgroup of their finish kernels)
-extern "C" int64_t carle_rnd_ae_partials_doubles(int64_t n) { return n < 0 ? 0 : 2 * ((n + 15) / 16); }
+extern "C" int64_t carle_rnd_ae_partials_doubles(int64_t n, int h, int w) {
+    if (n < 0 || !rnd2d_tiled_applies(h, w)) return 0;
+    const int64_t fwd = rnd_ae_tiled_blocks(n, h), train = (n + 1023) / 1024;
+    return 2 * (fwd > train ? fwd : train);
+}
 
 // The same stack in TRAINING mode (carle/train_mcl.py:34-38, 64-69): both wrappers' bonuses, reward updates and the
 // accumulation of both predictors' gradients of one step -- what carle_rnd2d_train_* followed by carle_ae2d_train_* do --

@@ -181,6 +181,91 @@ struct RndTileFinish {
     float reward_scale = 0.0f;
 };
 
+// The forward pair AE2D(RND2D(env)) without a finish launch: both nets' tile workgroups count their arrivals per grid;
+// the workgroup that delivers the LAST of a grid's 2 x tiles tiles forms both bonuses and the reward (the arithmetic of
+// rnd_ae_finish_kernel, agent-scope loads of the partial sums) and keeps (sum, sum of squares) of the rewards it formed for
+// the reward moments (one pair per workgroup of the launch, registered in the status block by workgroup 0).
+struct PairFinish {
+    int32_t *counters = nullptr;                     // n ints, zero before the launch and zero again behind it
+    const float *rpartial = nullptr, *apartial = nullptr, *pp = nullptr, *rp = nullptr;
+    float *rbonus = nullptr, *abonus = nullptr, *reward = nullptr;
+    float rscale = 0.0f, ascale = 0.0f, inv_pixels = 0.0f;
+    int dfeat = 0;
+    double *mom_partials = nullptr;
+    int32_t *status = nullptr;
+};
+
+// lanes 0..15 of wave 0; returns the final reward of grid g in lane 0
+__device__ __forceinline__ float pair_finish_grid(const PairFinish &f, int64_t g, int k, int tiles) {
+#pragma clang fp contract(off)                          // as rnd_finish_grid / rnd_ae_finish_kernel: bit-identical
+    auto ld = [](const float *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    float p = 0.0f, r = 0.0f, ae = 0.0f;
+    for (int t0 = 0; t0 < tiles; t0 += 16) {
+        float a[16], b[16], c[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = t0 + i < tiles ? t0 + i : tiles - 1;
+            a[i] = ld(f.rpartial + ((g * tiles + t) * 2 + 0) * 16 + k);
+            b[i] = ld(f.rpartial + ((g * tiles + t) * 2 + 1) * 16 + k);
+            c[i] = k == 0 ? ld(f.apartial + g * tiles + t) : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (t0 + i < tiles) { p += a[i]; r += b[i]; if (k == 0) ae += c[i]; }
+    }
+    p = tanhf(p + f.pp[77 + (int64_t)16 * f.dfeat + k]);
+    r = tanhf(r + f.rp[39 + (int64_t)16 * f.dfeat + k]);
+    float sq = (r - p) * (r - p);
+    sq += dpp_quad_xor1(sq);
+    sq += dpp_quad_xor2(sq);
+    sq += dpp_row_ror(sq, 0x124);
+    sq += dpp_row_ror(sq, 0x128);
+    float x = 0.0f;
+    if (k == 0) {
+        const float br = sq * (1.0f / 16.0f), ba = ae * f.inv_pixels;
+        f.rbonus[g] = br;
+        f.abonus[g] = ba;
+        if (f.reward) {
+            x = f.reward[g];
+            x = reward_accumulate(x, f.rscale, br);          // RND2D.step, then AE2D.step (mcl.py:403-405)
+            x = reward_accumulate(x, f.ascale, ba);
+            f.reward[g] = x;
+        }
+    }
+    return x;
+}
+
+// behind a tile of grid g whose partial sums went out as agent-scope stores: ticket, and the grid's finish by the last
+// arrival.  `last` = a word of LDS; `acc` (thread 0) gathers the rewards this workgroup formed.  Every thread calls.
+__device__ __forceinline__ void pair_ticket(const PairFinish &f, int &last, int64_t g, int tiles, int tid, double2 &acc) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        last = __hip_atomic_fetch_add(f.counters + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2 * tiles - 1;
+    __syncthreads();
+    if (last) {                                          // workgroup-uniform
+        if (tid < 16) {
+            const float r = pair_finish_grid(f, g, tid, tiles);
+            if (tid == 0 && f.reward) { acc.x += (double)r; acc.y = fma((double)r, (double)r, acc.y); }
+        }
+        if (tid == 0) __hip_atomic_store(f.counters + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// at the end of a workgroup of the pair launch: its pair of reward sums, and the registration by workgroup 0
+__device__ __forceinline__ void pair_leave_moments(const PairFinish &f, int tid, const double2 &acc, int64_t n) {
+    if (tid != 0 || !f.mom_partials || !f.status || !f.reward) return;
+    reinterpret_cast<double2 *>(f.mom_partials)[blockIdx.x] = acc;
+    if (blockIdx.x == 0) {
+        uint4 w5;
+        w5.x = (uint32_t)reinterpret_cast<uint64_t>(f.mom_partials);
+        w5.y = (uint32_t)(reinterpret_cast<uint64_t>(f.mom_partials) >> 32);
+        w5.z = gridDim.x;
+        w5.w = (uint32_t)n;
+        reinterpret_cast<uint4 *>(f.status)[5] = w5;                  // CARLE_ST_MOM_PARTIALS / _COUNT / _N
+    }
+}
+
 // PACKED: obs = bit-packed grids (H rows of W/64 words); else fp32 (N,1,H,W), any non-zero number = alive
 // (body as a device function: the stand-alone kernel below and the launch that runs the RND2D and AE2D tiles of a
 // wrapper stack side by side, rnd_ae_tile_kernel, call it with their own workgroup index / count)
@@ -189,8 +274,9 @@ __device__ __forceinline__ void rnd_tile_body(RndTileShared &s, const void *__re
                                               const float *__restrict__ pp, const float *__restrict__ rp,
                                               float *__restrict__ partial, float *__restrict__ featbuf,
                                               int64_t n, int size, unsigned bid, unsigned nblk,
-                                              const RndTileFinish fin = RndTileFinish()) {
+                                              const RndTileFinish fin = RndTileFinish(), const PairFinish pf = PairFinish()) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double2 mom_acc = make_double2(0.0, 0.0);           // PairFinish: rewards this workgroup formed (thread 0)
     rnd_block_init(s.net, ws, tid);
     const int tps = size >> 6, tiles = tps * tps;      // tiles per side / per grid
     const int d8 = size >> 3, dfeat = d8 * d8;          // feature columns per row / per net
@@ -278,10 +364,12 @@ __device__ __forceinline__ void rnd_tile_body(RndTileShared &s, const void *__re
             acc += dpp_quad_xor2(acc);
             acc += __shfl_xor(acc, 4, 64);
             if (fy == 0) {
-                if (fin.counters) __hip_atomic_store(partial + (t * 2 + net) * 16 + k, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fin.counters || pf.counters)
+                    __hip_atomic_store(partial + (t * 2 + net) * 16 + k, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else partial[(t * 2 + net) * 16 + k] = acc;
             }
         }
+        if (pf.counters) pair_ticket(pf, s.last, g, tiles, tid, mom_acc);     // kernel argument: workgroup-uniform
         if (fin.counters) {                             // kernel argument: the same for every workgroup
             // The tile's partial sums went out as agent-scope stores (written through to where every XCD reads them);
             // once they are acknowledged the workgroup takes its ticket.  No fences: an agent-scope fence writes back and
@@ -300,6 +388,7 @@ __device__ __forceinline__ void rnd_tile_body(RndTileShared &s, const void *__re
         }
         // rows / planes / feat are rewritten behind the next iteration's barriers
     }
+    if (pf.counters) pair_leave_moments(pf, tid, mom_acc, n);
 }
 
 template <bool PACKED>
@@ -617,6 +706,7 @@ struct AeTileShared {
     float a2[2 * kT2Plane];
     uint64_t rows[kAeRows + 2][2];
     float red[4];
+    int last;                          // PairFinish: this workgroup delivered the last tile of its grid
 };
 
 // 4 bits of a 78-bit row starting at local column c (0 <= c <= 74)
@@ -630,8 +720,10 @@ __device__ __forceinline__ float tile_sigmoid(float x) { return __frcp_rn(1.0f +
 template <bool PACKED>
 __device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__restrict__ obs_v, const float *__restrict__ ws,
                                              float *__restrict__ partial, float *__restrict__ recon,
-                                             int64_t n, int size, unsigned bid, unsigned nblk) {
+                                             int64_t n, int size, unsigned bid, unsigned nblk,
+                                             const PairFinish pf = PairFinish()) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double2 mom_acc = make_double2(0.0, 0.0);           // PairFinish: rewards this workgroup formed (thread 0)
     {
         const float4 *src = reinterpret_cast<const float4 *>(ws);
         lds_copy_f4<512, 256>(s.lut, src, tid);
@@ -852,8 +944,14 @@ __device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__rest
         if (lane == 0) s.red[wv] = sq;
         __syncthreads();                               // also: rows / A3 reads done before the next tile
         AE_W_HERE();
-        if (tid == 0) partial[t] = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+        if (tid == 0) {
+            const float sum = (s.red[0] + s.red[1]) + (s.red[2] + s.red[3]);
+            if (pf.counters) __hip_atomic_store(partial + t, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else partial[t] = sum;
+        }
+        if (pf.counters) pair_ticket(pf, s.last, g, tiles, tid, mom_acc);     // kernel argument: workgroup-uniform
     }
+    if (pf.counters) pair_leave_moments(pf, tid, mom_acc, n);
 }
 
 template <bool PACKED>
@@ -866,7 +964,7 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
 
 // ---------------------------------------------------------------------------------------------------------------
 // RND2D + AE2D forward of a wrapper stack (AE2D(RND2D(env)), carle/train_mcl.py:34-38, evaluation/eval.py:83-85) in
-// TWO launches instead of four: both nets read the same observation, so the tile workgroups of both run side by side
+// ONE launch instead of four (rnd_ae_finish_kernel: the finish as a launch of its own, kept as the reference form): both nets read the same observation, so the tile workgroups of both run side by side
 // in one launch -- workgroups [0, rnd_blocks) walk the RND2D tiles, the others the AE2D tiles, each with its own
 // barriers and LDS image -- and one finish kernel forms both bonuses and adds them to the reward in the wrappers'
 // order (reward += s_rnd * b_rnd, then += s_ae * b_ae: mcl.py:403-405 twice).  At the reference's default batch
@@ -882,12 +980,12 @@ __global__ __launch_bounds__(256, 4) void rnd_ae_tile_kernel(const void *__restr
                                                              const float *__restrict__ pp, const float *__restrict__ rp,
                                                              float *__restrict__ rpartial, const float *__restrict__ aws,
                                                              float *__restrict__ apartial, int64_t n, int size,
-                                                             unsigned rnd_blocks) {
+                                                             unsigned rnd_blocks, const PairFinish pf = PairFinish()) {
     __shared__ RndAeTileShared s;
     if (blockIdx.x < rnd_blocks)
-        rnd_tile_body<PACKED>(s.r, obs_v, rws, pp, rp, rpartial, nullptr, n, size, blockIdx.x, rnd_blocks);
+        rnd_tile_body<PACKED>(s.r, obs_v, rws, pp, rp, rpartial, nullptr, n, size, blockIdx.x, rnd_blocks, RndTileFinish(), pf);
     else
-        ae_tile_body<PACKED>(s.a, obs_v, aws, apartial, nullptr, n, size, blockIdx.x - rnd_blocks, gridDim.x - rnd_blocks);
+        ae_tile_body<PACKED>(s.a, obs_v, aws, apartial, nullptr, n, size, blockIdx.x - rnd_blocks, gridDim.x - rnd_blocks, pf);
 }
 
 // 16 threads per grid (as rnd_tile_finish_kernel); thread 0 of a grid also adds the AE2D tiles' squared errors
@@ -937,6 +1035,12 @@ __global__ __launch_bounds__(256) void rnd_ae_finish_kernel(const float *__restr
 void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
 
 // both wrappers' bonuses of one observation batch; workspaces as rnd2d_tiled / ae2d_tiled use them
+// workgroups of the forward pair launch (= reward-moment pairs it leaves)
+int64_t rnd_ae_tiled_blocks(int64_t n, int size) {
+    const int64_t total = n * (int64_t)(size >> 6) * (size >> 6);
+    return (total < 1024 ? total : 1024) + (total < 16384 ? total : 16384);
+}
+
 int rnd_ae_tiled(const void *obs, bool packed, int64_t n, int size, const float *pp, const float *rp, float *rws, float *rbonus,
                  float rscale, bool rnd_tables_valid, const float *ap, float *aws, float *abonus, float ascale,
                  bool ae_tables_valid, float *reward, double *mom_partials, int32_t *status, hipStream_t s) {
@@ -947,13 +1051,26 @@ int rnd_ae_tiled(const void *obs, bool packed, int64_t n, int size, const float 
     if ((n + 15) / 16 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_rnd_ae_bonus: batch too large");
     const unsigned rb = (unsigned)(total < 1024 ? total : 1024), ab = (unsigned)(total < 16384 ? total : 16384);
     float *rpartial = rws + kFusedWsTotal, *apartial = aws + kAeLutFloatsT + 128;
-    if (packed)
-        hipLaunchKernelGGL(rnd_ae_tile_kernel<true>, dim3(rb + ab), dim3(256), 0, s, obs, rws, pp, rp, rpartial, aws, apartial, n, size, rb);
-    else
-        hipLaunchKernelGGL(rnd_ae_tile_kernel<false>, dim3(rb + ab), dim3(256), 0, s, obs, rws, pp, rp, rpartial, aws, apartial, n, size, rb);
     const int d8 = size >> 3;
-    hipLaunchKernelGGL(rnd_ae_finish_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, rpartial, pp, rp, rbonus, apartial,
-                       abonus, reward, rscale, ascale, n, tiles, d8 * d8, 1.0f / ((float)size * (float)size), mom_partials, status);
+    // ONE launch: the workgroup that delivers the last of a grid's 2 x tiles tiles finishes the grid (PairFinish).  The
+    // arrival counters live behind the RND2D partial sums: zero whenever the RND2D tables are (re)built -- TABLES_VALID
+    // promises the workspace of a finished call with the same parameters AND the same (n, size) -- and zero again
+    // behind every launch.
+    PairFinish pf;
+    pf.counters = reinterpret_cast<int32_t *>(rpartial + total * 32);
+    pf.rpartial = rpartial; pf.apartial = apartial; pf.pp = pp; pf.rp = rp;
+    pf.rbonus = rbonus; pf.abonus = abonus; pf.reward = reward;
+    pf.rscale = rscale; pf.ascale = ascale; pf.inv_pixels = 1.0f / ((float)size * (float)size);
+    pf.dfeat = d8 * d8;
+    pf.mom_partials = mom_partials; pf.status = status;
+    if (!rnd_tables_valid) {
+        if (hipError_t e = hipMemsetAsync(pf.counters, 0, (size_t)n * sizeof(int32_t), s); e != hipSuccess)
+            return fail_hip(e, "carle_rnd_ae_bonus: hipMemsetAsync");
+    }
+    if (packed)
+        hipLaunchKernelGGL(rnd_ae_tile_kernel<true>, dim3(rb + ab), dim3(256), 0, s, obs, rws, pp, rp, rpartial, aws, apartial, n, size, rb, pf);
+    else
+        hipLaunchKernelGGL(rnd_ae_tile_kernel<false>, dim3(rb + ab), dim3(256), 0, s, obs, rws, pp, rp, rpartial, aws, apartial, n, size, rb, pf);
     return check_launch("carle_rnd_ae_bonus(tiled)");
 }
 

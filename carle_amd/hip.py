@@ -206,7 +206,7 @@ def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False,
 
 def rnd_ae_bonus(obs, rnd_pred, rnd_rand, rnd_ws, rnd_bonus, rnd_scale, rnd_valid, ae_params, ae_ws, ae_bonus, ae_scale,
                  ae_valid, reward, stream=None, partials=None, status=None):
-    """Both bonuses of a stacked RND2D + AE2D pair in two launches (carle_rnd_ae_bonus): binary obs, fp32 (N,1,H,W) or
+    """Both bonuses of a stacked RND2D + AE2D pair in one launch (carle_rnd_ae_bonus): binary obs, fp32 (N,1,H,W) or
     int64 bit-packed, H == W a multiple of 64 above 64.  Workspaces must already have their full size."""
     lib = _lib.load()
     packed = obs.dtype == torch.int64

@@ -234,14 +234,17 @@ class RND2D(Motivator):
         h = obs.shape[2]
         w = obs.shape[3] * 64 if obs.dtype == torch.int64 else obs.shape[3]
         fused = binary and h == w and h % 64 == 0        # 64x64: workgroup per grid; larger: per 64x64 tile
-        key = (id(self._ws), versions) if fused and self._ws is not None else None
+        # the batch geometry belongs to the key: the tiled workspaces also hold per-grid arrival counters, laid out by
+        # (n, size) and zeroed whenever the tables are rebuilt (carle_rnd_ae_bonus / carle_rnd_ae_train)
+        geom = (obs.shape[0], h)
+        key = (id(self._ws), versions) + geom if fused and self._ws is not None else None
         valid = key is not None and key == self._tables_key
-        self._tables_key_next = (fused, versions)
+        self._tables_key_next = (fused, versions, geom)
         return valid
 
     def _commit_tables(self):
-        fused, versions = self._tables_key_next
-        self._tables_key = (id(self._ws), versions) if fused else None
+        fused, versions, geom = self._tables_key_next
+        self._tables_key = (id(self._ws), versions) + geom if fused else None
 
     def _hip_forward(self, obs, want_outputs=False, reward=None, bonus_out=None, stream=None):
         obs, binary = self._obs(obs, allow_packed=True)
@@ -570,7 +573,7 @@ class RND2D(Motivator):
         if self._grad is None or self._grad.device != dev or self._grad.numel() != pb.numel():
             self._grad = torch.zeros(pb.numel(), dtype=torch.float32, device=dev)
         versions = (self._pred_blob.version,) if is_ae else (self._pred_blob.version, self._rand_blob.version)
-        valid = uses_tables and self._tables_key == (id(self._ws), versions)
+        valid = uses_tables and self._tables_key == (id(self._ws), versions, n, size)
         if is_ae:
             grad_scale = 2.0 / (size * size * n * (self.batch_size if batch is None else batch))
             hip.ae2d_train(o, pb, self._ws, self._partial, self._grad, bonus_out, reward,
@@ -579,7 +582,7 @@ class RND2D(Motivator):
             grad_scale = 2.0 / (self.rnd_dim * n * (self.batch_size if batch is None else batch))
             hip.rnd2d_train(o, pb, rb, self._ws, self._partial, self._grad, bonus_out, reward,
                             self.reward_scale, grad_scale, valid, stream, binary=uses_tables)
-        self._tables_key = (id(self._ws), versions) if uses_tables else None
+        self._tables_key = (id(self._ws), versions, n, size) if uses_tables else None
         self._grad_used = True
         return True
 
@@ -737,7 +740,7 @@ class AE2D(RND2D):
         self._commit_tables()
         return res
 
-    # -- stacked on an RND2D, forward only, tiled sizes: both bonuses in two launches (carle_rnd_ae_bonus) ----------
+    # -- stacked on an RND2D, forward only, tiled sizes: both bonuses in one launch (carle_rnd_ae_bonus) ----------
     def _can_pair_step(self):
         """0: the wrappers step one after the other; 1: paired forward (both without predictor updates); 2: paired
         training step (both with predictor updates through the HIP gradient kernels)."""
@@ -754,8 +757,8 @@ class AE2D(RND2D):
     def step(self, action):
         """AE2D(RND2D(CARLE)) -- the stack of train_mcl.py:34-38 / eval.py:83-85 -- at the reference's default geometry
         (binary grids, H = W a multiple of 64 above 64) without predictor updates: the environment step, then BOTH
-        wrappers' bonuses and reward updates in two launches (the tile workgroups of the two nets side by side, one
-        finish kernel) instead of four -- a step there is bound by its dependent dispatches.  Bit-identical to the
+        wrappers' bonuses and reward updates in ONE launch (the tile workgroups of the two nets side by side, the last
+        tile of a grid finishes it) instead of four -- a step there is bound by its dependent dispatches.  Bit-identical to the
         two wrappers stepping one after the other."""
         mode = self._can_pair_step()
         if not mode:
@@ -771,16 +774,17 @@ class AE2D(RND2D):
             rnd._bonus_into(obs, reward)
             self._bonus_into(obs, reward)
             return obs, reward, done, info
-        partials, status = self._pair_moment_buffers(o.shape[0], o.device)
-        if mode == 2:
-            return self._paired_train_step(o, obs, reward, done, info, partials, status)
         dev, n, size = o.device, o.shape[0], o.shape[2]
-        needs = self.__dict__.get("_pair_needs")             # (n, size) -> workspace floats of both nets: one library
-        if needs is None or needs[0] != (n, size):           # call each per geometry, not per step (the step is host-bound)
+        needs = self.__dict__.get("_pair_needs")             # (n, size) -> workspace floats of both nets, moment pairs: one
+        if needs is None or needs[0] != (n, size):           # library call each per geometry, not per step (host-bound step)
             from . import _lib
             lib = _lib.load()
             needs = self.__dict__["_pair_needs"] = ((n, size), lib.carle_rnd2d_workspace_floats(n, size, size),
-                                                    lib.carle_ae2d_workspace_floats(n, size, size))
+                                                    lib.carle_ae2d_workspace_floats(n, size, size),
+                                                    lib.carle_rnd_ae_partials_doubles(n, size, size))
+        partials, status = self._pair_moment_buffers(needs[3], dev)
+        if mode == 2:
+            return self._paired_train_step(o, obs, reward, done, info, partials, status)
         for w, need in ((rnd, needs[1]), (self, needs[2])):
             if w._ws is None or w._ws.numel() < need or w._ws.device != dev:
                 w._ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
@@ -797,14 +801,13 @@ class AE2D(RND2D):
         self._pair_moments_left(partials)
         return obs, reward, done, info
 
-    def _pair_moment_buffers(self, n, dev):
+    def _pair_moment_buffers(self, need, dev):
         """RunningRewardStats attached to this pair (``attach``): the pair's finish kernel leaves per-workgroup partial sums
         of the step's final rewards and registers them in the environment's status block; the next environment step (or
         ``settled_status``) merges them -- no moments launch per step."""
         if self.__dict__.get("_final_reward_stats") is None:
             return None, None
         env = self.inner_env
-        need = 2 * ((n + 15) // 16)                          # = carle_rnd_ae_partials_doubles(n)
         partials = self.__dict__.get("_mom_partials")
         if partials is None or partials.numel() < need or partials.device != dev:
             env.settled_status()                             # nothing may still point into the old buffer

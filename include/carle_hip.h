@@ -354,8 +354,9 @@ int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const floa
 
 /* RND2D.get_bonus and AE2D.get_bonus of the SAME observations (carle/mcl.py:343-352, 504-512) and both wrappers'
  * `reward += reward_scale * bonus` (mcl.py:403-405, RND2D's first: the stack AE2D(RND2D(env)) of train_mcl.py:34-38 and
- * eval.py:83-85) in TWO launches instead of four -- the tile workgroups of both nets run side by side in one launch, one
- * finish kernel forms both bonuses.  Binary observations with H == W a multiple of 64 above 64 (the reference's default
+ * eval.py:83-85) in ONE launch instead of four -- the tile workgroups of both nets run side by side, and the workgroup that
+ * delivers the last tile of a grid forms both bonuses and the reward.  CARLE_NET_TABLES_VALID in rnd_flags additionally
+ * promises that the previous call on rnd_workspace had the same (n, h, w): the workspace keeps per-grid arrival counters.  Binary observations with H == W a multiple of 64 above 64 (the reference's default
  * 256x256); obs_fmt CARLE_FMT_F32 (every value exactly 0.0f / 1.0f) or CARLE_FMT_B1.  Everything else -- parameter
  * blobs, workspaces (carle_*_workspace_floats), bonus vectors, CARLE_NET_TABLES_VALID per net -- as for
  * carle_rnd2d_bonus_* / carle_ae2d_bonus_*; results are bit-identical to calling those two. */
@@ -365,11 +366,11 @@ int carle_rnd_ae_bonus(const void *obs, int obs_fmt, int64_t n, int h, int w, co
                        int ae_flags, float *reward_accum, double *moment_partials, int32_t *status, void *stream);
 /* moment_partials + status (both or neither; reward_accum required): the rewards are final in the finish kernel of these
  * calls, so that kernel leaves per-workgroup (sum, sum of squares) pairs in moment_partials
- * (carle_rnd_ae_partials_doubles(n) fp64 values) and registers them in the status block of the environment
+ * (carle_rnd_ae_partials_doubles(n, h, w) fp64 values) and registers them in the status block of the environment
  * (CARLE_ST_MOM_*): the next launch on that block -- the next environment step -- or carle_env_settle merges them into the
  * running reward moments (CARLE_ST_MOMENTS_*), as for the one-launch RND2D step.  The block's previous pairs must have
  * been merged (any environment step or carle_env_settle since). */
-int64_t carle_rnd_ae_partials_doubles(int64_t n);
+int64_t carle_rnd_ae_partials_doubles(int64_t n, int h, int w);
 
 /* The same stack in TRAINING mode (carle/train_mcl.py:34-38, 64-69; mcl.py:368-386, 521-547): both wrappers' bonuses, both
  * `reward += reward_scale * bonus` and the accumulation of both predictors' gradients for one step -- what

@@ -1017,7 +1017,7 @@ def test_early_window_replay_keeps_its_scale():
 
 @pytest.mark.parametrize("storage,size,n", [("f32", 256, 16), ("f32", 128, 5), ("b1", 256, 7), ("u8", 192, 3), ("f32", 512, 2)])
 def test_paired_rnd_ae_step_equals_the_two_wrappers(storage, size, n):
-    """AE2D(RND2D(CARLE)) at tiled sizes, forward only: one carle_rnd_ae_bonus call (two launches) gives bit-identical
+    """AE2D(RND2D(CARLE)) at tiled sizes, forward only: one carle_rnd_ae_bonus call (one launch) gives bit-identical
     rewards and bonuses to the wrappers stepping one after the other (four launches), also after a parameter change
     (tables rebuilt) and for packed / uint8 observations."""
     from carle_amd.env import CARLE
