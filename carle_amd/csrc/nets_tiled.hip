@@ -130,7 +130,7 @@ __device__ __forceinline__ void rnd_finish_grid(const float *__restrict__ partia
                                                 float *__restrict__ reward, float reward_scale, int64_t g, bool valid, int k,
                                                 int tiles, int dfeat) {
     // no contraction: whether (r - p)^2 and the first DPP add become one fma depends on the code around this function, and
-    // its three users (finish kernel, finish by the last tile, rnd_ae_finish_kernel) must agree to the bit
+    // its users (finish kernel, finish by the last tile; pair_finish_grid repeats it) must agree to the bit
 #pragma clang fp contract(off)
     float sq = 0.0f;
     if (valid) {
@@ -167,7 +167,7 @@ __device__ __forceinline__ void rnd_finish_grid(const float *__restrict__ partia
         const float b = sq * (1.0f / 16.0f);
         bonus[g] = b;
         // mcl.py:403-405, as torch evaluates it: product and sum rounded separately (no contraction into an fma -- also
-        // what keeps the paired launch, rnd_ae_finish_kernel, bit-identical to the two wrappers one after the other)
+        // what keeps the paired launch, pair_finish_grid, bit-identical to the two wrappers one after the other)
         if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);
     }
 }
@@ -182,8 +182,8 @@ struct RndTileFinish {
 };
 
 // The forward pair AE2D(RND2D(env)) without a finish launch: both nets' tile workgroups count their arrivals per grid;
-// the workgroup that delivers the LAST of a grid's 2 x tiles tiles forms both bonuses and the reward (the arithmetic of
-// rnd_ae_finish_kernel, agent-scope loads of the partial sums) and keeps (sum, sum of squares) of the rewards it formed for
+// the workgroup that delivers the LAST of a grid's 2 x tiles tiles forms both bonuses and the reward (the arithmetic of the
+// two finish kernels, agent-scope loads of the partial sums) and keeps (sum, sum of squares) of the rewards it formed for
 // the reward moments (one pair per workgroup of the launch, registered in the status block by workgroup 0).
 struct PairFinish {
     int32_t *counters = nullptr;                     // n ints, zero before the launch and zero again behind it
@@ -197,7 +197,7 @@ struct PairFinish {
 
 // lanes 0..15 of wave 0; returns the final reward of grid g in lane 0
 __device__ __forceinline__ float pair_finish_grid(const PairFinish &f, int64_t g, int k, int tiles) {
-#pragma clang fp contract(off)                          // as rnd_finish_grid / rnd_ae_finish_kernel: bit-identical
+#pragma clang fp contract(off)                          // as rnd_finish_grid: bit-identical
     auto ld = [](const float *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     float p = 0.0f, r = 0.0f, ae = 0.0f;
     for (int t0 = 0; t0 < tiles; t0 += 16) {
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict_
 
 // ---------------------------------------------------------------------------------------------------------------
 // RND2D + AE2D forward of a wrapper stack (AE2D(RND2D(env)), carle/train_mcl.py:34-38, evaluation/eval.py:83-85) in
-// ONE launch instead of four (rnd_ae_finish_kernel: the finish as a launch of its own, kept as the reference form): both nets read the same observation, so the tile workgroups of both run side by side
+// ONE launch instead of four: both nets read the same observation, so the tile workgroups of both run side by side
 // in one launch -- workgroups [0, rnd_blocks) walk the RND2D tiles, the others the AE2D tiles, each with its own
 // barriers and LDS image -- and one finish kernel forms both bonuses and adds them to the reward in the wrappers'
 // order (reward += s_rnd * b_rnd, then += s_ae * b_ae: mcl.py:403-405 twice).  At the reference's default batch
@@ -986,50 +986,6 @@ __global__ __launch_bounds__(256, 4) void rnd_ae_tile_kernel(const void *__restr
         rnd_tile_body<PACKED>(s.r, obs_v, rws, pp, rp, rpartial, nullptr, n, size, blockIdx.x, rnd_blocks, RndTileFinish(), pf);
     else
         ae_tile_body<PACKED>(s.a, obs_v, aws, apartial, nullptr, n, size, blockIdx.x - rnd_blocks, gridDim.x - rnd_blocks, pf);
-}
-
-// 16 threads per grid (as rnd_tile_finish_kernel); thread 0 of a grid also adds the AE2D tiles' squared errors
-__global__ __launch_bounds__(256) void rnd_ae_finish_kernel(const float *__restrict__ rpartial, const float *__restrict__ pp,
-                                                            const float *__restrict__ rp, float *__restrict__ rbonus,
-                                                            const float *__restrict__ apartial, float *__restrict__ abonus,
-                                                            float *__restrict__ reward, float rscale, float ascale, int64_t n,
-                                                            int tiles, int dfeat, float inv_pixels,
-                                                            double *__restrict__ mom_partials, int32_t *__restrict__ status) {
-#pragma clang fp contract(off)                          // as rnd_finish_grid
-    __shared__ double2 mpart[16];
-    const int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int k = threadIdx.x & 15;
-    float sq = 0.0f, ae = 0.0f, final_reward = 0.0f;
-    if (g < n) {
-        float p = 0.0f, r = 0.0f;
-        for (int t = 0; t < tiles; ++t) {
-            p += rpartial[((g * tiles + t) * 2 + 0) * 16 + k];
-            r += rpartial[((g * tiles + t) * 2 + 1) * 16 + k];
-        }
-        p = tanhf(p + pp[77 + (int64_t)16 * dfeat + k]);
-        r = tanhf(r + rp[39 + (int64_t)16 * dfeat + k]);
-        sq = (r - p) * (r - p);
-        if (k == 0)
-            for (int t = 0; t < tiles; ++t) ae += apartial[g * tiles + t];       // ae_mse_finish_kernel's order
-    }
-    sq += dpp_quad_xor1(sq);
-    sq += dpp_quad_xor2(sq);
-    sq += dpp_row_ror(sq, 0x124);
-    sq += dpp_row_ror(sq, 0x128);
-    if (g < n && k == 0) {
-        const float br = sq * (1.0f / 16.0f), ba = ae * inv_pixels;
-        rbonus[g] = br;
-        abonus[g] = ba;
-        if (reward) {
-            float x = reward[g];
-            x = reward_accumulate(x, rscale, br);          // RND2D.step, then AE2D.step (mcl.py:403-405)
-            x = reward_accumulate(x, ascale, ba);
-            reward[g] = x;
-            final_reward = x;
-        }
-    }
-    if (mom_partials && status && reward)             // kernel arguments: the same for every workgroup
-        reward_moment_partials(mpart, g < n && k == 0, final_reward, mom_partials, status, (int)blockIdx.x, (int)gridDim.x, n);
 }
 
 void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
