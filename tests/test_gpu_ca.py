@@ -413,7 +413,7 @@ def test_random_geometries_and_rules_hypothesis():
     @given(st.data())
     def run(data):
         half = data.draw(st.integers(1, 40))
-        size = 2 * half if data.draw(st.booleans()) else data.draw(st.sampled_from([64, 64, 128, 256]))
+        size = 2 * half if data.draw(st.booleans()) else data.draw(st.sampled_from([64, 64, 128, 256, 512]))
         ahalf = data.draw(st.integers(1, size // 2))
         asize = 2 * ahalf if (size - 2 * ahalf) % 2 == 0 else size
         n = data.draw(st.integers(1, 5))
@@ -431,7 +431,7 @@ def test_random_geometries_and_rules_hypothesis():
         out8 = torch.empty(n, 1, size, size, dtype=torch.uint8, device="cuda")
         hip.ca_step_u8(d_u.to(torch.uint8), d_a.to(torch.uint8), out8, rule, None, 0)
         assert np.array_equal(out8.cpu().numpy(), exp.astype(np.uint8)), (size, asize, n, hex(rule))
-        if size in (64, 128, 256) and asize % 64 == 0:
+        if size in (64, 128, 256, 512) and asize % 64 == 0:      # 512: always the LDS strip modes of the packed kernel
             bits, abits = hip.pack_f32_b1(d_u), hip.pack_f32_b1(d_a)
             outb = torch.empty_like(bits)
             hip.ca_step_b1(bits, abits, outb, rule, None, 0)

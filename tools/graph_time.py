@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from carle_amd.env import CARLE                 # noqa: E402
 from carle_amd.graphs import StepGraph          # noqa: E402
-from carle_amd.mcl import AE2D, RND2D           # noqa: E402
+from carle_amd.mcl import AE2D, RND2D, PufferDetector, SpeedDetector           # noqa: E402
 
 
 def timed(fn, steps):
@@ -38,11 +38,15 @@ for name, n, size, stack, storage in (("configs[0]: N=1 64x64", 1, 64, False, "f
                                       ("reference default: N=16 256x256", 16, 256, False, "f32"),
                                       ("N=16 256x256 + RND2D + AE2D (forward)", 16, 256, True, "f32"),
                                       ("N=16 64x64 + RND2D + AE2D (forward)", 16, 64, True, "f32"),
+                                      ("N=16 256x256 evaluation stack (eval.py:83-87)", 16, 256, "eval", "f32"),
                                       ("configs[1]: N=4096 64x64", 4096, 64, False, "f32")):
     torch.manual_seed(0)
     env = CARLE(instances=n, width=size, height=size, device="cuda:0", storage=storage)
     if stack:
         env = AE2D(RND2D(env, train_predictor=False), train_predictor=False)
+    if stack == "eval":                          # RND2D -> AE2D -> SpeedDetector -> PufferDetector
+        env = PufferDetector(SpeedDetector(env))
+        env.eval()
     env.reset()
     ring = [(torch.rand(n, 1, 64, 64, device="cuda") < 0.1).float() for _ in range(6)]
     static = torch.zeros_like(ring[0])
