@@ -107,6 +107,8 @@ SIGNATURES = {
     "carle_instance_sums_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "carle_speed_update_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "carle_puffer_update_f32": (_c_int, [_c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
+    "carle_speed_puffer_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
+                                        _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
     "carle_rle_encode_body": (_c_i64, [_c_vp, _c_int, _c_int, _c_vp, _c_i64]),
     "carle_rle_decode_body": (_c_int, [ctypes.c_char_p, _c_i64, _c_vp, _c_int, _c_int]),
     "carle_ca_finish": (_c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_int, _c_int, _c_vp]),

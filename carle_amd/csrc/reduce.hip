@@ -11,14 +11,12 @@ namespace carle {
 // instantiation -- with `if (w0)` inside the loop every load was followed by its own s_waitcnt, four dependent
 // memory round trips per element (round 2, seen in the disassembly).  VEC: float4 accesses (elems % 4 == 0 and
 // 16-byte aligned planes), four independent quads per thread and iteration in flight.
-template <int WM, bool VEC>
-__global__ __launch_bounds__(1024) void instance_sums_kernel(const float *__restrict__ x, int64_t elems,
-                                                             const float *__restrict__ w0,
-                                                             const float *__restrict__ w1,
-                                                             const float *__restrict__ w2,
-                                                             float *__restrict__ out) {
-    __shared__ double part[4][16];
-    const int64_t g = blockIdx.x;
+// (body as a device function: the stand-alone kernel and speed_puffer_kernel, which finishes both wrappers behind it.
+// COHERENT: the four sums leave as agent-scope stores -- a workgroup on another XCD reads them in the same launch.)
+template <int WM, bool VEC, bool COHERENT>
+__device__ __forceinline__ void instance_sums_body(double (&part)[4][16], const float *__restrict__ x, int64_t elems,
+                                                   const float *__restrict__ w0, const float *__restrict__ w1,
+                                                   const float *__restrict__ w2, float *__restrict__ out, const int64_t g) {
     const float *gx = x + g * elems;
     double s = 0.0, a = 0.0, b = 0.0, c = 0.0;
     if (VEC) {
@@ -71,9 +69,21 @@ __global__ __launch_bounds__(1024) void instance_sums_kernel(const float *__rest
     if (threadIdx.x < 4) {
         double t = 0.0;
         for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += part[threadIdx.x][k];
-        out[g * 4 + threadIdx.x] = (float)t;
+        if (COHERENT) __hip_atomic_store(out + g * 4 + threadIdx.x, (float)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[g * 4 + threadIdx.x] = (float)t;
     }
 }
+
+template <int WM, bool VEC>
+__global__ __launch_bounds__(1024) void instance_sums_kernel(const float *__restrict__ x, int64_t elems,
+                                                             const float *__restrict__ w0,
+                                                             const float *__restrict__ w1,
+                                                             const float *__restrict__ w2,
+                                                             float *__restrict__ out) {
+    __shared__ double part[4][16];
+    instance_sums_body<WM, VEC, false>(part, x, elems, w0, w1, w2, out, (int64_t)blockIdx.x);
+}
+
 
 template <int WM>
 static void launch_instance_sums(bool vec, unsigned n, hipStream_t st, const float *x, int64_t elems, const float *w0,
@@ -93,58 +103,79 @@ static void launch_instance_sums(bool vec, unsigned n, hipStream_t st, const flo
 // the launch is identical every step, so a HIP graph can replay it).  fp32 quotients as the reference; the sum of
 // squares is accumulated in fp64 in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void speed_update_kernel(const float *__restrict__ sums4, const float *__restrict__ live4,
-                                                           int64_t n, float *__restrict__ com, int32_t *__restrict__ state,
-                                                           float *__restrict__ velocity, float *__restrict__ speed_out,
-                                                           float *__restrict__ live_out, float *__restrict__ reward) {
-    __shared__ double part[4];
-    __shared__ float s_speed;
+// (bodies as device functions: the first 256 threads of the workgroup work, every thread takes the barriers; COHERENT:
+// sums4 was stored by other workgroups of the same launch -> agent-scope loads)
+template <bool COHERENT>
+__device__ __forceinline__ float sums_ld(const float *p) {
+    return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
+template <bool COHERENT>
+__device__ __forceinline__ void speed_update_body(double (&part)[4], float &s_speed, const float *__restrict__ sums4,
+                                                  const float *__restrict__ live4, int64_t n, float *__restrict__ com,
+                                                  int32_t *__restrict__ state, float *__restrict__ velocity,
+                                                  float *__restrict__ speed_out, float *__restrict__ live_out,
+                                                  float *__restrict__ reward) {
+    const int tid = threadIdx.x;
     const bool has_prev = state[0] != 0;
     double sq = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float live = live4 ? live4[4 * i] : sums4[4 * i];
-        const float ch = sums4[4 * i + 1] / (live + 1e-7f), cw = sums4[4 * i + 2] / (live + 1e-7f);
-        if (has_prev) {
-            const float vh = com[i] - ch, vw = com[n + i] - cw;
-            velocity[i] = vh; velocity[n + i] = vw;
-            sq = fma((double)vh, (double)vh, fma((double)vw, (double)vw, sq));
+    if (tid < 256)
+        for (int64_t i = tid; i < n; i += 256) {
+            const float s0 = sums_ld<COHERENT>(sums4 + 4 * i), s1 = sums_ld<COHERENT>(sums4 + 4 * i + 1),
+                        s2 = sums_ld<COHERENT>(sums4 + 4 * i + 2);
+            const float live = live4 ? live4[4 * i] : s0;
+            const float ch = s1 / (live + 1e-7f), cw = s2 / (live + 1e-7f);
+            if (has_prev) {
+                const float vh = com[i] - ch, vw = com[n + i] - cw;
+                velocity[i] = vh; velocity[n + i] = vw;
+                sq = fma((double)vh, (double)vh, fma((double)vw, (double)vw, sq));
+            }
+            com[i] = ch; com[n + i] = cw;
+            live_out[i] = live;
         }
-        com[i] = ch; com[n + i] = cw;
-        live_out[i] = live;
-    }
 #pragma unroll
     for (int k = 32; k > 0; k >>= 1) sq += __shfl_xor(sq, k, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+    if (tid < 256 && (tid & 63) == 0) part[tid >> 6] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         const float sp = (float)sqrt((part[0] + part[1]) + (part[2] + part[3]));
         s_speed = sp;
         if (has_prev) speed_out[0] = sp;
         state[0] = 1;
     }
     __syncthreads();
-    if (has_prev && reward) {
+    if (has_prev && reward && tid < 256) {
         const float sp = s_speed;
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) reward[i] += sp;       // mcl.py:795
+        for (int64_t i = tid; i < n; i += 256) reward[i] += sp;                      // mcl.py:795
     }
+}
+
+__global__ __launch_bounds__(256) void speed_update_kernel(const float *__restrict__ sums4, const float *__restrict__ live4,
+                                                           int64_t n, float *__restrict__ com, int32_t *__restrict__ state,
+                                                           float *__restrict__ velocity, float *__restrict__ speed_out,
+                                                           float *__restrict__ live_out, float *__restrict__ reward) {
+    __shared__ double part[4];
+    __shared__ float s_speed;
+    speed_update_body<false>(part, s_speed, sums4, live4, n, com, state, velocity, speed_out, live_out, reward);
 }
 
 // PufferDetector.step after the reduction (carle/mcl.py:832-851) without its two host round trips: the history of
 // live-cell totals is a device ring (rstate = [head, count], cap = growth_threshold + 1 slots), the "no action this
 // step" predicate is the flag the step kernel left in the status block (any_flag; NULL = no action).
-__global__ __launch_bounds__(256) void puffer_update_kernel(const float *__restrict__ sums4, int64_t n,
-                                                            const int32_t *__restrict__ any_flag, float *__restrict__ ring,
-                                                            int32_t *__restrict__ rstate, int cap,
-                                                            float *__restrict__ live_total, float *__restrict__ reward) {
-    __shared__ double part[4];
-    __shared__ int s_bonus;
+template <bool COHERENT>
+__device__ __forceinline__ void puffer_update_body(double (&part)[4], int &s_bonus, const float *__restrict__ sums4, int64_t n,
+                                                   const int32_t *__restrict__ any_flag, float *__restrict__ ring,
+                                                   int32_t *__restrict__ rstate, int cap, float *__restrict__ live_total,
+                                                   float *__restrict__ reward) {
+    const int tid = threadIdx.x;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += (double)sums4[4 * i];
+    if (tid < 256)
+        for (int64_t i = tid; i < n; i += 256) s += (double)sums_ld<COHERENT>(sums4 + 4 * i);
 #pragma unroll
     for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    if (tid < 256 && (tid & 63) == 0) part[tid >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         const float total = (float)((part[0] + part[1]) + (part[2] + part[3]));     // torch.sum(universe), mcl.py:832
         live_total[0] = total;
         int head = rstate[0], count = rstate[1], bonus = 0;
@@ -165,8 +196,48 @@ __global__ __launch_bounds__(256) void puffer_update_kernel(const float *__restr
         s_bonus = bonus;
     }
     __syncthreads();
-    if (s_bonus && reward)
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) reward[i] += 1.0f;     // mcl.py:843
+    if (s_bonus && reward && tid < 256)
+        for (int64_t i = tid; i < n; i += 256) reward[i] += 1.0f;                    // mcl.py:843
+}
+
+__global__ __launch_bounds__(256) void puffer_update_kernel(const float *__restrict__ sums4, int64_t n,
+                                                            const int32_t *__restrict__ any_flag, float *__restrict__ ring,
+                                                            int32_t *__restrict__ rstate, int cap,
+                                                            float *__restrict__ live_total, float *__restrict__ reward) {
+    __shared__ double part[4];
+    __shared__ int s_bonus;
+    puffer_update_body<false>(part, s_bonus, sums4, n, any_flag, ring, rstate, cap, live_total, reward);
+}
+
+// PufferDetector(SpeedDetector(env)) -- the top of the evaluation stack, evaluation/eval.py:86-87 -- in ONE launch instead
+// of three: every workgroup reduces one instance (the two masked centre-of-mass planes, as SpeedDetector asks for them;
+// column 0 = the live cells both wrappers use), the workgroup that finishes LAST runs SpeedDetector's update and then
+// PufferDetector's (their bodies, their order: the reward gets the speed first, mcl.py:795, then the growth bonus,
+// mcl.py:843).  `counter`: one int32, zero before the launch and zero again behind it.
+template <bool VEC>
+__global__ __launch_bounds__(1024) void speed_puffer_kernel(const float *__restrict__ x, int64_t elems, const float *__restrict__ w0,
+                                                            const float *__restrict__ w1, float *__restrict__ sums4,
+                                                            int32_t *__restrict__ counter, int64_t n, float *__restrict__ com,
+                                                            int32_t *__restrict__ state, float *__restrict__ velocity,
+                                                            float *__restrict__ speed_out, float *__restrict__ live_out,
+                                                            const int32_t *__restrict__ any_flag, float *__restrict__ ring,
+                                                            int32_t *__restrict__ rstate, int cap,
+                                                            float *__restrict__ live_total, float *__restrict__ reward) {
+    __shared__ double part[4][16];
+    __shared__ double upart[4];
+    __shared__ float s_speed;
+    __shared__ int s_bonus, s_last;
+    instance_sums_body<3, VEC, true>(part, x, elems, w0, w1, nullptr, sums4, (int64_t)blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this instance's sums have been written through (no fence: an
+    __syncthreads();                                        // agent-scope fence invalidates the XCD's whole L2)
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;                                    // workgroup-uniform
+    speed_update_body<true>(upart, s_speed, sums4, nullptr, n, com, state, velocity, speed_out, live_out, reward);
+    __syncthreads();
+    puffer_update_body<true>(upart, s_bonus, sums4, n, any_flag, ring, rstate, cap, live_total, reward);
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace carle
@@ -192,6 +263,29 @@ extern "C" int carle_puffer_update_f32(const float *sums4, int64_t n, const int3
     hipLaunchKernelGGL(puffer_update_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), sums4, n, any_flag,
                        ring, ring_state, cap, live_total, reward);
     return check_launch("carle_puffer_update_f32");
+}
+
+extern "C" int carle_speed_puffer_f32(const float *obs, int64_t n, int64_t elems, const float *w_h, const float *w_w,
+                                      float *sums4, int32_t *counter, float *com, int32_t *state, float *velocity,
+                                      float *speed, float *live_out, const int32_t *any_flag, float *ring,
+                                      int32_t *ring_state, int cap, float *live_total, float *reward, void *stream) {
+    if (!obs || !w_h || !w_w || !sums4 || !counter || !com || !state || !velocity || !speed || !live_out || !ring ||
+        !ring_state || !live_total)
+        return fail_arg(CARLE_E_NULL, "carle_speed_puffer_f32: NULL pointer");
+    if (n < 0 || elems < 0 || cap < 2) return fail_arg(CARLE_E_DIMS, "carle_speed_puffer_f32: n, elems >= 0 and cap >= 2 required");
+    if (n == 0) return 0;
+    if (n > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_speed_puffer_f32: batch too large");
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool vec = elems % 4 == 0 && al16(obs) && al16(w_h) && al16(w_w);
+    const unsigned nt = elems <= 16384 ? 256u : 1024u;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (vec)
+        hipLaunchKernelGGL(speed_puffer_kernel<true>, dim3((unsigned)n), dim3(nt), 0, st, obs, elems, w_h, w_w, sums4, counter, n, com,
+                           state, velocity, speed, live_out, any_flag, ring, ring_state, cap, live_total, reward);
+    else
+        hipLaunchKernelGGL(speed_puffer_kernel<false>, dim3((unsigned)n), dim3(nt), 0, st, obs, elems, w_h, w_w, sums4, counter, n, com,
+                           state, velocity, speed, live_out, any_flag, ring, ring_state, cap, live_total, reward);
+    return check_launch("carle_speed_puffer_f32");
 }
 
 extern "C" int carle_instance_sums_f32(const float *x, int64_t n, int64_t elems, const float *w0,

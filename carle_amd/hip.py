@@ -660,6 +660,21 @@ def puffer_update_f32(sums4, any_flag_ptr, ring, ring_state, live_total, reward)
         _lib.check(rc, "carle_puffer_update_f32")
 
 
+def speed_puffer_f32(obs, w_h, w_w, sums4, counter, com, state, velocity, speed, live_out, any_flag_ptr, ring, ring_state,
+                     live_total, reward):
+    """SpeedDetector's reduction and update and PufferDetector's update in one launch (carle_speed_puffer_f32)."""
+    lib = _lib.load()
+    n = obs.shape[0]
+    with _on_device(obs.device):
+        rc = lib.carle_speed_puffer_f32(obs.data_ptr(), n, obs.numel() // max(n, 1), w_h.data_ptr(), w_w.data_ptr(),
+                                        sums4.data_ptr(), counter.data_ptr(), com.data_ptr(), state.data_ptr(),
+                                        velocity.data_ptr(), speed.data_ptr(), live_out.data_ptr(), any_flag_ptr,
+                                        ring.data_ptr(), ring_state.data_ptr(), ring.numel(), live_total.data_ptr(),
+                                        _ptr(reward), _stream(obs))
+    if rc != 0:
+        _lib.check(rc, "carle_speed_puffer_f32")
+
+
 def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_flags, pred_params,
                      rand_params, workspace, bonus, reward_scale, tables_valid,
                      event_handle, stream_env, stream_reward, merge_moments=False, deferred=False, partials=None):

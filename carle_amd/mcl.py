@@ -1002,6 +1002,11 @@ class SpeedDetector(Motivator):
 
     def step(self, action):
         obs, reward, done, info = self.env.step(action)
+        self._apply(obs, reward)
+        return obs, reward, done, info
+
+    def _apply(self, obs, reward):
+        """The wrapper's own part of a step: reduction + update behind the step of the stack below."""
         inner = self.inner_env
         dev = inner.my_device
         o = _as_device_f32(obs, dev)
@@ -1016,6 +1021,10 @@ class SpeedDetector(Motivator):
         if not reward.is_contiguous():                      # (never for the rewards this package produces)
             raise ValueError("SpeedDetector needs a contiguous reward tensor")
         hip.speed_update_f32(sums, live4, com, has_prev, vel, speed, live, reward.reshape(-1))
+        self._after_update(com, vel, speed, live)
+
+    def _after_update(self, com, vel, speed, live):
+        """The attributes the reference's step leaves (mcl.py:781-797), as views of the device buffers."""
         seen = self.__dict__["_steps_seen"]
         if seen == 0 and self.center_of_mass is None:
             self.center_of_mass = com                       # mcl.py:781-782: stored, nothing else
@@ -1025,7 +1034,6 @@ class SpeedDetector(Motivator):
             self.center_of_mass = com
         self.__dict__["_steps_seen"] = seen + 1
         self.live_cells = live
-        return obs, reward, done, info
 
 
 class PufferDetector(Motivator):
@@ -1090,10 +1098,29 @@ class PufferDetector(Motivator):
         pass                                    # recomputed every step (mcl.py:832)
 
     def step(self, action):
-        obs, reward, done, info = self.env.step(action)
+        sp = self.env
         inner = self.inner_env
         dev = inner.my_device
-        sums = _live_sums(inner, dev)
+        # directly on a SpeedDetector (the top of evaluation/eval.py:83-87) over fp32 state: the reduction and both
+        # wrappers' updates in ONE launch (carle_speed_puffer_f32) instead of three
+        pair = type(sp) is SpeedDetector and type(self) is PufferDetector and getattr(inner, "storage", "f32") == "f32"
+        if pair:
+            obs, reward, done, info = sp.env.step(action)
+            pair = obs is inner.__dict__.get("universe") and obs.dtype == torch.float32 and obs.is_contiguous() \
+                and reward.is_contiguous()
+            if not pair:
+                sp._apply(obs, reward)                      # (the stack below returned something else: Speed's own update)
+        else:
+            obs, reward, done, info = sp.step(action)
+        sums = None
+        if pair:
+            sums = self.__dict__.get("_pair_sums")
+            n = obs.shape[0]
+            if sums is None or sums.shape[0] != n or sums.device != dev:
+                sums = self.__dict__["_pair_sums"] = torch.zeros(n, 4, dtype=torch.float32, device=dev)
+                self.__dict__["_pair_counter"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        else:
+            sums = _live_sums(inner, dev)
         ring, state, total = self._ring_state(dev)
         flag_ptr = None
         if action is not None:
@@ -1106,6 +1133,14 @@ class PufferDetector(Motivator):
             else:
                 # ANY_NONZERO of the slot the step just used (the flags stay until the next step recycles them)
                 flag_ptr = st.data_ptr() + 4 * (inner._slot ^ 1)
+        if pair:
+            com, vel, speed, live, has_prev = sp._dev_buffers(obs.shape[0], dev)
+            hip.speed_puffer_f32(obs, _cached_device(sp, "mass_weight_h", dev), _cached_device(sp, "mass_weight_w", dev), sums,
+                                 self.__dict__["_pair_counter"], com, has_prev, vel, speed, live, flag_ptr, ring, state, total,
+                                 reward.reshape(-1))
+            inner.__dict__["_live_cache"] = (weakref.ref(obs), obs._version, sums)
+            sp._after_update(com, vel, speed, live)
+            return obs, reward, done, info
         if not reward.is_contiguous():
             raise ValueError("PufferDetector needs a contiguous reward tensor")
         hip.puffer_update_f32(sums, flag_ptr, ring, state, total, reward.reshape(-1))

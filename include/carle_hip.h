@@ -503,6 +503,15 @@ int carle_speed_update_f32(const float *sums4, const float *live4, int64_t n, fl
  * ring: cap floats, ring_state: int32[2] = {head, count}, both caller-owned and zero-initialised. */
 int carle_puffer_update_f32(const float *sums4, int64_t n, const int32_t *any_flag, float *ring,
                             int32_t *ring_state, int cap, float *live_total, float *reward, void *stream);
+/* PufferDetector(SpeedDetector(env)) -- the top of the evaluation stack, evaluation/eval.py:86-87 -- in ONE launch instead
+ * of three: carle_instance_sums_f32(obs, w_h, w_w) into sums4 (n x 4 floats, an output), then -- by the workgroup that
+ * finishes last -- carle_speed_update_f32 (live4 = NULL: the observation is the inner universe) and
+ * carle_puffer_update_f32 on those sums, in that order (mcl.py:795, then mcl.py:843).  counter: one device int32, zero
+ * before the first call (the kernel leaves it zero).  All other arguments as for the three entry points. */
+int carle_speed_puffer_f32(const float *obs, int64_t n, int64_t elems, const float *w_h, const float *w_w, float *sums4,
+                           int32_t *counter, float *com, int32_t *state, float *velocity, float *speed, float *live_out,
+                           const int32_t *any_flag, float *ring, int32_t *ring_state, int cap, float *live_total,
+                           float *reward, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Reward statistics for batch-sharded runs (build-side feature required by the north star; the
