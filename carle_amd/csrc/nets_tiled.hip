@@ -1605,13 +1605,19 @@ int rnd2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *
     if ((n + 15) / 16 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_rnd2d_bonus: batch too large");
     const unsigned blocks = (unsigned)(total < 1024 ? total : 1024);      // persistent: 4 workgroups per CU
     float *partial = ws + kFusedWsTotal;
+    // ONE launch: the workgroup that delivers a grid's last tile finishes the grid (RndTileFinish; counters behind the
+    // partial sums, zero whenever the tables are rebuilt -- TABLES_VALID also promises the previous call's (n, size))
+    RndTileFinish fin;
+    fin.counters = reinterpret_cast<int32_t *>(partial + total * 32);
+    fin.bonus = bonus; fin.pred = pred_out; fin.targ = target_out; fin.reward = reward; fin.reward_scale = reward_scale;
+    if (!tables_valid) {
+        if (hipError_t e = hipMemsetAsync(fin.counters, 0, (size_t)n * sizeof(int32_t), s); e != hipSuccess)
+            return fail_hip(e, "carle_rnd2d_bonus: hipMemsetAsync");
+    }
     if (packed)
-        hipLaunchKernelGGL(rnd_tile_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, ws, pp, rp, partial, static_cast<float *>(nullptr), n, size);
+        hipLaunchKernelGGL(rnd_tile_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, ws, pp, rp, partial, static_cast<float *>(nullptr), n, size, fin);
     else
-        hipLaunchKernelGGL(rnd_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, ws, pp, rp, partial, static_cast<float *>(nullptr), n, size);
-    const int d8 = size >> 3;
-    hipLaunchKernelGGL(rnd_tile_finish_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, partial, pp, rp, bonus,
-                       pred_out, target_out, reward, reward_scale, n, tiles, d8 * d8);
+        hipLaunchKernelGGL(rnd_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, ws, pp, rp, partial, static_cast<float *>(nullptr), n, size, fin);
     return check_launch("carle_rnd2d_bonus(tiled)");
 }
 
