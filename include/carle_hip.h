@@ -276,7 +276,8 @@ int64_t carle_rnd2d_workspace_floats(int64_t n, int h, int w);
  * table lookup on the binary image.  Without the flag obs values are used as fp32 numbers. */
 #define CARLE_NET_OBS_BINARY 1
 /* CARLE_NET_TABLES_VALID: `workspace` still holds the lookup tables a previous fused call built
- * from the SAME parameter values (the caller tracks parameter updates); skips the table build.  * Binary observations with H == W a multiple of 64 above 64 (tiled kernels): ONE launch -- the workgroup that delivers a
+ * from the SAME parameter values (the caller tracks parameter updates); skips the table build.
+ * Binary observations with H == W a multiple of 64 above 64 (tiled kernels): ONE launch -- the workgroup that delivers a
  * grid's last tile finishes the grid -- and CARLE_NET_TABLES_VALID additionally promises that the previous call on the
  * workspace had the same (n, h, w) (the workspace keeps per-grid arrival counters behind the tables).
  */
