@@ -24,6 +24,11 @@ run "cfg4 (BASELINE configs[3]): + RND2D forward (fused kernel)" --rnd --no-cpu-
 run "cfg4 + AE2D forward" --rnd --ae --no-cpu-baseline
 run "reference default geometry: N=16 256x256 + RND2D + AE2D forward" --size 256 --instances 16 --rnd --ae --steps 512 --no-cpu-baseline
 run "reference default geometry, training mode (RND2D + AE2D forward+backward)" --size 256 --instances 16 --rnd --ae --train --steps 512 --no-cpu-baseline
+run "reference default geometry forward, recorded calls (--replay calls)" --size 256 --instances 16 --rnd --ae --steps 512 --replay calls --no-cpu-baseline
+run "reference default geometry bare: N=16 256x256" --size 256 --instances 16 --steps 512 --no-cpu-baseline
+run "reference default geometry bare, recorded calls" --size 256 --instances 16 --steps 512 --replay calls --no-cpu-baseline
+run "configs[0] through the per-step API: N=1 64x64" --instances 1 --steps 512 --no-cpu-baseline
+run "configs[0] through the per-step API, recorded calls" --instances 1 --steps 512 --replay calls --no-cpu-baseline
 run "cfg3 shape: N=4096 256x256 f32" --size 256 --steps 64 --warmup 8 --no-cpu-baseline
 run "N=1024 512x512 f32" --size 512 --instances 1024 --steps 64 --warmup 8 --no-cpu-baseline
 run "N=4096 256x256 uint8 (uint8 actions)" --format u8 --size 256 --steps 128 --warmup 8 --no-cpu-baseline
