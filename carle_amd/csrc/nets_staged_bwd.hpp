@@ -557,11 +557,20 @@ int ae2d_train_staged(const float *obs, int64_t n, int h, int w, const float *ap
 
 }  // namespace carle
 
+namespace carle {
+bool rnd2d_tiled_applies(int h, int w);                                   // nets_tiled.hip
+int64_t rnd2d_tiled_bits_offset_floats(int64_t n, int size);
+}  // namespace carle
+
 using namespace carle;
 
 extern "C" int64_t carle_rnd2d_train_scratch_floats(int64_t n, int h, int w) {
     if (n < 0 || h < 8 || w < 8 || h != w || (h % 8) != 0) return 0;
-    return rnd2d_train_staged_scratch_floats(n, h, w);
+    const int64_t staged = rnd2d_train_staged_scratch_floats(n, h, w);
+    // tiled sizes: + a bit-packed copy of fp32 observations behind it (carle_rnd_ae_train: the tile gradients and the AE2D
+    // tiles read the copy the forward tiles leave)
+    if (rnd2d_tiled_applies(h, w)) return rnd2d_tiled_bits_offset_floats(n, h) + n * (int64_t)h * (w / 64) * 2;
+    return staged;
 }
 
 extern "C" int64_t carle_ae2d_train_scratch_floats(int64_t n, int h, int w) {

@@ -179,6 +179,9 @@ struct RndTileFinish {
     int32_t *counters = nullptr;
     float *bonus = nullptr, *pred = nullptr, *targ = nullptr, *reward = nullptr;
     float reward_scale = 0.0f;
+    // fp32 observations, training: every tile also leaves its own 64 x 64 cells bit-packed (H rows of W/64 words) --
+    // the kernels behind this one (tile gradients, AE2D) then read 512 bytes per tile instead of 22 KB of fp32
+    uint64_t *bits_out = nullptr;
 };
 
 // The forward pair AE2D(RND2D(env)) without a finish launch: both nets' tile workgroups count their arrivals per grid;
@@ -336,6 +339,8 @@ __device__ __forceinline__ void rnd_tile_body(RndTileShared &s, const void *__re
         const float *wrow = (lnet == 0 ? pp + 77 : rp + 39) + (int64_t)lk * dfeat + (int64_t)(8 * ty + lfy) * d8 + 8 * tx;
         const F4T wa = *reinterpret_cast<const F4T *>(wrow), wb = *reinterpret_cast<const F4T *>(wrow + 4);
         __syncthreads();
+        if (!PACKED && fin.bits_out && tid < 64)        // the tile's own cells: bits 5 .. 68 of rows 5 .. 68 of the window
+            fin.bits_out[(g * size + 64 * ty + tid) * tps + tx] = (s.rows[tid + 5][0] >> 5) | (s.rows[tid + 5][1] << 59);
         // ---- conv1 + pool of the 18x18 windows (window (wy, wx) = pooled position (16ty - 1 + wy, 16tx - 1 + wx))
         {
             const int q4 = size >> 2;
@@ -651,6 +656,14 @@ __global__ __launch_bounds__(256, 2) void rnd_bwd_pair_kernel(const void *__rest
         rnd_tile_bwd_body<PACKED>(s, obs_v, ws, pp, pred, targ, rows_out, gs, n, size, (int)blockIdx.x, brows);
     else
         rnd_bwd_linear_body(featbuf, pred, targ, grad, gs, n, (size >> 3) * (size >> 3), (int64_t)blockIdx.x - brows);
+}
+
+// floats of the RND2D training scratch in front of the bit-packed copy of fp32 observations (rnd_ae_tiled_train): the
+// layout of the staged path's scratch (the larger of the two), rounded to an even count (8-byte words behind it)
+int64_t rnd2d_tiled_bits_offset_floats(int64_t n, int size) {
+    const int64_t d = (int64_t)(size >> 3) * (size >> 3);
+    const int64_t staged = 2 * n * 16 + 2 * n * d + 1024 * (37 + 40) + 64;      // = rnd2d_train_staged_scratch_floats
+    return (staged + 1) & ~1ll;
 }
 
 // number of partial rows (= workgroups) of the tiled backward kernel
@@ -1542,6 +1555,15 @@ int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const 
     RndTileFinish fin;
     fin.counters = reinterpret_cast<int32_t *>(rpartial + total * 32);
     fin.bonus = rbonus; fin.pred = pred; fin.targ = targ; fin.reward = reward; fin.reward_scale = rscale;
+    // fp32 observations: the forward tiles leave a bit-packed copy at the end of the RND2D scratch
+    // (carle_rnd2d_train_scratch_floats reserves it); the gradient tiles and the AE2D tiles read that
+    const void *obs2 = obs;
+    bool packed2 = packed;
+    if (!packed) {
+        fin.bits_out = reinterpret_cast<uint64_t *>(rscratch + rnd2d_tiled_bits_offset_floats(n, size));
+        obs2 = fin.bits_out;
+        packed2 = true;
+    }
     if (!rvalid) {
         if (hipError_t e = hipMemsetAsync(fin.counters, 0, (size_t)n * sizeof(int32_t), s); e != hipSuccess)
             return fail_hip(e, "carle_rnd_ae_train: hipMemsetAsync");
@@ -1552,13 +1574,13 @@ int rnd_ae_tiled_train(const void *obs, bool packed, int64_t n, int size, const 
         hipLaunchKernelGGL(rnd_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, rws, pp, rp, rpartial, featbuf, n, size, fin);
     const int brows = rnd2d_tiled_bwd_rows(n, size);
     const unsigned lin = (unsigned)(((int64_t)kRndK * d + kRndK + 255) / 256);
-    if (packed)
-        hipLaunchKernelGGL(rnd_bwd_pair_kernel<true>, dim3((unsigned)brows + lin), dim3(256), 0, s, obs, rws, pp, pred, targ,
+    if (packed2)
+        hipLaunchKernelGGL(rnd_bwd_pair_kernel<true>, dim3((unsigned)brows + lin), dim3(256), 0, s, obs2, rws, pp, pred, targ,
                            rrows, featbuf, rgrad, rgrad_scale, n, size, brows);
     else
-        hipLaunchKernelGGL(rnd_bwd_pair_kernel<false>, dim3((unsigned)brows + lin), dim3(256), 0, s, obs, rws, pp, pred, targ,
+        hipLaunchKernelGGL(rnd_bwd_pair_kernel<false>, dim3((unsigned)brows + lin), dim3(256), 0, s, obs2, rws, pp, pred, targ,
                            rrows, featbuf, rgrad, rgrad_scale, n, size, brows);
-    if (int e = ae2d_tiled_train(obs, packed, n, size, ap, aws, arows, agrad_scale, avalid, s)) return e;
+    if (int e = ae2d_tiled_train(obs2, packed2, n, size, ap, aws, arows, agrad_scale, avalid, s)) return e;
     hipLaunchKernelGGL(rnd_ae_train_tail_kernel, dim3(9u + (unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, rrows, brows, rgrad,
                        arows, ae2d_tiled_train_rows(n, size), agrad, aws + kAeLutFloatsT + 128, abonus, reward, ascale, n, tiles,
                        1.0f / ((float)size * (float)size), mom_partials, status);
