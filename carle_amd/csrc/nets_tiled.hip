@@ -304,15 +304,15 @@ __device__ __forceinline__ void rnd_tile_body(RndTileShared &s, const void *__re
                 phi = (w0 >> 59) | ((wp & 0x1Full) << 5);
             }
         } else {
+            // UNCONDITIONAL loads of clamped addresses, validity applied in the ballot below (as rnd_tile_bwd_kernel): the
+            // conditional form cost ~14 instructions and a branch per load (38 loads per wave at the head of the tile)
             const float *gin = reinterpret_cast<const float *>(obs_v) + g * (int64_t)size * size;
-            const int xa = x0 + lane, xb = x0 + 64 + lane;
+            const int xac = min(max(x0 + lane, 0), size - 1), xbc = min(x0 + 64 + min(lane, 9), size - 1);
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
-                const int r = wv + 4 * i, y = y0 + r;
-                const bool yin = r < kTileRows && y >= 0 && y < size;
-                va[i] = 0u; vb[i] = 0u;
-                if (yin && xa >= 0 && xa < size) va[i] = __float_as_uint(gin[(int64_t)y * size + xa]);
-                if (yin && lane < 10 && xb < size) vb[i] = __float_as_uint(gin[(int64_t)y * size + xb]);
+                const int yc = min(max(y0 + wv + 4 * i, 0), size - 1);
+                va[i] = __float_as_uint(gin[(int64_t)yc * size + xac]);
+                vb[i] = __float_as_uint(gin[(int64_t)yc * size + xbc]);
             }
         }
     };
@@ -325,11 +325,14 @@ __device__ __forceinline__ void rnd_tile_body(RndTileShared &s, const void *__re
         if (PACKED) {
             if (tid < kTileRows) { s.rows[tid][0] = plo; s.rows[tid][1] = phi; }
         } else {
+            const int y0 = 64 * ty - 5, x0 = 64 * tx - 5;
+            const int xa = x0 + lane, xb = x0 + 64 + lane;
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
-                const int r = wv + 4 * i;
-                const uint64_t lo = __ballot((va[i] & 0x7FFFFFFFu) != 0u);
-                const uint64_t hi = __ballot((vb[i] & 0x7FFFFFFFu) != 0u);
+                const int r = wv + 4 * i, y = y0 + r;
+                const bool yin = r < kTileRows && y >= 0 && y < size;
+                const uint64_t lo = __ballot(yin && xa >= 0 && xa < size && (va[i] & 0x7FFFFFFFu) != 0u);
+                const uint64_t hi = __ballot(yin && lane < 10 && xb < size && (vb[i] & 0x7FFFFFFFu) != 0u);
                 if (lane == 0 && r < kTileRows) { s.rows[r][0] = lo; s.rows[r][1] = hi; }
             }
         }
@@ -772,15 +775,14 @@ __device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__rest
                 phi = (w0 >> 57) | ((wp & 0x7Full) << 7);
             }
         } else {
+            // unconditional loads of clamped addresses, validity applied in the ballot below (see rnd_tile_body)
             const float *gin = reinterpret_cast<const float *>(obs_v) + g * (int64_t)size * size;
-            const int xa = x0 + lane, xb = x0 + 64 + lane;
+            const int xac = min(max(x0 + lane, 0), size - 1), xbc = min(x0 + 64 + min(lane, 13), size - 1);
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
-                const int r = wv + 4 * i, y = y0 + r;
-                const bool yin = r < kAeRows && y >= 0 && y < size;
-                va[i] = 0u; vb[i] = 0u;
-                if (yin && xa >= 0 && xa < size) va[i] = __float_as_uint(gin[(int64_t)y * size + xa]);
-                if (yin && lane < 14 && xb < size) vb[i] = __float_as_uint(gin[(int64_t)y * size + xb]);
+                const int yc = min(max(y0 + wv + 4 * i, 0), size - 1);
+                va[i] = __float_as_uint(gin[(int64_t)yc * size + xac]);
+                vb[i] = __float_as_uint(gin[(int64_t)yc * size + xbc]);
             }
         }
     };
@@ -793,11 +795,14 @@ __device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__rest
         if (PACKED) {
             if (tid < kAeRows) { s.rows[tid][0] = plo; s.rows[tid][1] = phi; }
         } else {
+            const int y0 = 64 * ty - 7, x0 = 64 * tx - 7;
+            const int xa = x0 + lane, xb = x0 + 64 + lane;
 #pragma unroll
             for (int i = 0; i < kPer; ++i) {
-                const int r = wv + 4 * i;
-                const uint64_t lo = __ballot((va[i] & 0x7FFFFFFFu) != 0u);
-                const uint64_t hi = __ballot((vb[i] & 0x7FFFFFFFu) != 0u);
+                const int r = wv + 4 * i, y = y0 + r;
+                const bool yin = r < kAeRows && y >= 0 && y < size;
+                const uint64_t lo = __ballot(yin && xa >= 0 && xa < size && (va[i] & 0x7FFFFFFFu) != 0u);
+                const uint64_t hi = __ballot(yin && lane < 14 && xb < size && (vb[i] & 0x7FFFFFFFu) != 0u);
                 if (lane == 0 && r < kAeRows) { s.rows[r][0] = lo; s.rows[r][1] = hi; }
             }
         }
