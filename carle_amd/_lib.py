@@ -78,6 +78,8 @@ SIGNATURES = {
     "carle_normalize_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp, ctypes.c_double, _c_vp]),
     "carle_env_step_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
                                     _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp]),
+    "carle_env_step_f32_bits": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
+                                    _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp, ctypes.POINTER(ctypes.c_int), _c_vp]),
     "carle_env_run_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
                                    ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _c_int, _c_vp, _c_int, _c_int,
                                    _c_vp]),

@@ -209,7 +209,7 @@ int env_run_noaction64(const float *u_in, float *u_out, float *reward, int64_t n
                        int32_t *status, int slot0, int step_flags, void *stream);
 int env_step_one_launch_f32(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h,
                             int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
-                            void *stream);
+                            void *stream, uint64_t *bits_out = nullptr, int *bits_written = nullptr);
 int env_step_one_launch_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out, float *reward,
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
                            int step_flags, void *stream);
@@ -250,6 +250,21 @@ extern "C" int carle_env_step_f32(const float *u_in, const float *action, float 
     return ca_finish_impl(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot,
                           action != nullptr, nullptr, 0, nullptr, 0.0f,
                           publish_flags & CARLE_STEP_MERGE_MOMENTS, stream);
+}
+
+// carle_env_step_f32 that ALSO leaves a bit-packed copy of the new state where the launch can produce it for free (the
+// one-launch step of 256 / 512-column grids: the tiled reward-net kernels read 512 bytes per tile instead of 22 KB);
+// *bits_written (host) says whether it did -- 0: bits_out was not touched.
+extern "C" int carle_env_step_f32_bits(const float *u_in, const float *action, float *u_out, float *reward, int64_t n,
+                                       int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
+                                       int publish_flags, uint64_t *bits_out, int *bits_written, void *stream) {
+    if (bits_written) *bits_written = 0;
+    if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_bits: status is NULL");
+    if (bits_out && (publish_flags & CARLE_STEP_DEFERRED) && !(h == 64 && w == 64))
+        if (const int e = env_step_one_launch_f32(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
+                                                  publish_flags, stream, bits_out, bits_written); e != -1000)
+            return e;
+    return carle_env_step_f32(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot, publish_flags, stream);
 }
 
 extern "C" int carle_ca_step_b1(const uint64_t *, const uint64_t *, uint64_t *, int64_t, int, int, int,

@@ -16,6 +16,7 @@ What is different underneath:
   * this build is GPU-only: without a HIP device ``reset``/``step`` raise (no CPU fallback).
 """
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -192,6 +193,26 @@ class CARLE(RLEMixin, nn.Module):
         ptrs = torch.tensor([stats._batch.data_ptr(), stats._pending.data_ptr()], dtype=torch.int64)
         self._status[hip.ST_MOMENTS_OUT:hip.ST_MOMENTS_OUT + 4] = \
             ptrs.view(torch.int32).to(self._status.device, non_blocking=True)
+
+    def _bits_buffer(self, out, slot):
+        """Where the one-launch step of a 256- / 512-column fp32 grid leaves a bit-packed copy of its output (one buffer
+        per step parity) -- only while a reward net that reads it sits on this environment (``want_packed_copy``)."""
+        if not self.__dict__.get("want_packed_copy") or out.dtype != torch.float32 or out.shape[3] not in (256, 512) \
+                or out.shape[2] != out.shape[3]:
+            return None
+        bufs = self.__dict__.get("_bits_bufs")
+        shape = (out.shape[0], 1, out.shape[2], out.shape[3] // 64)
+        if bufs is None or tuple(bufs[0].shape) != shape or bufs[0].device != out.device:
+            bufs = self.__dict__["_bits_bufs"] = [torch.empty(shape, dtype=torch.int64, device=out.device) for _ in (0, 1)]
+        return bufs[slot]
+
+    def packed_copy_of(self, obs):
+        """The bit-packed copy (int64 (N,1,H,W/64)) the last step left of ``obs``, or None: only for the very tensor the
+        step returned, unmodified since."""
+        hit = self.__dict__.get("_obs_bits")
+        if hit is not None and hit[0]() is obs and hit[1] == obs._version:
+            return hit[2]
+        return None
 
     def settled_status(self):
         """The status block with every finished step applied to the counters: the one-launch step
@@ -392,7 +413,10 @@ class CARLE(RLEMixin, nn.Module):
             # for an oversize action evaluate them on the uncropped tensor (cold path, no sync)
             hip.action_flags_f32(full.contiguous(), self._status, slot)
         if launch is None:
-            hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, publish, merge)
+            bits = self._bits_buffer(out, slot)
+            if hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, publish, merge, bits_out=bits):
+                # the launch left a bit-packed copy of the new state: the tiled reward nets read that
+                self.__dict__["_obs_bits"] = (weakref.ref(out), out._version, bits)
             self._moments_merged = merge
         else:
             launch(u_in, act, out, reward, rule, self._status, slot, publish)

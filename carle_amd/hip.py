@@ -3,6 +3,8 @@
 PyTorch is used for device memory and streams; every function here enqueues hand-written HIP
 kernels on torch's current stream of the tensors' device and returns without synchronising.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -284,12 +286,16 @@ def _step_flags(publish_flags, merge_moments, deferred=False):
     return (1 if publish_flags else 0) | (2 if merge_moments else 0) | (4 if deferred else 0)
 
 
+_bits_written = ctypes.c_int(0)
+
+
 def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False,
-                 deferred=True):
+                 deferred=True, bits_out=None):
     """CARLE.step hot path, one library call (shapes are validated by the caller; pointers by the library).
     deferred (default): ONE kernel launch where the library has a one-launch step (64x64 grids: master reset and
     reward inside the step kernel, counters settled lazily -- read them through ``env_settle``); else step kernel +
-    epilogue kernel."""
+    epilogue kernel.  bits_out (int64 (N,1,H,W/64), optional): the launch also leaves a bit-packed copy of the new
+    state there where it can (carle_env_step_f32_bits); returns True iff it did."""
     lib = _lib.load()
     n, _, h, w = u_in.shape
     if action is None:
@@ -297,11 +303,18 @@ def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=
     else:
         ap, ah, aw = action.data_ptr(), action.shape[2], action.shape[3]
     with _on_device(u_in.device):
-        rc = lib.carle_env_step_f32(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h,
-                                    w, ah, aw, rule, status.data_ptr(), slot,
-                                    _step_flags(publish_flags, merge_moments, deferred), _stream(u_in))
+        if bits_out is None:
+            rc = lib.carle_env_step_f32(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h,
+                                        w, ah, aw, rule, status.data_ptr(), slot,
+                                        _step_flags(publish_flags, merge_moments, deferred), _stream(u_in))
+        else:
+            rc = lib.carle_env_step_f32_bits(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h,
+                                             w, ah, aw, rule, status.data_ptr(), slot,
+                                             _step_flags(publish_flags, merge_moments, deferred), bits_out.data_ptr(),
+                                             ctypes.byref(_bits_written), _stream(u_in))
     if rc != 0:
         _lib.check(rc, "carle_env_step_f32")
+    return bits_out is not None and _bits_written.value != 0
 
 
 def env_run_f32(u_in, buf_a, buf_b, actions, reward, rule, status, slot0, k, ah=0, aw=0, p=-1.0, seed=0, offset=0,

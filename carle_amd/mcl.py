@@ -18,6 +18,8 @@ Puffer) keep their per-step state on the device: no host synchronisation per ste
 """
 import weakref
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -151,6 +153,10 @@ class RND2D(Motivator):
         # False: step() only evaluates the bonus (forward pass), no window retention / Adam update
         self.train_predictor = bool(kwargs.get("train_predictor", True))
         self.accumulate_loss = 0.0
+        # fp32 state of 256 / 512 columns: ask the environment's one-launch step for a bit-packed copy of every new
+        # state (CARLE._bits_buffer) -- the tiled kernels of this wrapper read that instead of the fp32 cells
+        if getattr(self.inner_env, "storage", None) == "f32" and os.environ.get("CARLE_PACKED_COPY", "1") != "0":
+            self.inner_env.__dict__["want_packed_copy"] = True       # (CARLE_PACKED_COPY=0: A/B switch)
 
     # ------------------------------------------------------------------ networks
     def initialize_predictor(self):
@@ -222,6 +228,10 @@ class RND2D(Motivator):
             return (obs != 0).to(torch.float32), True
         binary = self.assume_binary_obs or (getattr(env, "storage", "f32") == "f32" and
                                             obs is env.__dict__.get("universe"))
+        if allow_packed and self._packed_any_size and obs.dtype == torch.float32:
+            bits = env.packed_copy_of(obs) if hasattr(env, "packed_copy_of") else None
+            if bits is not None:                          # the step left a bit-packed copy of this very observation
+                return bits, True
         if obs.device != dev or obs.dtype != torch.float32 or not obs.is_contiguous():
             obs = obs.to(dev, torch.float32).contiguous()
         if obs.dim() == 3:
