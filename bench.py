@@ -78,6 +78,9 @@ def parse(argv=None):
                          "kernels got faster: the cross-stream events cost more than they hide)")
     ap.add_argument("--sync-reward", action="store_true", help="(default since late round 2; kept for old command lines)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1")
+    ap.add_argument("--per-rank-predictors", action="store_true",
+                    help="--train with --gpus > 1: every rank trains its own predictor on its shard instead of the "
+                         "data-parallel predictor (carle_amd.dist.data_parallel: gradient all-reduce per Adam step)")
     ap.add_argument("--share-gpus", action="store_true",
                     help="rehearsal only: let several ranks share a device when the node has fewer "
                          "than --gpus (needs --backend gloo; RCCL refuses two ranks on one device)")
@@ -467,6 +470,9 @@ def run_rank(args):
             wenv = AE2D(wenv, **kw)
         wenv.eval()
         wenv.to(dev)
+        if args.train and world > 1 and not args.per_rank_predictors:
+            # the reference's loss is the mean over the WHOLE batch: flat-gradient all-reduce before every Adam step
+            cdist.data_parallel(wenv, broadcast=False)       # same seed on every rank: the networks already agree
     # Measured (late round 2, N=4096 64x64 / the reference's default 16 x 256x256): one stream 0.0767 / 0.0513 ms/step with
     # RND2D + AE2D forward, 0.171 / 0.088 in training mode; reward stream 0.0810 / 0.098 and 0.169 / 0.111 -- the
     # cross-stream events cost more than the overlap hides, most of all for small batches: one stream is the default
@@ -677,7 +683,9 @@ def run_rank(args):
                                        if (args.rnd or args.ae) else ""),
                        "reward_consumers": "reward stream" if rs is not None else "same stream",
                        "collective": f"all-gather of 24 B/rank reward moments every {args.stats_every} steps"
-                                     f" ({args.backend if world > 1 else 'single rank'})",
+                                     f" ({args.backend if world > 1 else 'single rank'})" +
+                                     ("; all-reduce of the flat predictor gradients before every Adam step"
+                                      if args.train and world > 1 and not args.per_rank_predictors else ""),
                        "state_bytes_per_array": int(env.universe_bits.numel() * 8 if packed else
                                                     env.universe.numel() * env.universe.element_size())},
             "cell_updates_per_s": world * n * args.steps * size * size / dt,

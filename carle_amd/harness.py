@@ -22,27 +22,32 @@ def _drain(sums):
     return torch.stack(sums).detach().cpu().numpy() if sums else np.zeros(0, np.float32)
 
 
-def _warn_if_sharded():
+def _data_parallel_or_warn(env):
     """Batch-sharded training (one process per GPU, carle_amd.dist): the reference's predictor loss is a mean over the
-    WHOLE batch (carle/mcl.py:362,376); here every rank trains its own predictor on its own shard -- no gradient
-    all-reduce (SURVEY 8(e) lists it as optional, the north star names the reward statistics as the only exchange).
-    The ranks' predictors therefore drift apart and a sharded run is not the unsharded one in training mode.  Said
-    once per process instead of silently."""
+    WHOLE batch (carle/mcl.py:362,376).  With a process group up, the wrappers' predictors are trained data-parallel
+    (``dist.data_parallel``: rank 0's networks broadcast once, the flat gradient all-reduced before every Adam step),
+    so the sharded run takes the unsharded run's updates.  WORLD_SIZE > 1 WITHOUT a process group means every rank
+    trains its own predictor on its shard: said once instead of silently."""
     import os
     import warnings
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        warnings.warn("carle_amd.harness.train under WORLD_SIZE > 1: every rank trains its own RND2D / AE2D predictor on "
-                      "its shard of the batch (no gradient all-reduce); rewards and saved weights differ per rank and "
-                      "from an unsharded run (DESIGN.md, multi-GPU)", stacklevel=3)
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        from . import dist as cdist
+        cdist.data_parallel(env)
+    elif int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        warnings.warn("carle_amd.harness.train under WORLD_SIZE > 1 without an initialised process group: every rank "
+                      "trains its own RND2D / AE2D predictor on its shard of the batch (no gradient all-reduce); call "
+                      "carle_amd.dist.init_from_env() first to train them data-parallel (DESIGN.md, multi-GPU)",
+                      stacklevel=3)
 
 
 def train(agent_fn, instances=16, steps=(64, 2048), rules=(((3,), (2, 3)),), mcl=(RND2D, AE2D),
           out_dir="./logs/mcl", verbose=True, **env_kwargs):
-    _warn_if_sharded()
     env_kwargs.setdefault("use_cuda", True)
     env = CARLE(instances=instances, **env_kwargs)
     for wrapper in mcl:
         env = wrapper(env)
+    _data_parallel_or_warn(env)
     agent = agent_fn(observation_width=env.inner_env.width, observation_height=env.inner_env.height,
                      action_width=env.inner_env.action_width, action_height=env.inner_env.action_height)
     exp_id = "mcl" + str(int(time.time()))

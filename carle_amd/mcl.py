@@ -318,6 +318,7 @@ class RND2D(Motivator):
 
     def update_predictor(self, loss):
         loss.backward()
+        self._sync_gradients(self._pred_blob.params or list(self.predictor.parameters()))
         self.optimizer.step()
         self.optimizer.zero_grad()
         self.updates += 1
@@ -442,6 +443,7 @@ class RND2D(Motivator):
         if self._window:
             self.accumulate_loss = self.accumulate_loss + self._replay_window(replay_scale)
         params = self._pred_blob.params or list(self.predictor.parameters())
+        self._sync_gradients(params)
         if self._grad_used and self._hip_adam_applies(params):
             self._hip_adam_step(params)
             return
@@ -454,6 +456,28 @@ class RND2D(Motivator):
             self._grad.zero_()
             self._grad_used = False
         self.optimizer.step()
+
+    def _sync_gradients(self, params):
+        """Data-parallel predictor (``carle_amd.dist.data_parallel``): the reference's loss is the mean over the WHOLE
+        batch (mcl.py:362,376), so under batch sharding the window's gradient is the instance-weighted sum of the
+        ranks' gradients -- one all-reduce of the flat gradient (1 117 floats at 64x64, 16.5 k at 256x256) per Adam
+        step, on the stream the gradient kernels ran on.  Every rank then takes the same Adam step."""
+        sync = self.__dict__.get("_grad_sync")
+        if sync is None:
+            return
+        import torch.distributed as tdist
+        group, weight = sync
+        if self._grad_used:
+            self._grad.mul_(weight)
+            tdist.all_reduce(self._grad, group=group)
+        grads = [p.grad for p in params if p.grad is not None]       # autograd replay / caller's own backward
+        if grads:
+            flat = torch.cat([g.reshape(-1) for g in grads]).mul_(weight)
+            tdist.all_reduce(flat, group=group)
+            off = 0
+            for g in grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
 
     def _hip_adam_applies(self, params):
         opt = self.optimizer
@@ -868,6 +892,7 @@ class AE2D(RND2D):
 
     def update_predictor(self, loss):
         loss.backward()
+        self._sync_gradients(self._pred_blob.params or list(self.predictor.parameters()))
         self.optimizer.step()
 
     def _after_update(self):

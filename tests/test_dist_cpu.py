@@ -140,3 +140,61 @@ def test_bench_launcher_propagates_rank_failure():
     # one rank dies (bad backend name): the launcher stops the others and exits non-zero
     out = _bench("--gpus", "2", "--backend", "no_such_backend", "--launch-check", timeout=120)
     assert out.returncode != 0
+
+
+def _dp_worker(rank, world, port, q):
+    """Host logic of the data-parallel predictor on CPU: broadcast of rank 0's networks, the instance-weighted
+    all-reduce of the gradients in front of the optimiser step (here the caller's own autograd loss through
+    ``update_predictor``; the HIP gradient kernels take the same hook, tests/test_gpu_stats.py)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from carle_amd import dist as cd
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total = 8
+        start, count = (0, 3) if rank == 0 else (3, 5)                # unequal shards: weights 3/8 and 5/8
+        torch.manual_seed(100 + rank)                                 # the ranks start from DIFFERENT networks
+        ae = AE2D(RND2D(CARLE(width=64, height=64, instances=count, device="cpu")))
+        rnd = ae.env
+        ae.eval()                                                     # Dropout = identity, as in the HIP kernels
+        enabled = cd.data_parallel(ae)
+        assert enabled == [ae, rnd] and rnd._grad_sync[1] == count / total
+        obs = (torch.rand(total, 1, 64, 64, generator=torch.Generator().manual_seed(7)) < 0.3).float()
+        for w in (rnd, ae):
+            for _ in range(2):
+                w.update_predictor(torch.mean(w._torch_loss(obs[start:start + count])))
+        q.put((rank, {k: v.numpy().copy() for k, v in ae.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_predictor_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k                # the ranks stay bit-identical
+    # the unsharded run from rank 0's networks
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D
+    torch.manual_seed(100)
+    ae = AE2D(RND2D(CARLE(width=64, height=64, instances=8, device="cpu")))
+    ae.eval()
+    obs = (torch.rand(8, 1, 64, 64, generator=torch.Generator().manual_seed(7)) < 0.3).float()
+    for w in (ae.env, ae):
+        for _ in range(2):
+            w.update_predictor(torch.mean(w._torch_loss(obs)))
+    for k, v in ae.state_dict().items():
+        # Adam's first steps are +-lr whatever the gradient's size: a sign error or a missing weight shows at 1e-1
+        np.testing.assert_allclose(res[0][k], v.numpy(), rtol=0, atol=2e-5, err_msg=k)

@@ -223,6 +223,80 @@ def test_running_stats_flush_two_ranks_on_device():
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2]      # bit-identical on both ranks
 
 
+def _dp_inputs(size, total, steps):
+    g = torch.Generator().manual_seed(size + total)
+    u0 = (torch.rand(total, 1, size, size, generator=g) < 0.35).float()
+    acts = (torch.rand(steps, total, 1, 64, 64, generator=g) < 0.1).float()
+    return u0, acts
+
+
+def _dp_trajectory(size, start, count, total, steps, batch_size, sync):
+    """`steps` training steps of AE2D(RND2D(CARLE)) on instances [start, start + count) of the seeded batch; returns
+    (rewards (steps, count), state_dict as numpy)."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D
+    u0, acts = _dp_inputs(size, total, steps)
+    torch.manual_seed(0)
+    env = CARLE(width=size, height=size, instances=count, device="cuda:0")
+    ae = AE2D(RND2D(env))
+    ae.reset()
+    for w in (ae, ae.env):
+        w.batch_size = batch_size
+    if sync:
+        from carle_amd import dist as cd
+        assert cd.data_parallel(ae, broadcast=True) == [ae, ae.env]
+    env.universe = u0[start:start + count].cuda()
+    rewards = []
+    for t in range(steps):
+        rewards.append(ae.step(acts[t, start:start + count].cuda())[1].reshape(-1).cpu().numpy().copy())
+    torch.cuda.synchronize()
+    return np.stack(rewards), {k: v.cpu().numpy().copy() for k, v in ae.state_dict().items()}
+
+
+def _dp_worker(rank, world, port, size, total, steps, batch_size, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from carle_amd import dist as cd
+    cd.init_from_env("gloo", share_devices=True)             # two ranks on the one device of the test box
+    try:
+        start, count = cd.shard(total)
+        q.put((rank, start, count) + _dp_trajectory(size, start, count, total, steps, batch_size, True))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("size,total", [(64, 11), (256, 6)])
+def test_data_parallel_predictors_take_the_unsharded_updates(size, total):
+    """carle_amd.dist.data_parallel: two ranks, each stepping its shard of the batch through AE2D(RND2D(CARLE)) in
+    training mode (HIP gradient kernels; 64x64: the fused kernels with unequal shards 6 + 5, 256x256: the paired tiled
+    call), all-reduce their flat gradients before every Adam step.  Rewards and weights must be those of ONE process
+    stepping the whole batch -- the reference's loss is the mean over the whole batch (carle/mcl.py:362,376)."""
+    import socket
+    import torch.multiprocessing as mp
+    steps, batch_size = 9, 4                                 # two Adam steps inside the trajectory
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, size, total, steps, batch_size, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    whole_rewards, whole_sd = _dp_trajectory(size, 0, total, total, steps, batch_size, False)
+    for k in whole_sd:
+        assert np.array_equal(res[0][4][k], res[1][4][k]), k                      # the ranks never drift apart
+        np.testing.assert_allclose(res[0][4][k], whole_sd[k], rtol=0, atol=2e-5, err_msg=k)
+    sharded = np.concatenate([res[0][3], res[1][3]], axis=1)
+    assert sharded.shape == whole_rewards.shape and res[0][2] + res[1][2] == total
+    np.testing.assert_allclose(sharded[:batch_size], whole_rewards[:batch_size], rtol=0, atol=1e-6)   # before any update
+    np.testing.assert_allclose(sharded, whole_rewards, rtol=0, atol=2e-5)
+    assert np.abs(whole_rewards[-1] - whole_rewards[0]).max() > 1e-3              # the updates did change the rewards
+
+
 @pytest.mark.parametrize("n", [1, 7, 16, 40])
 def test_run_merges_reward_moments_like_the_step_loop(n):
     """CARLE.run with attached statistics: the k steps of a small batch run in one launch (ca_env_run_small64_kernel)

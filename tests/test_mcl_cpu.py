@@ -69,17 +69,18 @@ def test_param_blob_tracks_updates():
     assert b is not a and torch.equal(b[:6], lin.weight.detach().reshape(-1))
 
 
-def test_train_warns_under_sharding(monkeypatch):
-    """harness.train says so when WORLD_SIZE > 1 (per-rank predictors, no gradient all-reduce)."""
+def test_train_warns_under_sharding_without_a_process_group(monkeypatch):
+    """harness.train says so when WORLD_SIZE > 1 and no process group is up (per-rank predictors, no gradient
+    all-reduce); with a group it enables carle_amd.dist.data_parallel instead (tests/test_gpu_stats.py)."""
     import warnings
     from carle_amd import harness
     monkeypatch.setenv("WORLD_SIZE", "2")
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
-        harness._warn_if_sharded()
+        harness._data_parallel_or_warn(None)
     assert any("every rank trains its own" in str(w.message) for w in rec)
     monkeypatch.setenv("WORLD_SIZE", "1")
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
-        harness._warn_if_sharded()
+        harness._data_parallel_or_warn(None)
     assert not rec
