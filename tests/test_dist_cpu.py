@@ -126,6 +126,24 @@ def test_bench_launcher_spawns_one_rank_per_gpu(world):
         [(r, r, world) for r in range(world)]
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's launch form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- every process is one rank (RANK / LOCAL_RANK / WORLD_SIZE from the env),
+    nobody spawns anything, rank 0 prints the one JSON line."""
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check"],
+                         capture_output=True, text=True, timeout=240, cwd=ROOT, env=e)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and [(r["rank"], r["local_rank"], r["world_size"]) for r in d["ranks"]] == [(0, 0, 2), (1, 1, 2)]
+
+
 def test_bench_refuses_mismatched_world():
     # --gpus disagrees with WORLD_SIZE: fail loudly before the rendezvous (no hang, no 1-GPU number)
     out = _bench("--gpus", "4", "--launch-check", env={"WORLD_SIZE": "2", "RANK": "0"}, timeout=60)
