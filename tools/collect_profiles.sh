@@ -47,5 +47,6 @@ pmc cfg2 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 4096 64 f32
 pmc cfg2_n65536 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 65536 64 f32 --instances 65536
 pmc cfg4 "ca_step_rnd64_kernel<true" 4096 64 f32 --rnd
 pmc cfg5 "ca_step_b1_kernel" 4096 512 b1 --format b1 --size 512 --instances 4096 --rule B36/S23
+pmc f32_256 "ca_step_wide_kernel" 4096 256 f32 --size 256
 cp $R/profiles/pmc_latest.json $O/pmc_latest.json
 echo "all done"
