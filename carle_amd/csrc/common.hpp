@@ -7,6 +7,16 @@
 
 #include "../../include/carle_hip.h"
 
+// gfx950 only.  Besides the instruction selection (v_bitop3, DPP, v_permlane32_swap, LDS-DMA), the last-arrival finish
+// protocols of nets_tiled.hip / reduce.hip / ca_cells.hpp hand data between workgroups WITHOUT agent-scope fences:
+// write-through (sc1) stores, every storing wave's s_waitcnt vmcnt(0), a workgroup barrier, ONE relaxed agent-scope
+// ticket, sc1 loads by the workgroup whose ticket came last.  That is a hand-off form validated on gfx950 / ROCm 7.2
+// (MI355X_MICROARCH.md, "Valid forms" of inter-workgroup visibility), not an architectural guarantee: a build for any
+// other architecture must not compile these paths silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libcarle_hip is written for gfx950 (MI355X): its fence-free inter-workgroup hand-offs are validated there only"
+#endif
+
 namespace carle {
 
 // thread-local error text behind carle_last_error()

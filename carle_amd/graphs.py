@@ -142,6 +142,11 @@ class StepGraph:
     def _capture(self):
         env, base = self.env, self.base
         state = base._raw_state()                      # raises before reset()
+        # a one-launch step before us may have left its counters PENDING and its reward moments as per-workgroup
+        # partial sums registered in the status block (words 20..23): settle them NOW, or the warm-up steps would merge
+        # them into accumulators that the restore below rolls back, while the restored status block would point at
+        # partial buffers that by then hold the capture steps' rewards
+        base.settled_status()
         keep_state, keep_status, keep_slot = state.clone(), base._status.clone(), base._slot
         side_before = self._side_state()
         side_keep = {id(t): t.clone() for t in side_before}
@@ -182,6 +187,8 @@ class StepGraph:
                            env.__dict__.get("_moments_merged", False), base.__dict__.get("_moments_pending", False)))
         self._graphs = graphs
         self._action_ptr = self.action.data_ptr()
+        # the recorded calls carry the raw handle of the stream that was current at capture
+        self._stream = hip._stream(state)
         self._params = self._param_key()
         # back to where the caller was: wrapper state that existed before is restored, state the warm-up created
         # (lazily allocated histories) starts empty
@@ -241,6 +248,11 @@ class StepGraph:
             self._capture()
         p = base._slot
         buf = self._bufs[p]
+        if self.backend == "calls" and hip._stream(buf) != self._stream:
+            # the recorded launches go to the capture stream; the state copy below and the caller's action producer run
+            # on the CURRENT stream: replaying under another stream context would race
+            raise RuntimeError("StepGraph(backend='calls') replays on the stream that was current at capture: call it "
+                               "under that stream (or build the StepGraph under the stream it will be used on)")
         state = base._raw_state()
         if state is not buf:                            # reset(), an assigned pattern, eager steps in between
             buf.copy_(state)
@@ -264,14 +276,17 @@ class StepGraph:
             g.replay()
         else:
             swap = action_ptr != self._action_ptr
-            for fn, args, where in g:
-                if swap and where:
-                    args = list(args)
-                    for i in where:
-                        args[i] = action_ptr
-                rc = fn(*args)
-                if rc:
-                    _lib.check(rc, getattr(fn, "__name__", "library call"))
+            # eager steps make the environment's device current for each launch; so does the replay (an environment on
+            # cuda:1 replayed while cuda:0 is current would launch on a foreign device's stream handle)
+            with hip._on_device(self._bufs[0].device):
+                for fn, args, where in g:
+                    if swap and where:
+                        args = list(args)
+                        for i in where:
+                            args[i] = action_ptr
+                    rc = fn(*args)
+                    if rc:
+                        _lib.check(rc, getattr(fn, "__name__", "library call"))
         base._set_raw_state(self._bufs[p ^ 1])
         base._slot = p ^ 1
         base._moments_merged = merged

@@ -318,7 +318,9 @@ class RND2D(Motivator):
 
     def update_predictor(self, loss):
         loss.backward()
-        self._sync_gradients(self._pred_blob.params or list(self.predictor.parameters()))
+        # torch's optimizer.step() below consumes the autograd .grad tensors only: the kernel gradient of a window in
+        # flight (self._grad) is reduced where it is consumed, in _apply_update
+        self._sync_gradients(self._pred_blob.params or list(self.predictor.parameters()), kernel_gradient=False)
         self.optimizer.step()
         self.optimizer.zero_grad()
         self.updates += 1
@@ -457,17 +459,20 @@ class RND2D(Motivator):
             self._grad_used = False
         self.optimizer.step()
 
-    def _sync_gradients(self, params):
+    def _sync_gradients(self, params, kernel_gradient=True):
         """Data-parallel predictor (``carle_amd.dist.data_parallel``): the reference's loss is the mean over the WHOLE
         batch (mcl.py:362,376), so under batch sharding the window's gradient is the instance-weighted sum of the
         ranks' gradients -- one all-reduce of the flat gradient (1 117 floats at 64x64, 16.5 k at 256x256) per Adam
-        step, on the stream the gradient kernels ran on.  Every rank then takes the same Adam step."""
+        step, on the stream the gradient kernels ran on.  Every rank then takes the same Adam step.
+        ``kernel_gradient=False`` (``update_predictor``: torch's own step on a caller's loss) reduces the autograd
+        ``.grad`` tensors only and leaves the flat kernel gradient of a window in flight alone: it is weighted and
+        reduced exactly once, by the ``_apply_update`` that consumes it."""
         sync = self.__dict__.get("_grad_sync")
         if sync is None:
             return
         import torch.distributed as tdist
         group, weight = sync
-        if self._grad_used:
+        if kernel_gradient and self._grad_used:
             self._grad.mul_(weight)
             tdist.all_reduce(self._grad, group=group)
         grads = [p.grad for p in params if p.grad is not None]       # autograd replay / caller's own backward
@@ -498,24 +503,31 @@ class RND2D(Motivator):
         st = self.__dict__.get("_adam")
         if st is None or st[0].device != dev or st[0].numel() != total:
             st = self.__dict__["_adam"] = [torch.zeros(total, dtype=torch.float32, device=dev),
-                                          torch.zeros(total, dtype=torch.float32, device=dev), 0]
-        m, v, step = st
+                                          torch.zeros(total, dtype=torch.float32, device=dev)]
+        m, v = st
         # Adam's moments are shared with the torch optimiser: its per-parameter state tensors are views of the flat
-        # vectors.  A state somebody else installed (optimizer.load_state_dict, earlier torch steps) is adopted.
+        # vectors.  A state somebody else installed (optimizer.load_state_dict, earlier torch steps) is adopted.  The
+        # step count is ALWAYS the optimiser's own: a torch-path optimizer.step() in between (update_predictor, the
+        # autograd replay) advances it on the shared views, and the bias corrections must follow
+        off, step = 0, 0
+        for p in params:
+            k = p.numel()
+            ps = self.optimizer.state.get(p)
+            if ps and "exp_avg" in ps:
+                step = max(step, int(float(ps["step"])))
+                if ps["exp_avg"].data_ptr() != m.data_ptr() + 4 * off:
+                    m[off:off + k].copy_(ps["exp_avg"].reshape(-1))
+                    v[off:off + k].copy_(ps["exp_avg_sq"].reshape(-1))
+            off += k
         off = 0
         for p in params:
             k = p.numel()
             ps = self.optimizer.state.get(p)
-            if ps and "exp_avg" in ps and ps["exp_avg"].data_ptr() != m.data_ptr() + 4 * off:
-                m[off:off + k].copy_(ps["exp_avg"].reshape(-1))
-                v[off:off + k].copy_(ps["exp_avg_sq"].reshape(-1))
-                step = int(float(ps["step"]))
-            if not ps or ps["exp_avg"].data_ptr() != m.data_ptr() + 4 * off:
+            if not ps or "exp_avg" not in ps or ps["exp_avg"].data_ptr() != m.data_ptr() + 4 * off:
                 self.optimizer.state[p] = {"step": torch.tensor(float(step)), "exp_avg": m[off:off + k].view_as(p),
                                            "exp_avg_sq": v[off:off + k].view_as(p)}
             off += k
         step += 1
-        st[2] = step
         g = self.optimizer.param_groups[0]
         blob = self._pred_blob.get(dev)
         hip.adam_update_f32([p.data for p in params], blob, self._grad, m, v, g["lr"], g["betas"][0], g["betas"][1],
@@ -892,7 +904,7 @@ class AE2D(RND2D):
 
     def update_predictor(self, loss):
         loss.backward()
-        self._sync_gradients(self._pred_blob.params or list(self.predictor.parameters()))
+        self._sync_gradients(self._pred_blob.params or list(self.predictor.parameters()), kernel_gradient=False)
         self.optimizer.step()
 
     def _after_update(self):

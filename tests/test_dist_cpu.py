@@ -181,9 +181,21 @@ def _dp_worker(rank, world, port, q):
         enabled = cd.data_parallel(ae)
         assert enabled == [ae, rnd] and rnd._grad_sync[1] == count / total
         obs = (torch.rand(total, 1, 64, 64, generator=torch.Generator().manual_seed(7)) < 0.3).float()
+        # a kernel gradient of a window in flight (what the HIP training kernels accumulate in w._grad): update_predictor
+        # must leave it alone -- it is weighted and all-reduced ONCE, by the _apply_update that consumes it
+        inflight = {}
+        for w in (rnd, ae):
+            w._grad = torch.full((7,), float(rank + 1))
+            w._grad_used = True
+            inflight[w.my_name] = w._grad
         for w in (rnd, ae):
             for _ in range(2):
                 w.update_predictor(torch.mean(w._torch_loss(obs[start:start + count])))
+        for w in (rnd, ae):
+            assert w._grad is inflight[w.my_name] and torch.equal(w._grad, torch.full((7,), float(rank + 1)))
+            w._sync_gradients(list(w.predictor.parameters()))          # as _apply_update does
+            assert torch.allclose(w._grad, torch.full((7,), 1 * 3 / 8 + 2 * 5 / 8)), w._grad
+            w._grad, w._grad_used = None, False
         q.put((rank, {k: v.numpy().copy() for k, v in ae.state_dict().items()}))
     finally:
         dist.destroy_process_group()

@@ -946,6 +946,42 @@ def test_update_window_through_the_adam_kernel_equals_torch_adam(cls, size, n):
     assert float(ws[0].optimizer.state_dict()["state"][0]["step"]) == 5.0
 
 
+@pytest.mark.parametrize("cls,size,n", [("RND2D", 64, 5), ("AE2D", 64, 3)])
+def test_torch_steps_between_kernel_windows_keep_adams_step_count(cls, size, n):
+    """update_predictor(loss) -- torch's own optimizer.step() on a caller's loss -- between and INSIDE the kernel
+    windows: the Adam kernel takes its bias corrections from the optimiser's step count (which the torch steps advance
+    on the shared state), so the interleaved run equals the same run with torch's optimizer.step() everywhere."""
+    from carle_amd.env import CARLE
+    import carle_amd.mcl as M
+    ws = []
+    for use_hip in (True, False):
+        torch.manual_seed(11)
+        env = CARLE(width=size, height=size, instances=n, device="cuda:0")
+        w = getattr(M, cls)(env)
+        w.eval(); w.reset()
+        w.batch_size = 2
+        w.assume_binary_obs = True
+        if not use_hip:
+            w._hip_adam_applies = lambda params: False
+        ws.append(w)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    expected_step = 0
+    for t in range(8):
+        obs = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+        for w in ws:
+            w.get_bonus_accumulate(obs)
+        expected_step += (t % 2 == 1)
+        if t in (1, 4, 5):                                   # after a window, inside one, after the next
+            for w in ws:
+                w.update_predictor(torch.mean(w._torch_loss(obs)))
+            expected_step += 1
+    assert ws[0].__dict__.get("_adam") is not None and ws[1].__dict__.get("_adam") is None
+    for w in ws:
+        assert float(w.optimizer.state_dict()["state"][0]["step"]) == float(expected_step) == 7.0
+    for (k, a), (_, b) in zip(ws[0].state_dict().items(), ws[1].state_dict().items()):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (k, (a - b).abs().max())
+
+
 @pytest.mark.parametrize("cls,size,n", [("RND2D", 64, 7), ("AE2D", 64, 4), ("RND2D", 256, 2), ("AE2D", 256, 2), ("AE2D", 24, 3)])
 def test_get_bonus_update_runs_on_the_hip_path(cls, size, n, monkeypatch):
     """get_bonus_update (mcl.py:354-366): bonus + one Adam step on the gradient of mean_n(loss_n), through the training

@@ -337,6 +337,68 @@ def test_step_graph_refuses_what_it_cannot_replay():
     assert g()[1].shape == (2, 1)
 
 
+@pytest.mark.parametrize("backend", ["graph", "calls"])
+def test_step_graph_built_behind_a_pending_one_launch_step(backend):
+    """A StepGraph constructed right after an eager one-launch CA + RND2D step with attached reward statistics: that
+    step's reward moments are still per-workgroup partial sums registered in the status block, its counters PENDING.
+    The capture settles them first -- the statistics and counters of eager step + replays equal the all-eager run."""
+    from carle_amd import dist as cd
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D
+    from carle_amd.graphs import StepGraph
+    n = 40                                                   # > 16 grids: the one-launch fused CA + RND2D step
+    g = torch.Generator(device="cuda").manual_seed(3)
+    u0 = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.4).float()
+    acts = [(torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.1).float() for _ in range(6)]
+    res = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(2)
+        env = CARLE(width=64, height=64, instances=n, device="cuda:0")
+        w = RND2D(env, train_predictor=False)
+        stats = cd.RunningRewardStats("cuda:0", sync_every=1000)
+        assert stats.attach(env)
+        w.reset()
+        env.universe = u0.clone()
+        rewards = [w.step(acts[0])[1].clone()]
+        if mode == "graph":
+            assert env.__dict__.get("_moments_pending")      # the situation under test
+            graph = StepGraph(w, torch.zeros_like(acts[0]), backend=backend)
+        for a in acts[1:]:
+            if mode == "eager":
+                rewards.append(w.step(a)[1].clone())
+            elif backend == "calls":
+                rewards.append(graph(a)[1].clone())
+            else:
+                graph.action.copy_(a)
+                rewards.append(graph()[1].clone())
+        status = env.settled_status().cpu().tolist()[4:12]
+        res.append((torch.stack(rewards).cpu().numpy(), stats._pending.cpu().numpy().copy(), status,
+                    env.universe.cpu().numpy()))
+    a, b = res
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[0], b[0])
+    assert a[1][0] == len(acts) * n
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-12)
+    assert a[2] == b[2], (a[2], b[2])
+
+
+def test_step_graph_calls_refuses_a_foreign_stream():
+    """backend='calls' replays on the stream that was current at capture; under another stream context the state
+    copy and the caller's action producer would race with the recorded launches: refused."""
+    from carle_amd.env import CARLE
+    from carle_amd.graphs import StepGraph
+    env = CARLE(instances=3, width=64, height=64, device="cuda:0")
+    env.reset()
+    a = torch.zeros(3, 1, 64, 64, device="cuda")
+    graph = StepGraph(env, a, backend="calls")
+    graph(a)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="stream"):
+            graph(a)
+    torch.cuda.synchronize()
+    assert graph(a)[0].shape == (3, 1, 64, 64)
+
+
 @pytest.mark.parametrize("n,shape", [(3, (1, 64, 64)), (16, (1, 256, 256)), (5, (1, 7, 9)), (2, (1, 130, 130)), (1, (4099,)),
                                      (4, (1, 6, 6))])
 def test_instance_sums_every_plane_combination(n, shape):
