@@ -17,7 +17,7 @@ while i < len(text):
     name = m.group(1)
     mix = {"valu": 0, "salu": 0, "lds": 0, "vmem": 0, "smem": 0, "wait": 0, "branch": 0, "other": 0}
     j = i + 1
-    while j < len(text) and "s_endpgm" not in text[j]:
+    while j < len(text) and not text[j].startswith(".Lfunc_end"):     # (a kernel may hold several s_endpgm)
         t = text[j].strip().split()
         if t and not t[0].startswith((";", ".", "_")) and not t[0].endswith(":"):
             op = t[0]
