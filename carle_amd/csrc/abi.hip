@@ -25,8 +25,6 @@ static Knobs read_knobs() {
     k.wide_blocks = env_i64("CARLE_WIDE_BLOCKS");
     k.rnd_blocks = env_i64("CARLE_RND_BLOCKS");
     k.rnd_cached_load_max_bytes = env_i64("CARLE_RND_CACHED_LOAD_MAX_BYTES");
-    k.rnd_rows_min_n = env_i64("CARLE_RND_ROWS_MIN_N");
-    k.rnd_rows_stagger = env_i64("CARLE_RND_ROWS_STAGGER");
     k.net_blocks = env_i64("CARLE_NET_BLOCKS");
     k.b1_dbg = env_i64("CARLE_B1_DBG");
     k.two_launch_step = env_i64("CARLE_TWO_LAUNCH_STEP");

@@ -348,29 +348,13 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
 
 void rnd2d_prepare_tables(const float *pp, const float *rp, float *ws, hipStream_t s);
 
-// wavefront-per-grid form (ca_rnd_rows.hip): large batches without an action or with the full 64x64 window
-int64_t rnd_rows_blocks(int64_t n);
-int ca_step_rnd_rows(const float *u_in, const float *action, float *u_out, int64_t n, uint32_t rule, int32_t *status, int slot,
-                     const float *ws, float *bonus, bool nt_st, hipStream_t s, const RndEnvArgs *env);
-static bool use_rows_kernel(int64_t n, bool has_action, int aw) {
-    const int64_t v = knobs().rnd_rows_min_n;          // experiment knob, read once; 0 = never
-    const int64_t min_n = v > 0 ? v : INT64_MAX;            // experiment: off unless asked for (slower, EXPERIMENTS.md 4.1)
-    return n >= min_n && (!has_action || aw == 64);
-}
-
-// workgroups of the workgroup-per-grid launch
-static int64_t rnd64_wg_blocks(int64_t n) {
+// workgroups of the fused launch (= reward-moment partial pairs of the one-launch step)
+int64_t rnd64_blocks(int64_t n) {
     int64_t blocks = n <= 1024 ? n : (n + 1) / 2;
     if (blocks < 1024 && n > 1024) blocks = 1024;
     const int64_t v = knobs().rnd_blocks;              // experiment knob (tools/kbench_rnd.py), read once
     if (v > 0) blocks = v < n ? v : n;
     return blocks < 1 ? 1 : blocks;
-}
-
-// upper bound of the workgroups of either launch form (= reward-moment partial pairs of the one-launch step)
-int64_t rnd64_blocks(int64_t n) {
-    const int64_t a = rnd64_wg_blocks(n), b = rnd_rows_blocks(n);
-    return a > b ? a : b;
 }
 
 // validated by the caller (carle_env_step_f32_rnd); bonus has n + 1 elements.  env != nullptr: the one-launch step.
@@ -384,12 +368,10 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
     // profiles/r02_rnd_blocks.txt): N=4096 1024 / 2048 / 4096 workgroups 37.3-38.7 / 36.9 / 40.0 us, N=16384 1024 /
     // 8192 / 16384: 138 / 129.5 / 139 us, N=65536 1024 / 8192 / 32768 / 65536: 585 / 552 / 510 / 535 us (0.69 -> 0.79
     // of 8 TB/s).  (Before the table set-up stopped waiting for each of its loads, fewer, longer workgroups won.)
-    const int64_t blocks = rnd64_wg_blocks(n);
+    const int64_t blocks = rnd64_blocks(n);
     // store policy by the size of one state array (ca_step_cells.hip: stream_stores): write-back up to 256 MiB
     const int64_t lim = knobs().stream_store_min_bytes >= 0 ? knobs().stream_store_min_bytes - 1 : 256ll << 20;
     const bool nt_st = n * 16384 > lim;
-    if (use_rows_kernel(n, action != nullptr, aw))
-        return ca_step_rnd_rows(u_in, action, u_out, n, rule, status, slot, ws, bonus, nt_st, s, env);
     const int64_t ld_lim = knobs().rnd_cached_load_max_bytes >= 0 ? knobs().rnd_cached_load_max_bytes : 128ll << 20;
     const bool cached_ld = !nt_st && n * 16384 <= ld_lim;
     const dim3 grid((unsigned)blocks), block(256);

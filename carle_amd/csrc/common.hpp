@@ -68,8 +68,6 @@ struct Knobs {
     int64_t wide_blocks;                 // CARLE_WIDE_BLOCKS: launch cap of the wavefront-per-strip kernels
     int64_t rnd_blocks;                  // CARLE_RND_BLOCKS: workgroups of the fused CA + RND2D kernel
     int64_t rnd_cached_load_max_bytes;   // CARLE_RND_CACHED_LOAD_MAX_BYTES
-    int64_t rnd_rows_stagger;            // CARLE_RND_ROWS_STAGGER: start of the wavefront-per-grid kernel (0 all at once, 1, 2 by groups)
-    int64_t rnd_rows_min_n;              // CARLE_RND_ROWS_MIN_N: batches from this size take the wavefront-per-grid kernel (0: never)
     int64_t net_blocks;                  // CARLE_NET_BLOCKS: workgroups of the 64x64 reward-net kernels
     int64_t b1_dbg;                      // CARLE_B1_DBG
     int64_t two_launch_step;             // CARLE_TWO_LAUNCH_STEP: 1 = step kernel + epilogue kernel everywhere (A/B)

@@ -332,53 +332,6 @@ def test_one_launch_rnd_step_equals_two_launch_path_and_oracle(n, aw, stats, mon
         np.testing.assert_allclose(m1[0], [allr.size, allr.mean(), ((allr - allr.mean()) ** 2).sum()], rtol=1e-10)
 
 
-@pytest.mark.parametrize("n,stats", [(1, False), (16, True), (17, True), (100, False), (1000, True), (2050, True)])
-def test_rnd_wavefront_per_grid_kernel_equals_workgroup_per_grid_kernel(n, stats, monkeypatch):
-    """The two forms of the fused CA + RND2D kernel -- a wavefront per grid with lane = row (ca_rnd_rows.hip, batches
-    from 2048 grids by default) and a workgroup per grid (ca_rnd_fused.hip) -- forced onto the same batch through
-    CARLE_RND_ROWS_MIN_N: observations (also against the C oracle), rewards and counters bit-identical, reward statistics
-    equal to fp64 rounding.  Crafted actions as above (master resets, all ones but one element, NaN, -0.0, infinities,
-    no action), plus denormal and negative-zero STATE values written by the caller."""
-    from carle_amd import hip
-    rng = np.random.default_rng(7 * n + 1)
-    u0 = (rng.random((n, 1, 64, 64)) < 0.4).astype(np.float32)
-    u0[0, 0, 3, :8] = np.array([1e-40, -1e-40, -0.0, np.nan, np.inf, -np.inf, 0.5, -2.0], np.float32)
-    acts = [a for a in _crafted_actions(rng, n, 64)]
-    a = (rng.random((n, 1, 64, 64)) < 0.2).astype(np.float32); a[a != 0] = np.float32(1e-41); acts.insert(1, a)   # denormal toggles
-    res = []
-    try:
-        for rows in ("1", "0"):
-            monkeypatch.setenv("CARLE_RND_ROWS_MIN_N", rows)
-            env, w, st = _rnd_env(n, 64, stats, False, monkeypatch)        # (reloads the knobs)
-            env.universe = torch.from_numpy(u0).cuda()
-            out = []
-            for t, a in enumerate(acts):
-                act = torch.zeros(n, 1, 64, 64, device="cuda") if a is None else torch.from_numpy(a).cuda()
-                obs, reward, done, info = w.step(act)
-                if st is not None:
-                    st.after_step(w, reward)
-                out.append((obs.clone(), reward.clone()))
-            snap = None
-            if st is not None:
-                st.flush()
-                snap = (st.state.cpu().numpy().copy(), st.last_batch.cpu().numpy().copy())
-            res.append((out, env.step_number, env.steps_since_action, env.master_resets, snap))
-    finally:
-        monkeypatch.delenv("CARLE_RND_ROWS_MIN_N", raising=False)
-        hip.reload_knobs()
-    ref = _oracle_loop(u0, [np.zeros((n, 1, 64, 64), np.float32) if a is None else a for a in acts], O.rule_mask([3], [2, 3]))
-    (o1, sn1, ssa1, r1, m1), (o2, sn2, ssa2, r2, m2) = res
-    for t, ((oa, ra), (ob, rb)) in enumerate(zip(o1, o2)):
-        assert np.array_equal(oa.cpu().numpy(), ref[t][0]), t
-        assert torch.equal(oa, ob), t
-        assert torch.equal(ra, rb), (t, (ra - rb).abs().max())
-        assert float(ra.min()) > 0
-    assert (sn1, ssa1, r1) == (sn2, ssa2, r2) == ref[-1][1:]
-    if stats:
-        np.testing.assert_allclose(m1[0], m2[0], rtol=1e-12, atol=1e-15)
-        np.testing.assert_allclose(m1[1], m2[1], rtol=1e-12, atol=1e-15)
-
-
 def test_pending_rnd_moments_are_merged_by_whatever_comes_next(monkeypatch):
     """The partial sums a one-launch CA + RND2D step leaves behind are merged by the next launch on the status block:
     another wrapper step, a bare step of the inner environment, run(), multistep(), a stats flush -- same totals."""
