@@ -372,6 +372,7 @@ class RND2D(Motivator):
         then one Adam step -- no autograd graph.  Geometries the kernels do not cover (H != W or not a multiple
         of 8) replay the observation through autograd."""
         self.predictor.zero_grad()                           # drops whatever a window had accumulated, as the reference
+        self._clear_kept_gradient()
         if self._grad is not None and self._grad_used:
             self._grad.zero_()
             self._grad_used = False
@@ -392,6 +393,7 @@ class RND2D(Motivator):
         bonus = torch.empty(n, dtype=torch.float32, device=o.device)
         if self.buffer_length == 0:
             self.predictor.zero_grad()
+            self._clear_kept_gradient()
             self.accumulate_loss = 0.0
             self._drop_window()
         if not self._fused_train(obs, None, bonus, None):
@@ -406,6 +408,17 @@ class RND2D(Motivator):
         self.optimizer.zero_grad()           # RND2D.update_predictor, mcl.py:339
         self.updates += 1
 
+    # AE2D.update_predictor steps WITHOUT zeroing the gradients (mcl.py:498-502): the window's gradient stays in .grad
+    # until the next window starts, and a backward in between (a caller's own update_predictor) accumulates on top of it
+    _update_keeps_grads = False
+
+    def _clear_kept_gradient(self):
+        """Start of a window / of ``get_bonus_update``: the gradient the previous update left behind (AE2D: as ``.grad``
+        views of the flat kernel gradient) is dropped from the flat buffer too."""
+        if self.__dict__.get("_grad_kept"):
+            self._grad.zero_()
+            self.__dict__["_grad_kept"] = False
+
     # ------------------------------------------------------------------ gym surface
     def _bonus_into(self, obs, reward, stream=None):
         """reward += reward_scale * bonus(obs), fused into the bonus kernel (mcl.py:403-405); in
@@ -419,6 +432,7 @@ class RND2D(Motivator):
             return
         if self.buffer_length == 0:
             self.predictor.zero_grad()
+            self._clear_kept_gradient()
             self.accumulate_loss = 0.0
             self._drop_window()
         if not self._fused_train(obs, reward, self._bonus_buf, stream):
@@ -530,10 +544,19 @@ class RND2D(Motivator):
         step += 1
         g = self.optimizer.param_groups[0]
         blob = self._pred_blob.get(dev)
+        keep = self._update_keeps_grads
         hip.adam_update_f32([p.data for p in params], blob, self._grad, m, v, g["lr"], g["betas"][0], g["betas"][1],
-                            g["eps"], step, zero_grad=True)
+                            g["eps"], step, zero_grad=not keep)
+        off = 0
         for p in params:
             self.optimizer.state[p]["step"].fill_(float(step))        # host tensors
+            if keep:
+                # as the reference leaves it after AE2D.update_predictor: the window's gradient stays in .grad (views of
+                # the flat buffer, no copy) until the next window's zero_grad
+                p.grad = self._grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        if keep:
+            self.__dict__["_grad_kept"] = True
         self._pred_blob.updated_in_place(dev)
         self._grad_used = False
 
@@ -873,6 +896,7 @@ class AE2D(RND2D):
         for w in (rnd, self):
             if w.buffer_length == 0:
                 w.predictor.zero_grad()
+                w._clear_kept_gradient()
                 w.accumulate_loss = 0.0
                 w._drop_window()
         pb, rb, rvalid, rkey, rgs = rnd._tiled_train_buffers(o)
@@ -906,6 +930,8 @@ class AE2D(RND2D):
         loss.backward()
         self._sync_gradients(self._pred_blob.params or list(self.predictor.parameters()), kernel_gradient=False)
         self.optimizer.step()
+
+    _update_keeps_grads = True
 
     def _after_update(self):
         self.updates += 0                    # AE2D.update_predictor neither zeroes grads nor

@@ -356,7 +356,7 @@ def test_step_graph_built_behind_a_pending_one_launch_step(backend):
         env = CARLE(width=64, height=64, instances=n, device="cuda:0")
         w = RND2D(env, train_predictor=False)
         stats = cd.RunningRewardStats("cuda:0", sync_every=1000)
-        assert stats.attach(env)
+        assert stats.attach(w)                               # the statistics of the wrapper's (final) reward
         w.reset()
         env.universe = u0.clone()
         rewards = [w.step(acts[0])[1].clone()]
