@@ -141,9 +141,13 @@ __global__ __launch_bounds__(256) void rnd_linear_bonus_kernel(
     const float *f = ws2 + (g * 2 + net) * (int64_t)d;
     const float *lw = (net == 0 ? pp + 77 : rp + 39) + (int64_t)k * d;
     const float *lb = (net == 0 ? pp + 77 : rp + 39) + (int64_t)kRndDim * d;
-    const int len = d >> 3, i0 = seg * len;               // d is a multiple of 64 (H = W multiple of 64) or 8
+    // d = (H / 8)^2: a multiple of 64 for H a multiple of 64, but ODD for H = 8 * odd (120, 136, 264 ...): the eight
+    // float4 slices cover d only when d is a multiple of 32; every other d goes through the scalar loop, whose last
+    // slice takes the remainder.  (Until round 4 the test was `len % 4 == 0` alone: at d = 225, 289, 1089 ... -- len = 28,
+    // 36, 136 -- the vector path dropped the last d % 8 inputs of every output; found by tools/fuzz_nets.py.)
+    const int len = d >> 3, i0 = seg * len;
     float acc = 0.0f;
-    if (len > 0 && (len & 3) == 0 && (((uintptr_t)(lw + i0) | (uintptr_t)(f + i0)) & 15u) == 0) {
+    if (len > 0 && (d & 31) == 0 && (((uintptr_t)(lw + i0) | (uintptr_t)(f + i0)) & 15u) == 0) {
         const float4 *w4 = reinterpret_cast<const float4 *>(lw + i0);
         const float4 *f4 = reinterpret_cast<const float4 *>(f + i0);
         for (int i = 0; i < (len >> 2); ++i) {

@@ -76,9 +76,12 @@ def test_stacked_wrappers_rewards():
     assert np.array_equal(obs.cpu().numpy(), G.unpack(z["stack_final_obs"], (n, 1, 64, 64)))
 
 
-@pytest.mark.parametrize("size,n", [(8, 3), (16, 5), (32, 2), (64, 33), (96, 2), (128, 3), (200, 1)])
+@pytest.mark.parametrize("size,n", [(8, 3), (16, 5), (32, 2), (64, 33), (96, 2), (128, 3), (200, 1),
+                                    (120, 2), (136, 3), (264, 1), (56, 4), (72, 1)])
 def test_abi_against_oracle_random_weights(size, n):
-    """carle_*_bonus_f32 vs oracle/nets.py (torch CPU fp32) with fresh random weights."""
+    """carle_*_bonus_f32 vs oracle/nets.py (torch CPU fp32) with fresh random weights.  120 / 136 / 264: H = 8 * odd
+    with (H / 8)^2 / 8 a multiple of four -- the linear layer's float4 slices once dropped the last input there
+    (found by tools/fuzz_nets.py in round 4; bonuses off by up to 3e-3)."""
     from carle_amd import hip
     torch.manual_seed(size)
     env, rnd, ae = _stack(size, n)
@@ -550,7 +553,7 @@ def _autograd_grad(w, g):
 
 
 @pytest.mark.parametrize("size,n,binary", [(8, 3, True), (32, 5, True), (64, 4, False), (128, 3, True),
-                                            (256, 2, True), (256, 16, True), (96, 2, False)])
+                                            (256, 2, True), (256, 16, True), (96, 2, False), (120, 2, True), (136, 1, False)])
 def test_staged_backward_matches_autograd(size, n, binary):
     """carle_rnd2d_train_f32 / carle_ae2d_train_f32 on sizes without a fused gradient kernel (and on
     non-binary observations): bonus = the forward bonus, accumulated gradient = autograd's, for both

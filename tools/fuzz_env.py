@@ -99,11 +99,11 @@ def one_case(case, rng):
                 u = np.zeros_like(u)
                 sn, ssa, resets = 0, 0, resets + 1
             else:
-                # the oracle decides the reset from the action it is given, the surface from the uncropped one: doubled
-                # values toggle the same cells and never read as "all ones"
-                with np.errstate(all="ignore"):
-                    u, reset, _ = O.c_env_step(u, (aj * np.float32(2.0)).astype(np.float32), rule)
-                assert not reset
+                # (oracle_env_step decides the reset by the reference's sum == count, which values other than 0 / 1 can
+                # satisfy without being all ones -- the documented deviation of the default predicates: toggle and
+                # generation are taken separately here)
+                toggled = O.np_apply_action(u, aj).astype(np.float32)
+                u = O.c_env_step(toggled, None, rule)[0]
                 sn += 1
         t += len(acts)
         got = obs.float().cpu().numpy()
