@@ -102,10 +102,12 @@ def one_case(case, rng):
     for (name, p), q, g in zip(w.predictor.named_parameters(), ref.parameters(), grads):
         # Adam's first step moves a weight by lr * g / (|g| + eps): a gradient component that is off by e (the kernels: up
         # to ~6e-7 of the tensor's largest component, profiles/r03_grad_error_table.txt) moves it by lr * e / |g| more --
-        # the bound per element is lr * min(2, 1e-5 * max|g| / |g|), i.e. tight where the gradient is large and void where
-        # it is at the noise floor (there the sign of noise decides between +lr and -lr)
+        # and sums of many cancelling terms (conv1 weights over 33 x 128 x 128 pixels) are off by eps * sum|terms|, which
+        # the largest component does not bound.  Per element: lr * min(2, 1e-4 * max|g| / |g|) -- tight where the gradient
+        # is large, void at the noise floor (there the sign of noise decides between +lr and -lr); a wrong tap or a
+        # dropped element shows at 1e-2 and more
         ga = g.abs()
-        tol_e = lr * torch.clamp(1e-5 * float(ga.max()) / ga.clamp_min(1e-30), max=2.0) + 2e-6
+        tol_e = lr * torch.clamp(1e-4 * float(ga.max()) / ga.clamp_min(1e-30), max=2.0) + 2e-6
         d = (p.detach().double() - q.detach()).abs()
         if bool((d > tol_e).any()):
             i = int(torch.argmax(d - tol_e))
