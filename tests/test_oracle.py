@@ -144,3 +144,29 @@ def test_c_and_numpy_oracles_agree_on_random_rules():
         c_out, c_reset, _ = O.c_env_step(u, a, rule)
         n_out, n_reset = O.np_env_step(u, a, rule)
         assert c_reset == n_reset and np.array_equal(c_out, n_out), (trial, size, asize, rule)
+
+
+@pytest.mark.parametrize("name", ["corner", "speed", "puffer"])
+def test_wrappers_oracle_reproduces_the_reference_fixtures(name):
+    """oracle/wrappers.py (numpy restatement of mcl.py:86-105, 197-231, 730-853) replays the rewards recorded from the
+    genuine reference's CornerBonus / SpeedDetector / PufferDetector (tests/golden/wrappers.npz); the grids underneath
+    come from the CA oracle.  (The open-ended version of this check against the reference itself:
+    tools/fuzz_oracle_vs_reference.py, build container only.)"""
+    import json
+    import os
+    from oracle import wrappers as OW
+    z = np.load(os.path.join(G.GOLDEN, "wrappers.npz"))
+    m = json.loads(bytes(z[f"{name}/meta"]).decode())
+    n, size, steps = m["n"], m["size"], m["steps"]
+    u = G.unpack(z[f"{name}/init"], (n, 1, size, size))
+    acts = G.unpack(z[f"{name}/actions"], (steps, n, 1, 64, 64))
+    w = {"corner": lambda: OW.CornerBonus(size, size), "speed": lambda: OW.SpeedDetector(size, size, 64, 64),
+         "puffer": lambda: OW.PufferDetector(6)}[name]()
+    life = O.rule_mask([3], [2, 3])
+    for t in range(steps):
+        u, reset, _ = O.c_env_step(u, acts[t], life)
+        assert not reset
+        r = w.step(u, np.zeros((n, 1), np.float32), acts[t])
+        np.testing.assert_allclose(r.reshape(n, -1), z[f"{name}/rewards"][t], rtol=1e-6, atol=1e-4 if name == "speed" else 0,
+                                   err_msg=f"{name} step {t}")
+    assert np.array_equal(u, G.unpack(z[f"{name}/final_obs"], (n, 1, size, size)))

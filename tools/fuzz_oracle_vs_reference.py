@@ -22,6 +22,7 @@ import make_golden as MG                        # noqa: E402   (import_reference
 torch, ref_env, ref_mcl = MG.import_reference()
 sys.path.append("/root/repo")
 from oracle import ca as O                      # noqa: E402
+from oracle import wrappers as OW               # noqa: E402
 from carle_amd import rle as R                  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -116,10 +117,51 @@ def one_case(case, rng):
             raise AssertionError(f"case {case}: rle_to_grid differs (size {size})")
 
 
+def wrapper_case(case, rng):
+    """oracle/wrappers.py against the reference's CornerBonus / SpeedDetector / PufferDetector / ParsimonyBonus stacked
+    in random order over a reference CARLE (0 / 1 actions, with action-free stretches for the growth detector)."""
+    size = int(rng.choice([64, 64, 96, 128]))
+    n = int(rng.integers(1, 4))
+    env = ref_env.CARLE(width=size, height=size, instances=n, device="cpu")
+    kinds = [k for k in ("corner", "speed", "puffer") if rng.random() < 0.7] or ["speed"]
+    if n == 1 and rng.random() < 0.5:
+        kinds.append("parsimony")                            # (N > 1: the reference's division broadcasts to (N, N))
+    rng.shuffle(kinds)
+    top, mine = env, []
+    for k in kinds:
+        if k == "corner":
+            top = ref_mcl.CornerBonus(top); mine.append(OW.CornerBonus(size, size))
+        elif k == "speed":
+            top = ref_mcl.SpeedDetector(top); mine.append(OW.SpeedDetector(size, size, 64, 64))
+        elif k == "puffer":
+            top = ref_mcl.PufferDetector(top); top.growth_threshold = int(rng.integers(1, 5))
+            mine.append(OW.PufferDetector(top.growth_threshold))
+        else:
+            top = ref_mcl.ParsimonyBonus(top); mine.append(OW.ParsimonyBonus())
+    env.birth, env.survive = [[3], [2, 3]] if rng.random() < 0.5 else [[3, 4, 5], [0, 1, 2, 3, 4, 5, 6, 7, 8]]   # Life / a growing rule
+    top.reset()
+    u = (rng.random((n, 1, size, size)) < 0.2).astype(np.float32)
+    env.universe = torch.from_numpy(u.copy())
+    rule = O.rule_mask(env.birth, env.survive)
+    for t in range(int(rng.integers(6, 16))):
+        a = (rng.random((n, 1, 64, 64)) < (0.0 if rng.random() < 0.6 else rng.choice([0.01, 0.2]))).astype(np.float32)
+        obs, reward, done, info = top.step(torch.from_numpy(a.copy()))
+        u, reset, _ = O.c_env_step(u, a, rule)
+        assert np.array_equal(obs.detach().numpy(), u)
+        r = np.zeros((n, 1), np.float32)
+        for w in mine:
+            r = w.step(u, r, a)
+        got = reward.detach().numpy().reshape(n, -1)
+        if not np.allclose(got, r.reshape(n, -1), rtol=1e-6, atol=2e-5):
+            raise AssertionError(f"wrapper case {case} step {t}: rewards differ ({kinds}, size {size}, n {n}): {got.ravel()} != {r.ravel()}")
+
+
 t_end = time.time() + budget
 case = 0
 while time.time() < t_end:
     one_case(case, np.random.default_rng(seed0 * 99991 + case))
+    if case % 4 == 0:
+        wrapper_case(case, np.random.default_rng(seed0 * 77773 + case))
     case += 1
     if case % 200 == 0:
         print(f"{case} cases ok", flush=True)
