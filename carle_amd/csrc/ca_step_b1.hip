@@ -194,7 +194,28 @@ struct StripLds {
     uint4 img[64 * WW / 2];          // the strip
     uint4 halo[2][WW / 2 > 0 ? WW / 2 : 1];   // row above, row below
     uint4 act[32];                   // the grid's packed 64x64 action record (64 row words), see load_strip<.., ACTREC>
+    uint2 hsum[2][2 * WW];           // (g0, g1): horizontal triple sums of the two bordering rows per 32-bit chunk (strip_halo_sums)
 };
+
+// The horizontal triple sums (west + centre + east, two bit planes) of the strip's two bordering rows, for all chunks at
+// once: lane k < NC takes chunk k of the row above, lane NC + k chunk k of the row below (lane = CHUNK here, not row),
+// reads the chunk and its two neighbours from the rows' LDS image (after the window toggle), and leaves (g0, g1) in
+// l.hsum.  ~10 VALU instructions per strip.  The compute phase then reads ONE 8-byte pair per chunk as the `old` operand
+// of its DPP row shifts instead of forming the sums itself in every lane: the two alignbit + two bitop3 per chunk that
+// only lanes 0 and 63 had a use for were 64 of the ~600 VALU instructions of a strip -- and the packed kernel is
+// VALU-bound at N = 4096 (round 4).
+template <int WW>
+__device__ __forceinline__ void strip_halo_sums(StripLds<WW> &l, int lane) {
+    constexpr int NC = 2 * WW;
+    static_assert(2 * NC <= 64, "one lane per chunk of the two rows");
+    const int row = (lane >> (NC == 16 ? 4 : NC == 8 ? 3 : NC == 4 ? 2 : 1)) & 1, k = lane & (NC - 1);
+    const uint32_t *h32 = reinterpret_cast<const uint32_t *>(l.halo[row]);
+    const uint32_t hk = h32[k], hprev = h32[(k + NC - 1) & (NC - 1)], hnext = h32[(k + 1) & (NC - 1)];
+    const uint32_t hw = __builtin_amdgcn_alignbit(hk, hprev, 31);     // (h << 1) | (prev >> 31): x torus seam at k = 0
+    const uint32_t he = __builtin_amdgcn_alignbit(hnext, hk, 1);
+    const uint32_t g0 = bop3<kXor3>(hw, hk, he), g1 = bop3<kMaj>(hw, hk, he);
+    if (lane < 2 * NC) l.hsum[row][k] = make_uint2(g0, g1);
+}
 
 // REC (kernels with the 64-column window), `with_rec` (wave-uniform): the grid's 512-byte action record (the 64 row words
 // of the window) is requested behind the strip's loads -- one more coalesced access, 8 bytes per lane -- and laid down in
@@ -428,6 +449,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
                                                  c, hal, act + g * (int64_t)ah, touches_, on_image);
         } else
             load_strip<WW, LDS_NT, false, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
+        if constexpr (HROLL) strip_halo_sums<(LDS_T ? WW : 2)>(lds, lane);     // behind the window toggle (LDS keeps a wave's order)
     } else {
         load_row<WW>(gin + (int64_t)r * WW, c);
 #pragma unroll
@@ -520,14 +542,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
         cc[2 * j] = (uint32_t)c[j]; cc[2 * j + 1] = (uint32_t)(c[j] >> 32);
         hc[2 * j] = HROLL ? 0u : (uint32_t)hal[j]; hc[2 * j + 1] = HROLL ? 0u : (uint32_t)(hal[j] >> 32);
     }
-    // HROLL: chunks k - 1 .. k + 1 of the lane's bordering row (lane 63: the row below, every other lane the row above --
-    // only lanes 0 and 63 have a use for theirs), read from the LDS image one chunk ahead of their use
-    const uint32_t *hrow32 = reinterpret_cast<const uint32_t *>(&lds.halo[0][0]);
-    uint32_t hidx = lane == 63 ? NC : 0;
-    uint32_t hw0 = 0u, hw1 = 0u, hw2 = 0u;
-    if constexpr (HROLL) {
-        hw0 = hrow32[hidx + NC - 1]; hw1 = hrow32[hidx]; hw2 = hrow32[hidx + 1];
-    }
+    // HROLL: the triple sums of the lane's bordering row (lane 63: the row below, every other lane the row above -- only
+    // lanes 0 and 63 have a use for theirs) come from l.hsum, one 8-byte pair per chunk, read one chunk ahead of its use
+    const uint2 *hsum = &lds.hsum[0][0] + (lane == 63 ? NC : 0);
+    uint2 gs = make_uint2(0u, 0u), gs_next = make_uint2(0u, 0u);
+    uint32_t hidx = 0;
+    if constexpr (HROLL) { gs = hsum[0]; gs_next = hsum[1 % NC]; }
     uint32_t nx32[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
@@ -538,11 +558,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
         row_sums(wst, cc[k], est, h0, h1, p0, p1);
         uint32_t a0, a1, b0, b1;
         if (MULTI) {
-            const uint32_t hprev = HROLL ? hw0 : hc[(k + NC - 1) % NC], hk = HROLL ? hw1 : hc[k],
-                           hnext = HROLL ? hw2 : hc[(k + 1) % NC];
-            const uint32_t hw = __builtin_amdgcn_alignbit(hk, hprev, 31);
-            const uint32_t he = __builtin_amdgcn_alignbit(hnext, hk, 1);
-            const uint32_t g0 = bop3<kXor3>(hw, hk, he), g1 = bop3<kMaj>(hw, hk, he);
+            uint32_t g0, g1;
+            if constexpr (HROLL) {
+                g0 = gs.x; g1 = gs.y;
+            } else {
+                const uint32_t hprev = hc[(k + NC - 1) % NC], hk = hc[k], hnext = hc[(k + 1) % NC];
+                const uint32_t hw = __builtin_amdgcn_alignbit(hk, hprev, 31);
+                const uint32_t he = __builtin_amdgcn_alignbit(hnext, hk, 1);
+                g0 = bop3<kXor3>(hw, hk, he); g1 = bop3<kMaj>(hw, hk, he);
+            }
             // lanes with no source keep `old` = the sums of the halo row they loaded themselves
             a0 = __builtin_amdgcn_update_dpp(g0, h0, 0x138, 0xF, 0xF, false);   // wave_shr:1, row above
             a1 = __builtin_amdgcn_update_dpp(g1, h1, 0x138, 0xF, 0xF, false);
@@ -561,8 +585,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
         if ((HROLL || (ACT == 1 && !RAND)) && k + 1 < NC) {
             if constexpr (HROLL) {
                 asm volatile("" : "+v"(cc[k + 1]), "+v"(hidx) : "v"(nx32[k]));
-                hw0 = hw1; hw1 = hw2;
-                hw2 = hrow32[hidx + (k + 2) % NC];
+                gs = gs_next;
+                gs_next = hsum[hidx + (k + 2) % NC];
             } else {
                 asm volatile("" : "+v"(cc[k + 1]) : "v"(nx32[k]));
             }
