@@ -404,6 +404,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
     // overwrites its strips with zeros if the answer is yes -- no call while rows are in registers, no fetch ahead of
     // the strips, any strip order
     bool unit_notone = false;
+    // single-strip units (dbg bit 3) of the one-launch step: a strip WITHOUT rows under the window cannot see the action; it
+    // looks at a sample instead -- the first row word of its grid's record (uniform: a scalar load, needed only behind the
+    // strip) -- and knows "no reset" unless that word is all ones, as the wavefront-per-strip fp32 kernel does
+    // (ca_step_wide_kernel<..., ENV>); only then does it ask the batch
+    uint64_t sample = 0ull;
+    if (ENV && ACT == 1 && !halves && ea.publish) sample = act[g * (int64_t)ah];
     // one strip: `first` = the unit's first strip (its window strip when the window words were fetched above)
     auto strip = [&](const int sub, const bool first) __attribute__((always_inline)) {
     const int64_t wid = halves ? unit * per_unit + sub : unit;          // stamp index
@@ -424,6 +430,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
     const int oy_ = (H - ah) >> 1;
     const bool touches_ = ACT == 1 && ((r0 < oy_ + ah && r0 + 64 > oy_) ||
                                        (MULTI && ((rt >= oy_ && rt < oy_ + ah) || (rb >= oy_ && rb < oy_ + ah))));
+    if (ENV && ACT == 1 && !halves && ea.publish && !(r0 < oy_ + ah && r0 + 64 > oy_))
+        unit_notone |= sample != ~0ull;                      // no row of this strip is under the window: the sample decides
     if constexpr (LDS_T) {
         if constexpr (act_lds) {
             // a strip under the window: predicates and the toggle happen on the LDS image, before any row occupies a
@@ -801,8 +809,15 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     }
     if (env && aw == 64) {                        // one-launch step, the 64-column window
         const B1EnvArgs ea = *env;
-        const dim3 grid(full), block(64);
-        const int dbg = knobs().b1_dbg >= 0 ? (int)knobs().b1_dbg & ~8 : 0;            // half-grid units
+        // half-grid units; single strips -- the strips outside the window decide the master reset from a sample of the
+        // grid's record -- for 512-column grids beyond the Infinity Cache (streaming strip mode).  Same process
+        // (tools/kbench_b1_env.py, profiles/r04_kbench_b1_env.txt): 512x512 N=8192 98.8 -> 96.9 us (0.684 -> 0.698), N=4096
+        // 46.4 against 46.8 (units stay); 256x256 (two of four strips under the window) N=16384 48.9 against 51.1, N=32768
+        // 98.5 against 102.0 (units stay).  CARLE_B1_DBG bit 3 forces single strips, bit 4 half-grid units.
+        int dbg = knobs().b1_dbg >= 0 ? (int)knobs().b1_dbg : 0;
+        if (lds == 2 && WW == 8 && !(dbg & 16)) dbg |= 8;
+        if (!lds || WW == 1 || (dbg & 16)) dbg &= ~8;
+        const dim3 grid((dbg & 8) ? blocks(n8 * WW) : full), block(64);
         if (lds == 2) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 2, true>), grid, block, 0, s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg, ea);
         else if (lds == 1) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 1, true>), grid, block, 0, s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg, ea);
         else hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 0, true>), grid, block, 0, s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg, ea);

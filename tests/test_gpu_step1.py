@@ -377,13 +377,33 @@ def _np_pack(a):
     return bits.reshape(n, 1, h, w // 64, 8).copy().view("<u8").reshape(n, 1, h, w // 64).astype(np.int64)
 
 
+@pytest.fixture
+def _b1_walk(request, monkeypatch):
+    """"single": the one-launch packed step walks single strips (CARLE_B1_DBG bit 3, LDS strip modes forced): strips
+    outside the window decide the master reset from a sample of the grid's action record."""
+    from carle_amd import hip
+    if request.param == "single":
+        monkeypatch.setenv("CARLE_B1_DBG", "8")
+        monkeypatch.setenv("CARLE_B1_LDS_MIN_BYTES", "0")
+        monkeypatch.setenv("CARLE_B1_NT_MIN_BYTES", str(1 << 60))
+    hip.reload_knobs()
+    yield request.param
+    monkeypatch.delenv("CARLE_B1_DBG", raising=False)
+    monkeypatch.delenv("CARLE_B1_LDS_MIN_BYTES", raising=False)
+    monkeypatch.delenv("CARLE_B1_NT_MIN_BYTES", raising=False)
+    hip.reload_knobs()
+
+
 @pytest.mark.parametrize("n,size", [(1, 64), (9, 64), (40, 64), (3, 128), (5, 256), (2, 512), (33, 512)])
 @pytest.mark.parametrize("publish", [True, False])
-def test_one_launch_packed_step_against_oracle_and_two_launch_path(n, size, publish):
+@pytest.mark.parametrize("_b1_walk", ["units", "single"], indirect=True)
+def test_one_launch_packed_step_against_oracle_and_two_launch_path(n, size, publish, _b1_walk):
     """carle_env_step_b1 with CARLE_STEP_DEFERRED against the oracle and the packed step kernel + epilogue: packed
     64x64 action windows (flags derived from the bits by the kernel, or stored beforehand as carle_pack_f32_b1 does),
     crafted all-ones / all-but-one-bit / all-ones-grid cases, no action; grids, reward, counters, moments."""
     from carle_amd import hip
+    if _b1_walk == "single" and size not in (256, 512):
+        pytest.skip("single-strip walk: LDS strip modes (256 / 512 columns)")
     rng = np.random.default_rng(n * 10 + size)
     rule = O.rule_mask([3, 6], [2, 3])
     u0 = (rng.random((n, 1, size, size)) < 0.4).astype(np.float32)
@@ -417,9 +437,10 @@ def test_one_launch_packed_step_against_oracle_and_two_launch_path(n, size, publ
             cur = nxt
 
 
-def test_packed_master_reset_of_a_batch_larger_than_the_resident_wavefronts():
+@pytest.mark.parametrize("_b1_walk", ["units", "single"], indirect=True)
+def test_packed_master_reset_of_a_batch_larger_than_the_resident_wavefronts(_b1_walk):
     from carle_amd import hip
-    n, size = 9000, 256                                    # 18000 half-grid units, 8192 wavefronts resident
+    n, size = 9000, 256                                    # 18000 half-grid units (36000 strips), 8192 wavefronts resident
     rule = O.rule_mask([3], [2, 3])
     g = torch.Generator(device="cuda").manual_seed(3)
     u = hip.pack_f32_b1((torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.4).float())
