@@ -368,7 +368,11 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
     // profiles/r02_rnd_blocks.txt): N=4096 1024 / 2048 / 4096 workgroups 37.3-38.7 / 36.9 / 40.0 us, N=16384 1024 /
     // 8192 / 16384: 138 / 129.5 / 139 us, N=65536 1024 / 8192 / 32768 / 65536: 585 / 552 / 510 / 535 us (0.69 -> 0.79
     // of 8 TB/s).  (Before the table set-up stopped waiting for each of its loads, fewer, longer workgroups won.)
-    const int64_t blocks = rnd64_blocks(n);
+    int64_t blocks = rnd64_blocks(n);
+    // the one-launch step (ENV instantiation: 106 SGPRs, a longer tail) is 1 % faster with the 1024 resident workgroups
+    // walking all grids up to N = 8192 (same process, tools/kbench_rnd_sched.py: N=4096 36.92 -> 36.56 us, N=6144 51.27 ->
+    // 50.74, N=8192 65.6 either way); the plain kernel keeps two grids per workgroup (N=6144: 49.9 against 50.7)
+    if (env && n > 1024 && n <= 8192 && knobs().rnd_blocks <= 0) blocks = 1024;
     // store policy by the size of one state array (ca_step_cells.hip: stream_stores): write-back up to 256 MiB
     const int64_t lim = knobs().stream_store_min_bytes >= 0 ? knobs().stream_store_min_bytes - 1 : 256ll << 20;
     const bool nt_st = n * 16384 > lim;
