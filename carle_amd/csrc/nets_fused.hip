@@ -194,8 +194,10 @@ __global__ __launch_bounds__(512) void ae_prepare_kernel(const float *__restrict
 
 // sigmoid through v_exp_f32 + v_rcp_f32 (~2 ulp each; |error| < 5e-7 absolute): the libm expf + IEEE division
 // pair costs ~25 instructions per cell, a third of the AE2D forward kernel
+// (round 4: __frcp_rn is the correctly ROUNDED reciprocal -- v_div_scale x 2, v_rcp, four fma, v_div_fmas, v_div_fixup: ten
+// instructions per cell, 16 % of the forward kernel's VALU instructions; the bare v_rcp_f32 is within 1 ulp)
 __device__ __forceinline__ float fast_sigmoid(float x) {
-    return __frcp_rn(1.0f + __expf(-x));
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
 __device__ __forceinline__ float wave_sum_f32(float v) {

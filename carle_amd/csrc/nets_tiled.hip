@@ -731,7 +731,7 @@ __device__ __forceinline__ uint32_t row_seg4(uint64_t lo, uint64_t hi, int c) {
     return (uint32_t)v & 0xFu;
 }
 
-__device__ __forceinline__ float tile_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }   // as nets_fused.hip
+__device__ __forceinline__ float tile_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // as nets_fused.hip
 
 template <bool PACKED>
 __device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__restrict__ obs_v, const float *__restrict__ ws,

@@ -41,7 +41,7 @@ for n in [int(a) for a in sys.argv[1:]] or [4096]:
     for rep in range(4):
         for name, fn in (("kernel alone", kernel), ("one-launch step", step)):
             for form, env_kv in (("library's choice", {}), ("1024 workgroups", {"CARLE_RND_BLOCKS": "1024"}),
-                                 ("1280 workgroups", {"CARLE_RND_BLOCKS": "1280"}), ("2048 workgroups", {"CARLE_RND_BLOCKS": "2048"})):
+                                 ("768 workgroups", {"CARLE_RND_BLOCKS": "768"}), ("512 workgroups", {"CARLE_RND_BLOCKS": "512"}), ("896 workgroups", {"CARLE_RND_BLOCKS": "896"})):
                 os.environ.pop("CARLE_RND_BLOCKS", None)
                 os.environ.update(env_kv)
                 hip.reload_knobs()
