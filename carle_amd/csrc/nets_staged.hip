@@ -605,6 +605,30 @@ extern "C" int carle_rnd2d_bonus_f32(const float *obs, int64_t n, int h, int w,
     return check_launch("carle_rnd2d_bonus_f32");
 }
 
+// AE2D forward through the per-layer kernels: decoder(obs), squared error against `target` (= obs for AE2D.get_bonus,
+// a later frame for PredictionBonus), any H = W multiple of 8, any fp32 values
+static int ae2d_bonus_staged(const float *obs, const float *target, int64_t n, int h, int w, const float *params,
+                             float *workspace, float *bonus, float *recon_out, float *reward_accum, float reward_scale,
+                             hipStream_t s, const char *who) {
+    const int64_t q = (int64_t)(h / 2) * (w / 2);
+    const int chunks = (h * w + kMseChunk - 1) / kMseChunk;
+    if (n * q / 256 > 0x7FFFFFFFll || n * chunks > 0x7FFFFFFFll) {
+        static thread_local char buf[96];
+        snprintf(buf, sizeof buf, "%s: batch too large", who);
+        return fail_arg(CARLE_E_DIMS, buf);
+    }
+    float *a1 = workspace, *a2 = a1 + n * 4 * q, *a3 = a2 + n * 2 * (q / 4);
+    hipLaunchKernelGGL(ae_conv1_pool2_kernel, dim3(blocks_for(n * q)), dim3(256), 0, s, obs, params, a1, n, h, w);
+    hipLaunchKernelGGL(ae_conv2_pool2_kernel, dim3(blocks_for(n * (q / 4))), dim3(256), 0, s, a1, params, a2, n, h, w);
+    hipLaunchKernelGGL(ae_convt1_kernel, dim3(blocks_for(n * q)), dim3(256), 0, s, a2, params, a3, n, h, w);
+    float *part = a3 + n * q;
+    hipLaunchKernelGGL(ae_convt2_mse_kernel, dim3((unsigned)(n * chunks)), dim3(256), 0, s, target, a3, params, part,
+                       recon_out, chunks, h, w);
+    hipLaunchKernelGGL(ae_mse_finish_kernel, dim3(blocks_for(n)), dim3(256), 0, s, part, bonus, reward_accum,
+                       reward_scale, n, chunks, 1.0f / (float)(h * w));
+    return check_launch(who);
+}
+
 extern "C" int64_t carle_ae2d_workspace_floats(int64_t n, int h, int w) {
     if (n < 0 || h < 8 || w < 8) return 0;
     const int64_t q = (int64_t)(h / 2) * (w / 2);
@@ -659,23 +683,33 @@ extern "C" int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, c
                            reward_accum, reward_scale, n, tiles, 1.0f / ((float)h * (float)w));
         return check_launch("carle_ae2d_bonus_f32");
     }
-    const int64_t q = (int64_t)(h / 2) * (w / 2);
-    if (n * q / 256 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ae2d_bonus_f32: batch too large");
-    float *a1 = workspace, *a2 = a1 + n * 4 * q, *a3 = a2 + n * 2 * (q / 4);
-    hipLaunchKernelGGL(ae_conv1_pool2_kernel, dim3(blocks_for(n * q)), dim3(256), 0, s, obs, params,
-                       a1, n, h, w);
-    hipLaunchKernelGGL(ae_conv2_pool2_kernel, dim3(blocks_for(n * (q / 4))), dim3(256), 0, s, a1,
-                       params, a2, n, h, w);
-    hipLaunchKernelGGL(ae_convt1_kernel, dim3(blocks_for(n * q)), dim3(256), 0, s, a2, params, a3, n,
-                       h, w);
-    const int chunks = (h * w + kMseChunk - 1) / kMseChunk;
-    float *part = a3 + n * q;
-    if (n * chunks > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ae2d_bonus_f32: batch too large");
-    hipLaunchKernelGGL(ae_convt2_mse_kernel, dim3((unsigned)(n * chunks)), dim3(256), 0, s, obs, a3, params,
-                       part, recon_out, chunks, h, w);
-    hipLaunchKernelGGL(ae_mse_finish_kernel, dim3(blocks_for(n)), dim3(256), 0, s, part, bonus, reward_accum,
-                       reward_scale, n, chunks, 1.0f / (float)(h * w));
-    return check_launch("carle_ae2d_bonus_f32");
+    return ae2d_bonus_staged(obs, obs, n, h, w, params, workspace, bonus, recon_out, reward_accum, reward_scale, s,
+                             "carle_ae2d_bonus_f32");
+}
+
+// PredictionBonus.get_bonus (carle/mcl.py:581-605): decoder(obs) against `target`, a later frame of the same universes
+extern "C" int carle_ae2d_predict_bonus_f32(const float *obs, const float *target, int64_t n, int h, int w,
+                                            const float *params, float *workspace, float *bonus, float *recon_out,
+                                            void *stream) {
+    if (!obs || !target || !params || !workspace || !bonus)
+        return fail_arg(CARLE_E_NULL, "carle_ae2d_predict_bonus_f32: NULL pointer");
+    if (int e = check_net_dims(n, h, w, "carle_ae2d_predict_bonus_f32")) return e;
+    if (n == 0) return 0;
+    return ae2d_bonus_staged(obs, target, n, h, w, params, workspace, bonus, recon_out, nullptr, 0.0f,
+                             static_cast<hipStream_t>(stream), "carle_ae2d_predict_bonus_f32");
+}
+
+// ... and with the gradient of grad_scale/2 * sum_i sum_hw (target_i - decoder(obs_i))^2 accumulated into grad[0..164)
+// (PredictionBonus.get_bonus_accumulate / get_bonus_update, mcl.py:644-677); buffers as carle_ae2d_train_f32's staged path
+extern "C" int carle_ae2d_predict_train_f32(const float *obs, const float *target, int64_t n, int h, int w,
+                                            const float *params, float *workspace, float *scratch, float *grad,
+                                            float *bonus, float grad_scale, void *stream) {
+    if (!obs || !target || !params || !workspace || !scratch || !grad || !bonus)
+        return fail_arg(CARLE_E_NULL, "carle_ae2d_predict_train_f32: NULL pointer");
+    if (int e = check_net_dims(n, h, w, "carle_ae2d_predict_train_f32")) return e;
+    if (n == 0) return 0;
+    return ae2d_train_staged(obs, target, n, h, w, params, workspace, scratch, grad, bonus, nullptr, 0.0f, grad_scale,
+                             static_cast<hipStream_t>(stream));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -778,8 +812,8 @@ static int ae2d_train_common(const void *obs, bool packed, int64_t n, int h, int
             return fail_arg(CARLE_E_DIMS, "carle_ae2d_train_b1: bit-packed observations need H = W a multiple of 64");
         if (int e = check_net_dims(n, h, w, "carle_ae2d_train_f32")) return e;
         if (n == 0) return 0;
-        return ae2d_train_staged(static_cast<const float *>(obs), n, h, w, params, workspace, partial, grad, bonus,
-                                 reward_accum, reward_scale, grad_scale, static_cast<hipStream_t>(stream));
+        return ae2d_train_staged(static_cast<const float *>(obs), static_cast<const float *>(obs), n, h, w, params, workspace,
+                                 partial, grad, bonus, reward_accum, reward_scale, grad_scale, static_cast<hipStream_t>(stream));
     }
     if (n == 0) return 0;
     return ae2d_train64(obs, packed, n, params, workspace, bonus, reward_accum, reward_scale, grad_scale,

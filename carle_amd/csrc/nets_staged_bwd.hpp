@@ -521,8 +521,11 @@ int64_t ae2d_train_staged_scratch_floats(int64_t n, int h, int w) {
     return px + n * q + 2 * (n * 2 * (q / 4)) + 1024 * (17 + 33 + 40 + 74) + 64;
 }
 
-int ae2d_train_staged(const float *obs, int64_t n, int h, int w, const float *ap, float *ws, float *scratch,
-                      float *grad, float *bonus, float *reward, float reward_scale, float grad_scale,
+// `target`: the frame the reconstruction is compared with -- `obs` itself for AE2D (mcl.py:504-512), a LATER frame for
+// PredictionBonus (mcl.py:581-605: decoder(frame t-k) against frame t); conv1's weight gradient reads `obs`, the error
+// term and the output layer's gradient read `target`
+int ae2d_train_staged(const float *obs, const float *target, int64_t n, int h, int w, const float *ap, float *ws,
+                      float *scratch, float *grad, float *bonus, float *reward, float reward_scale, float grad_scale,
                       hipStream_t s) {
     const int64_t q = (int64_t)(h / 2) * (w / 2), px = n * (int64_t)h * w;
     if (px / 256 > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ae2d_train: batch too large");
@@ -539,12 +542,12 @@ int ae2d_train_staged(const float *obs, int64_t n, int h, int w, const float *ap
     hipLaunchKernelGGL(ae_conv1_pool2_kernel, dim3(blocks256(n * q)), dim3(256), 0, s, obs, ap, a1, n, h, w);
     hipLaunchKernelGGL(ae_conv2_pool2_kernel, dim3(blocks256(n * (q / 4))), dim3(256), 0, s, a1, ap, a2, n, h, w);
     hipLaunchKernelGGL(ae_convt1_kernel, dim3(blocks256(n * q)), dim3(256), 0, s, a2, ap, a3, n, h, w);
-    hipLaunchKernelGGL(ae_convt2_mse_kernel, dim3((unsigned)(n * chunks)), dim3(256), 0, s, obs, a3, ap, mse_part,
+    hipLaunchKernelGGL(ae_convt2_mse_kernel, dim3((unsigned)(n * chunks)), dim3(256), 0, s, target, a3, ap, mse_part,
                        static_cast<float *>(nullptr), chunks, h, w);
     hipLaunchKernelGGL(ae_mse_finish_kernel, dim3(blocks256(n)), dim3(256), 0, s, mse_part, bonus, reward,
                        reward_scale, n, chunks, 1.0f / (float)(h * w));
     // backward
-    hipLaunchKernelGGL(ae_bwd_out_kernel, dim3(rows4), dim3(256), 0, s, obs, a3, ap, dpre4, part4, grad_scale, n, h, w);
+    hipLaunchKernelGGL(ae_bwd_out_kernel, dim3(rows4), dim3(256), 0, s, target, a3, ap, dpre4, part4, grad_scale, n, h, w);
     hipLaunchKernelGGL(ae_bwd_a3_kernel, dim3(rows3), dim3(256), 0, s, a2, a3, ap, dpre4, dpre3, part3, n, h, w);
     hipLaunchKernelGGL(ae_bwd_a2_kernel, dim3(rows2), dim3(256), 0, s, a1, a2, ap, dpre3, dsel_d, dsel_s, part2, n, h, w);
     hipLaunchKernelGGL(ae_bwd_a1_kernel, dim3(rows1), dim3(256), 0, s, obs, a1, ap, dsel_d, dsel_s, part1, n, h, w);

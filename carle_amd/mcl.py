@@ -574,7 +574,7 @@ class RND2D(Motivator):
         table key to commit, gradient scale of one step)."""
         from . import _lib
         lib = _lib.load()
-        is_ae = type(self) is AE2D
+        is_ae = _HIP_NET_FAMILY.get(type(self)) == "ae"
         dev, n, size = o.device, o.shape[0], o.shape[2]
         pb = self._pred_blob.get(dev)
         rb = None if is_ae else self._rand_blob.get(dev)
@@ -605,9 +605,12 @@ class RND2D(Motivator):
         kernels for every other square size that is a multiple of 8 (the reference's default 256x256).
         Returns False when neither applies (the caller then retains the observation for the autograd
         replay)."""
-        is_ae = type(self) is AE2D
-        if not is_ae and type(self) is not RND2D:
+        # the gradient kernels implement exactly these classes' networks: a subclass of unknown architecture falls
+        # back to the autograd replay of its own ``_torch_loss``
+        family = _HIP_NET_FAMILY.get(type(self))
+        if family is None:
             return False
+        is_ae = family == "ae"
         o, binary = self._obs(obs, allow_packed=True)
         packed = o.dtype == torch.int64
         fused64 = binary and o.shape[2] == 64 and (packed or o.shape[3] == 64)
@@ -936,6 +939,137 @@ class AE2D(RND2D):
     def _after_update(self):
         self.updates += 0                    # AE2D.update_predictor neither zeroes grads nor
         # counts updates (mcl.py:498-502); grads are zeroed at the start of the next window
+
+
+def _zero_for_empty_grids(inner, bonus):
+    """``bonus[i] *= 0`` where instance i has no live cell (mcl.py:687-691, 716-720: a Python loop with one host
+    synchronisation per instance there; one masked select on the per-instance sums here).  -> (bonus (N,1), sums)"""
+    sums = _live_sums(inner, bonus.device)
+    live = sums[:, 0:1]
+    if live.shape[0] != bonus.shape[0]:
+        live = live.expand(bonus.shape[0], 1)
+    return torch.where(live == 0, torch.zeros_like(bonus), bonus), sums
+
+
+class PredictionBonus(AE2D):
+    """Frame-prediction reward (mcl.py:558-699): the AE2D predictor is applied to the OLDEST frame of a short buffer
+    (``prediction_steps`` = 5 steps back once the buffer is full; the frame itself on the first call) and compared with
+    the newest frame; ``reward += reward_scale * (0.1 - error)``, zero for instances without a live cell.
+
+    HIP path: ``carle_ae2d_predict_bonus_f32`` / ``carle_ae2d_predict_train_f32`` (the per-layer AE2D kernels with the
+    error term and the output layer's gradient taken against the target frame), any H = W multiple of 8; the window's
+    gradient goes through ``carle_adam_update_f32`` as AE2D's.  Eval-mode semantics (Dropout = identity) as everywhere.
+    Frames are kept as private fp32 copies: the reference keeps the tensor objects ``env.step`` returned (a new tensor
+    per step there, env.py:229)."""
+
+    def __init__(self, env, **kwargs):
+        super().__init__(env, **kwargs)
+        # assigned after the optimiser exists, as in the reference (mcl.py:563): Adam still runs at 6e-2
+        self.learning_rate = 3e-4
+        self.my_name = "PredictionBonus"
+        self.prediction_steps = 5
+        self.grid_buffer = []
+        self.__dict__["_scratch"] = None
+
+    def _frame(self, obs):
+        o, _ = self._obs(obs)
+        if o.dim() != 4 or o.shape[2] != o.shape[3] or o.shape[2] % 8 or o.shape[2] < 8:
+            raise NotImplementedError("PredictionBonus: the HIP kernels need square grids with H = W a multiple of 8 "
+                                      f"(got {tuple(o.shape)})")
+        return o.clone() if o is obs or o.data_ptr() == obs.data_ptr() else o
+
+    def _predict(self, obs, with_grad, batch=None):
+        """mcl.py:581-605 (+ the gradient of mean_n(loss) / batch for the update paths)."""
+        self.grid_buffer.append(self._frame(obs))
+        first, target = self.grid_buffer[0], self.grid_buffer[-1]
+        dev, n, size = first.device, first.shape[0], first.shape[2]
+        pb = self._pred_blob.get(dev)
+        grad = None
+        if with_grad:
+            if self._grad is None or self._grad.device != dev or self._grad.numel() != pb.numel():
+                self._grad = torch.zeros(pb.numel(), dtype=torch.float32, device=dev)
+            grad = self._grad
+        gs = 2.0 / (size * size * n * (self.batch_size if batch is None else batch))
+        bonus, _, self._ws, self.__dict__["_scratch"] = hip.ae2d_predict(
+            first, target, pb, self._ws, self.__dict__.get("_scratch"), grad, gs)
+        self._tables_key = None                  # the per-layer kernels overwrite the workspace the tables live in
+        if with_grad:
+            self._grad_used = True
+        if len(self.grid_buffer) > self.prediction_steps:
+            self.grid_buffer.pop(0)
+        return bonus
+
+    def forward(self, obs):
+        return super().forward(obs)
+
+    def get_bonus(self, obs):
+        return self._predict(obs, False)
+
+    def get_bonus_only(self, obs):
+        return self.get_bonus(obs)
+
+    def get_bonus_update(self, obs):
+        """mcl.py:644-656: zero_grad, the loss of this call, one Adam step on the gradient of its batch mean."""
+        self.predictor.zero_grad()
+        self._clear_kept_gradient()
+        if self._grad is not None and self._grad_used:
+            self._grad.zero_()
+            self._grad_used = False
+        self._drop_window()
+        bonus = self._predict(obs, True, batch=1)
+        self._apply_update()
+        self._after_update()
+        return bonus
+
+    def get_bonus_accumulate(self, obs):
+        """mcl.py:658-677: the loss now, an Adam step on the window's mean gradient every ``batch_size`` calls."""
+        if self.buffer_length == 0:
+            self.predictor.zero_grad()
+            self._clear_kept_gradient()
+            self.accumulate_loss = 0.0
+            self._drop_window()
+        bonus = self._predict(obs, True)
+        self.buffer_length += 1
+        if self.buffer_length >= self.batch_size:
+            self._finish_window()
+        return bonus
+
+    def _fused_train(self, obs, reward, bonus_out, stream, batch=None):
+        return False                             # (AE2D's kernels compare a frame with itself)
+
+    def step(self, action):
+        """mcl.py:679-699."""
+        if isinstance(action, torch.Tensor):
+            action = action.to(self.inner_env.my_device)
+        obs, reward, done, info = self.env.step(action)
+        err = (self.get_bonus_accumulate(obs) if self.train_predictor else self.get_bonus(obs)).unsqueeze(1)
+        bonus, sums = _zero_for_empty_grids(self.inner_env, 0.1 - err)
+        reward += self.reward_scale * bonus
+        self.live_cells = sums[:, 0].sum()
+        return obs, reward, done, info
+
+
+class SurpriseBonus(AE2D):
+    """Reconstruction error as the reward, zero for instances without a live cell (mcl.py:701-728); the bonus and the
+    predictor updates are AE2D's (fused / tiled / staged HIP kernels)."""
+
+    def __init__(self, env, **kwargs):
+        super().__init__(env, **kwargs)
+        self.ca_steps = 3
+
+    def step(self, action):
+        if isinstance(action, torch.Tensor):
+            action = action.to(self.inner_env.my_device)
+        obs, reward, done, info = self.env.step(action)
+        err = (self.get_bonus_accumulate(obs) if self.train_predictor else self.get_bonus(obs)).unsqueeze(1)
+        bonus, sums = _zero_for_empty_grids(self.inner_env, err)
+        reward += self.reward_scale * bonus
+        self.live_cells = sums[:, 0].sum()
+        return obs, reward, done, info
+
+
+# which gradient-kernel family serves a wrapper class (RND2D._fused_train): exact types only
+_HIP_NET_FAMILY = {RND2D: "rnd", AE2D: "ae", SurpriseBonus: "ae"}
 
 
 # ---------------------------------------------------------------------------------------------

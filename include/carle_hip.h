@@ -364,6 +364,18 @@ int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const floa
                         float *workspace, float *bonus, float *recon_out,
                         float *reward_accum, float reward_scale, int flags, void *stream);
 
+/* PredictionBonus.get_bonus (carle/mcl.py:581-605): the AE2D predictor applied to frame t-k (`obs`), squared error against
+ * frame t (`target`, same shape): bonus[i] = mean_{h,w} (target_i - decoder(obs_i))^2.  Per-layer kernels: any H = W
+ * multiple of 8, any fp32 values; workspace = carle_ae2d_workspace_floats(n, h, w) floats; recon_out optional.
+ * carle_ae2d_predict_train_f32 additionally accumulates d/dtheta [ grad_scale/2 * sum_i sum_hw (target_i - decoder(obs_i))^2 ]
+ * into grad[0..164) (PredictionBonus.get_bonus_accumulate / get_bonus_update, mcl.py:644-677; grad_scale as
+ * carle_ae2d_train_f32); scratch = carle_ae2d_train_scratch_floats(n, h, w) floats. */
+int carle_ae2d_predict_bonus_f32(const float *obs, const float *target, int64_t n, int h, int w, const float *params,
+                                 float *workspace, float *bonus, float *recon_out, void *stream);
+int carle_ae2d_predict_train_f32(const float *obs, const float *target, int64_t n, int h, int w, const float *params,
+                                 float *workspace, float *scratch, float *grad, float *bonus, float grad_scale,
+                                 void *stream);
+
 /* RND2D.get_bonus and AE2D.get_bonus of the SAME observations (carle/mcl.py:343-352, 504-512) and both wrappers'
  * `reward += reward_scale * bonus` (mcl.py:403-405, RND2D's first: the stack AE2D(RND2D(env)) of train_mcl.py:34-38 and
  * eval.py:83-85) in ONE launch instead of four -- the tile workgroups of both nets run side by side, and the workgroup that

@@ -85,3 +85,34 @@ def nets(size):
     if key not in _CACHE:
         _CACHE[key] = np.load(os.path.join(GOLDEN, f"nets_{size}.npz"))
     return _CACHE[key]
+
+
+class PredictionCase:
+    """A trajectory of tests/golden/prediction.npz (PredictionBonus / SurpriseBonus driven by the reference)."""
+
+    def __init__(self, z, name):
+        self.name = name
+        m = self.meta = json.loads(bytes(z[f"{name}/meta"]).decode())
+        n, s, t = m["n"], m["size"], m["steps"]
+        self.n, self.size, self.steps = n, s, t
+        self.batch_size, self.scale, self.cls = m["batch_size"], m["scale"], m["cls"]
+        self.init = unpack(z[f"{name}/init"], (n, 1, s, s))
+        self.actions = unpack(z[f"{name}/actions"], (t, n, 1, 64, 64))
+        self.rewards = z[f"{name}/rewards"]
+        self.live_cells = z[f"{name}/live_cells"]
+        self.final_obs = unpack(z[f"{name}/final_obs"], (n, 1, s, s))
+        self.init_sd = load_sd(z, f"{name}/init_sd")
+        self.final_sd = load_sd(z, f"{name}/final_sd")
+
+
+def prediction_file():
+    if "prediction" not in _CACHE:
+        _CACHE["prediction"] = np.load(os.path.join(GOLDEN, "prediction.npz"))
+    return _CACHE["prediction"]
+
+
+PREDICTION_CASES = ("pred64", "pred64_scaled", "surprise64", "pred256_glider")
+
+
+def prediction_case(name):
+    return PredictionCase(prediction_file(), name)

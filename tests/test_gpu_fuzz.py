@@ -1,0 +1,28 @@
+"""A fixed slice of the differential fuzzers (tools/fuzz_*.py) inside the GPU suite: the same random cases on every
+run -- environment surface, reward nets, wrappers stepping on the environment, hand-coded wrappers, paired against
+sequential training steps, StepGraph replay against the eager loop -- each against the oracle (or, for the last two,
+the HIP path against itself).  The open-ended runs stay tools; their findings become crafted cases in the other files.
+The seeds differ from the tools' default (seed 0), so a plain tool run covers other cases than this file."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tool(name):
+    spec = importlib.util.spec_from_file_location(f"_fuzz_tool_{name}", os.path.join(ROOT, "tools", f"fuzz_{name}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("name,cases", [("env", 120), ("nets", 60), ("stack", 40), ("wrappers", 80),
+                                        ("train_paths", 25), ("graph", 120)])
+def test_fixed_slice_of_the_fuzzer(name, cases):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    assert _tool(name).main(seed0=20260401, cases=cases) == cases

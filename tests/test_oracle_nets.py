@@ -60,3 +60,39 @@ def test_agent_oracle_matches_reference():
         sd["network.7.weight"] = z["lin_scaled"]
         np.testing.assert_allclose(ON.agent_output(obs, sd).numpy(), z["output_scaled"], rtol=0, atol=1e-6)
         np.testing.assert_array_equal(ON.agent_action(obs, sd, float(z["toggle_rate"])).numpy(), z["action_scaled"].reshape(6, -1))
+
+
+# ---- PredictionBonus / SurpriseBonus (carle/mcl.py:558-728): oracle/prediction.py against the reference's trajectories
+@pytest.mark.parametrize("name", G.PREDICTION_CASES)
+def test_prediction_oracle_reproduces_the_reference_trajectories(name):
+    from oracle import ca as O
+    from oracle import prediction as OP
+    c = G.prediction_case(name)
+    w = getattr(OP, c.cls)(c.init_sd, batch_size=c.batch_size, reward_scale=c.scale)
+    life = O.rule_mask([3], [2, 3])
+    u = c.init
+    for t in range(c.steps):
+        u, reset, _ = O.c_env_step(u, c.actions[t], life)
+        reward = w.step(u, np.zeros((c.n, 1), np.float32))
+        np.testing.assert_allclose(reward, c.rewards[t], rtol=2e-5, atol=2e-6, err_msg=f"{name} step {t}")
+        assert w.live_cells == c.live_cells[t]
+    assert np.array_equal(u, c.final_obs)
+    got = w.state()
+    for k, v in c.final_sd.items():
+        if k.startswith("predictor."):
+            np.testing.assert_allclose(got[k], v, rtol=2e-4, atol=2e-5, err_msg=f"{name} {k}")
+
+
+def test_prediction_oracle_explicit_calls():
+    """get_bonus (frames 0-2) then get_bonus_update (frames 3-6: one Adam step each), mcl.py:581-605, 644-656."""
+    from oracle import prediction as OP
+    z = G.prediction_file()
+    frames = G.unpack(z["calls/frames"], (7, 2, 1, 64, 64))
+    w = OP.PredictionBonus(G.load_sd(z, "calls/init_sd"))
+    for t in range(7):
+        r = w.get_bonus(frames[t]) if t < 3 else w.get_bonus_update(frames[t])
+        np.testing.assert_allclose(r.detach().numpy(), z["calls/bonus"][t], rtol=2e-5, atol=2e-6, err_msg=f"call {t}")
+    got, want = w.state(), G.load_sd(z, "calls/final_sd")
+    for k, v in want.items():
+        if k.startswith("predictor."):
+            np.testing.assert_allclose(got[k], v, rtol=2e-4, atol=2e-5, err_msg=k)

@@ -29,6 +29,14 @@ pmc() {     # name, kernel substring, instances, size, format, bench flags...
         "profiles/${TAG}_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py $*)" >> $O/${TAG}_pmc.txt
     echo "done pmc $name"
 }
+# (the PMC passes first: bench.py reports `traffic` from profiles/pmc_latest.json only when that record was taken on the
+# kernel sources of the library it runs, so the bench lines collected below carry this run's traffic figures)
+: > $O/${TAG}_pmc.txt
+pmc cfg2 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 4096 64 f32
+pmc cfg2_n65536 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 65536 64 f32 --instances 65536
+pmc cfg4 "ca_step_rnd64_kernel<true" 4096 64 f32 --rnd
+pmc cfg5 "ca_step_b1_kernel" 4096 512 b1 --format b1 --size 512 --instances 4096 --rule B36/S23
+pmc f32_256 "ca_step_wide_kernel" 4096 256 f32 --size 256
 stats cfg2_f32 --steps 256 --warmup 16
 stats cfg2_f32_n65536 --instances 65536 --steps 64 --warmup 8
 stats cfg4_rnd --rnd --steps 256 --warmup 16
@@ -42,11 +50,5 @@ python3 $R/tools/agent_time.py > $O/${TAG}_agent_net.txt 2>&1
 { python3 $R/tools/kbench_b1.py 4096 512 0 0; python3 $R/tools/kbench_b1.py 8192 512 0 0; python3 $R/tools/kbench_b1.py 16384 256 0 0; } 2>&1 | grep -v amdgpu.ids > $O/${TAG}_kbench_b1_final.txt
 python3 $R/tools/profile_host.py --stack rnd+ae --size 256 --instances 16 --burst 200 2>&1 | grep -v amdgpu.ids > $O/${TAG}_host_default_geom.txt
 for i in 1 2 3; do python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{'; done > $O/${TAG}_driver_style_bench.json
-: > $O/${TAG}_pmc.txt
-pmc cfg2 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 4096 64 f32
-pmc cfg2_n65536 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true" 65536 64 f32 --instances 65536
-pmc cfg4 "ca_step_rnd64_kernel<true" 4096 64 f32 --rnd
-pmc cfg5 "ca_step_b1_kernel" 4096 512 b1 --format b1 --size 512 --instances 4096 --rule B36/S23
-pmc f32_256 "ca_step_wide_kernel" 4096 256 f32 --size 256
 cp $R/profiles/pmc_latest.json $O/pmc_latest.json
 echo "all done"

@@ -18,8 +18,6 @@ from carle_amd.env import CARLE                # noqa: E402
 from carle_amd.mcl import RND2D                # noqa: E402
 from oracle import ca as O                     # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 VALUES = np.array([1.0, 1.0, 1.0, 0.5, -1.0, 2.0, np.inf, -np.inf, np.nan, 1e-40, -1e-41], np.float32)
 
 
@@ -125,12 +123,21 @@ def one_case(case, rng):
     return desc
 
 
-t_end = time.time() + budget
-case = 0
-while time.time() < t_end:
-    rng = np.random.default_rng(seed0 * 1000003 + case)
-    d = one_case(case, rng)
-    case += 1
-    if case % 25 == 0:
-        print(f"{case} cases ok (last: {d})", flush=True)
-print(f"fuzz_env: {case} cases, no difference")
+SEED_MULT = 1000003
+
+
+def main(budget=60.0, seed0=0, cases=None):
+    """Runs cases until `budget` seconds have passed (or exactly `cases` of them: tests/test_gpu_fuzz.py)."""
+    t_end = time.time() + budget
+    case = 0
+    while (case < cases) if cases is not None else (time.time() < t_end):
+        d = one_case(case, np.random.default_rng(seed0 * SEED_MULT + case))
+        case += 1
+        if case % 25 == 0 and cases is None:
+            print(f"{case} cases ok (last: {d})", flush=True)
+    print(f"fuzz_env: {case} cases, no difference")
+    return case
+
+
+if __name__ == "__main__":
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -31,6 +31,9 @@ Fixture files
                    linear layer scaled up so that toggles actually occur)
   wrappers.npz     CornerBonus / SpeedDetector / PufferDetector / ParsimonyBonus and the eval.py
                    wrapper stack: inputs and per-step rewards
+  prediction.npz   PredictionBonus / SurpriseBonus (carle/mcl.py:558-728): training trajectories (rewards per step,
+                   initial and final state_dicts) incl. the reference's own glider scenario at 256x256, and explicit
+                   get_bonus / get_bonus_update calls
 """
 import argparse
 import io
@@ -551,6 +554,83 @@ def make_wrappers(torch, ref_env, ref_mcl, outdir):
     print("wrappers.npz written")
 
 
+def make_prediction(torch, ref_env, ref_mcl, outdir):
+    """PredictionBonus / SurpriseBonus (carle/mcl.py:558-728) driven by the genuine reference in eval mode (no dropout):
+    per case the initial state_dict and grids, the actions, the reward of every step, the final state_dict.  batch_size 2,
+    so the frame buffer fills (prediction_steps = 5) while Adam updates happen; one instance stays empty (the
+    zero-for-empty-grids branch, mcl.py:687-691); 64x64 and the default 256x256 (the reference's own test scenario:
+    tests/test_mcl.py:17-53, a glider then idle steps)."""
+    import contextlib
+    sink = io.StringIO()
+    out = {}
+    rng = np.random.default_rng(558)
+
+    def run(name, cls, n, size, steps, init_fn, act_fn, batch_size=2, scale=1.0):
+        torch.manual_seed(7)
+        with contextlib.redirect_stdout(sink):
+            env = ref_env.CARLE(width=size, height=size, instances=n, device="cpu")
+            w = cls(env)
+        w.eval()
+        w.batch_size = batch_size
+        w.reward_scale = scale
+        w.reset()
+        sd_to_npz(f"{name}/init_sd", w.state_dict(), out)
+        init = init_fn(n, size)
+        env.universe = torch.from_numpy(init.copy())
+        acts, rews, live = [], [], []
+        for t in range(steps):
+            a = act_fn(t, n)
+            obs, reward, done, info = w.step(torch.from_numpy(a.copy()))
+            acts.append(a)
+            rews.append(np.asarray(reward.detach().numpy(), dtype=np.float32).reshape(n, -1).copy())
+            live.append(float(w.live_cells))
+        out[f"{name}/init"], _ = pack(init)
+        out[f"{name}/actions"], _ = pack(np.stack(acts))
+        out[f"{name}/rewards"] = np.stack(rews)
+        out[f"{name}/live_cells"] = np.array(live, np.float64)
+        out[f"{name}/final_obs"], _ = pack(obs.detach().numpy())
+        sd_to_npz(f"{name}/final_sd", w.state_dict(), out)
+        out[f"{name}/meta"] = np.frombuffer(json.dumps(dict(n=n, size=size, steps=steps, batch_size=batch_size,
+                                                            scale=scale, cls=cls.__name__)).encode(), dtype=np.uint8)
+        return w
+
+    def init_one_empty(n, size):
+        g = (rng.random((n, 1, size, size)) < 0.25).astype(np.float32)
+        g[-1] = 0.0                                           # the last instance stays empty (zero actions below)
+        return g
+
+    def sparse_keep_last_empty(t, n):
+        a = (rng.random((n, 1, 64, 64)) <= (0.05 if t % 3 == 0 else 0.0)).astype(np.float32)
+        a[-1] = 0.0
+        return a
+
+    run("pred64", ref_mcl.PredictionBonus, 3, 64, 10, init_one_empty, sparse_keep_last_empty)
+    run("pred64_scaled", ref_mcl.PredictionBonus, 2, 64, 7, init_one_empty, sparse_keep_last_empty, batch_size=3, scale=0.5)
+    run("surprise64", ref_mcl.SurpriseBonus, 3, 64, 6, init_one_empty, sparse_keep_last_empty)
+    glider = ref_mcl.get_glider().numpy().astype(np.float32)
+    run("pred256_glider", ref_mcl.PredictionBonus, 1, 256, 8, lambda n, size: np.zeros((n, 1, size, size), np.float32),
+        lambda t, n: glider.copy() if t == 0 else np.zeros_like(glider))
+    # get_bonus (no gradient), get_bonus_update (one Adam step per call) on explicit frames
+    torch.manual_seed(11)
+    with contextlib.redirect_stdout(sink):
+        env = ref_env.CARLE(width=64, height=64, instances=2, device="cpu")
+        w = ref_mcl.PredictionBonus(env)
+    w.eval()
+    w.reset()
+    sd_to_npz("calls/init_sd", w.state_dict(), out)
+    frames = (rng.random((7, 2, 1, 64, 64)) < 0.3).astype(np.float32)
+    res = []
+    for t in range(7):
+        f = torch.from_numpy(frames[t].copy())
+        r = w.get_bonus(f) if t < 3 else w.get_bonus_update(f)
+        res.append(r.detach().numpy().copy())
+    out["calls/frames"], _ = pack(frames.reshape(14, 1, 64, 64))
+    out["calls/bonus"] = np.stack(res)
+    sd_to_npz("calls/final_sd", w.state_dict(), out)
+    np.savez_compressed(os.path.join(outdir, "prediction.npz"), **out)
+    print("prediction.npz written")
+
+
 def make_agent_net(torch, ref_env, outdir):
     """RandomNetworkAgent of the reference.  Its constructor ignores ``observation_width`` (the key it
     tests for is misspelt, agents.py:56-58) and always builds for width 256; ``observation_height``
@@ -626,7 +706,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch, ref_env, ref_mcl = import_reference()
     torch.set_num_threads(8)
-    todo = args.only.split(",") if args.only else ["ca", "predicates", "known", "nets", "train256", "wrappers", "rle", "agent"]
+    todo = args.only.split(",") if args.only else ["ca", "predicates", "known", "nets", "train256", "wrappers", "rle", "agent", "prediction"]
     if "ca" in todo:
         make_ca(torch, ref_env, args.out)
     if "predicates" in todo:
@@ -643,6 +723,8 @@ def main():
         make_rle(torch, ref_env, args.out)
     if "agent" in todo:
         make_agent_net(torch, ref_env, args.out)
+    if "prediction" in todo:
+        make_prediction(torch, ref_env, ref_mcl, args.out)
 
 
 if __name__ == "__main__":
