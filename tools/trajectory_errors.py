@@ -46,3 +46,32 @@ z64 = G.nets(64)
 run(64, 4, z64, "upd_init", "upd_actions", "upd_rewards", ("upd_rnd_sd", "upd_ae_sd"))
 z256 = np.load(os.path.join(G.GOLDEN, "nets_256_train.npz"))
 run(256, 2, z256, "init", "actions", "rewards", ("final_rnd_sd", "final_ae_sd"))
+
+
+def run_prediction(name):
+    """PredictionBonus / SurpriseBonus trajectories of tests/golden/prediction.npz (tests/test_gpu_prediction.py)."""
+    import carle_amd.mcl as M
+    c = G.prediction_case(name)
+    env = CARLE(width=c.size, height=c.size, instances=c.n, device="cuda:0")
+    w = getattr(M, c.cls)(env)
+    w.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in c.init_sd.items()}, strict=True)
+    w.eval()
+    w.batch_size, w.reward_scale = c.batch_size, c.scale
+    w.reset()
+    env.universe = torch.from_numpy(c.init).cuda()
+    print(f"--- {name}: {c.cls} {c.size}x{c.size}, N={c.n}, batch_size {c.batch_size}, {c.steps} steps")
+    worst = 0.0
+    for t in range(c.steps):
+        obs, reward, done, info = w.step(torch.from_numpy(c.actions[t]))
+        d = np.abs(reward.cpu().numpy() - c.rewards[t]).max()
+        worst = max(worst, d)
+        print(f"step {t}: reward ~{np.abs(c.rewards[t]).max():.3e}  max abs diff {d:.2e}")
+    for k, v in w.state_dict().items():
+        if "predictor" in k:
+            d = np.abs(v.cpu().numpy() - c.final_sd[k])
+            print(f"{k:22s} max |w| {np.abs(c.final_sd[k]).max():.3e}  max abs diff {d.max():.2e}")
+    print(f"worst reward difference {worst:.2e}")
+
+
+for nm in G.PREDICTION_CASES:
+    run_prediction(nm)
