@@ -240,6 +240,29 @@ __global__ __launch_bounds__(1024) void speed_puffer_kernel(const float *__restr
     if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// PredictionBonus / SurpriseBonus, behind the bonus (carle/mcl.py:686-694, 715-723): b_i = offset + sign * err_i (0.1 - err
+// or err), b_i *= 0 where instance i has no live cell (sums4[4i] == 0: the reference's per-instance Python loop with a host
+// synchronisation each), reward_i += scale * b_i -- product and sum rounded separately, as torch does.  live_total: the
+// step's obs.sum() (mcl.py:697, 726), one float.
+__global__ __launch_bounds__(256) void bonus_nonempty_kernel(float *__restrict__ reward, const float *__restrict__ err,
+                                                             const float *__restrict__ sums4, float offset, float sign,
+                                                             float scale, int64_t n, float *__restrict__ live_total) {
+    __shared__ float part[4];
+    float live = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float cells = sums4[4 * i];
+        live += cells;
+        float b = __fadd_rn(offset, __fmul_rn(sign, err[i]));
+        if (cells == 0.0f) b = __fmul_rn(b, 0.0f);
+        reward[i] = __fadd_rn(reward[i], __fmul_rn(scale, b));
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) live += __shfl_xor(live, sft, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = live;
+    __syncthreads();
+    if (threadIdx.x == 0 && live_total) *live_total = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 }  // namespace carle
 
 using namespace carle;
@@ -286,6 +309,16 @@ extern "C" int carle_speed_puffer_f32(const float *obs, int64_t n, int64_t elems
         hipLaunchKernelGGL(speed_puffer_kernel<false>, dim3((unsigned)n), dim3(nt), 0, st, obs, elems, w_h, w_w, sums4, counter, n, com,
                            state, velocity, speed, live_out, any_flag, ring, ring_state, cap, live_total, reward);
     return check_launch("carle_speed_puffer_f32");
+}
+
+extern "C" int carle_bonus_nonempty_f32(float *reward, const float *err, const float *sums4, float offset, float sign,
+                                        float scale, int64_t n, float *live_total, void *stream) {
+    if (!reward || !err || !sums4) return fail_arg(CARLE_E_NULL, "carle_bonus_nonempty_f32: NULL pointer");
+    if (n < 0) return fail_arg(CARLE_E_DIMS, "carle_bonus_nonempty_f32: negative size");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bonus_nonempty_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), reward, err, sums4,
+                       offset, sign, scale, n, live_total);
+    return check_launch("carle_bonus_nonempty_f32");
 }
 
 extern "C" int carle_instance_sums_f32(const float *x, int64_t n, int64_t elems, const float *w0,

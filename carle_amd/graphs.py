@@ -101,6 +101,9 @@ class StepGraph:
             if getattr(w, "async_reward", False):
                 raise NotImplementedError("async_reward=True forks to a second stream per step; capture the "
                                           "same-stream form")
+            if hasattr(w, "grid_buffer"):
+                raise NotImplementedError(f"{type(w).__name__} rotates its frame buffer on the host every step (other "
+                                          "frames, other pointers): its step cannot be replayed")
             if backend == "calls" and type(w).__name__ not in _LIBRARY_ONLY_WRAPPERS:
                 raise NotImplementedError(f"{type(w).__name__}.step also launches torch kernels: its step is not made of "
                                           "library calls alone -- use backend='graph'")

@@ -708,6 +708,21 @@ def puffer_update_f32(sums4, any_flag_ptr, ring, ring_state, live_total, reward)
         _lib.check(rc, "carle_puffer_update_f32")
 
 
+def bonus_nonempty_f32(reward, err, sums4, offset, sign, scale, live_total=None):
+    """reward += scale * (offset + sign * err), zero for instances without a live cell (carle_bonus_nonempty_f32:
+    PredictionBonus / SurpriseBonus.step, mcl.py:686-694, 715-723); live_total: optional 1-element fp32 output."""
+    lib = _lib.load()
+    n = err.shape[0]
+    if not (reward.is_contiguous() and err.is_contiguous() and sums4.is_contiguous() and reward.numel() == n
+            and sums4.shape[0] == n and sums4.shape[1] == 4):
+        raise ValueError("bonus_nonempty_f32: contiguous reward (n,1), err (n,), sums4 (n,4) expected")
+    with _on_device(reward.device):
+        rc = lib.carle_bonus_nonempty_f32(reward.data_ptr(), err.data_ptr(), sums4.data_ptr(), float(offset), float(sign),
+                                          float(scale), n, _ptr(live_total), _stream(reward))
+    if rc != 0:
+        _lib.check(rc, "carle_bonus_nonempty_f32")
+
+
 def speed_puffer_f32(obs, w_h, w_w, sums4, counter, com, state, velocity, speed, live_out, any_flag_ptr, ring, ring_state,
                      live_total, reward):
     """SpeedDetector's reduction and update and PufferDetector's update in one launch (carle_speed_puffer_f32)."""

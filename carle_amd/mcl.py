@@ -941,14 +941,14 @@ class AE2D(RND2D):
         # counts updates (mcl.py:498-502); grads are zeroed at the start of the next window
 
 
-def _zero_for_empty_grids(inner, bonus):
-    """``bonus[i] *= 0`` where instance i has no live cell (mcl.py:687-691, 716-720: a Python loop with one host
-    synchronisation per instance there; one masked select on the per-instance sums here).  -> (bonus (N,1), sums)"""
-    sums = _live_sums(inner, bonus.device)
-    live = sums[:, 0:1]
-    if live.shape[0] != bonus.shape[0]:
-        live = live.expand(bonus.shape[0], 1)
-    return torch.where(live == 0, torch.zeros_like(bonus), bonus), sums
+def _reward_live_grids(w, reward, err, offset, sign):
+    """``reward += reward_scale * (offset + sign * err)``, zero where the instance has no live cell, and
+    ``live_cells = obs.sum()`` (mcl.py:686-697, 715-726: a Python loop with one host synchronisation per instance
+    there) -- one launch on the per-instance sums of the universe (carle_bonus_nonempty_f32), no synchronisation."""
+    sums = _live_sums(w.inner_env, reward.device)
+    total = torch.empty((), dtype=torch.float32, device=reward.device)
+    hip.bonus_nonempty_f32(reward, err, sums, offset, sign, w.reward_scale, total)
+    w.live_cells = total
 
 
 class PredictionBonus(AE2D):
@@ -1042,10 +1042,8 @@ class PredictionBonus(AE2D):
         if isinstance(action, torch.Tensor):
             action = action.to(self.inner_env.my_device)
         obs, reward, done, info = self.env.step(action)
-        err = (self.get_bonus_accumulate(obs) if self.train_predictor else self.get_bonus(obs)).unsqueeze(1)
-        bonus, sums = _zero_for_empty_grids(self.inner_env, 0.1 - err)
-        reward += self.reward_scale * bonus
-        self.live_cells = sums[:, 0].sum()
+        err = self.get_bonus_accumulate(obs) if self.train_predictor else self.get_bonus(obs)
+        _reward_live_grids(self, reward, err, 0.1, -1.0)
         return obs, reward, done, info
 
 
@@ -1061,10 +1059,8 @@ class SurpriseBonus(AE2D):
         if isinstance(action, torch.Tensor):
             action = action.to(self.inner_env.my_device)
         obs, reward, done, info = self.env.step(action)
-        err = (self.get_bonus_accumulate(obs) if self.train_predictor else self.get_bonus(obs)).unsqueeze(1)
-        bonus, sums = _zero_for_empty_grids(self.inner_env, err)
-        reward += self.reward_scale * bonus
-        self.live_cells = sums[:, 0].sum()
+        err = self.get_bonus_accumulate(obs) if self.train_predictor else self.get_bonus(obs)
+        _reward_live_grids(self, reward, err, 0.0, 1.0)
         return obs, reward, done, info
 
 

@@ -527,6 +527,12 @@ int carle_speed_update_f32(const float *sums4, const float *live4, int64_t n, fl
  * ring: cap floats, ring_state: int32[2] = {head, count}, both caller-owned and zero-initialised. */
 int carle_puffer_update_f32(const float *sums4, int64_t n, const int32_t *any_flag, float *ring,
                             int32_t *ring_state, int cap, float *live_total, float *reward, void *stream);
+/* PredictionBonus / SurpriseBonus.step behind the bonus (carle/mcl.py:686-694, 715-723): b_i = offset + sign * err[i]
+ * (offset 0.1, sign -1: PredictionBonus; 0, +1: SurpriseBonus), b_i *= 0 where sums4[4 i] == 0 (an instance without a live
+ * cell; sums4 = carle_instance_sums_f32 of the observation), reward[i] += scale * b_i (two roundings, as torch);
+ * live_total (nullable): one float, the observation's total live cells (mcl.py:697, 726).  One launch, no host sync. */
+int carle_bonus_nonempty_f32(float *reward, const float *err, const float *sums4, float offset, float sign, float scale,
+                             int64_t n, float *live_total, void *stream);
 /* PufferDetector(SpeedDetector(env)) -- the top of the evaluation stack, evaluation/eval.py:86-87 -- in ONE launch instead
  * of three: carle_instance_sums_f32(obs, w_h, w_w) into sums4 (n x 4 floats, an output), then -- by the workgroup that
  * finishes last -- carle_speed_update_f32 (live4 = NULL: the observation is the inner universe) and

@@ -1,8 +1,9 @@
 """A fixed slice of the differential fuzzers (tools/fuzz_*.py) inside the GPU suite: the same random cases on every
-run -- environment surface, reward nets, wrappers stepping on the environment, hand-coded wrappers, paired against
-sequential training steps, StepGraph replay against the eager loop -- each against the oracle (or, for the last two,
-the HIP path against itself).  The open-ended runs stay tools; their findings become crafted cases in the other files.
-The seeds differ from the tools' default (seed 0), so a plain tool run covers other cases than this file."""
+run -- environment surface, reward nets, wrappers stepping on the environment, hand-coded wrappers, PredictionBonus /
+SurpriseBonus with predictor updates (each against the oracle), paired against sequential training steps and StepGraph
+replay against the eager loop (the HIP path against itself).  The open-ended runs stay tools; their findings become
+crafted cases in the other files.  The seeds differ from the tools' default (seed 0), so a plain tool run covers other
+cases than this file."""
 import importlib.util
 import os
 
@@ -20,7 +21,7 @@ def _tool(name):
 
 
 @pytest.mark.parametrize("name,cases", [("env", 120), ("nets", 60), ("stack", 40), ("wrappers", 80),
-                                        ("train_paths", 25), ("graph", 120)])
+                                        ("train_paths", 25), ("graph", 120), ("prediction", 12)])
 def test_fixed_slice_of_the_fuzzer(name, cases):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():

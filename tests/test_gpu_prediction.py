@@ -226,3 +226,17 @@ def test_state_dict_and_names_follow_the_reference():
     assert (p.my_name, p.prediction_steps, p.learning_rate, p.optimizer.param_groups[0]["lr"]) == ("PredictionBonus", 5, 3e-4, 6e-2)
     assert (s.my_name, s.ca_steps) == ("AE2D", 3)
     assert alias.PredictionBonus is PredictionBonus and alias.SurpriseBonus is SurpriseBonus
+
+
+def test_step_graph_refuses_the_frame_buffer():
+    """A replay would keep reading the frames of the captured step: refused, not silently wrong."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import PredictionBonus
+    from carle_amd.graphs import StepGraph
+    env = CARLE(width=64, height=64, instances=2, device="cuda:0")
+    w = PredictionBonus(env, train_predictor=False)
+    w.reset()
+    a = torch.zeros(2, 1, 64, 64, device="cuda")
+    for backend in ("graph", "calls"):
+        with pytest.raises(NotImplementedError):
+            StepGraph(w, a, backend=backend)

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of PredictionBonus / SurpriseBonus (carle/mcl.py:558-728) stepping on the environment WITH
+predictor updates against oracle/prediction.py (fp32 autograd + torch Adam on the CPU) + the CA oracle, run on the GPU box:
+sizes 8 .. 256 (multiples of 8), all three storages, batches of 1 .. 6, update windows of 1 .. 4 steps, reward scales,
+empty instances (the zero-for-empty-grids rule), master resets, Life and HighLife.  Rewards within 1e-5 -- the Adam steps
+at lr 6e-2 amplify fp32 noise of the gradient, so a case stops comparing after 4 updates -- grids bit-exact.  Not part of
+the test suite (open-ended; a fixed slice runs in tests/test_gpu_fuzz.py).   python tools/fuzz_prediction.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from carle_amd.env import CARLE                # noqa: E402
+import carle_amd.mcl as M                      # noqa: E402
+from oracle import ca as O                     # noqa: E402
+from oracle import prediction as OP            # noqa: E402
+
+
+def one_case(case, rng):
+    cls = str(rng.choice(["PredictionBonus", "SurpriseBonus"]))
+    storage = str(rng.choice(["f32", "f32", "u8", "b1"]))
+    size = int(rng.choice([64, 128, 256])) if storage == "b1" else int(rng.choice([8, 16, 24, 40, 64, 64, 72, 128, 136, 256]))
+    n = int(rng.integers(1, 7)) if size <= 128 else int(rng.integers(1, 3))
+    asize = min(size, 64)
+    bs = int(rng.integers(1, 5))
+    scale = float(rng.choice([1.0, 0.5, 2.0]))
+    torch.manual_seed(int(rng.integers(0, 2 ** 31 - 1)))
+    env = CARLE(width=size, height=size, action_width=asize, action_height=asize, instances=n, device="cuda:0",
+                storage=storage, **({"obs": "f32"} if storage != "f32" else {}))
+    w = getattr(M, cls)(env)
+    w.eval()
+    w.batch_size, w.reward_scale = bs, scale
+    w.reset()
+    env.birth, env.survive = ([3], [2, 3]) if rng.random() < 0.7 else ([3, 6], [2, 3])
+    rule = O.rule_mask(env.birth, env.survive)
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in w.state_dict().items()}
+    ow = getattr(OP, cls)(sd, batch_size=bs, reward_scale=scale)
+    u = (rng.random((n, 1, size, size)) < rng.choice([0.05, 0.3, 0.6])).astype(np.float32)
+    empty = rng.random(n) < 0.3
+    u[empty] = 0
+    env.universe = torch.from_numpy(u).cuda()
+    desc = f"case {case}: {cls} storage={storage} size={size} n={n} batch_size={bs} scale={scale}"
+    for t in range(min(4 * bs, int(rng.integers(3, 12)))):
+        p = float(rng.choice([0.0, 0.0, 0.1, 1.0 if rng.random() < 0.2 else 0.3]))
+        a = (rng.random((n, 1, asize, asize)) < p).astype(np.float32)
+        if p < 1.0:
+            a[empty] = 0
+        obs, reward, done, info = w.step(torch.from_numpy(a).cuda())
+        u, reset, _ = O.c_env_step(u, a, rule)
+        if not np.array_equal(obs.float().cpu().numpy(), u):
+            raise AssertionError(f"{desc}: grids differ at step {t}")
+        exp = ow.step(u, np.zeros((n, 1), np.float32))
+        got = reward.detach().cpu().numpy()
+        if not np.allclose(got, exp, rtol=0, atol=1e-5):
+            raise AssertionError(f"{desc}: rewards differ at step {t} (p={p}, reset={reset}): {got.ravel()} != {exp.ravel()}")
+        if float(w.live_cells) != ow.live_cells:
+            raise AssertionError(f"{desc}: live_cells {float(w.live_cells)} != {ow.live_cells} at step {t}")
+    return desc
+
+
+SEED_MULT = 86028121
+
+
+def main(budget=60.0, seed0=0, cases=None):
+    """Runs cases until `budget` seconds have passed (or exactly `cases` of them: tests/test_gpu_fuzz.py)."""
+    t_end = time.time() + budget
+    case = 0
+    while (case < cases) if cases is not None else (time.time() < t_end):
+        d = one_case(case, np.random.default_rng(seed0 * SEED_MULT + case))
+        case += 1
+        if case % 20 == 0 and cases is None:
+            print(f"{case} cases ok (last: {d})", flush=True)
+    print(f"fuzz_prediction: {case} cases, no difference")
+    return case
+
+
+if __name__ == "__main__":
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
