@@ -130,6 +130,7 @@ def test_wrappers_against_the_oracle(cls, size, n, storage):
     u[-1] = 0
     env.universe = torch.from_numpy(u).cuda()
     life = O_ca.rule_mask([3], [2, 3])
+    worst = 0.0
     for t in range(11):
         a = (rng.random((n, 1, asz, asz)) < (0.1 if t % 2 else 0.0)).astype(np.float32)
         a[-1] = 0
@@ -140,11 +141,15 @@ def test_wrappers_against_the_oracle(cls, size, n, storage):
         assert np.array_equal(obs.float().cpu().numpy(), u)
         exp = ow.step(u, np.zeros((n, 1), np.float32))
         np.testing.assert_allclose(reward.cpu().numpy(), exp, rtol=0, atol=5e-6, err_msg=f"step {t}")
+        worst = max(worst, float(np.abs(reward.cpu().numpy() - exp).max()))
         if t == 6:
             assert reset and not reward.any()
     got = {k: v.detach().cpu().numpy() for k, v in w.state_dict().items()}
+    wworst = 0.0
     for k, v in ow.state().items():
         np.testing.assert_allclose(got[k], v, rtol=0, atol=5e-5, err_msg=k)
+        wworst = max(wworst, float(np.abs(got[k] - v).max()))
+    print(f"largest differences: reward {worst:.2e}, weights {wworst:.2e}")
 
 
 def test_reference_test_prediction_bonus_learns():
