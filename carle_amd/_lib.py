@@ -76,6 +76,9 @@ SIGNATURES = {
     "carle_bonus_nonempty_f32": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _c_i64,
                                           _c_vp, _c_vp]),
     "carle_ae2d_predict_bonus_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "carle_ae2d_predict_bonus_b1": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
+    "carle_ae2d_predict_train_b1": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
+                                             ctypes.c_float, _c_int, _c_vp]),
     "carle_ae2d_predict_train_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                               ctypes.c_float, _c_vp]),
     "carle_batch_moments_f32": (_c_int, [_c_vp, _c_i64, _c_vp, _c_vp, _c_vp]),

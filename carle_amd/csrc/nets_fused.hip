@@ -214,15 +214,19 @@ struct AeBlockShared {
     float a1[4 * kA1Plane];          // A1; A3 later overlays plane 0
     float a2[2 * kA2Plane];
     uint64_t rows[66];               // the grid, one 64-bit word per row at [1..64]; [0], [65] stay zero
+    uint64_t trows[64];              // TGT: the frame the reconstruction is compared with (PredictionBonus)
     float red[4];
 };
 
 // (kfloat / opaque_uniform: common.hpp)
 
-template <bool PACKED_OBS>
+// TGT (PredictionBonus, mcl.py:581-605): the squared error is taken against another bit-packed frame `tgt` of the same
+// universes instead of the input itself
+template <bool PACKED_OBS, bool TGT = false>
 __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
     const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
-    float *__restrict__ recon, float *__restrict__ reward, float reward_scale, int64_t n) {
+    float *__restrict__ recon, float *__restrict__ reward, float reward_scale, int64_t n,
+    const uint64_t *__restrict__ tgt) {
     __shared__ AeBlockShared s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float *prm = ws + kAeLutFloats;            // uniform parameter block
@@ -232,8 +236,11 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
     const int py = tid >> 4, px = tid & 15;          // compute mapping
     const int64_t first = blockIdx.x, stride = gridDim.x;
     uint4 v[4];
-    uint64_t word = 0;
+    uint64_t word = 0, tword = 0;
     auto issue = [&](int64_t g) {
+        if (TGT) {
+            if (tid < 64) tword = tgt[g * 64 + tid];
+        }
         if (PACKED_OBS) {
             if (tid < 64) word = reinterpret_cast<const uint64_t *>(obs_v)[g * 64 + tid];
         } else {
@@ -253,6 +260,9 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
     __syncthreads();
     for (int64_t g = first; g < n; g += stride) {
         // ---- the grid as 64 row words in LDS
+        if (TGT) {
+            if (tid < 64) s.trows[tid] = tword;
+        }
         if (PACKED_OBS) {
             if (tid < 64) s.rows[1 + tid] = word;
         } else {
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t bits = (uint32_t)(s.rows[1 + 4 * py + r] >> (4 * px)) & 0xFu;
+                const uint32_t bits = (uint32_t)((TGT ? s.trows[4 * py + r] : s.rows[1 + 4 * py + r]) >> (4 * px)) & 0xFu;
                 float out4[4];
 #pragma unroll
                 for (int cx = 0; cx < 4; ++cx) {
@@ -429,17 +439,22 @@ void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s) {
 }
 
 int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
-                 float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s) {
+                 float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s,
+                 const uint64_t *tgt) {
     if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
     int64_t blocks = n < 1280 ? n : 1280;             // persistent: 5 workgroups are resident per CU
     if (const int64_t v = knobs().net_blocks; v > 0) blocks = v < n ? v : n;   // experiment knob, read once
     if (blocks < 1) blocks = 1;
-    if (packed)
-        hipLaunchKernelGGL(ae_block64_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,
-                           recon, reward, reward_scale, n);
+    const uint64_t *no_tgt = nullptr;
+    if (tgt)                                          // (bit-packed frames only)
+        hipLaunchKernelGGL((ae_block64_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,
+                           recon, reward, reward_scale, n, tgt);
+    else if (packed)
+        hipLaunchKernelGGL((ae_block64_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,
+                           recon, reward, reward_scale, n, no_tgt);
     else
-        hipLaunchKernelGGL(ae_block64_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,
-                           recon, reward, reward_scale, n);
+        hipLaunchKernelGGL((ae_block64_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,
+                           recon, reward, reward_scale, n, no_tgt);
     return check_launch("carle_ae2d_bonus(fused 64x64)");
 }
 
@@ -817,6 +832,7 @@ struct AeTrainShared {
     uint16_t nb[1024];               // 4x4 cell neighbourhood of every A1 position (32x32, row-major)
     uint8_t am[1024];                // 2-bit arg-max index (dy * 2 + dx) of the four conv1 channels
     uint64_t rows[66];
+    uint64_t trows[64];              // TGT: the frame the reconstruction is compared with (PredictionBonus)
     float red[4][52];
 };
 static_assert(sizeof(AeTrainShared) <= 54272, "three workgroups per CU");
@@ -871,11 +887,11 @@ __device__ __forceinline__ float quad_class_sum(float v) {
 
 
 
-template <bool PACKED_OBS>
+template <bool PACKED_OBS, bool TGT = false>
 __global__ __launch_bounds__(256, 3) void ae_train_block64_kernel(
     const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
     float *__restrict__ reward, float reward_scale, float grad_scale, float *__restrict__ partial,
-    int64_t n) {
+    int64_t n, const uint64_t *__restrict__ tgt) {
     __shared__ AeTrainShared s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
@@ -907,7 +923,7 @@ __global__ __launch_bounds__(256, 3) void ae_train_block64_kernel(
     const int64_t first = blockIdx.x, stride = gridDim.x;
     uint4 v[4];
     uint32_t xr[4];                                  // fp32 observations: this lane's dword of rows 16wv+4i+q
-    uint64_t word = 0;
+    uint64_t word = 0, tword = 0;
     auto convert = [&]() {                            // waits for the loads; 4 live registers instead of 16
         if (!PACKED_OBS) {
 #pragma unroll
@@ -919,6 +935,9 @@ __global__ __launch_bounds__(256, 3) void ae_train_block64_kernel(
         }
     };
     auto issue = [&](int64_t g) {
+        if (TGT) {
+            if (tid < 64) tword = tgt[g * 64 + tid];
+        }
         if (PACKED_OBS) {
             if (tid < 64) word = reinterpret_cast<const uint64_t *>(obs_v)[g * 64 + tid];
         } else {
@@ -930,6 +949,9 @@ __global__ __launch_bounds__(256, 3) void ae_train_block64_kernel(
     if (first < n) { issue(first); convert(); }
     for (int64_t g = first; g < n; g += stride) {
         // ---- the grid as 64 row words in LDS
+        if (TGT) {
+            if (tid < 64) s.trows[tid] = tword;
+        }
         if (PACKED_OBS) {
             if (tid < 64) s.rows[1 + tid] = word;
         } else {
@@ -952,6 +974,11 @@ __global__ __launch_bounds__(256, 3) void ae_train_block64_kernel(
             }
             own_bits = ((seg[1] >> 1) & 15u) | (((seg[2] >> 1) & 15u) << 4) | (((seg[3] >> 1) & 15u) << 8) |
                        (((seg[4] >> 1) & 15u) << 12);
+            if (TGT) {                                // the error is taken against the target frame's cells
+                own_bits = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) own_bits |= ((uint32_t)(s.trows[4 * py + r] >> (4 * px)) & 15u) << (4 * r);
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 float4 e[2][4];                       // the eight lookups of A1 row 2py+a in flight together
@@ -1354,15 +1381,19 @@ int ae2d_train64_rows(int64_t n) {                 // = workgroups of ae_train_b
 
 int ae2d_train64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *reward, float reward_scale, float grad_scale, float *partial, float *grad,
-                 bool tables_valid, hipStream_t s) {
+                 bool tables_valid, hipStream_t s, const uint64_t *tgt) {
     if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
     const int rows = ae2d_train64_rows(n);
-    if (packed)
-        hipLaunchKernelGGL(ae_train_block64_kernel<true>, dim3((unsigned)rows), dim3(256), 0, s, obs, ws, bonus,
-                           reward, reward_scale, grad_scale, partial, n);
+    const uint64_t *no_tgt = nullptr;
+    if (tgt)                                          // (bit-packed frames only)
+        hipLaunchKernelGGL((ae_train_block64_kernel<true, true>), dim3((unsigned)rows), dim3(256), 0, s, obs, ws, bonus,
+                           reward, reward_scale, grad_scale, partial, n, tgt);
+    else if (packed)
+        hipLaunchKernelGGL((ae_train_block64_kernel<true, false>), dim3((unsigned)rows), dim3(256), 0, s, obs, ws, bonus,
+                           reward, reward_scale, grad_scale, partial, n, no_tgt);
     else
-        hipLaunchKernelGGL(ae_train_block64_kernel<false>, dim3((unsigned)rows), dim3(256), 0, s, obs, ws, bonus,
-                           reward, reward_scale, grad_scale, partial, n);
+        hipLaunchKernelGGL((ae_train_block64_kernel<false, false>), dim3((unsigned)rows), dim3(256), 0, s, obs, ws, bonus,
+                           reward, reward_scale, grad_scale, partial, n, no_tgt);
     hipLaunchKernelGGL(rnd_grad_reduce_kernel, dim3((kAeParams + 31) / 32), dim3(1024), 0, s, partial, rows, grad,
                        kAeParams);
     return check_launch("carle_ae2d_train(fused 64x64)");

@@ -459,17 +459,18 @@ int rnd2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const f
                       float reward_scale, float grad_scale, bool tables_valid, hipStream_t s);
 int ae2d_tiled_train_rows(int64_t n, int size);
 int ae2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *rows,
-                     float grad_scale, bool tables_valid, hipStream_t s);
+                     float grad_scale, bool tables_valid, hipStream_t s, const uint64_t *tgt = nullptr);
 int64_t ae2d_tiled_workspace_floats(int64_t n, int size);
 int ae2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *recon,
-               bool tables_valid, hipStream_t s);
+               bool tables_valid, hipStream_t s, const uint64_t *tgt = nullptr);
 int ae2d_train64_rows(int64_t n);
 int ae2d_train64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *reward, float reward_scale, float grad_scale, float *partial, float *grad,
-                 bool tables_valid, hipStream_t s);
+                 bool tables_valid, hipStream_t s, const uint64_t *tgt = nullptr);
 int64_t ae2d_fused_workspace_floats();
 int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
-                 float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s);
+                 float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s,
+                 const uint64_t *tgt = nullptr);
 }
 
 using namespace carle;
@@ -710,6 +711,48 @@ extern "C" int carle_ae2d_predict_train_f32(const float *obs, const float *targe
     if (n == 0) return 0;
     return ae2d_train_staged(obs, target, n, h, w, params, workspace, scratch, grad, bonus, nullptr, 0.0f, grad_scale,
                              static_cast<hipStream_t>(stream));
+}
+
+// The same on BIT-PACKED frames (binary grids, H = W a multiple of 64: what CARLE.step returns): the fused 64x64 kernels /
+// the tiled kernels of AE2D with the error term (and the output layer's gradient) taken against `target`.
+// workspace / partial / flags as carle_ae2d_bonus_b1 / carle_ae2d_train_b1.
+extern "C" int carle_ae2d_predict_bonus_b1(const uint64_t *obs, const uint64_t *target, int64_t n, int h, int w,
+                                           const float *params, float *workspace, float *bonus, float *recon_out,
+                                           int flags, void *stream) {
+    if (!obs || !target || !params || !workspace || !bonus)
+        return fail_arg(CARLE_E_NULL, "carle_ae2d_predict_bonus_b1: NULL pointer");
+    if (n < 0 || h != w || h < 64 || (h & 63))
+        return fail_arg(CARLE_E_DIMS, "carle_ae2d_predict_bonus_b1: bit-packed frames need H = W a multiple of 64");
+    if (recon_out && !aligned16(recon_out)) return fail_arg(CARLE_E_ALIGN, "carle_ae2d_predict_bonus_b1: recon_out alignment");
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool valid = (flags & CARLE_NET_TABLES_VALID) != 0;
+    if (h == 64) return ae2d_fused64(obs, true, n, params, workspace, bonus, recon_out, nullptr, 0.0f, valid, s, target);
+    if (int e = ae2d_tiled(obs, true, n, h, params, workspace, recon_out, valid, s, target)) return e;
+    const int tiles = (h >> 6) * (h >> 6);
+    hipLaunchKernelGGL(ae_mse_finish_kernel, dim3(blocks_for(n)), dim3(256), 0, s, workspace + 2048 + 128, bonus,
+                       static_cast<float *>(nullptr), 0.0f, n, tiles, 1.0f / ((float)h * (float)w));
+    return check_launch("carle_ae2d_predict_bonus_b1");
+}
+
+extern "C" int carle_ae2d_predict_train_b1(const uint64_t *obs, const uint64_t *target, int64_t n, int h, int w,
+                                           const float *params, float *workspace, float *partial, float *grad,
+                                           float *bonus, float grad_scale, int flags, void *stream) {
+    if (!obs || !target || !params || !workspace || !partial || !grad || !bonus)
+        return fail_arg(CARLE_E_NULL, "carle_ae2d_predict_train_b1: NULL pointer");
+    if (n < 0 || h != w || h < 64 || (h & 63))
+        return fail_arg(CARLE_E_DIMS, "carle_ae2d_predict_train_b1: bit-packed frames need H = W a multiple of 64");
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool valid = (flags & CARLE_NET_TABLES_VALID) != 0;
+    if (h == 64)
+        return ae2d_train64(obs, true, n, params, workspace, bonus, nullptr, 0.0f, grad_scale, partial, grad, valid, s, target);
+    if (int e = ae2d_tiled_train(obs, true, n, h, params, workspace, partial, grad_scale, valid, s, target)) return e;
+    const int tiles = (h >> 6) * (h >> 6);
+    hipLaunchKernelGGL(ae_mse_finish_kernel, dim3(blocks_for(n)), dim3(256), 0, s, workspace + 2048 + 128, bonus,
+                       static_cast<float *>(nullptr), 0.0f, n, tiles, 1.0f / ((float)h * (float)w));
+    hipLaunchKernelGGL(staged_grad_reduce_kernel, dim3(6), dim3(1024), 0, s, partial, ae2d_tiled_train_rows(n, h), grad, 164);
+    return check_launch("carle_ae2d_predict_train_b1");
 }
 
 // ---------------------------------------------------------------------------------------------

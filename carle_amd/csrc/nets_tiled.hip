@@ -721,6 +721,7 @@ struct AeTileShared {
     float a1[4 * kT1Plane];            // A3 (34 x 36) overlays plane 0 once conv2 has read A1
     float a2[2 * kT2Plane];
     uint64_t rows[kAeRows + 2][2];
+    uint64_t trows[64];                // TGT: the tile's own cells of the frame the reconstruction is compared with
     float red[4];
     int last;                          // PairFinish: this workgroup delivered the last tile of its grid
 };
@@ -733,11 +734,13 @@ __device__ __forceinline__ uint32_t row_seg4(uint64_t lo, uint64_t hi, int c) {
 
 __device__ __forceinline__ float tile_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // as nets_fused.hip
 
-template <bool PACKED>
+// TGT (PredictionBonus, mcl.py:581-605): the squared error of a tile is taken against the same cells of another bit-packed
+// frame `tgt` (one aligned word per tile row) instead of the input
+template <bool PACKED, bool TGT = false>
 __device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__restrict__ obs_v, const float *__restrict__ ws,
                                              float *__restrict__ partial, float *__restrict__ recon,
                                              int64_t n, int size, unsigned bid, unsigned nblk,
-                                             const PairFinish pf = PairFinish()) {
+                                             const PairFinish pf = PairFinish(), const uint64_t *__restrict__ tgt = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double2 mom_acc = make_double2(0.0, 0.0);           // PairFinish: rewards this workgroup formed (thread 0)
     {
@@ -759,11 +762,14 @@ __device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__rest
     // assembles row r's two words): issued a whole iteration ahead
     constexpr int kPer = (kAeRows + 3) / 4;
     uint32_t va[kPer], vb[kPer];
-    uint64_t plo = 0ull, phi = 0ull;
+    uint64_t plo = 0ull, phi = 0ull, tword = 0ull;
     auto issue = [&](int64_t t) {
         const int64_t g = t / tiles;
         const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
         const int y0 = 64 * ty - 7, x0 = 64 * tx - 7;
+        if (TGT) {
+            if (tid < 64) tword = tgt[(g * size + 64 * ty + tid) * tps + tx];
+        }
         if (PACKED) {
             plo = 0ull; phi = 0ull;
             const int y = y0 + tid;
@@ -792,6 +798,9 @@ __device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__rest
         const int64_t g = t / tiles;
         const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
         // ---- the tile's kAeRows rows as bit words: from the registers the previous iteration (or the prologue) filled
+        if (TGT) {
+            if (tid < 64) s.trows[tid] = tword;
+        }
         if (PACKED) {
             if (tid < kAeRows) { s.rows[tid][0] = plo; s.rows[tid][1] = phi; }
         } else {
@@ -933,7 +942,8 @@ __device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__rest
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t bits = row_seg4(s.rows[7 + 4 * py + r][0], s.rows[7 + 4 * py + r][1], 7 + 4 * px);
+                const uint32_t bits = TGT ? (uint32_t)(s.trows[4 * py + r] >> (4 * px)) & 0xFu
+                                          : row_seg4(s.rows[7 + 4 * py + r][0], s.rows[7 + 4 * py + r][1], 7 + 4 * px);
                 float out4[4];
 #pragma unroll
                 for (int cx = 0; cx < 4; ++cx) {
@@ -972,12 +982,12 @@ __device__ __forceinline__ void ae_tile_body(AeTileShared &s, const void *__rest
     if (pf.counters) pair_leave_moments(pf, tid, mom_acc, n);
 }
 
-template <bool PACKED>
+template <bool PACKED, bool TGT = false>
 __global__ __launch_bounds__(256, 4) void ae_tile_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
                                                          float *__restrict__ partial, float *__restrict__ recon,
-                                                         int64_t n, int size) {
+                                                         int64_t n, int size, const uint64_t *__restrict__ tgt) {
     __shared__ AeTileShared s;
-    ae_tile_body<PACKED>(s, obs_v, ws, partial, recon, n, size, blockIdx.x, gridDim.x);
+    ae_tile_body<PACKED, TGT>(s, obs_v, ws, partial, recon, n, size, blockIdx.x, gridDim.x, PairFinish(), tgt);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1067,6 +1077,7 @@ struct AeTileTrainShared {
     float dpre[64][64];                // d loss / d pre-sigmoid of the tile's own cells
     float dmap[2][40][40];             // d loss / d conv2 output (local position + 2), zero ring
     uint64_t rows[kAeRows + 2][2];
+    uint64_t trows[64];                // TGT: the tile's own cells of the target frame (PredictionBonus)
     uint16_t nb[kT1 * kT1];            // 4x4 cell neighbourhood of every A1 position
     uint8_t am[kT1 * kT1];             // 2-bit arg-max index of the four conv1 channels
     uint8_t sel2[2][18 * 18];          // arg-max of the 2x2 conv2 outputs under every A2 position
@@ -1076,10 +1087,11 @@ struct AeTileTrainShared {
 // NT threads per tile: 512 (one workgroup per CU) for small batches -- a tile is a chain of dependent LDS round trips,
 // twice the waves halve it (N=16: 67 -> 41 us per call) -- 256 (two workgroups per CU) for large ones (N=256: 374
 // against 399 us)
-template <bool PACKED, int NT>
+template <bool PACKED, int NT, bool TGT = false>
 __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(const void *__restrict__ obs_v, const float *__restrict__ ws,
                                                                float *__restrict__ partial, float *__restrict__ rows_out,
-                                                               float gs, int64_t n, int size) {
+                                                               float gs, int64_t n, int size,
+                                                               const uint64_t *__restrict__ tgt) {
     __shared__ AeTileTrainShared s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
@@ -1118,6 +1130,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
         const int tt = (int)(t % tiles), ty = tt / tps, tx = tt % tps;
         const int y0 = 64 * ty - 7, x0 = 64 * tx - 7;
         // ---- P0: rows
+        if (TGT) {                                     // the tile's own cells of the target frame: one aligned word per row
+            if (tid >= NT - 64) s.trows[tid - (NT - 64)] = tgt[(g * size + 64 * ty + (tid - (NT - 64))) * tps + tx];
+        }
         if (PACKED) {
             if (tid < kAeRows) {
                 const int y = y0 + tid;
@@ -1291,7 +1306,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 1 : 2) void ae_tile_train_kernel(co
             }
             auto cell_row = [&](auto rc) {               // rc: compile-time row of the 4x4 block
                 constexpr int r = decltype(rc)::value;
-                const uint32_t bits = row_seg4(s.rows[7 + 4 * py + r][0], s.rows[7 + 4 * py + r][1], 7 + 4 * px);
+                const uint32_t bits = TGT ? (uint32_t)(s.trows[4 * py + r] >> (4 * px)) & 0xFu
+                                          : row_seg4(s.rows[7 + 4 * py + r][0], s.rows[7 + 4 * py + r][1], 7 + 4 * px);
                 float d4[4];
 #pragma unroll
                 for (int cx = 0; cx < 4; ++cx) {
@@ -1492,21 +1508,26 @@ void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
 
 // tables in ws[0 .. 2176), one squared-error partial per tile behind them; gradient rows -> rows
 int ae2d_tiled_train(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *rows,
-                     float grad_scale, bool tables_valid, hipStream_t s) {
+                     float grad_scale, bool tables_valid, hipStream_t s, const uint64_t *tgt = nullptr) {
     if (!tables_valid) ae2d_prepare_tables(ap, ws, s);
     const unsigned blocks = (unsigned)ae2d_tiled_train_rows(n, size);
     float *partial = ws + kAeLutFloatsT + 128;
     const int64_t total = n * (int64_t)(size >> 6) * (size >> 6);
+    const uint64_t *no_tgt = nullptr;
     if (total <= 512) {                                // at most two tiles per CU: 512 threads per tile
-        if (packed)
-            hipLaunchKernelGGL((ae_tile_train_kernel<true, 512>), dim3(blocks), dim3(512), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+        if (tgt)                                       // (bit-packed frames only)
+            hipLaunchKernelGGL((ae_tile_train_kernel<true, 512, true>), dim3(blocks), dim3(512), 0, s, obs, ws, partial, rows, grad_scale, n, size, tgt);
+        else if (packed)
+            hipLaunchKernelGGL((ae_tile_train_kernel<true, 512, false>), dim3(blocks), dim3(512), 0, s, obs, ws, partial, rows, grad_scale, n, size, no_tgt);
         else
-            hipLaunchKernelGGL((ae_tile_train_kernel<false, 512>), dim3(blocks), dim3(512), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+            hipLaunchKernelGGL((ae_tile_train_kernel<false, 512, false>), dim3(blocks), dim3(512), 0, s, obs, ws, partial, rows, grad_scale, n, size, no_tgt);
     } else {
-        if (packed)
-            hipLaunchKernelGGL((ae_tile_train_kernel<true, 256>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+        if (tgt)
+            hipLaunchKernelGGL((ae_tile_train_kernel<true, 256, true>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size, tgt);
+        else if (packed)
+            hipLaunchKernelGGL((ae_tile_train_kernel<true, 256, false>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size, no_tgt);
         else
-            hipLaunchKernelGGL((ae_tile_train_kernel<false, 256>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size);
+            hipLaunchKernelGGL((ae_tile_train_kernel<false, 256, false>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, rows, grad_scale, n, size, no_tgt);
     }
     return check_launch("carle_ae2d_train(tiled)");
 }
@@ -1600,17 +1621,20 @@ int64_t ae2d_tiled_workspace_floats(int64_t n, int size) {
 
 // tables in ws[0 .. 2176), one partial per tile behind them; the caller's finish kernel sums them
 int ae2d_tiled(const void *obs, bool packed, int64_t n, int size, const float *ap, float *ws, float *recon,
-               bool tables_valid, hipStream_t s) {
+               bool tables_valid, hipStream_t s, const uint64_t *tgt) {
     if (!tables_valid) ae2d_prepare_tables(ap, ws, s);
     const int64_t total = n * (int64_t)(size >> 6) * (size >> 6);
     // up to 16384 workgroups (4 per CU resident, the others start out of phase as those retire): N=2048 x 256x256
     // 532 -> 475 us, N=256 75 -> 72 us against 1024 persistent ones; the RND2D tile kernel measured flat (stays at 1024)
     const unsigned blocks = (unsigned)(total < 16384 ? total : 16384);
     float *partial = ws + kAeLutFloatsT + 128;
-    if (packed)
-        hipLaunchKernelGGL(ae_tile_kernel<true>, dim3(blocks), dim3(256), 0, s, obs, ws, partial, recon, n, size);
+    const uint64_t *no_tgt = nullptr;
+    if (tgt)                                           // (bit-packed frames only)
+        hipLaunchKernelGGL((ae_tile_kernel<true, true>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, recon, n, size, tgt);
+    else if (packed)
+        hipLaunchKernelGGL((ae_tile_kernel<true, false>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, recon, n, size, no_tgt);
     else
-        hipLaunchKernelGGL(ae_tile_kernel<false>, dim3(blocks), dim3(256), 0, s, obs, ws, partial, recon, n, size);
+        hipLaunchKernelGGL((ae_tile_kernel<false, false>), dim3(blocks), dim3(256), 0, s, obs, ws, partial, recon, n, size, no_tgt);
     return check_launch("carle_ae2d_bonus(tiled)");
 }
 

@@ -207,35 +207,53 @@ def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False,
 
 
 def ae2d_predict(obs, target, params, workspace=None, scratch=None, grad=None, grad_scale=0.0, want_recon=False,
-                 bonus_out=None, stream=None):
-    """PredictionBonus.get_bonus (carle/mcl.py:581-605): bonus (N,) = mean_hw (target - decoder(obs))^2 for two fp32
-    frames (N,1,H,W) of the same universes, H == W a multiple of 8 (per-layer kernels).  With ``grad`` (flat 164 floats)
-    the predictor's gradient of grad_scale/2 * sum (target - decoder(obs))^2 is accumulated into it on the way
-    (carle_ae2d_predict_train_f32).  Returns (bonus, recon or None, workspace, scratch)."""
+                 bonus_out=None, stream=None, tables_valid=False):
+    """PredictionBonus.get_bonus (carle/mcl.py:581-605): bonus (N,) = mean_hw (target - decoder(obs))^2 for two frames
+    of the same universes -- both fp32 (N,1,H,W), H == W a multiple of 8 (per-layer kernels), or both int64 bit-packed
+    (N,1,H,H/64), H a multiple of 64 (AE2D's fused 64x64 / tiled kernels with a target).  With ``grad`` (flat 164 floats)
+    the predictor's gradient of grad_scale/2 * sum (target - decoder(obs))^2 is accumulated into it on the way.
+    Returns (bonus, recon or None, workspace, scratch)."""
     lib = _lib.load()
-    _chk_grid(obs, "obs", torch.float32)
-    _chk_grid(target, "target", torch.float32)
+    packed = obs.dtype == torch.int64
+    _chk_grid(obs, "obs", torch.int64 if packed else torch.float32)
+    _chk_grid(target, "target", torch.int64 if packed else torch.float32)
     if target.shape != obs.shape or target.device != obs.device:
         raise ValueError(f"ae2d_predict: obs {tuple(obs.shape)} and target {tuple(target.shape)} must match")
     n, _, h, w = obs.shape
+    if packed:
+        w *= 64
     need = lib.carle_ae2d_workspace_floats(n, h, w)
     if workspace is None or workspace.numel() < need or workspace.device != obs.device:
         workspace = torch.empty(max(need, 1), dtype=torch.float32, device=obs.device)
+        tables_valid = False
     bonus = bonus_out if bonus_out is not None else torch.empty(n, dtype=torch.float32, device=obs.device)
     recon = None
     st = stream if stream is not None else _stream(obs)
+    flags = 2 if tables_valid else 0
     with _on_device(obs.device):
         if grad is None:
             recon = torch.empty(n, 1, h, w, dtype=torch.float32, device=obs.device) if want_recon else None
-            rc = lib.carle_ae2d_predict_bonus_f32(obs.data_ptr(), target.data_ptr(), n, h, w, params.data_ptr(),
-                                                  workspace.data_ptr(), bonus.data_ptr(), _ptr(recon), st)
+            if packed:
+                rc = lib.carle_ae2d_predict_bonus_b1(obs.data_ptr(), target.data_ptr(), n, h, w, params.data_ptr(),
+                                                     workspace.data_ptr(), bonus.data_ptr(), _ptr(recon), flags, st)
+            else:
+                rc = lib.carle_ae2d_predict_bonus_f32(obs.data_ptr(), target.data_ptr(), n, h, w, params.data_ptr(),
+                                                      workspace.data_ptr(), bonus.data_ptr(), _ptr(recon), st)
         else:
-            sneed = lib.carle_ae2d_train_scratch_floats(n, h, w)
+            if packed and h == 64:
+                sneed = lib.carle_ae2d_train_partial_floats(n)
+            else:
+                sneed = lib.carle_ae2d_train_scratch_floats(n, h, w)
             if scratch is None or scratch.numel() < sneed or scratch.device != obs.device:
                 scratch = torch.empty(max(sneed, 1), dtype=torch.float32, device=obs.device)
-            rc = lib.carle_ae2d_predict_train_f32(obs.data_ptr(), target.data_ptr(), n, h, w, params.data_ptr(),
-                                                  workspace.data_ptr(), scratch.data_ptr(), grad.data_ptr(),
-                                                  bonus.data_ptr(), float(grad_scale), st)
+            if packed:
+                rc = lib.carle_ae2d_predict_train_b1(obs.data_ptr(), target.data_ptr(), n, h, w, params.data_ptr(),
+                                                     workspace.data_ptr(), scratch.data_ptr(), grad.data_ptr(),
+                                                     bonus.data_ptr(), float(grad_scale), flags, st)
+            else:
+                rc = lib.carle_ae2d_predict_train_f32(obs.data_ptr(), target.data_ptr(), n, h, w, params.data_ptr(),
+                                                      workspace.data_ptr(), scratch.data_ptr(), grad.data_ptr(),
+                                                      bonus.data_ptr(), float(grad_scale), st)
     if rc != 0:
         _lib.check(rc, "carle_ae2d_predict")
     return bonus, recon, workspace, scratch

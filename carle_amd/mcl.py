@@ -956,11 +956,12 @@ class PredictionBonus(AE2D):
     (``prediction_steps`` = 5 steps back once the buffer is full; the frame itself on the first call) and compared with
     the newest frame; ``reward += reward_scale * (0.1 - error)``, zero for instances without a live cell.
 
-    HIP path: ``carle_ae2d_predict_bonus_f32`` / ``carle_ae2d_predict_train_f32`` (the per-layer AE2D kernels with the
-    error term and the output layer's gradient taken against the target frame), any H = W multiple of 8; the window's
-    gradient goes through ``carle_adam_update_f32`` as AE2D's.  Eval-mode semantics (Dropout = identity) as everywhere.
-    Frames are kept as private fp32 copies: the reference keeps the tensor objects ``env.step`` returned (a new tensor
-    per step there, env.py:229)."""
+    HIP path: binary frames with H = W a multiple of 64 (what ``CARLE.step`` returns at 64 / 128 / 256 / 512) are kept
+    bit-packed and go through AE2D's fused 64x64 / tiled kernels with the error term and the output layer's gradient
+    taken against the target frame (``carle_ae2d_predict_bonus_b1`` / ``carle_ae2d_predict_train_b1``); any other H = W
+    multiple of 8 and non-binary frames through the per-layer kernels (``..._f32``); the window's gradient goes through
+    ``carle_adam_update_f32`` as AE2D's.  Eval-mode semantics (Dropout = identity) as everywhere.  Frames are private
+    copies: the reference keeps the tensor objects ``env.step`` returned (a new tensor per step there, env.py:229)."""
 
     def __init__(self, env, **kwargs):
         super().__init__(env, **kwargs)
@@ -972,16 +973,25 @@ class PredictionBonus(AE2D):
         self.__dict__["_scratch"] = None
 
     def _frame(self, obs):
-        o, _ = self._obs(obs)
+        """A private copy of the observation for the frame buffer: bit-packed (512 bytes per 64x64 grid) when it is binary
+        with H = W a multiple of 64 -- whatever CARLE.step returned -- fp32 otherwise."""
+        o, binary = self._obs(obs, allow_packed=True)
+        if o.dtype == torch.int64:
+            return o.clone()                     # (the environment's own buffers are rewritten by later steps)
         if o.dim() != 4 or o.shape[2] != o.shape[3] or o.shape[2] % 8 or o.shape[2] < 8:
             raise NotImplementedError("PredictionBonus: the HIP kernels need square grids with H = W a multiple of 8 "
                                       f"(got {tuple(o.shape)})")
+        if binary and o.shape[2] % 64 == 0:
+            return hip.pack_f32_b1(o)
         return o.clone() if o is obs or o.data_ptr() == obs.data_ptr() else o
 
     def _predict(self, obs, with_grad, batch=None):
         """mcl.py:581-605 (+ the gradient of mean_n(loss) / batch for the update paths)."""
         self.grid_buffer.append(self._frame(obs))
         first, target = self.grid_buffer[0], self.grid_buffer[-1]
+        if first.dtype != target.dtype:          # a caller mixed binary and non-binary frames: per-layer kernels on fp32
+            first, target = [hip.unpack_b1_f32(f) if f.dtype == torch.int64 else f for f in (first, target)]
+        packed = first.dtype == torch.int64
         dev, n, size = first.device, first.shape[0], first.shape[2]
         pb = self._pred_blob.get(dev)
         grad = None
@@ -990,9 +1000,13 @@ class PredictionBonus(AE2D):
                 self._grad = torch.zeros(pb.numel(), dtype=torch.float32, device=dev)
             grad = self._grad
         gs = 2.0 / (size * size * n * (self.batch_size if batch is None else batch))
+        key = (id(self._ws), (self._pred_blob.version,), n, size)
+        valid = packed and self._ws is not None and self._tables_key == key
         bonus, _, self._ws, self.__dict__["_scratch"] = hip.ae2d_predict(
-            first, target, pb, self._ws, self.__dict__.get("_scratch"), grad, gs)
-        self._tables_key = None                  # the per-layer kernels overwrite the workspace the tables live in
+            first, target, pb, self._ws, self.__dict__.get("_scratch"), grad, gs, tables_valid=valid)
+        # packed frames: the conv1 tables of AE2D's fused / tiled kernels now sit in the workspace; fp32 frames: the
+        # per-layer kernels overwrote it
+        self._tables_key = (id(self._ws), (self._pred_blob.version,), n, size) if packed else None
         if with_grad:
             self._grad_used = True
         if len(self.grid_buffer) > self.prediction_steps:

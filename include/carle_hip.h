@@ -375,6 +375,14 @@ int carle_ae2d_predict_bonus_f32(const float *obs, const float *target, int64_t 
 int carle_ae2d_predict_train_f32(const float *obs, const float *target, int64_t n, int h, int w, const float *params,
                                  float *workspace, float *scratch, float *grad, float *bonus, float grad_scale,
                                  void *stream);
+/* the same on bit-packed frames (CARLE_FMT_B1; binary grids, H = W a multiple of 64 -- what CARLE.step returns): AE2D's fused
+ * 64x64 / tiled kernels with the error term and the output layer's gradient taken against `target`; workspace, partial,
+ * flags (CARLE_NET_TABLES_VALID) as carle_ae2d_bonus_b1 / carle_ae2d_train_b1 */
+int carle_ae2d_predict_bonus_b1(const uint64_t *obs, const uint64_t *target, int64_t n, int h, int w, const float *params,
+                                float *workspace, float *bonus, float *recon_out, int flags, void *stream);
+int carle_ae2d_predict_train_b1(const uint64_t *obs, const uint64_t *target, int64_t n, int h, int w, const float *params,
+                                float *workspace, float *partial, float *grad, float *bonus, float grad_scale, int flags,
+                                void *stream);
 
 /* RND2D.get_bonus and AE2D.get_bonus of the SAME observations (carle/mcl.py:343-352, 504-512) and both wrappers'
  * `reward += reward_scale * bonus` (mcl.py:403-405, RND2D's first: the stack AE2D(RND2D(env)) of train_mcl.py:34-38 and

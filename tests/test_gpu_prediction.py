@@ -14,7 +14,7 @@ from oracle import prediction as OP
 
 pytestmark = pytest.mark.gpu
 # measured against the reference-recorded trajectories (fp32 autograd + torch Adam on the CPU there;
-# profiles/r04_trajectory_errors.txt): rewards <= 3e-8 at 64x64 and <= 7.6e-7 in the 256x256 glider scenario, weights <= 9e-7
+# profiles/r04_trajectory_errors.txt): rewards <= 3e-8 at 64x64 and <= 6.3e-7 in the 256x256 glider scenario, weights <= 9e-7
 # but for one bias at 5.2e-6 (4 Adam steps at lr 6e-2 on an almost empty grid)
 REWARD_TOL = 2e-6
 WEIGHT_TOL = 2e-5
@@ -73,21 +73,26 @@ def test_reference_explicit_calls():
         np.testing.assert_allclose(v.cpu().numpy(), want[k], rtol=0, atol=WEIGHT_TOL, err_msg=k)
 
 
-@pytest.mark.parametrize("size,n,binary", [(8, 5, True), (24, 3, False), (72, 2, True), (136, 1, True), (256, 2, True)])
-def test_predict_kernels_against_the_oracle(size, n, binary):
-    """carle_ae2d_predict_bonus_f32 / _train_f32 on random frame pairs: bonus within 1e-5 of oracle/nets.py, the
-    gradient of mean_n(loss) within 3e-6 of the tensor's largest component of fp64 autograd (the bound of the AE2D
-    gradient kernels)."""
+@pytest.mark.parametrize("size,n,mode", [(8, 5, "binary"), (24, 3, "real"), (72, 2, "binary"), (136, 1, "binary"),
+                                         (256, 2, "binary"), (64, 5, "packed"), (64, 300, "packed"), (128, 3, "packed"),
+                                         (256, 2, "packed"), (256, 40, "packed"), (512, 1, "packed")])
+def test_predict_kernels_against_the_oracle(size, n, mode):
+    """carle_ae2d_predict_bonus_* / _train_* on random frame pairs -- fp32 frames through the per-layer kernels, bit-packed
+    frames through AE2D's fused 64x64 / tiled kernels with a target: bonus within 1e-5 of oracle/nets.py, the gradient of
+    mean_n(loss) within 3e-6 of the tensor's largest component of fp64 autograd (the bound of the AE2D gradient kernels,
+    DESIGN section 6)."""
     from carle_amd import hip
     rng = np.random.default_rng(size * 31 + n)
     torch.manual_seed(size)
-    env, w = _build("PredictionBonus", size, n)
+    env, w = _build("PredictionBonus", size, min(n, 4))
     sd = {k: v.detach().cpu().numpy() for k, v in w.state_dict().items()}
-    mk = (lambda: (rng.random((n, 1, size, size)) < 0.3).astype(np.float32)) if binary else \
-        (lambda: rng.standard_normal((n, 1, size, size)).astype(np.float32))
+    mk = (lambda: rng.standard_normal((n, 1, size, size)).astype(np.float32)) if mode == "real" else \
+        (lambda: (rng.random((n, 1, size, size)) < 0.3).astype(np.float32))
     obs, target = mk(), mk()
     pb = w._pred_blob.get(torch.device("cuda:0"))
     o, t = torch.from_numpy(obs).cuda(), torch.from_numpy(target).cuda()
+    if mode == "packed":
+        o, t = hip.pack_f32_b1(o), hip.pack_f32_b1(t)
     bonus, recon, ws, _ = hip.ae2d_predict(o, t, pb, want_recon=True)
     with torch.no_grad():
         pred = ON.ae_predictor(torch.from_numpy(obs), sd)
@@ -96,8 +101,12 @@ def test_predict_kernels_against_the_oracle(size, n, binary):
     np.testing.assert_allclose(recon.cpu().numpy(), pred.numpy(), rtol=0, atol=1e-5)
     grad = torch.zeros(pb.numel(), device="cuda")
     gs = 2.0 / (size * size * n)
-    bonus2, _, _, _ = hip.ae2d_predict(o, t, pb, ws, None, grad, gs)
-    assert torch.equal(bonus2, bonus)
+    bonus2, _, ws, _ = hip.ae2d_predict(o, t, pb, ws, None, grad, gs)
+    np.testing.assert_allclose(bonus2.cpu().numpy(), bonus.cpu().numpy(), rtol=0, atol=0 if mode != "packed" else 2e-7)
+    if mode == "packed":                                         # and once more on the tables the first call left
+        g2 = torch.zeros_like(grad)
+        bonus3, _, _, _ = hip.ae2d_predict(o, t, pb, ws, None, g2, gs, tables_valid=True)
+        assert torch.equal(bonus3, bonus2) and torch.equal(g2, grad)
     import copy
     ref_net = copy.deepcopy(w.predictor).cpu().double().eval()           # fp64 autograd through the torch modules
     p64 = ref_net(torch.from_numpy(obs).double()).reshape(obs.shape)
