@@ -6,7 +6,9 @@ widens the pin with open-ended random cases: sizes 4 .. 40 (even squares), 1 .. 
 reference takes them (lists of counts, duplicates and single-element lists included), action values 0 / 1 / 0.5 / -1 /
 2 / NaN / inf / -0.0, oversize actions (centre crop), all-ones actions, values that cancel or average to exactly 1.0
 (env.py:191, 208) -- grids, reset decision, step_number, steps_since_action after every step; get_rle / rle_to_grid of
-random grids byte for byte.  Any difference found becomes a golden fixture.
+random grids byte for byte; the hand-coded wrappers and PredictionBonus / SurpriseBonus (with predictor updates, eval
+mode) in random configurations against oracle/wrappers.py / oracle/prediction.py.  Any difference found becomes a golden
+fixture.
 
     cd /tmp && MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference \
         python /root/repo/tools/fuzz_oracle_vs_reference.py [seconds] [seed]"""
@@ -23,6 +25,7 @@ torch, ref_env, ref_mcl = MG.import_reference()
 sys.path.append("/root/repo")
 from oracle import ca as O                      # noqa: E402
 from oracle import wrappers as OW               # noqa: E402
+from oracle import prediction as OP             # noqa: E402
 from carle_amd import rle as R                  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -156,12 +159,53 @@ def wrapper_case(case, rng):
             raise AssertionError(f"wrapper case {case} step {t}: rewards differ ({kinds}, size {size}, n {n}): {got.ravel()} != {r.ravel()}")
 
 
+def prediction_case(case, rng):
+    """oracle/prediction.py against the reference's PredictionBonus / SurpriseBonus (mcl.py:558-728) in eval mode with
+    predictor updates: random sizes (multiples of 4: the decoder's geometry), batches, windows, scales, empty instances."""
+    import contextlib
+    import io
+    cls = str(rng.choice(["PredictionBonus", "SurpriseBonus"]))
+    size = 4 * int(rng.integers(2, 17))
+    asize = 2 * int(rng.integers(1, size // 2 + 1))
+    n = int(rng.integers(1, 4))
+    bs = int(rng.integers(1, 4))
+    scale = float(rng.choice([1.0, 0.5, 2.0]))
+    torch.manual_seed(int(rng.integers(0, 2 ** 31 - 1)))
+    with contextlib.redirect_stdout(io.StringIO()):
+        env = ref_env.CARLE(width=size, height=size, action_width=asize, action_height=asize, instances=n, device="cpu")
+        w = getattr(ref_mcl, cls)(env)
+    w.eval()
+    w.batch_size, w.reward_scale = bs, scale
+    w.reset()
+    sd = {k: v.detach().numpy().copy() for k, v in w.state_dict().items()}
+    ow = getattr(OP, cls)(sd, batch_size=bs, reward_scale=scale)
+    u = (rng.random((n, 1, size, size)) < 0.3).astype(np.float32)
+    empty = rng.random(n) < 0.3
+    u[empty] = 0
+    env.universe = torch.from_numpy(u.copy())
+    rule = O.rule_mask([3], [2, 3])
+    for t in range(min(3 * bs + 1, int(rng.integers(3, 10)))):
+        a = (rng.random((n, 1, asize, asize)) < float(rng.choice([0.0, 0.1, 0.3]))).astype(np.float32)
+        a[empty] = 0
+        obs, reward, done, info = w.step(torch.from_numpy(a.copy()))
+        u, reset, _ = O.c_env_step(u, a, rule)
+        assert np.array_equal(obs.detach().numpy(), u)
+        exp = ow.step(u, np.zeros((n, 1), np.float32))
+        got = reward.detach().numpy().reshape(n, -1)
+        if not np.allclose(got, exp, rtol=0, atol=5e-6):
+            raise AssertionError(f"prediction case {case} step {t}: {cls} size {size} n {n} batch_size {bs}: "
+                                 f"{got.ravel()} != {exp.ravel()}")
+        assert float(w.live_cells) == ow.live_cells
+
+
 t_end = time.time() + budget
 case = 0
 while time.time() < t_end:
     one_case(case, np.random.default_rng(seed0 * 99991 + case))
     if case % 4 == 0:
         wrapper_case(case, np.random.default_rng(seed0 * 77773 + case))
+    if case % 8 == 0:
+        prediction_case(case, np.random.default_rng(seed0 * 55529 + case))
     case += 1
     if case % 200 == 0:
         print(f"{case} cases ok", flush=True)
