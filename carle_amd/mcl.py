@@ -1013,9 +1013,6 @@ class PredictionBonus(AE2D):
             self.grid_buffer.pop(0)
         return bonus
 
-    def forward(self, obs):
-        return super().forward(obs)
-
     def get_bonus(self, obs):
         return self._predict(obs, False)
 
@@ -1048,8 +1045,9 @@ class PredictionBonus(AE2D):
             self._finish_window()
         return bonus
 
-    def _fused_train(self, obs, reward, bonus_out, stream, batch=None):
-        return False                             # (AE2D's kernels compare a frame with itself)
+    def _bonus_into(self, obs, reward, stream=None):
+        raise NotImplementedError("PredictionBonus forms its reward in step() (0.1 - error, mcl.py:686), not by "
+                                  "reward += scale * bonus")
 
     def step(self, action):
         """mcl.py:679-699."""
