@@ -254,3 +254,25 @@ def test_step_graph_refuses_the_frame_buffer():
     for backend in ("graph", "calls"):
         with pytest.raises(NotImplementedError):
             StepGraph(w, a, backend=backend)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 257, 5000])
+def test_bonus_epilogue_is_bit_exact(n):
+    """carle_bonus_nonempty_f32 against the fp32 arithmetic of mcl.py:686-694 / 715-723 (two roundings in
+    reward + scale * bonus, zero for empty grids), bit for bit, and the live-cell total."""
+    from carle_amd import hip
+    rng = np.random.default_rng(n)
+    err = rng.random(n).astype(np.float32)
+    reward = rng.standard_normal((n, 1)).astype(np.float32)
+    sums = np.zeros((n, 4), np.float32)
+    sums[:, 0] = rng.integers(0, 4, n) * rng.integers(0, 3000, n)       # about a third of the instances empty
+    sums[:, 1:] = rng.standard_normal((n, 3))
+    for offset, sign, scale in ((0.1, -1.0, 1.0), (0.0, 1.0, 0.5), (0.1, -1.0, 1.7)):
+        r = torch.from_numpy(reward.copy()).cuda()
+        total = torch.empty((), device="cuda")
+        hip.bonus_nonempty_f32(r, torch.from_numpy(err).cuda(), torch.from_numpy(sums).cuda(), offset, sign, scale, total)
+        b = (np.float32(offset) + np.float32(sign) * err).astype(np.float32)
+        b = np.where(sums[:, 0] == 0, b * np.float32(0.0), b).astype(np.float32)
+        exp = (reward[:, 0] + (np.float32(scale) * b).astype(np.float32)).astype(np.float32)
+        assert np.array_equal(r.cpu().numpy()[:, 0], exp)
+        assert float(total) == pytest.approx(float(sums[:, 0].astype(np.float64).sum()), rel=1e-6)
