@@ -73,6 +73,9 @@ SIGNATURES = {
                                       _c_vp, ctypes.c_float, _c_int, _c_vp]),
     "carle_ae2d_bonus_b1": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
                                      _c_vp, ctypes.c_float, _c_int, _c_vp]),
+    "carle_morpho_partial_floats": (_c_i64, [_c_i64, _c_int]),
+    "carle_morpho_match_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
+                                        ctypes.c_float, _c_vp]),
     "carle_bonus_nonempty_f32": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _c_i64,
                                           _c_vp, _c_vp]),
     "carle_ae2d_predict_bonus_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),

@@ -726,6 +726,33 @@ def puffer_update_f32(sums4, any_flag_ptr, ring, ring_state, live_total, reward)
         _lib.check(rc, "carle_puffer_update_f32")
 
 
+def morpho_match_f32(universe, action, patterns, reward=None, reward_scale=1.0, partial=None):
+    """MorphoBonus (carle_morpho_match_f32, mcl.py:170-183): (N,2) = [max, min] over all patterns and positions of
+    conv2d(|universe - action|, patterns); with ``reward`` (N,1): reward += reward_scale * (max + min).
+    universe / action: fp32 (N,1,H,W) of the same shape; patterns: fp32 (K,1,8,8).  Returns (out, partial)."""
+    lib = _lib.load()
+    _chk_grid(universe, "universe", torch.float32)
+    _chk_grid(action, "action", torch.float32)
+    if action.shape != universe.shape or action.device != universe.device:
+        raise ValueError(f"morpho_match_f32: the action {tuple(action.shape)} must have the universe's shape "
+                         f"{tuple(universe.shape)} (mcl.py:172 subtracts them)")
+    if not (patterns.is_cuda and patterns.dtype == torch.float32 and patterns.is_contiguous() and patterns.dim() == 4
+            and patterns.shape[1:] == (1, 8, 8)):
+        raise ValueError("morpho_match_f32: patterns must be a contiguous fp32 (K,1,8,8) device tensor")
+    n, _, h, w = universe.shape
+    need = lib.carle_morpho_partial_floats(n, h)
+    if partial is None or partial.numel() < need or partial.device != universe.device:
+        partial = torch.empty(max(need, 1), dtype=torch.float32, device=universe.device)
+    out = torch.empty(n, 2, dtype=torch.float32, device=universe.device)
+    with _on_device(universe.device):
+        rc = lib.carle_morpho_match_f32(universe.data_ptr(), action.data_ptr(), patterns.data_ptr(), patterns.shape[0],
+                                        n, h, w, partial.data_ptr(), out.data_ptr(), _ptr(reward), float(reward_scale),
+                                        _stream(universe))
+    if rc != 0:
+        _lib.check(rc, "carle_morpho_match_f32")
+    return out, partial
+
+
 def bonus_nonempty_f32(reward, err, sums4, offset, sign, scale, live_total=None):
     """reward += scale * (offset + sign * err), zero for instances without a live cell (carle_bonus_nonempty_f32:
     PredictionBonus / SurpriseBonus.step, mcl.py:686-694, 715-723); live_total: optional 1-element fp32 output."""

@@ -535,6 +535,13 @@ int carle_speed_update_f32(const float *sums4, const float *live4, int64_t n, fl
  * ring: cap floats, ring_state: int32[2] = {head, count}, both caller-owned and zero-initialised. */
 int carle_puffer_update_f32(const float *sums4, int64_t n, const int32_t *any_flag, float *ring,
                             int32_t *ring_state, int cap, float *live_total, float *reward, void *stream);
+/* MorphoBonus.step (carle/mcl.py:170-183): my_grid = |universe - action| (the grid BEFORE the environment step; action with
+ * the universe's shape), conv_obs = conv2d(my_grid, patterns) with K <= 32 patterns of 8 x 8 and no padding,
+ * out2[2 i] / out2[2 i + 1] = max / min of instance i's conv_obs over all patterns and positions, and (reward nullable)
+ * reward[i] += reward_scale * (max + min).  8 <= H, 8 <= W <= 512; partial: carle_morpho_partial_floats(n, h) floats. */
+int64_t carle_morpho_partial_floats(int64_t n, int h);
+int carle_morpho_match_f32(const float *universe, const float *action, const float *patterns, int k_patterns, int64_t n,
+                           int h, int w, float *partial, float *out2, float *reward, float reward_scale, void *stream);
 /* PredictionBonus / SurpriseBonus.step behind the bonus (carle/mcl.py:686-694, 715-723): b_i = offset + sign * err[i]
  * (offset 0.1, sign -1: PredictionBonus; 0, +1: SurpriseBonus), b_i *= 0 where sums4[4 i] == 0 (an instance without a live
  * cell; sums4 = carle_instance_sums_f32 of the observation), reward[i] += scale * b_i (two roundings, as torch);

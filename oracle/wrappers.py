@@ -124,3 +124,37 @@ class PufferDetector:
         else:
             self.cells = []
         return r
+
+
+class MorphoBonus:
+    """mcl.py:107-195.  ``patterns``: the (K,1,8,8) target kernels (what ``add_rle_pattern`` builds, mcl.py:144-167:
+    ``make_patterns`` below restates it from a decoded RLE grid).  ``step`` takes the grid BEFORE the environment step and
+    the action (same shape), and the reward the wrapped environment returned: reward += scale * (max + min) of
+    conv2d(|grid - action|, patterns) over all patterns and positions, per instance (mcl.py:172-181).  The correlation is a
+    plain fp64 sum here (the reference: ATen's fp32 conv2d; the comparison carries a 1e-5 tolerance)."""
+
+    def __init__(self, patterns, reward_scale=1.0):
+        self.patterns = np.asarray(patterns, dtype=np.float64).reshape(-1, 8, 8)
+        self.reward_scale = F(reward_scale)
+
+    @staticmethod
+    def make_patterns(grid, dim=8):
+        """grid: the (H,W) 0/1 array ``rle_to_grid`` returns -> the six oriented kernels (6,1,dim,dim), float32."""
+        g = np.pad(_f32(grid), ((2, 1), (1, 1)))[:dim, :dim].copy()          # ZeroPad2d((1,1,2,1)): left, right, top, bottom
+        g[g == 0] = -1
+        live = g == 1
+        g[live] = g[live] * F(F(15.0) / g[live].sum(dtype=np.float32))
+        p = g[None, None]
+        t = np.transpose(p, (0, 1, 3, 2))
+        return np.concatenate([p, p[:, :, ::-1], p[:, :, :, ::-1], t[:, :, ::-1], t[:, :, :, ::-1], t]).astype(np.float32)
+
+    def match(self, grid_before, action):
+        g = np.abs(_f32(grid_before) - _f32(action)).astype(np.float64)[:, 0]
+        n, h, w = g.shape
+        win = np.lib.stride_tricks.sliding_window_view(g, (8, 8), axis=(1, 2))        # (n, h-7, w-7, 8, 8)
+        conv = np.einsum("nyxij,kij->nkyx", win, self.patterns)
+        return conv.reshape(n, -1).max(axis=1), conv.reshape(n, -1).min(axis=1)
+
+    def step(self, grid_before, reward, action):
+        mx, mn = self.match(grid_before, action)
+        return _f32(reward) + self.reward_scale * (_f32(mx) + _f32(mn))[:, None]

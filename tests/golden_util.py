@@ -116,3 +116,20 @@ PREDICTION_CASES = ("pred64", "pred64_scaled", "surprise64", "pred256_glider")
 
 def prediction_case(name):
     return PredictionCase(prediction_file(), name)
+
+
+class MorphoCase:
+    """tests/golden/morpho.npz: MorphoBonus driven by the reference on the pattern files this package ships."""
+
+    def __init__(self, name):
+        if "morpho" not in _CACHE:
+            _CACHE["morpho"] = np.load(os.path.join(GOLDEN, "morpho.npz"))
+        z = _CACHE["morpho"]
+        m = self.meta = json.loads(bytes(z[f"{name}/meta"]).decode())
+        self.n, self.steps, self.scale = m["n"], m["steps"], m["scale"]
+        self.birth, self.survive, self.extra_rle = m["birth"], m["survive"], m["extra_rle"]
+        self.patterns = z[f"{name}/patterns"]
+        self.reset_obs = unpack(z[f"{name}/reset_obs"], (self.n, 1, 64, 64))
+        self.actions = unpack(z[f"{name}/actions"], (self.steps, self.n, 1, 64, 64))
+        self.rewards = z[f"{name}/rewards"]
+        self.final_obs = unpack(z[f"{name}/final_obs"], (self.n, 1, 64, 64))

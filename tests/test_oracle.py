@@ -3,6 +3,8 @@
 CPU only.  This is what PINS the oracle: every fixture was produced by the genuine reference
 (tools/make_golden.py); both restatements must reproduce every recorded grid bit for bit.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -170,3 +172,37 @@ def test_wrappers_oracle_reproduces_the_reference_fixtures(name):
         np.testing.assert_allclose(r.reshape(n, -1), z[f"{name}/rewards"][t], rtol=1e-6, atol=1e-4 if name == "speed" else 0,
                                    err_msg=f"{name} step {t}")
     assert np.array_equal(u, G.unpack(z[f"{name}/final_obs"], (n, 1, size, size)))
+
+
+# ---- MorphoBonus (carle/mcl.py:107-195): oracle/wrappers.py against the reference-recorded fixture
+def _rle_body(path_or_text, is_text=False):
+    text = path_or_text if is_text else open(path_or_text).read()
+    body, add = "", False
+    for line in text.splitlines(keepends=True):
+        if add:
+            body += line
+        if "rule" in line:
+            add = True
+    return body
+
+
+@pytest.mark.parametrize("name", ["default", "extra"])
+def test_morpho_oracle_reproduces_the_reference_fixture(name):
+    from carle_amd import rle as R
+    from oracle import wrappers as OW
+    c = G.MorphoCase(name)
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "carle_amd")
+    bodies = [_rle_body(os.path.join(pkg, "glider_1.rle")), _rle_body(os.path.join(pkg, "glider_2.rle"))]
+    if c.extra_rle:
+        bodies.append(_rle_body(c.extra_rle, True))
+    pats = np.concatenate([OW.MorphoBonus.make_patterns(R.decode_body(b, 64, 64).astype(np.float32)) for b in bodies])
+    assert np.array_equal(pats, c.patterns)                       # padding, crop, normalisation, six orientations
+    w = OW.MorphoBonus(pats, c.scale)
+    rule = O.rule_mask(c.birth, c.survive)
+    u = c.reset_obs
+    for t in range(c.steps):
+        before = u
+        u, reset, _ = O.c_env_step(u, c.actions[t], rule)
+        reward = w.step(before, np.zeros((c.n, 1), np.float32), c.actions[t])
+        np.testing.assert_allclose(reward, c.rewards[t], rtol=1e-6, atol=1e-5, err_msg=f"{name} step {t}")
+    assert np.array_equal(u, c.final_obs)

@@ -31,6 +31,8 @@ Fixture files
                    linear layer scaled up so that toggles actually occur)
   wrappers.npz     CornerBonus / SpeedDetector / PufferDetector / ParsimonyBonus and the eval.py
                    wrapper stack: inputs and per-step rewards
+  morpho.npz       MorphoBonus (carle/mcl.py:107-195) on the pattern files this package ships (the reference's own defaults
+                   are missing from its tree): pattern tensors, grids after the seeded reset, actions, rewards per step
   prediction.npz   PredictionBonus / SurpriseBonus (carle/mcl.py:558-728): training trajectories (rewards per step,
                    initial and final state_dicts) incl. the reference's own glider scenario at 256x256, and explicit
                    get_bonus / get_bonus_update calls
@@ -631,6 +633,59 @@ def make_prediction(torch, ref_env, ref_mcl, outdir):
     print("prediction.npz written")
 
 
+def make_morpho(torch, ref_env, ref_mcl, outdir):
+    """MorphoBonus (carle/mcl.py:107-195).  Its constructor reads glider_1.rle / glider_2.rle beside mcl.py, which the
+    reference tree does not contain: the class is driven through a two-line subclass whose ``add_default_patterns`` points
+    at the two pattern files THIS package ships under those names (carle_amd/glider_*.rle) and at one more pattern written
+    here; everything else -- RLE parsing, padding, cropping, normalisation, the six orientations, reset's random seed
+    cells, the correlation and the reward -- is the reference's code.  Recorded: the pattern tensor, the grids after
+    reset (seeded CPU generator), actions, rewards per step."""
+    import contextlib
+    import tempfile
+    sink = io.StringIO()
+    out = {}
+    rng = np.random.default_rng(107)
+    pkg = "/root/repo/carle_amd"
+    extra_rle = "x = 5, y = 4, rule = B3/S23\nb3o$o3bo$2bo$o2bo!\n"
+    with tempfile.TemporaryDirectory() as tmp:
+        extra = os.path.join(tmp, "extra.rle")
+        with open(extra, "w") as f:
+            f.write(extra_rle)
+
+        class Morpho(ref_mcl.MorphoBonus):
+            def add_default_patterns(self):
+                self.add_rle_pattern(os.path.join(pkg, "glider_1.rle"))
+                self.add_rle_pattern(os.path.join(pkg, "glider_2.rle"))
+
+        for name, n, steps, with_extra in (("default", 3, 6, False), ("extra", 2, 4, True)):
+            torch.manual_seed(107)
+            with contextlib.redirect_stdout(sink):
+                env = ref_env.CARLE(width=64, height=64, instances=n, device="cpu")
+                w = Morpho(env)
+                if with_extra:
+                    w.add_rle_pattern(extra)
+            w.reward_scale = 0.5 if with_extra else 1.0
+            obs = w.reset()
+            out[f"{name}/patterns"] = w.target_patterns.detach().numpy().copy()
+            out[f"{name}/reset_obs"], _ = pack(obs.detach().numpy())
+            acts, rews = [], []
+            for t in range(steps):
+                a = (rng.random((n, 1, 64, 64)) <= (0.02 if t % 2 == 0 else 0.0)).astype(np.float32)
+                if t == 0:
+                    a[0, 0, 10:13, 20:23] = np.array([[0, 1, 0], [0, 0, 1], [1, 1, 1]], np.float32)   # a glider: a full match
+                obs, reward, done, info = w.step(torch.from_numpy(a.copy()))
+                acts.append(a)
+                rews.append(np.asarray(reward.detach().numpy(), dtype=np.float32).reshape(n, -1).copy())
+            out[f"{name}/actions"], _ = pack(np.stack(acts))
+            out[f"{name}/rewards"] = np.stack(rews)
+            out[f"{name}/final_obs"], _ = pack(obs.detach().numpy())
+            out[f"{name}/meta"] = np.frombuffer(json.dumps(dict(n=n, steps=steps, scale=float(w.reward_scale),
+                                                                birth=list(env.birth), survive=list(env.survive),
+                                                                extra_rle=extra_rle if with_extra else "")).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(outdir, "morpho.npz"), **out)
+    print("morpho.npz written")
+
+
 def make_agent_net(torch, ref_env, outdir):
     """RandomNetworkAgent of the reference.  Its constructor ignores ``observation_width`` (the key it
     tests for is misspelt, agents.py:56-58) and always builds for width 256; ``observation_height``
@@ -706,7 +761,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch, ref_env, ref_mcl = import_reference()
     torch.set_num_threads(8)
-    todo = args.only.split(",") if args.only else ["ca", "predicates", "known", "nets", "train256", "wrappers", "rle", "agent", "prediction"]
+    todo = args.only.split(",") if args.only else ["ca", "predicates", "known", "nets", "train256", "wrappers", "rle", "agent", "prediction", "morpho"]
     if "ca" in todo:
         make_ca(torch, ref_env, args.out)
     if "predicates" in todo:
@@ -725,6 +780,8 @@ def main():
         make_agent_net(torch, ref_env, args.out)
     if "prediction" in todo:
         make_prediction(torch, ref_env, ref_mcl, args.out)
+    if "morpho" in todo:
+        make_morpho(torch, ref_env, ref_mcl, args.out)
 
 
 if __name__ == "__main__":
