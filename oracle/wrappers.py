@@ -143,7 +143,9 @@ class MorphoBonus:
         g = np.pad(_f32(grid), ((2, 1), (1, 1)))[:dim, :dim].copy()          # ZeroPad2d((1,1,2,1)): left, right, top, bottom
         g[g == 0] = -1
         live = g == 1
-        g[live] = g[live] * F(F(15.0) / g[live].sum(dtype=np.float32))
+        # ``15. / tensor`` is torch's __rtruediv__: reciprocal first, then the product (one ulp from 15 / sum at 14 cells:
+        # found by tools/fuzz_oracle_vs_reference.py)
+        g[live] = g[live] * F(F(F(1.0) / g[live].sum(dtype=np.float32)) * F(15.0))
         p = g[None, None]
         t = np.transpose(p, (0, 1, 3, 2))
         return np.concatenate([p, p[:, :, ::-1], p[:, :, :, ::-1], t[:, :, ::-1], t[:, :, :, ::-1], t]).astype(np.float32)

@@ -29,7 +29,7 @@ def _build(n, extra_rle="", tmp_path=None):
     return env, w
 
 
-@pytest.mark.parametrize("name", ["default", "extra"])
+@pytest.mark.parametrize("name", ["default", "extra", "cells14"])
 def test_reference_trajectory(name, tmp_path):
     c = G.MorphoCase(name)
     env, w = _build(c.n, c.extra_rle, tmp_path)

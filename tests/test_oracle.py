@@ -186,7 +186,7 @@ def _rle_body(path_or_text, is_text=False):
     return body
 
 
-@pytest.mark.parametrize("name", ["default", "extra"])
+@pytest.mark.parametrize("name", ["default", "extra", "cells14"])
 def test_morpho_oracle_reproduces_the_reference_fixture(name):
     from carle_amd import rle as R
     from oracle import wrappers as OW

@@ -198,6 +198,59 @@ def prediction_case(case, rng):
         assert float(w.live_cells) == ow.live_cells
 
 
+def morpho_case(case, rng):
+    """oracle/wrappers.py::MorphoBonus against the reference's MorphoBonus (mcl.py:107-195) -- driven through a subclass
+    whose default patterns are the two glider files this package ships (the reference's own are missing from its tree) --
+    plus a random extra pattern written as RLE: pattern tensors bit for bit, rewards within 1e-5 of the window's weight."""
+    import contextlib
+    import io
+    import tempfile
+    pkg = "/root/repo/carle_amd"
+
+    class Morpho(ref_mcl.MorphoBonus):
+        def add_default_patterns(self):
+            self.add_rle_pattern(os.path.join(pkg, "glider_1.rle"))
+            self.add_rle_pattern(os.path.join(pkg, "glider_2.rle"))
+
+    n = int(rng.integers(1, 4))
+    with contextlib.redirect_stdout(io.StringIO()):
+        env = ref_env.CARLE(width=64, height=64, instances=n, device="cpu")
+        w = Morpho(env)
+    grids = []
+    for name in ("glider_1.rle", "glider_2.rle"):
+        body = env.read_rle(os.path.join(pkg, name))
+        grids.append(env.rle_to_grid(body).numpy())
+    if rng.random() < 0.7:
+        g = np.zeros((64, 64), np.float32)
+        ph, pw = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+        g[:ph, :pw] = (rng.random((ph, pw)) < 0.6)
+        if g.sum() == 0:
+            g[0, 0] = 1
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "p.rle")
+            with open(path, "w") as f:
+                f.write(f"x = {pw}, y = {ph}, rule = B3/S23\n" + R.encode_body(g) + "\n")
+            w.add_rle_pattern(path)
+            grids.append(env.rle_to_grid(env.read_rle(path)).numpy())
+    pats = np.concatenate([OW.MorphoBonus.make_patterns(g) for g in grids])
+    if not np.array_equal(pats, w.target_patterns.numpy()):
+        raise AssertionError(f"morpho case {case}: pattern tensors differ")
+    w.reward_scale = float(rng.choice([1.0, 0.5]))
+    ow = OW.MorphoBonus(pats, w.reward_scale)
+    w.reset()
+    u = env.universe.numpy().copy()
+    rule = O.rule_mask(env.birth, env.survive)
+    for t in range(int(rng.integers(2, 6))):
+        a = (rng.random((n, 1, 64, 64)) < float(rng.choice([0.0, 0.02, 0.3]))).astype(np.float32)
+        obs, reward, done, info = w.step(torch.from_numpy(a.copy()))
+        exp = ow.step(u, np.zeros((n, 1), np.float32), a)
+        u, reset, _ = O.c_env_step(u, a, rule)
+        assert np.array_equal(obs.detach().numpy(), u)
+        got = reward.detach().numpy().reshape(n, -1)
+        if not np.allclose(got, exp, rtol=1e-6, atol=2e-4):
+            raise AssertionError(f"morpho case {case} step {t}: {got.ravel()} != {exp.ravel()}")
+
+
 t_end = time.time() + budget
 case = 0
 while time.time() < t_end:
@@ -206,6 +259,8 @@ while time.time() < t_end:
         wrapper_case(case, np.random.default_rng(seed0 * 77773 + case))
     if case % 8 == 0:
         prediction_case(case, np.random.default_rng(seed0 * 55529 + case))
+    if case % 16 == 0:
+        morpho_case(case, np.random.default_rng(seed0 * 33331 + case))
     case += 1
     if case % 200 == 0:
         print(f"{case} cases ok", flush=True)

@@ -647,6 +647,9 @@ def make_morpho(torch, ref_env, ref_mcl, outdir):
     rng = np.random.default_rng(107)
     pkg = "/root/repo/carle_amd"
     extra_rle = "x = 5, y = 4, rule = B3/S23\nb3o$o3bo$2bo$o2bo!\n"
+    # 14 live cells: 15 / 14 and (1 / 14) * 15 -- what torch's ``15. / tensor`` computes -- differ by one ulp in fp32
+    # (a difference tools/fuzz_oracle_vs_reference.py found in the first restatement of the normalisation)
+    cells14_rle = "x = 4, y = 5, rule = B3/S23\n3o$b3o$2o$2obo$ob2o!\n"
     with tempfile.TemporaryDirectory() as tmp:
         extra = os.path.join(tmp, "extra.rle")
         with open(extra, "w") as f:
@@ -657,13 +660,16 @@ def make_morpho(torch, ref_env, ref_mcl, outdir):
                 self.add_rle_pattern(os.path.join(pkg, "glider_1.rle"))
                 self.add_rle_pattern(os.path.join(pkg, "glider_2.rle"))
 
-        for name, n, steps, with_extra in (("default", 3, 6, False), ("extra", 2, 4, True)):
+        extra14 = os.path.join(tmp, "cells14.rle")
+        with open(extra14, "w") as f:
+            f.write(cells14_rle)
+        for name, n, steps, with_extra in (("default", 3, 6, False), ("extra", 2, 4, True), ("cells14", 1, 3, extra14)):
             torch.manual_seed(107)
             with contextlib.redirect_stdout(sink):
                 env = ref_env.CARLE(width=64, height=64, instances=n, device="cpu")
                 w = Morpho(env)
                 if with_extra:
-                    w.add_rle_pattern(extra)
+                    w.add_rle_pattern(extra if with_extra is True else with_extra)
             w.reward_scale = 0.5 if with_extra else 1.0
             obs = w.reset()
             out[f"{name}/patterns"] = w.target_patterns.detach().numpy().copy()
@@ -681,7 +687,8 @@ def make_morpho(torch, ref_env, ref_mcl, outdir):
             out[f"{name}/final_obs"], _ = pack(obs.detach().numpy())
             out[f"{name}/meta"] = np.frombuffer(json.dumps(dict(n=n, steps=steps, scale=float(w.reward_scale),
                                                                 birth=list(env.birth), survive=list(env.survive),
-                                                                extra_rle=extra_rle if with_extra else "")).encode(), dtype=np.uint8)
+                                                                extra_rle=(extra_rle if with_extra is True else cells14_rle) if with_extra else "")).encode(),
+                                                         dtype=np.uint8)
     np.savez_compressed(os.path.join(outdir, "morpho.npz"), **out)
     print("morpho.npz written")
 
