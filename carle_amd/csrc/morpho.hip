@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void morpho_finish_kernel(const float *__restr
     }
     out2[2 * i] = vmax;
     out2[2 * i + 1] = vmin;
-    if (reward) reward[i] = __fadd_rn(reward[i], __fmul_rn(scale, __fadd_rn(vmax, vmin)));
+    if (reward) reward[i] = reward_accumulate(reward[i], scale, vmax + vmin);   // no contraction into an fma (common.hpp)
 }
 
 }  // namespace carle

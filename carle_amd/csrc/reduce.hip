@@ -252,9 +252,9 @@ __global__ __launch_bounds__(256) void bonus_nonempty_kernel(float *__restrict__
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const float cells = sums4[4 * i];
         live += cells;
-        float b = __fadd_rn(offset, __fmul_rn(sign, err[i]));
-        if (cells == 0.0f) b = __fmul_rn(b, 0.0f);
-        reward[i] = __fadd_rn(reward[i], __fmul_rn(scale, b));
+        float b = offset + sign * err[i];             // sign = +-1: the product is exact, one rounding either way
+        if (cells == 0.0f) b = b * 0.0f;
+        reward[i] = reward_accumulate(reward[i], scale, b);   // no contraction into an fma (common.hpp)
     }
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) live += __shfl_xor(live, sft, 64);

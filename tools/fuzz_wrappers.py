@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Differential fuzzing of the hand-coded reward wrappers (CornerBonus / SpeedDetector / PufferDetector / ParsimonyBonus,
-carle/mcl.py:86-105, 197-231, 730-853) against oracle/wrappers.py + the CA oracle, run on the GPU box: random stacks in
+"""Differential fuzzing of the hand-coded reward wrappers (CornerBonus / SpeedDetector / PufferDetector / ParsimonyBonus /
+MorphoBonus, carle/mcl.py:86-231, 730-853) against oracle/wrappers.py + the CA oracle, run on the GPU box: random stacks in
 random order (incl. PufferDetector directly on a SpeedDetector: the one-launch pair of eval.py:86-87), sizes 64 .. 512, all
 three storages, batches of 1 .. 40, action windows of 8 .. 64, growth thresholds of 1 .. 5 with action-free stretches,
 master resets.  Rewards within 1e-4 (the SpeedDetector's fp32 centre of mass; exact for the
@@ -30,6 +30,8 @@ def one_case(case, rng):
     kinds = [k for k in ("corner", "speed", "puffer") if rng.random() < 0.7] or ["puffer"]
     if rng.random() < 0.4:
         kinds.append("parsimony")
+    if size == 64 and asize == 64 and rng.random() < 0.4:
+        kinds.append("morpho")                               # (mcl.py:172: the action must have the universe's shape)
     rng.shuffle(kinds)
     if rng.random() < 0.4 and "speed" in kinds and "puffer" in kinds:        # the one-launch pair: Puffer directly on Speed
         kinds.remove("puffer")
@@ -43,6 +45,9 @@ def one_case(case, rng):
         elif k == "puffer":
             top = M.PufferDetector(top); top.growth_threshold = int(rng.integers(1, 6))
             mine.append(OW.PufferDetector(top.growth_threshold))
+        elif k == "morpho":
+            top = M.MorphoBonus(top); top.reward_scale = float(rng.choice([1.0, 0.25]))
+            mine.append(OW.MorphoBonus(top.target_patterns.cpu().numpy(), top.reward_scale))
         else:
             top = M.ParsimonyBonus(top); mine.append(OW.ParsimonyBonus())
     growing = rng.random() < 0.5
@@ -56,13 +61,14 @@ def one_case(case, rng):
         p = 0.0 if rng.random() < 0.6 else float(rng.choice([0.01, 0.2, 1.0]))
         a = (rng.random((n, 1, asize, asize)) < p).astype(np.float32)
         obs, reward, done, info = top.step(torch.from_numpy(a).cuda())
+        before = u
         u, reset, _ = O.c_env_step(u, a, rule)
         got_obs = obs.float().cpu().numpy()
         if not np.array_equal(got_obs, u):
             raise AssertionError(f"{desc}: grids differ at step {t}")
         r = np.zeros((n, 1), np.float32)
         for w in mine:
-            r = w.step(u, r, a)
+            r = w.step(before if isinstance(w, OW.MorphoBonus) else u, r, a)
         got = reward.detach().float().cpu().numpy().reshape(n, -1)
         # (512 x 512: the weighted sums exceed 2^24, their fp32 rounding depends on the summation order)
         if not np.allclose(got, r.reshape(n, -1), rtol=2e-6, atol=1e-4 if size <= 256 else 2e-3):
