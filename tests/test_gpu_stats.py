@@ -230,23 +230,25 @@ def _dp_inputs(size, total, steps):
     return u0, acts
 
 
-def _dp_trajectory(size, start, count, total, steps, batch_size, sync, midwindow=False):
+def _dp_trajectory(size, start, count, total, steps, batch_size, sync, midwindow=False, stack="rnd+ae"):
     """`steps` training steps of AE2D(RND2D(CARLE)) on instances [start, start + count) of the seeded batch; returns
     (rewards (steps, count), state_dict as numpy).  ``midwindow``: after step 5 (inside the second update window) both
     wrappers also take ``update_predictor(mean loss of the current observation)`` -- torch's own optimiser step on a
     caller's loss while the kernel gradient of the window is in flight."""
     from carle_amd.env import CARLE
-    from carle_amd.mcl import RND2D, AE2D
+    import carle_amd.mcl as M
     u0, acts = _dp_inputs(size, total, steps)
     torch.manual_seed(0)
     env = CARLE(width=size, height=size, instances=count, device="cuda:0")
-    ae = AE2D(RND2D(env))
+    # (stack: "rnd+ae" = AE2D(RND2D(CARLE)); otherwise one wrapper class by name: PredictionBonus / SurpriseBonus)
+    ae = M.AE2D(M.RND2D(env)) if stack == "rnd+ae" else getattr(M, stack)(env)
+    wrappers = [ae, ae.env] if stack == "rnd+ae" else [ae]
     ae.reset()
-    for w in (ae, ae.env):
+    for w in wrappers:
         w.batch_size = batch_size
     if sync:
         from carle_amd import dist as cd
-        assert cd.data_parallel(ae, broadcast=True) == [ae, ae.env]
+        assert cd.data_parallel(ae, broadcast=True) == wrappers
     env.universe = u0[start:start + count].cuda()
     rewards = []
     for t in range(steps):
@@ -260,7 +262,7 @@ def _dp_trajectory(size, start, count, total, steps, batch_size, sync, midwindow
     return np.stack(rewards), {k: v.cpu().numpy().copy() for k, v in ae.state_dict().items()}
 
 
-def _dp_worker(rank, world, port, size, total, steps, batch_size, q, midwindow=False):
+def _dp_worker(rank, world, port, size, total, steps, batch_size, q, midwindow=False, stack="rnd+ae"):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -269,13 +271,14 @@ def _dp_worker(rank, world, port, size, total, steps, batch_size, q, midwindow=F
     cd.init_from_env("gloo", share_devices=True)             # two ranks on the one device of the test box
     try:
         start, count = cd.shard(total)
-        q.put((rank, start, count) + _dp_trajectory(size, start, count, total, steps, batch_size, True, midwindow))
+        q.put((rank, start, count) + _dp_trajectory(size, start, count, total, steps, batch_size, True, midwindow, stack))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("size,total,midwindow", [(64, 11, False), (256, 6, False), (64, 11, True)])
-def test_data_parallel_predictors_take_the_unsharded_updates(size, total, midwindow):
+@pytest.mark.parametrize("size,total,midwindow,stack", [(64, 11, False, "rnd+ae"), (256, 6, False, "rnd+ae"), (64, 11, True, "rnd+ae"),
+                                                        (64, 7, False, "PredictionBonus"), (128, 5, False, "SurpriseBonus")])
+def test_data_parallel_predictors_take_the_unsharded_updates(size, total, midwindow, stack):
     """carle_amd.dist.data_parallel: two ranks, each stepping its shard of the batch through AE2D(RND2D(CARLE)) in
     training mode (HIP gradient kernels; 64x64: the fused kernels with unequal shards 6 + 5, 256x256: the paired tiled
     call), all-reduce their flat gradients before every Adam step.  Rewards and weights must be those of ONE process
@@ -286,14 +289,14 @@ def test_data_parallel_predictors_take_the_unsharded_updates(size, total, midwin
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, size, total, steps, batch_size, q, midwindow)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, size, total, steps, batch_size, q, midwindow, stack)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda r: r[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    whole_rewards, whole_sd = _dp_trajectory(size, 0, total, total, steps, batch_size, False, midwindow)
+    whole_rewards, whole_sd = _dp_trajectory(size, 0, total, total, steps, batch_size, False, midwindow, stack)
     for k in whole_sd:
         assert np.array_equal(res[0][4][k], res[1][4][k]), k                      # the ranks never drift apart
         np.testing.assert_allclose(res[0][4][k], whole_sd[k], rtol=0, atol=2e-5, err_msg=k)
