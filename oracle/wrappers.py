@@ -16,7 +16,7 @@ leave ``obs`` alone).  ``obs`` is the inner environment's universe after the ste
 
 Parity status: PINNED -- against the reference-recorded rewards of tests/golden/wrappers.npz
 (tests/test_oracle.py::test_wrappers_oracle_reproduces_the_reference_fixtures) and, in the build container, against the
-genuine reference on open-ended random cases (tools/fuzz_oracle_vs_reference.py).
+genuine reference on open-ended random cases (tests/tools/fuzz_oracle_vs_reference.py).
 """
 import numpy as np
 
@@ -144,7 +144,7 @@ class MorphoBonus:
         g[g == 0] = -1
         live = g == 1
         # ``15. / tensor`` is torch's __rtruediv__: reciprocal first, then the product (one ulp from 15 / sum at 14 cells:
-        # found by tools/fuzz_oracle_vs_reference.py)
+        # found by tests/tools/fuzz_oracle_vs_reference.py)
         g[live] = g[live] * F(F(F(1.0) / g[live].sum(dtype=np.float32)) * F(15.0))
         p = g[None, None]
         t = np.transpose(p, (0, 1, 3, 2))

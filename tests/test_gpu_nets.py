@@ -81,7 +81,7 @@ def test_stacked_wrappers_rewards():
 def test_abi_against_oracle_random_weights(size, n):
     """carle_*_bonus_f32 vs oracle/nets.py (torch CPU fp32) with fresh random weights.  120 / 136 / 264: H = 8 * odd
     with (H / 8)^2 / 8 a multiple of four -- the linear layer's float4 slices once dropped the last input there
-    (found by tools/fuzz_nets.py in round 4; bonuses off by up to 3e-3)."""
+    (found by tests/tools/fuzz_nets.py in round 4; bonuses off by up to 3e-3)."""
     from carle_amd import hip
     torch.manual_seed(size)
     env, rnd, ae = _stack(size, n)

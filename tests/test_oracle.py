@@ -153,7 +153,7 @@ def test_wrappers_oracle_reproduces_the_reference_fixtures(name):
     """oracle/wrappers.py (numpy restatement of mcl.py:86-105, 197-231, 730-853) replays the rewards recorded from the
     genuine reference's CornerBonus / SpeedDetector / PufferDetector (tests/golden/wrappers.npz); the grids underneath
     come from the CA oracle.  (The open-ended version of this check against the reference itself:
-    tools/fuzz_oracle_vs_reference.py, build container only.)"""
+    tests/tools/fuzz_oracle_vs_reference.py, build container only.)"""
     import json
     import os
     from oracle import wrappers as OW

@@ -1,7 +1,7 @@
 """BASELINE configs[0]: Conway's Life, N=1, 64x64, 256 steps on the CPU port of the reference step
 (oracle/torch_port.py = the reference's ATen op sequence), and the same through this build on the GPU."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle.torch_port import TorchPortEnv
 g = torch.Generator().manual_seed(1234)
 acts = [(torch.rand(1, 1, 64, 64, generator=g) <= 0.1).float() for _ in range(4)]

@@ -5,7 +5,7 @@ random geometries (even squares 2 .. 130 and 256 / 512), batches of 1 .. 300 ins
 oversize actions (centre crop, env.py:164-167), all-ones actions (master reset), no-toggle steps, state assignment
 and reset() between steps, CARLE.run chunks, an RND2D wrapper on top for 64x64.  Grids bit-exact, counters exact.
 Not part of the test suite (open-ended); every failure it ever finds becomes a regression test.
-    python tools/fuzz_env.py [seconds] [seed]"""
+    python tests/tools/fuzz_env.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from carle_amd.env import CARLE                # noqa: E402
 from carle_amd.mcl import RND2D                # noqa: E402
 from oracle import ca as O                     # noqa: E402

@@ -4,7 +4,7 @@ pair of environments from the same seed -- one stepped eagerly, one through a St
 sequence of replayed steps, eager steps in between, reset(), assigned universes, rule changes, master resets, with random
 storages, sizes, batches and forward-only wrapper stacks (RND2D, AE2D(RND2D), + SpeedDetector / PufferDetector); reward
 statistics attached at random.  Observations bit-identical, rewards within 1e-6, counters and statistics equal after
-every step.  Not part of the test suite (open-ended).      python tools/fuzz_graph.py [seconds] [seed]"""
+every step.  Not part of the test suite (open-ended).      python tests/tools/fuzz_graph.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -12,7 +12,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from carle_amd import dist as cd               # noqa: E402
 from carle_amd.env import CARLE                # noqa: E402
 from carle_amd.graphs import StepGraph         # noqa: E402

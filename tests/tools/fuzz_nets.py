@@ -5,7 +5,7 @@ the kernel families' borders 56 / 64 / 72 / 120 / 128 / 136 / 192 / 256 included
 non-binary observations, fp32 and bit-packed inputs, randomly scaled parameters, through the wrappers' own entry points:
 ``get_bonus_only`` (forward: fused 64x64 / tiled / staged kernels) within 1e-5 absolute, ``get_bonus_accumulate`` with
 batch_size 1 (forward + gradient + the Adam kernel) against one torch.optim.Adam step on the fp64 autograd gradient.
-Not part of the test suite (open-ended).      python tools/fuzz_nets.py [seconds] [seed]"""
+Not part of the test suite (open-ended).      python tests/tools/fuzz_nets.py [seconds] [seed]"""
 import copy
 import os
 import sys
@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from carle_amd import hip                      # noqa: E402
 from carle_amd.env import CARLE                # noqa: E402
 import carle_amd.mcl as M                      # noqa: E402

@@ -11,14 +11,14 @@ mode) in random configurations against oracle/wrappers.py / oracle/prediction.py
 fixture.
 
     cd /tmp && MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference \
-        python /root/repo/tools/fuzz_oracle_vs_reference.py [seconds] [seed]"""
+        python /root/repo/tests/tools/fuzz_oracle_vs_reference.py [seconds] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools"))
 import make_golden as MG                        # noqa: E402   (import_reference)
 
 torch, ref_env, ref_mcl = MG.import_reference()

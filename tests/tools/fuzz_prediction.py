@@ -4,7 +4,7 @@ predictor updates against oracle/prediction.py (fp32 autograd + torch Adam on th
 sizes 8 .. 256 (multiples of 8), all three storages, batches of 1 .. 6, update windows of 1 .. 4 steps, reward scales,
 empty instances (the zero-for-empty-grids rule), master resets, Life and HighLife.  Rewards within 1e-5 -- the Adam steps
 at lr 6e-2 amplify fp32 noise of the gradient, so a case stops comparing after 4 updates -- grids bit-exact.  Not part of
-the test suite (open-ended; a fixed slice runs in tests/test_gpu_fuzz.py).   python tools/fuzz_prediction.py [seconds] [seed]"""
+the test suite (open-ended; a fixed slice runs in tests/test_gpu_fuzz.py).   python tests/tools/fuzz_prediction.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -12,7 +12,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from carle_amd.env import CARLE                # noqa: E402
 import carle_amd.mcl as M                      # noqa: E402
 from oracle import ca as O                     # noqa: E402

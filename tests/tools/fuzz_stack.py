@@ -5,7 +5,7 @@ CARLE in all three storages, sizes 64 / 128 / 256, batches of 1 .. 300 (64x64) o
 surface takes by itself: the fused CA + RND2D kernel (one launch for N > 16), the tiled pair kernel behind the one-launch
 wide step (bit-packed copy of the new state), packed state, uint8 state, the stand-alone kernels otherwise.  Rewards within
 1e-5 of the oracle's (relative beyond 1), grids bit-exact, master resets included (every reward then equals the all-dead
-grid's).  Not part of the test suite (open-ended).      python tools/fuzz_stack.py [seconds] [seed]"""
+grid's).  Not part of the test suite (open-ended).      python tests/tools/fuzz_stack.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from carle_amd.env import CARLE                # noqa: E402
 import carle_amd.mcl as M                      # noqa: E402
 from oracle import ca as O                     # noqa: E402

@@ -6,7 +6,7 @@ state) and once with the pairing switched off (each wrapper steps by itself) -- 
 weights after several update windows: bit-identical where both runs use the same kernels per net (the pairing only
 changes how launches are grouped), within 2e-6 otherwise.  Random sizes 64 / 128 / 192 / 256, storages, batches, window
 lengths 1 .. 4, reward scales, master resets inside windows.  And against oracle/nets.py: the rewards of the FIRST window
-(before any update) within 1e-5.  Not part of the test suite (open-ended).   python tools/fuzz_train_paths.py [seconds] [seed]"""
+(before any update) within 1e-5.  Not part of the test suite (open-ended).   python tests/tools/fuzz_train_paths.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from carle_amd.env import CARLE                # noqa: E402
 import carle_amd.mcl as M                      # noqa: E402
 from oracle import ca as O                     # noqa: E402

@@ -4,7 +4,7 @@ MorphoBonus, carle/mcl.py:86-231, 730-853) against oracle/wrappers.py + the CA o
 random order (incl. PufferDetector directly on a SpeedDetector: the one-launch pair of eval.py:86-87), sizes 64 .. 512, all
 three storages, batches of 1 .. 40, action windows of 8 .. 64, growth thresholds of 1 .. 5 with action-free stretches,
 master resets.  Rewards within 1e-4 (the SpeedDetector's fp32 centre of mass; exact for the
-others), grids bit-exact.  Not part of the test suite (open-ended).      python tools/fuzz_wrappers.py [seconds] [seed]"""
+others), grids bit-exact.  Not part of the test suite (open-ended).      python tests/tools/fuzz_wrappers.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -12,7 +12,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from carle_amd.env import CARLE                # noqa: E402
 import carle_amd.mcl as M                      # noqa: E402
 from oracle import ca as O                     # noqa: E402

@@ -648,7 +648,7 @@ def make_morpho(torch, ref_env, ref_mcl, outdir):
     pkg = "/root/repo/carle_amd"
     extra_rle = "x = 5, y = 4, rule = B3/S23\nb3o$o3bo$2bo$o2bo!\n"
     # 14 live cells: 15 / 14 and (1 / 14) * 15 -- what torch's ``15. / tensor`` computes -- differ by one ulp in fp32
-    # (a difference tools/fuzz_oracle_vs_reference.py found in the first restatement of the normalisation)
+    # (a difference tests/tools/fuzz_oracle_vs_reference.py found in the first restatement of the normalisation)
     cells14_rle = "x = 4, y = 5, rule = B3/S23\n3o$b3o$2o$2obo$ob2o!\n"
     with tempfile.TemporaryDirectory() as tmp:
         extra = os.path.join(tmp, "extra.rle")
