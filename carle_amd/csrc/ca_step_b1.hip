@@ -787,11 +787,17 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
                           int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s, const B1EnvArgs *env = nullptr) {
     const int64_t n8 = (n + 7) / 8 * 8;         // the XCD-aware mapping walks the batch in groups of 8 grids
     const int lds = b1_strip_mode(n, WW);
-    // persistent: just under 32 one-wave workgroups per CU (8 per SIMD).  8 x 1021: a multiple of 8 (a
-    // wave stays on "its" XCD's grids) whose per-XCD stride 1021 is prime, so a wave's successive work
+    // 64-row grids (a unit = a whole grid): persistent, just under 32 one-wave workgroups per CU (8 per SIMD).  8 x 1021: a
+    // multiple of 8 (a wave stays on "its" XCD's grids) whose per-XCD stride 1021 is prime, so a wave's successive work
     // items rotate through the strips -- with a stride that is a multiple of the strip count every wave
-    // kept ONE strip index, and the waves of the two strips under the action window finished last
-    int64_t cap = 8 * 1021;
+    // kept ONE strip index, and the waves of the two strips under the action window finished last.
+    // Taller grids (round 4): ONE WAVE PER STRIP, no persistence -- the dispatcher places a new wave wherever one retires,
+    // which evens out what a fixed assignment cannot (the counters say the window costs the average wave 5.5 % and the
+    // launch 14.5 %: profiles/r04_pmc_b1_window.txt).  Same-process sweeps of the launch cap (profiles/r04_b1_launch_cap.txt):
+    // 512x512 with the window N=4096 44.2-46.7 -> 42.1-46.1 us (best 41.9 at 0.75 of the units), N=8192 96.6 -> 88.3 (0.70 ->
+    // 0.77), 256x256 N=32768 98.4 -> 84.7 (0.70 -> 0.82); without a window 256x256 N=16384 42.5 -> 38.4 (0.87), 512x512 N=8192
+    // 92.5 -> 87.5, 128x128 N=65536 44.2 -> 40.5.  (64-row grids lose with one wave per grid: 88 -> 95 us at N=262144.)
+    int64_t cap = WW > 1 ? 0x7FFFFF00ll : 8 * 1021;
     if (const int64_t v = knobs().b1_blocks; v >= 8) cap = v / 8 * 8;   // experiment knob
     auto blocks = [&](int64_t wg) { return (unsigned)(wg < cap ? wg : cap); };
     // window launches of multi-strip grids walk half-grid units (see the kernel): 8192 waves = 32 per CU, all
@@ -809,13 +815,14 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     }
     if (env && aw == 64) {                        // one-launch step, the 64-column window
         const B1EnvArgs ea = *env;
-        // half-grid units; single strips -- the strips outside the window decide the master reset from a sample of the
-        // grid's record -- for 512-column grids beyond the Infinity Cache (streaming strip mode).  Same process
-        // (tools/kbench_b1_env.py, profiles/r04_kbench_b1_env.txt): 512x512 N=8192 98.8 -> 96.9 us (0.684 -> 0.698), N=4096
-        // 46.4 against 46.8 (units stay); 256x256 (two of four strips under the window) N=16384 48.9 against 51.1, N=32768
-        // 98.5 against 102.0 (units stay).  CARLE_B1_DBG bit 3 forces single strips, bit 4 half-grid units.
+        // single strips -- the strips outside the window decide the master reset from a sample of the grid's record --
+        // wherever the strips travel through LDS (512-column grids; 256-column grids from 64 MiB), half-grid units in the
+        // row-per-lane mode.  With persistent waves the two walks tied at N=4096 and single strips won only beyond the Infinity
+        // Cache (profiles/r04_kbench_b1_env.txt); with one wave per strip (above) single strips win everywhere: 512x512 N=256
+        // 8.2 -> 5.7 us, N=1024 13.7 -> 12.2, N=2048 23.9 -> 22.2, N=4096 44.9-46.8 -> 42.1-46.1, 256x256 N=16384 52.3 -> 51.4,
+        // N=32768 98.4 -> 84.7 (profiles/r04_b1_launch_cap.txt).  CARLE_B1_DBG bit 3 forces single strips, bit 4 half-grid units.
         int dbg = knobs().b1_dbg >= 0 ? (int)knobs().b1_dbg : 0;
-        if (lds == 2 && WW == 8 && !(dbg & 16)) dbg |= 8;
+        if (lds && WW > 1 && !(dbg & 16)) dbg |= 8;
         if (!lds || WW == 1 || (dbg & 16)) dbg &= ~8;
         const dim3 grid((dbg & 8) ? blocks(n8 * WW) : full), block(64);
         if (lds == 2) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 1, RULE_MODE, false, 2, true>), grid, block, 0, s, u_in, act, u_out, n, ah, aw, rule, status, slot, 0, WW, RandB1(), dbg, ea);
