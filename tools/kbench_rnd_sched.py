@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Same-process A/B of the workgroup count of the fused CA + RND2D kernel at N x 64x64 (CARLE_RND_BLOCKS; 0 = the library's
-choice) -- kernel alone and the one-launch step.   python tools/kbench_rnd_sched.py [N ...]"""
+choice; KBENCH_RND_BLOCKS=a,b,c: the counts to compare) -- kernel alone and the one-launch step.
+    python tools/kbench_rnd_sched.py [N ...]"""
 import os
 import sys
 
@@ -38,10 +39,10 @@ for n in [int(a) for a in sys.argv[1:]] or [4096]:
         hip.env_step_f32_rnd(bufs[i & 1], ring[i % 6], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1, True, pb, rb, w._ws,
                              w._step_bonus, 1.0, True, None, raw, None, True, deferred=True, partials=partials)
 
-    for rep in range(4):
+    for rep in range(int(os.environ.get("KBENCH_REPS", "4"))):
         for name, fn in (("kernel alone", kernel), ("one-launch step", step)):
-            for form, env_kv in (("library's choice", {}), ("1024 workgroups", {"CARLE_RND_BLOCKS": "1024"}),
-                                 ("768 workgroups", {"CARLE_RND_BLOCKS": "768"}), ("512 workgroups", {"CARLE_RND_BLOCKS": "512"}), ("896 workgroups", {"CARLE_RND_BLOCKS": "896"})):
+            counts = os.environ.get("KBENCH_RND_BLOCKS", "1024,768,512,896").split(",")      # workgroup counts to compare
+            for form, env_kv in [("library's choice", {})] + [(f"{c} workgroups", {"CARLE_RND_BLOCKS": c}) for c in counts]:
                 os.environ.pop("CARLE_RND_BLOCKS", None)
                 os.environ.update(env_kv)
                 hip.reload_knobs()
