@@ -166,9 +166,12 @@ __device__ __forceinline__ uint32_t next_state(const Count4<uint32_t> &n, uint32
 //            N=16384          rows 40.9 / 58.6   lds 41.7 / 53.4   nt 49.0 / 52.6
 //            N=32768          rows 108 / 117     lds 101 / 107     nt 98.4 / 105.8
 // Up to the size of the Infinity Cache the output of step t is (partly) still cached when step t+1 reads it: no
-// streaming hint below 192 MiB per array.
-static int b1_strip_mode(int64_t n, int ww) {
-    int64_t lds_bytes = ww == 8 ? 0 : 64ll << 20, nt_bytes = 192ll << 20;
+// streaming hint below 192 MiB per array.  256-column grids UNDER THE 64x64 WINDOW (half of their strips meet it) take the
+// hints from 112 MiB (round 4, one wave per strip: N=12288 = 96 MiB 30.9 us without against 34.7 with, N=16384 = 128 MiB
+// 50.9 against 45.0, N=20480 62.0 against 54.8; without a window N=16384 stays better without: 38.6 against 42.6; 512-column
+// grids at 128 MiB too: 41.8 against 44.9).
+static int b1_strip_mode(int64_t n, int ww, bool window = false) {
+    int64_t lds_bytes = ww == 8 ? 0 : 64ll << 20, nt_bytes = (ww == 4 && window) ? 112ll << 20 : 192ll << 20;
     if (knobs().b1_lds_min_bytes >= 0) lds_bytes = knobs().b1_lds_min_bytes;      // experiment knobs, read once
     if (knobs().b1_nt_min_bytes >= 0) nt_bytes = knobs().b1_nt_min_bytes;
     const int64_t bytes = n * (int64_t)(64 * ww) * ww * 8;
@@ -786,7 +789,7 @@ template <int WW, int RULE_MODE>
 static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
                           int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s, const B1EnvArgs *env = nullptr) {
     const int64_t n8 = (n + 7) / 8 * 8;         // the XCD-aware mapping walks the batch in groups of 8 grids
-    const int lds = b1_strip_mode(n, WW);
+    const int lds = b1_strip_mode(n, WW, act != nullptr && aw == 64);
     // 64-row grids (a unit = a whole grid): persistent, just under 32 one-wave workgroups per CU (8 per SIMD).  8 x 1021: a
     // multiple of 8 (a wave stays on "its" XCD's grids) whose per-XCD stride 1021 is prime, so a wave's successive work
     // items rotate through the strips -- with a stride that is a multiple of the strip count every wave
