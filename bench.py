@@ -98,6 +98,12 @@ def parse(argv=None):
                          "forward-only stacks under the action ring.  Off by default: the headline is the eager surface")
     ap.add_argument("--repeats", type=int, default=0,
                     help="number of timed blocks of --steps steps (default: >= 5, until >= 50 ms are timed)")
+    ap.add_argument("--single-rank-group", action="store_true",
+                    help="--gpus 1 only: join a process group of ONE rank (backend as --backend, nccl = RCCL) and send every "
+                         "exchange of the path through it (carle_amd.dist.force_collectives): what a one-GPU box can execute "
+                         "of the multi-GPU path")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="headline run only: skip the short timed blocks of the other BASELINE configs (key \"configs\")")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
@@ -335,6 +341,22 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
         name = name.replace("true, ...>", "true, ..., ENV>")
     nets = args.rnd or args.ae
     fused_rnd = args.rnd and not args.train and args.format == "f32" and size == 64
+    fused_rnd_ae = fused_rnd and args.ae and n > 16 and wenv._can_pair_step() == 3
+    if fused_rnd_ae:
+        # the stack of train_mcl.py:36-40, forward passes: CA step + RND2D + AE2D + reward are ONE kernel
+        rnd = wenv.env
+        dev_ = state.device
+        pb, rb, ab = rnd._pred_blob.get(dev_), rnd._rand_blob.get(dev_), wenv._pred_blob.get(dev_)
+        partials = wenv.__dict__.get("_mom_partials")
+
+        def ca_rnd_ae(i):
+            hip.env_step_f32_rnd_ae(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1, True,
+                                    pb, rb, rnd._ws, rnd._step_bonus, 1.0, True, ab, wenv._ws, wenv._bonus_buf, 1.0, True,
+                                    partials is not None, partials)
+        rnd_flop = 474112
+        ae_flop = 2 * 9 * 4096 * 4 + 2 * 9 * 4 * 2 * 1024 + 2 * 4 * 2 * 1024 + 2 * 4 * 4096
+        cand.append(("ca_step_rnd_ae64_kernel<true, ...>", ca_rnd_ae, alg + 4 * n, n * (rnd_flop + ae_flop)))
+        return cand
     if fused_rnd:
         # BASELINE configs[3]: the CA step and the RND2D forward are ONE kernel -- and, for more than 16 instances, the
         # whole RND2D.step is that one launch (reward and reward-moment partial sums included)
@@ -412,7 +434,13 @@ def run_rank(args):
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a "
               f"{env_world}-GPU number as a {args.gpus}-GPU one", file=sys.stderr)
         sys.exit(2)
-    rank, world, dev = cdist.init_from_env(args.backend, share_devices=args.share_gpus)
+    if args.single_rank_group:
+        if args.gpus != 1:
+            print("bench.py: --single-rank-group is for --gpus 1", file=sys.stderr)
+            sys.exit(2)
+        cdist.force_collectives(True)
+    rank, world, dev = cdist.init_from_env(args.backend, share_devices=args.share_gpus,
+                                           single_rank_group=args.single_rank_group)
     if args.launch_check:
         launch_check(rank, world, dev, args.backend)
         return
@@ -422,6 +450,64 @@ def run_rank(args):
     if world > 1 and not args.share_gpus and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
         print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s)", file=sys.stderr)
         sys.exit(2)
+    # proof of N ranks for the record: gathered THROUGH the group (a collective: every rank calls it)
+    coll = cdist.collective_info(dev)
+    out = measure(args, rank, world, dev, pinned)
+    if rank == 0:
+        out["collective"] = coll
+        headline = (args.format == "f32" and args.size == 64 and not (args.rnd or args.ae or args.train)
+                    and args.agent == "ring" and args.replay == "none")
+        if world == 1 and headline and not args.no_extra_configs:
+            # the other BASELINE configs, short blocks with the same estimator: one driver-timed line carries all five
+            out["configs"] = extra_configs(args, rank, world, dev, pinned)
+        print(json.dumps(out), flush=True)
+    if cdist.exchanging() or world > 1:
+        import torch.distributed as tdist
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+EXTRA_CONFIGS = (
+    # (label, argument overrides): BASELINE.json configs[2] (one GPU's shard), [3], [4] and the stacked forward of the north star
+    ("configs[2] shard", dict(size=256, steps=8, warmup=2)),
+    ("configs[3] + RND2D forward", dict(rnd=True, steps=64, warmup=8)),
+    ("configs[4] bit-packed HighLife", dict(format="b1", size=512, rule="B36/S23", steps=32, warmup=4)),
+    ("RND2D + AE2D forward stack (train_mcl.py:36-40)", dict(rnd=True, ae=True, steps=64, warmup=8)),
+)
+
+
+def extra_configs(args, rank, world, dev, pinned):
+    import copy
+    rows = []
+    for label, over in EXTRA_CONFIGS:
+        a = copy.copy(args)
+        a.instances = 4096
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.repeats = 5
+        t0 = time.perf_counter()
+        try:
+            o = measure(a, rank, world, dev, pinned, light=True)
+        except Exception as e:                                   # a failing side config must not cost the headline line
+            rows.append({"label": label, "error": f"{type(e).__name__}: {e}"})
+            continue
+        r = o["roofline"]
+        rows.append({"label": label, "workload": o["config"]["workload"], "ms_per_step": o["ms_per_step"],
+                     "env_steps_per_s": o["value"], "cell_updates_per_s": o["cell_updates_per_s"], "steps": o["steps"],
+                     "repeats": o["timing"]["repeats"], "dtype": o["dtype"],
+                     "roofline": {k: r[k] for k in ("kernel", "frac", "avg_launch_us", "achieved", "unit",
+                                                    "algorithmic_bytes_per_launch", "launches_timed", "other_kernels_us",
+                                                    "traffic") if k in r},
+                     "wall_s": round(time.perf_counter() - t0, 2)})
+        gc.collect()
+        torch.cuda.empty_cache()
+    return rows
+
+
+def measure(args, rank, world, dev, pinned, light=False):
+    """One workload: warm-up, timed blocks, roofline of its dominant kernel; returns the JSON object (rank 0) or None.
+    ``light``: a side config of the headline run -- fewer roofline launches, no CPU baseline."""
+    from carle_amd import dist as cdist
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -614,9 +700,9 @@ def run_rank(args):
     cands = dominant_kernels(args, env, wenv, ring, hip, n, size, asize)
     timed = []
     for name, launch, alg, flop in cands:
-        reps = 256
+        reps = 64 if light else 256
         k_ms = time_kernel(launch, reps, dev)
-        while k_ms * reps < 2 * MIN_TIMED_MS and reps < 8192:     # >= 10 ms of launches per estimate
+        while k_ms * reps < (0.8 if light else 2) * MIN_TIMED_MS and reps < 8192:     # >= 10 ms of launches per estimate (side configs: 4)
             reps *= 4
             k_ms = time_kernel(launch, reps, dev)
         timed.append((k_ms, name, alg, flop, reps))
@@ -695,13 +781,11 @@ def run_rank(args):
         }
         if warnings:
             out["warnings"] = warnings
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not light:
             b, s = env.birth, env.survive
             out["cpu_baseline"] = cpu_baseline(n, size, (b, s), args.cpu_seconds)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 def main(argv=None):

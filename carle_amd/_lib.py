@@ -52,6 +52,10 @@ SIGNATURES = {
                                         _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
                                         _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "carle_rnd_step_partials_doubles": (_c_i64, [_c_i64]),
+    "carle_rnd_ae_step_partials_doubles": (_c_i64, [_c_i64]),
+    "carle_env_step_f32_rnd_ae": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
+                                           _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int,
+                                           _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp]),
     "carle_ca_step_f32_rnd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
                                        _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
     "carle_rnd2d_train_partial_floats": (_c_i64, [_c_i64]),
@@ -122,6 +126,9 @@ SIGNATURES = {
     "carle_puffer_update_f32": (_c_int, [_c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
     "carle_speed_puffer_f32": (_c_int, [_c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                         _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp]),
+    "carle_wrapper_scalars_local_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int,
+                                                 _c_vp]),
+    "carle_wrapper_scalars_apply_f32": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_vp]),
     "carle_rle_encode_body": (_c_i64, [_c_vp, _c_int, _c_int, _c_vp, _c_i64]),
     "carle_rle_decode_body": (_c_int, [ctypes.c_char_p, _c_i64, _c_vp, _c_int, _c_int]),
     "carle_ca_finish": (_c_int, [_c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_int, _c_int, _c_vp]),

@@ -55,7 +55,7 @@ class RandomAgent(nn.Module):
 
 class RandomNetworkAgent(nn.Module):
     """Frozen random convnet -> sigmoid <= toggle_rate (carle/agents.py:45-102).  ``network`` is the
-    reference's ``nn.Sequential`` (same indices: its state_dict loads strictly); the forward pass runs
+    reference's ``nn.Sequential`` (same indices: its state_dict loads strictly; it is never evaluated); the forward pass runs
     in two HIP kernels (``carle_agent_rn_forward_f32``: tiled convolutions + pooling, then the linear
     layer on the fp32 matrix cores with sigmoid and threshold fused) on the observation's device.
     Deviation: the reference reads ``observation_width`` only when the misspelt key
@@ -108,17 +108,10 @@ class RandomNetworkAgent(nn.Module):
         if next(self.network.parameters()).device != obs.device:
             self.network.to(obs.device)
         if not self._kernel_domain(obs):
-            # geometries outside the kernels' domain that the reference's nn.Sequential accepts (e.g. 100x100 with a
-            # 625-input linear layer): the module itself on the device, announced once -- never silently
-            if not self.__dict__.get("_warned_fallback"):
-                import warnings
-                warnings.warn(f"RandomNetworkAgent: observation {tuple(obs.shape)} is outside the HIP kernels' domain "
-                              "(H, W multiples of 8, fp32, N <= 65535): evaluating the torch module on the device")
-                self.__dict__["_warned_fallback"] = True
-            with torch.no_grad():
-                output = self.network(obs)
-            action = (1.0 * (output <= self.toggle_rate)).reshape(instances, 1, self.action_width, self.action_height)
-            return (action, output) if want_output else action
+            # geometries the reference's nn.Sequential accepts and the kernels do not (e.g. 100x100 with a 625-input linear
+            # layer): no torch evaluation in their place -- this package has no fallback path
+            raise NotImplementedError(f"RandomNetworkAgent: observation {tuple(obs.shape)} is outside the HIP kernels' domain "
+                                      "(H, W multiples of 8, fp32 weights, at most 65535 instances)")
         w1, w2, wl = (self.network[i].weight.detach().contiguous() for i in (0, 3, 7))
         action, output, self._ws = hip.agent_rn_forward(obs, w1, w2, wl, self.toggle_rate,
                                                         getattr(self, "_ws", None), want_output)

@@ -196,7 +196,7 @@ __device__ __forceinline__ void settle_moments_wave(int32_t *st, int lane) {
 #pragma unroll
     for (int k = 32; k > 0; k >>= 1) { s += __shfl_xor(s, k, 64); q += __shfl_xor(q, k, 64); }
     if (lane == 0) {
-        double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
+        double *mom_out = moments_out_slot(st, reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x));
         double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
         if (mom_out && mom_acc) {
             const double nb = (double)w5.w, mean = nb > 0.0 ? s / nb : 0.0;
@@ -229,7 +229,7 @@ static __device__ __noinline__ void env_step_bookkeeping(int32_t *status, int sl
     const uint4 w3 = s4[3];
     settle_pending(w0, w1, w2);
     if (merge_moments) {
-        double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
+        double *mom_out = moments_out_slot(status, reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x));
         double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
         if (mom_out && mom_acc) {
             const double nb = (double)n, na = mom_acc[0], ma = mom_acc[1], qa = mom_acc[2], tot = na + nb;

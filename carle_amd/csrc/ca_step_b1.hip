@@ -329,6 +329,9 @@ struct B1EnvArgs {
     int publish = 1;               // 0: the caller stored the action flags of `slot` beforehand (fp32 actions packed by
                                    //    carle_pack_f32_b1, which publishes the exact fp32 predicates)
     int merge_moments = 0;
+    // cached strip mode (LDS == 1): grids with an index >= nt_from travel with the streaming hint (loads and stores), the
+    // others with the default policy -- see b1_resident_grids()
+    int64_t nt_from = INT64_MAX;
 };
 
 // ACT: 0 = no action, 1 = 64-column window (toggle_row64), 2 = any packed window (toggle_row)
@@ -344,7 +347,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
     constexpr int H = 64 * WW;
     constexpr bool MULTI = WW > 1;                          // more than one 64-row strip per grid
     constexpr bool LDS_T = MULTI && LDS != 0;               // coalesced strip traffic through LDS (see StripLds)
-    constexpr bool LDS_NT = LDS == 2;
+    // (the streaming mode hints loads AND stores; CARLE_B1_PROBE_NT_LD / _ST -- probe builds only, tools/ab_libs.sh -- put
+    // the hint on one side of the cached mode: which of the two the Infinity-Cache reuse of step t's output hangs on)
+#ifdef CARLE_B1_PROBE_NT_LD
+    constexpr bool LD_NT = true;
+#else
+    constexpr bool LD_NT = LDS == 2;
+#endif
+#ifdef CARLE_B1_PROBE_NT_ST
+    constexpr bool ST_NT = true;
+#else
+    constexpr bool ST_NT = LDS == 2;
+#endif
     // the strip's two bordering rows stay in LDS and the compute phase reads them one 32-bit chunk at a time (a rolling
     // window of three): 16 registers that only lanes 0 and 63 had a use for (window kernels: 76 -> <= 64 VGPRs, eight
     // waves per SIMD instead of six).  Kernels that toggle the bordering rows in registers keep them there.
@@ -382,6 +396,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
     const int64_t j = unit >> 3;
     const int64_t g = halves ? 8 * (j >> 1) + (unit & 7) : 8 * (j / strip_count) + (unit & 7);
     if (g >= n) continue;
+    const bool unit_nt = ENV && LDS == 1 && g >= ea.nt_from;     // (wave-uniform) this grid is not kept in the Infinity Cache
     // the window words of the unit's window strip (HS >= 2: exactly one strip of a unit meets the 64-row
     // window, the one at the middle of the grid) and of that strip's bordering row
     uint32_t pa_lo = 0u, pa_hi = 0u, ph_lo = 0u, ph_hi = 0u;
@@ -456,10 +471,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
                 }
                 toggle_strip_image<WW>(lds, lane, in, wr, hin, wh);
             };
-            load_strip<WW, LDS_NT, true, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane,
-                                                 c, hal, act + g * (int64_t)ah, touches_, on_image);
-        } else
-            load_strip<WW, LDS_NT, false, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
+            if (unit_nt)
+                load_strip<WW, true, true, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane,
+                                                   c, hal, act + g * (int64_t)ah, touches_, on_image);
+            else
+                load_strip<WW, LD_NT, true, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane,
+                                                    c, hal, act + g * (int64_t)ah, touches_, on_image);
+        } else {
+            if (unit_nt)
+                load_strip<WW, true, false, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
+            else
+                load_strip<WW, LD_NT, false, !HROLL>(lds, gin + (int64_t)r0 * WW, gin + (int64_t)rt * WW, gin + (int64_t)rb * WW, MULTI, lane, c, hal);
+        }
         if constexpr (HROLL) strip_halo_sums<(LDS_T ? WW : 2)>(lds, lane);     // behind the window toggle (LDS keeps a wave's order)
     } else {
         load_row<WW>(gin + (int64_t)r * WW, c);
@@ -612,7 +635,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(90))) void ca_st
     }
     B1_STAMP(2);
     if constexpr (LDS_T) {
-        store_strip<WW, LDS_NT>(lds, u_out + (g * (int64_t)H + r0) * WW, lane, nx);
+        if (unit_nt) store_strip<WW, true>(lds, u_out + (g * (int64_t)H + r0) * WW, lane, nx);
+        else store_strip<WW, ST_NT>(lds, u_out + (g * (int64_t)H + r0) * WW, lane, nx);
     } else store_row<WW>(u_out + (g * (int64_t)H + r) * WW, nx);
     B1_STAMP(3);
     };
@@ -785,11 +809,33 @@ __global__ __launch_bounds__(256) void unpack_b1_f32_kernel(const uint64_t *__re
     dst[i] = o;
 }
 
+// How many grids of a packed state array stay cacheable (cached strip mode of the one-launch step): round 5.  The Infinity
+// Cache holds 256 MiB; step t + 1 re-reads what step t wrote, so with input + output at or just under 256 MiB (BASELINE
+// configs[4]: 2 x 128 MiB) the re-read hits only if NOTHING else displaces a line -- and whether that holds hung on the
+// physical pages the two allocations got: per pair of buffers, in one process, 42.5 us or 44.4-46 us, the same virtual
+// addresses on either level after a re-allocation, every pair equal (36.5 us) at 2 x 112 MiB, two levels again at 2 x 120 MiB,
+// the slow level for every pair when the stores do not allocate (EXPERIMENTS.md 5.3, profiles/r05_b1_levels.txt).  So the
+// first 112 MiB of each array keep the default policy -- 2 x 112 MiB fit with room to spare, their re-read always hits --
+// and the grids behind them stream past the cache with the nt hint instead of fighting for it: every process gets the
+// same time.  Multiple of 8 grids: the XCDs keep equal shares.  CARLE_B1_RESIDENT_BYTES overrides (0 = no limit: until round 4).
+static int64_t b1_resident_grids(int64_t n, int ww) {
+    int64_t res = 112ll << 20;
+    if (knobs().b1_resident_bytes >= 0) res = knobs().b1_resident_bytes;
+    if (res == 0) return INT64_MAX;
+    const int64_t grid_bytes = (int64_t)(64 * ww) * ww * 8;
+    const int64_t g = res / grid_bytes / 8 * 8;
+    return g >= n ? INT64_MAX : g;
+}
+
 template <int WW, int RULE_MODE>
 static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u_out, int64_t n, int ah,
                           int aw, uint32_t rule, int32_t *status, int slot, hipStream_t s, const B1EnvArgs *env = nullptr) {
     const int64_t n8 = (n + 7) / 8 * 8;         // the XCD-aware mapping walks the batch in groups of 8 grids
-    const int lds = b1_strip_mode(n, WW, act != nullptr && aw == 64);
+    int lds = b1_strip_mode(n, WW, act != nullptr && aw == 64);
+    // the one-launch step keeps a resident slice and streams the rest at EVERY size from the LDS threshold on (see
+    // b1_resident_grids): beyond the old streaming threshold too, the 112 MiB that do fit are re-read out of the cache
+    // (512x512 N=6144 66.6-67.5 -> 63.7-65.6 us, N=8192 89.4-91.0 -> 86.7-88.9; CARLE_B1_HYBRID_ALL=0: all-streaming there)
+    if (env && lds == 2 && knobs().b1_hybrid_all != 0) lds = 1;
     // 64-row grids (a unit = a whole grid): persistent, just under 32 one-wave workgroups per CU (8 per SIMD).  8 x 1021: a
     // multiple of 8 (a wave stays on "its" XCD's grids) whose per-XCD stride 1021 is prime, so a wave's successive work
     // items rotate through the strips -- with a stride that is a multiple of the strip count every wave
@@ -800,7 +846,10 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     // 512x512 with the window N=4096 44.2-46.7 -> 42.1-46.1 us (best 41.9 at 0.75 of the units), N=8192 96.6 -> 88.3 (0.70 ->
     // 0.77), 256x256 N=32768 98.4 -> 84.7 (0.70 -> 0.82); without a window 256x256 N=16384 42.5 -> 38.4 (0.87), 512x512 N=8192
     // 92.5 -> 87.5, 128x128 N=65536 44.2 -> 40.5.  (64-row grids lose with one wave per grid: 88 -> 95 us at N=262144.)
-    int64_t cap = WW > 1 ? 0x7FFFFF00ll : 8 * 1021;
+    // (the cap of the one-wave-per-strip launch keeps gridDim.x * blockDim.x = 64 * cap below 2^32: launch paths that validate
+    // the global work size against UINT32_MAX would refuse more -- 128x128 grids beyond N = 33.5 M; the kernel's grid-stride
+    // loop covers the rest)
+    int64_t cap = WW > 1 ? ((1ll << 32) / 64 - 8) : 8 * 1021;
     if (const int64_t v = knobs().b1_blocks; v >= 8) cap = v / 8 * 8;   // experiment knob
     auto blocks = [&](int64_t wg) { return (unsigned)(wg < cap ? wg : cap); };
     // window launches of multi-strip grids walk half-grid units (see the kernel): 8192 waves = 32 per CU, all
@@ -809,7 +858,8 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     if (const int64_t v = knobs().b1_units; v >= 8) ucap = v / 8 * 8;       // experiment knob
     const unsigned full = WW > 1 ? (unsigned)(n8 * 2 < ucap ? n8 * 2 : ucap) : blocks(n8 * WW);
     if (env && !act) {                            // one-launch step, no action
-        const B1EnvArgs ea = *env;
+        B1EnvArgs ea = *env;
+        ea.nt_from = b1_resident_grids(n, WW);
         const dim3 grid(blocks(n8 * WW)), block(64);
         if (lds == 2) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 2, true>), grid, block, 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW, RandB1(), 0, ea);
         else if (lds == 1) hipLaunchKernelGGL((ca_step_b1_kernel<WW, 0, RULE_MODE, false, 1, true>), grid, block, 0, s, u_in, act, u_out, n, 0, 0, rule, status, slot, 0, WW, RandB1(), 0, ea);
@@ -817,7 +867,8 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
         return check_launch("carle_env_step_b1");
     }
     if (env && aw == 64) {                        // one-launch step, the 64-column window
-        const B1EnvArgs ea = *env;
+        B1EnvArgs ea = *env;
+        ea.nt_from = b1_resident_grids(n, WW);
         // single strips -- the strips outside the window decide the master reset from a sample of the grid's record --
         // wherever the strips travel through LDS (512-column grids; 256-column grids from 64 MiB), half-grid units in the
         // row-per-lane mode.  With persistent waves the two walks tied at N=4096 and single strips won only beyond the Infinity

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(1024) void ca_env_step_small64_kernel(
     if (reward && threadIdx.x < n) reward[threadIdx.x] = 0.0f;          // env.py:238
     if (threadIdx.x == 0) {
         if (merge_moments && reward) {                     // moments of an all-zero reward vector
-            double *mom_out = reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x);
+            double *mom_out = moments_out_slot(st, reinterpret_cast<double *>(((uint64_t)w3.y << 32) | w3.x));
             double *mom_acc = reinterpret_cast<double *>(((uint64_t)w3.w << 32) | w3.z);
             if (mom_out && mom_acc) {
                 const double nb = (double)n, na = mom_acc[0], ma = mom_acc[1], qa = mom_acc[2], tot = na + nb;
@@ -425,7 +425,8 @@ __global__ __launch_bounds__(1024) void ca_env_run_small64_kernel(
     if (reward && threadIdx.x < n) reward[threadIdx.x] = 0.0f;          // env.py:238
     if (threadIdx.x == 0 && steps > 0) {
         if (moments) {
-            mom_out[0] = (double)n; mom_out[1] = 0.0; mom_out[2] = 0.0;
+            double *row = moments_out_slot_steps(st, mom_out, (double)n, steps);       // one row per step under a trace
+            row[0] = (double)n; row[1] = 0.0; row[2] = 0.0;
             mom_acc[0] = na; mom_acc[1] = ma; mom_acc[2] = qa;
         }
         // the status block as the last step's kernel + epilogue leave it: its flags in its slot, the other slot recycled
@@ -494,7 +495,8 @@ __global__ __launch_bounds__(64) void ca_run_noaction64_kernel(const float *__re
                         na = tot; ma = ma_new; qa = qa_new;
                     }
                 }
-                mom_out[0] = nb; mom_out[1] = 0.0; mom_out[2] = 0.0;
+                double *row = moments_out_slot_steps(st, mom_out, nb, steps);
+                row[0] = nb; row[1] = 0.0; row[2] = 0.0;
                 mom_acc[0] = na; mom_acc[1] = ma; mom_acc[2] = qa;
             }
         }

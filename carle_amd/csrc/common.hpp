@@ -64,9 +64,12 @@ struct Knobs {
     int64_t stream_store_min_bytes;      // CARLE_STREAM_STORE_MIN_BYTES: fp32 state arrays from this size use streaming stores
     int64_t b1_lds_min_bytes;            // CARLE_B1_LDS_MIN_BYTES: packed strips go through the LDS image from this size
     int64_t b1_nt_min_bytes;             // CARLE_B1_NT_MIN_BYTES: ... with streaming hints from this size
+    int64_t b1_resident_bytes;           // CARLE_B1_RESIDENT_BYTES: bytes per packed state array kept cacheable (0 = all)
+    int64_t b1_hybrid_all;               // CARLE_B1_HYBRID_ALL: 0 = all-streaming beyond the old threshold (until round 4) instead of resident slice + streamed rest
     int64_t b1_blocks, b1_units;         // CARLE_B1_BLOCKS / CARLE_B1_UNITS: launch caps of the packed kernel
     int64_t wide_blocks;                 // CARLE_WIDE_BLOCKS: launch cap of the wavefront-per-strip kernels
     int64_t rnd_blocks;                  // CARLE_RND_BLOCKS: workgroups of the fused CA + RND2D kernel
+    int64_t rnd_waves;                   // CARLE_RND_WAVES: 8 = eight wavefronts per grid (ca_step_rnd64x8_kernel), else four
     int64_t rnd_cached_load_max_bytes;   // CARLE_RND_CACHED_LOAD_MAX_BYTES
     int64_t net_blocks;                  // CARLE_NET_BLOCKS: workgroups of the 64x64 reward-net kernels
     int64_t b1_dbg;                      // CARLE_B1_DBG
@@ -80,6 +83,29 @@ __device__ __forceinline__ float reward_accumulate(float reward, float scale, fl
 #pragma clang fp contract(off)
     const float prod = scale * bonus;
     return reward + prod;
+}
+
+// Where the reward moments (count, mean, M2) of a step go: the triple at CARLE_ST_MOMENTS_OUT, or -- while a trace is
+// installed (CARLE_ST_TRACE_CAP > 1: MOMENTS_OUT then points at that many rows) -- the next row of the ring.  Called by the
+// ONE thread that writes a step's moments, once per step.
+__device__ __forceinline__ double *moments_out_slot(int32_t *st, double *base) {
+    const uint32_t cap = (uint32_t)st[CARLE_ST_TRACE_CAP];
+    if (cap <= 1u || base == nullptr) return base;
+    const uint32_t i = (uint32_t)st[CARLE_ST_TRACE_IDX];
+    st[CARLE_ST_TRACE_IDX] = (int32_t)(i + 1u);
+    return base + 3 * (size_t)(i % cap);
+}
+
+// k steps of a bare environment in one launch (all-zero rewards): k rows; the first k - 1 are written here as (n, 0, 0),
+// the last one is returned for the caller to write
+__device__ __forceinline__ double *moments_out_slot_steps(int32_t *st, double *base, double n, int steps) {
+    double *row = moments_out_slot(st, base);
+    if ((uint32_t)st[CARLE_ST_TRACE_CAP] <= 1u || base == nullptr) return row;
+    for (int t = 1; t < steps; ++t) {
+        row[0] = n; row[1] = 0.0; row[2] = 0.0;
+        row = moments_out_slot(st, base);
+    }
+    return row;
 }
 
 // Arguments of the one-launch CA + RND2D step (ca_step_rnd64_kernel<..., ENV>, ca_rnd_fused.hip)

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 4) void rnd_block64_kernel(const void *__restr
             const float b = rnd_linear_bonus(s_feat, s.lin, lane, g, pred_out, target_out);
             if (lane == 0) {
                 bonus[g] = b;
-                if (reward) reward[g] += reward_scale * b;       // mcl.py:403-405
+                if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);       // mcl.py:403-405
             }
         }
         // rows are rewritten at the top of the next iteration: every wave has passed the barrier
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
         if (tid == 0) {
             const float b = ((s.red[0] + s.red[1]) + (s.red[2] + s.red[3])) * (1.0f / 4096.0f);
             bonus[g] = b;
-            if (reward) reward[g] += reward_scale * b;
+            if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);
         }
     }
 }
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, 3) void rnd_train_block64_kernel(
             if (lane == 0) {
                 const float b = sq * (1.0f / 16.0f);
                 bonus[g] = b;
-                if (reward) reward[g] += reward_scale * b;
+                if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);
             }
             if (net == 0 && half == 0) s_dy[kk] = grad_scale * diff * (1.0f - out * out);   // d loss / d y_k
         }
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(256, 3) void ae_train_block64_kernel(
         if (tid == 0) {
             const float b = ((s.red[0][0] + s.red[1][0]) + (s.red[2][0] + s.red[3][0])) * (1.0f / 4096.0f);
             bonus[g] = b;
-            if (reward) reward[g] += reward_scale * b;
+            if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);
         }
 
         // ---- relu gate of A3, convT1 backward (thread's own 2x2 outputs)

@@ -125,6 +125,9 @@ __global__ __launch_bounds__(256) void rnd_conv2_pool2_kernel(
     ws2[(g * 2 + net) * (int64_t)d + fy * w8 + fx] = fmaxf(m, 0.0f);
 }
 
+struct __attribute__((aligned(4))) F4U { float x, y, z, w; };   // 16 bytes at 4-byte alignment: the weight rows sit
+                                                                 // 77 / 39 floats into the state_dict-ordered blobs
+
 // RND2D stage 3: linear(D->16) + tanh for both nets, bonus = mean_k (t_k - p_k)^2
 // one 256-thread workgroup per grid: thread = (net, k, eighth of D); every thread streams its own
 // contiguous slice of the weight row (float4 loads), the eight partial sums of an output are
@@ -147,11 +150,14 @@ __global__ __launch_bounds__(256) void rnd_linear_bonus_kernel(
     // 36, 136 -- the vector path dropped the last d % 8 inputs of every output; found by tools/fuzz_nets.py.)
     const int len = d >> 3, i0 = seg * len;
     float acc = 0.0f;
-    if (len > 0 && (d & 31) == 0 && (((uintptr_t)(lw + i0) | (uintptr_t)(f + i0)) & 15u) == 0) {
-        const float4 *w4 = reinterpret_cast<const float4 *>(lw + i0);
+    // (the weight rows sit 77 / 39 floats into the state_dict-ordered blobs -- 4-byte aligned only: F4U below, as the wide
+    // kernel reads them; with a float4 the alignment test never passed for the predictor and the vector path was dead)
+    if (len > 0 && (d & 31) == 0 && ((uintptr_t)(f + i0) & 15u) == 0) {
+        const F4U *w4 = reinterpret_cast<const F4U *>(lw + i0);
         const float4 *f4 = reinterpret_cast<const float4 *>(f + i0);
         for (int i = 0; i < (len >> 2); ++i) {
-            const float4 a = w4[i], b = f4[i];
+            const F4U a = w4[i];
+            const float4 b = f4[i];
             acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
             acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
         }
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256) void rnd_linear_bonus_kernel(
         }
         const float b = sq * (1.0f / kRndDim);
         bonus[g] = b;
-        if (reward) reward[g] += reward_scale * b;        // mcl.py:403-405
+        if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);        // mcl.py:403-405
     }
 }
 
@@ -186,8 +192,6 @@ __global__ __launch_bounds__(256) void rnd_linear_bonus_kernel(
 // 1024 threads per grid, thread = (net, k, one of 32 slices of D), the slice's D/128 float4 pairs all in
 // flight at once -- ONE memory latency instead of D/32 dependent ones (the 256-thread kernel above: 25 us at
 // N=16, 256x256; this one: see profiles/r02_fwd256.txt).  Fixed summation order.
-struct __attribute__((aligned(4))) F4U { float x, y, z, w; };   // 16 bytes at 4-byte alignment: the weight rows sit
-                                                                 // 77 / 39 floats into the state_dict-ordered blobs
 __global__ __launch_bounds__(1024) void rnd_linear_bonus_wide_kernel(
     const float *__restrict__ ws2, const float *__restrict__ pp, const float *__restrict__ rp,
     float *__restrict__ bonus, float *__restrict__ pred_out, float *__restrict__ target_out,
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(1024) void rnd_linear_bonus_wide_kernel(
         }
         const float b = sq * (1.0f / kRndDim);
         bonus[g] = b;
-        if (reward) reward[g] += reward_scale * b;        // mcl.py:403-405
+        if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);        // mcl.py:403-405
     }
 }
 

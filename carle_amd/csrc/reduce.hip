@@ -240,6 +240,96 @@ __global__ __launch_bounds__(1024) void speed_puffer_kernel(const float *__restr
     if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The two updates under BATCH SHARDING (carle_amd/dist.py: one process per GPU owns a slice of the instances).  The
+// reference's scalars couple the whole batch -- speed = sqrt(sum over ALL instances of velocity^2) (mcl.py:789), the
+// live-cell total and the action's truthiness of PufferDetector (mcl.py:832, 835) -- so each update is split around ONE
+// all-reduce(SUM) of exch = double[4] = { sum v^2, had a previous centre of mass, live cells, action had a non-zero }:
+// `local` does the per-instance work of this shard and leaves its four terms, the caller reduces them over the ranks,
+// `apply` finishes with the global values (same arithmetic as speed_update_body / puffer_update_body: fp64 sums, one
+// rounding to fp32).  what: bit 0 = SpeedDetector's part, bit 1 = PufferDetector's.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wrapper_scalars_local_kernel(const float *__restrict__ sums4, const float *__restrict__ live4,
+                                                                    int64_t n, float *__restrict__ com, int32_t *__restrict__ state,
+                                                                    float *__restrict__ velocity, float *__restrict__ live_out,
+                                                                    const int32_t *__restrict__ any_flag, double *__restrict__ exch,
+                                                                    int what) {
+    __shared__ double part[2][4];
+    const int tid = threadIdx.x;
+    const bool speed = (what & 1) != 0, puffer = (what & 2) != 0;
+    const bool has_prev = speed && state[0] != 0;
+    double sq = 0.0, cells = 0.0;
+    for (int64_t i = tid; i < n; i += 256) {
+        const float s0 = sums4[4 * i];
+        const float live = live4 ? live4[4 * i] : s0;
+        if (speed) {
+            const float s1 = sums4[4 * i + 1], s2 = sums4[4 * i + 2];
+            const float ch = s1 / (live + 1e-7f), cw = s2 / (live + 1e-7f);
+            if (has_prev) {
+                const float vh = com[i] - ch, vw = com[n + i] - cw;
+                velocity[i] = vh; velocity[n + i] = vw;
+                sq = fma((double)vh, (double)vh, fma((double)vw, (double)vw, sq));
+            }
+            com[i] = ch; com[n + i] = cw;
+            live_out[i] = live;
+        }
+        cells += (double)live;
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) { sq += __shfl_xor(sq, k, 64); cells += __shfl_xor(cells, k, 64); }
+    if ((tid & 63) == 0) { part[0][tid >> 6] = sq; part[1][tid >> 6] = cells; }
+    __syncthreads();                                        // every thread has read state[0] by now
+    if (tid == 0) {
+        exch[0] = speed ? (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]) : 0.0;
+        exch[1] = has_prev ? 1.0 : 0.0;
+        exch[2] = puffer ? (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]) : 0.0;
+        exch[3] = (puffer && any_flag != nullptr && any_flag[0] != 0) ? 1.0 : 0.0;
+        if (speed) state[0] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void wrapper_scalars_apply_kernel(const double *__restrict__ exch, int what,
+                                                                    float *__restrict__ speed_out, float *__restrict__ ring,
+                                                                    int32_t *__restrict__ rstate, int cap,
+                                                                    float *__restrict__ live_total, float *__restrict__ reward,
+                                                                    int64_t n) {
+    __shared__ int s_bonus;
+    const int tid = threadIdx.x;
+    const bool has_prev = (what & 1) && exch[1] != 0.0;
+    const float sp = has_prev ? (float)sqrt(exch[0]) : 0.0f;           // mcl.py:789 over the whole batch
+    if (tid == 0) {
+        if (has_prev) speed_out[0] = sp;
+        int bonus = 0;
+        if (what & 2) {
+            const float total = (float)exch[2];                         // torch.sum(universe) of the whole batch, mcl.py:832
+            live_total[0] = total;
+            int head = rstate[0], count = rstate[1];
+            if (exch[3] == 0.0) {                                       // no rank's action had a non-zero element, mcl.py:835
+                ring[(head + count) % cap] = total;
+                count += 1;
+                if (count > cap - 1) {
+                    const float slope = total - ring[head];
+                    head = (head + 1) % cap;
+                    count -= 1;
+                    bonus = slope > 0.01f ? 1 : 0;
+                }
+            } else {
+                head = 0; count = 0;
+            }
+            rstate[0] = head; rstate[1] = count;
+        }
+        s_bonus = bonus;
+    }
+    __syncthreads();
+    if (reward && (has_prev || s_bonus))
+        for (int64_t i = tid; i < n; i += 256) {
+            float r = reward[i];
+            if (has_prev) r += sp;                                      // mcl.py:795
+            if (s_bonus) r += 1.0f;                                     // mcl.py:843
+            reward[i] = r;
+        }
+}
+
 // PredictionBonus / SurpriseBonus, behind the bonus (carle/mcl.py:686-694, 715-723): b_i = offset + sign * err_i (0.1 - err
 // or err), b_i *= 0 where instance i has no live cell (sums4[4i] == 0: the reference's per-instance Python loop with a host
 // synchronisation each), reward_i += scale * b_i -- product and sum rounded separately, as torch does.  live_total: the
@@ -286,6 +376,31 @@ extern "C" int carle_puffer_update_f32(const float *sums4, int64_t n, const int3
     hipLaunchKernelGGL(puffer_update_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), sums4, n, any_flag,
                        ring, ring_state, cap, live_total, reward);
     return check_launch("carle_puffer_update_f32");
+}
+
+extern "C" int carle_wrapper_scalars_local_f32(const float *sums4, const float *live4, int64_t n, float *com, int32_t *state,
+                                               float *velocity, float *live_out, const int32_t *any_flag, double *exch,
+                                               int what, void *stream) {
+    if (!sums4 || !exch) return fail_arg(CARLE_E_NULL, "carle_wrapper_scalars_local_f32: NULL pointer");
+    if ((what & 1) && (!com || !state || !velocity || !live_out))
+        return fail_arg(CARLE_E_NULL, "carle_wrapper_scalars_local_f32: SpeedDetector's buffers are NULL");
+    if (n < 0 || (what & ~3) || what == 0) return fail_arg(CARLE_E_DIMS, "carle_wrapper_scalars_local_f32: n >= 0 and what in 1..3 required");
+    hipLaunchKernelGGL(wrapper_scalars_local_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), sums4, live4, n,
+                       com, state, velocity, live_out, any_flag, exch, what);
+    return check_launch("carle_wrapper_scalars_local_f32");
+}
+
+extern "C" int carle_wrapper_scalars_apply_f32(const double *exch, int what, float *speed, float *ring, int32_t *ring_state,
+                                               int cap, float *live_total, float *reward, int64_t n, void *stream) {
+    if (!exch) return fail_arg(CARLE_E_NULL, "carle_wrapper_scalars_apply_f32: NULL pointer");
+    if ((what & 1) && !speed) return fail_arg(CARLE_E_NULL, "carle_wrapper_scalars_apply_f32: speed is NULL");
+    if ((what & 2) && (!ring || !ring_state || !live_total))
+        return fail_arg(CARLE_E_NULL, "carle_wrapper_scalars_apply_f32: PufferDetector's buffers are NULL");
+    if (n < 0 || (what & ~3) || what == 0 || ((what & 2) && cap < 2))
+        return fail_arg(CARLE_E_DIMS, "carle_wrapper_scalars_apply_f32: n >= 0, what in 1..3 and cap >= 2 required");
+    hipLaunchKernelGGL(wrapper_scalars_apply_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), exch, what, speed,
+                       ring, ring_state, cap, live_total, reward, n);
+    return check_launch("carle_wrapper_scalars_apply_f32");
 }
 
 extern "C" int carle_speed_puffer_f32(const float *obs, int64_t n, int64_t elems, const float *w_h, const float *w_w,

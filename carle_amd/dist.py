@@ -12,10 +12,19 @@ rank, latency-bound, one hop on the fully connected xGMI mesh -- and Chan-merged
 on every rank, so all ranks hold bit-identical statistics.  The merged triple also yields the
 batch-global scalars of the reference's harness (total reward, train_mcl.py:68-69).
 
-The master reset of CARLE.step fires on "every element of the whole action batch == 1"
-(env.py:208); under sharding it is evaluated per rank (documented deviation):
-``global_all_ones`` offers the exact global predicate as a 1-int all-reduce for callers that
-need it.
+Batch-global scalars of the reference under sharding:
+  * ``SpeedDetector``'s speed = sqrt(sum over ALL instances of velocity^2) (mcl.py:789) and
+    ``PufferDetector``'s live-cell total / "the action has a non-zero element" (mcl.py:832,835):
+    with a process group up the wrappers exchange them -- one all-reduce(SUM) of four doubles per
+    step (``batch_scalar_group``; ``per_rank_scalars`` opts a stack out);
+  * the harness's per-step reward total (train_mcl.py:68-69, eval.py:69-70): the step kernels
+    leave every step's reward moments in a device ring (``RunningRewardStats.start_trace``), one
+    all-reduce of the ring per inner loop (``drain_trace``) makes the totals global;
+  * the two whole-batch action predicates of CARLE.step (env.py:191 `if torch.sum(action)`,
+    env.py:208 master reset on "every element of the whole action batch == 1"): evaluated per rank
+    by default (the in-kernel decision of the one-launch step; synthetic agents never trigger the
+    reset); ``CARLE(global_action_predicates=True)`` evaluates them on the action first and
+    all-reduces the two flags (MAX) before the step kernel reads them (``all_reduce_flags``).
 """
 import os
 
@@ -31,13 +40,33 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-def init_from_env(backend="nccl", share_devices=False):
+_FORCE_COLLECTIVES = False
+
+
+def force_collectives(on=True):
+    """One-rank rehearsal of the RCCL path: with a process group of ONE rank up (``init_from_env(...,
+    single_rank_group=True)``) every exchange of this module -- the all-gather of the reward moments, the all-reduce of
+    the wrappers' batch-global scalars, of the trace totals, of the predictor gradients, the parameter broadcast --
+    goes through the group although it is the identity there.  What a one-GPU box can execute of the multi-GPU path."""
+    global _FORCE_COLLECTIVES
+    _FORCE_COLLECTIVES = bool(on)
+
+
+def exchanging(group=None):
+    """True when the exchanges have somebody to talk to: more than one rank in ``group``, or a forced one-rank group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES
+
+
+def init_from_env(backend="nccl", share_devices=False, single_rank_group=False):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run,
     or bench.py's own launcher) and bind this process to its GPU.  Returns (rank, world, device).
 
     One process per GPU: LOCAL_RANK must name an existing device.  ``share_devices=True`` (gloo
     rehearsals of the multi-rank path on a node with fewer GPUs) wraps LOCAL_RANK around the
-    device count instead of failing."""
+    device count instead of failing.  ``single_rank_group=True`` creates the group for WORLD_SIZE 1 too (see
+    ``force_collectives``)."""
     w = int(os.environ.get("WORLD_SIZE", "1"))
     r = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
@@ -49,7 +78,7 @@ def init_from_env(backend="nccl", share_devices=False):
     dev = torch.device("cuda", lr % count) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(dev)
-    if w > 1 and not dist.is_initialized():
+    if (w > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -104,6 +133,73 @@ class RunningRewardStats:
         self._batch = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._pending_steps = 0
         self._gathered = None
+        self._trace = None                  # (cap, 3) ring of per-step batch triples (start_trace)
+        self._trace_pos = 0
+
+    # ---- per-step reward totals of a harness loop (train_mcl.py:68-69, eval.py:69-70) -----------------------------
+    def start_trace(self, env, cap):
+        """Keep the (count, mean, M2) triple of EVERY step of ``env`` in a device ring of ``cap`` rows instead of the
+        last one only: where the step epilogue reduces the rewards itself (``attach``) the kernel that writes a step's
+        moments takes the next row (CARLE_ST_TRACE_*: no launch per step, nothing to copy); otherwise ``after_step``
+        points the stand-alone moments kernel at the row.  ``drain_trace`` turns the rows into per-step totals, global
+        over the ranks.  Returns whether the epilogue feeds the ring."""
+        self._trace = torch.zeros(max(int(cap), 2), 3, dtype=torch.float64, device=self.device)
+        self._trace_pos = 0
+        attached = self.attach(env)
+        inner = self.__dict__.get("_inner_env")
+        if inner is not None:
+            inner._write_stats_pointers()
+        return attached
+
+    def stop_trace(self):
+        self._trace = None
+        self._trace_pos = 0
+        inner = self.__dict__.get("_inner_env")
+        if inner is not None:
+            inner._write_stats_pointers()
+
+    def drain_trace(self):
+        """Per-step reward totals since ``start_trace`` / the last drain, oldest first, as a float64 numpy vector (at
+        most ``cap``): sum over ALL ranks' instances -- ONE all-reduce of the vector per call, not one per step.  Also
+        flushes the running statistics.  Synchronises (the only host round trip of an inner loop)."""
+        if self._trace is None:
+            raise RuntimeError("drain_trace() without start_trace()")
+        inner = self.__dict__.get("_inner_env")
+        if inner is not None:
+            inner.settled_status()            # a one-launch step's moments are written by the next call on the block
+        cap = self._trace.shape[0]
+        k = min(self._trace_pos, cap)
+        rows = self._trace[:k] if self._trace_pos <= cap else \
+            torch.roll(self._trace, -(self._trace_pos % cap), 0)
+        totals = (rows[:, 0] * rows[:, 1]).contiguous()
+        if exchanging() and k > 0:
+            dist.all_reduce(totals)
+        self.flush()
+        self._trace_pos = 0
+        if inner is not None:
+            inner._write_stats_pointers()     # the ring starts over
+        return totals.cpu().numpy()
+
+    def _trace_step(self, env, reward, stream):
+        """One step in trace mode: nothing to do when the epilogue took a row, else the moments kernel writes it."""
+        cap = self._trace.shape[0]
+        if getattr(env, "_moments_merged", False):
+            self._trace_pos += 1
+            return
+        row = self._trace[self._trace_pos % cap]
+        if self.device.type == "cuda":
+            from . import hip
+            hip.batch_moments_f32(reward.reshape(-1), row, self._pending, stream)
+        else:
+            x = reward.reshape(-1).to(torch.float64)
+            row.copy_(torch.stack([torch.tensor(float(x.numel()), dtype=torch.float64), x.mean() if x.numel() else x.sum(),
+                                   ((x - x.mean()) ** 2).sum() if x.numel() else x.sum()]))
+            self._pending.copy_(chan_merge(torch.stack([self._pending, row])))
+        self._trace_pos += 1
+        inner = self.__dict__.get("_inner_env")
+        if inner is not None:                 # an attached environment whose step did not merge: keep the device index in step
+            inner.settled_status()
+            inner._write_stats_pointers()
 
     def local_moments(self, reward):
         from . import hip
@@ -113,7 +209,7 @@ class RunningRewardStats:
         """All-gather the per-rank triples, merge them, fold into the running state."""
         local_triple = local_triple.to(self.device, torch.float64).reshape(1, 3)
         w = world()
-        if w > 1:
+        if exchanging():
             gathered = torch.empty(w, 3, dtype=torch.float64, device=self.device)
             dist.all_gather_into_tensor(gathered, local_triple)
         else:
@@ -159,6 +255,12 @@ class RunningRewardStats:
     def after_step(self, env, reward, stream=None):
         """Account for one finished step of ``env``: nothing to launch when its epilogue already
         merged the rewards (see ``attach``), else ``update(reward, stream)``."""
+        if self._trace is not None:
+            self._trace_step(env, reward, stream)
+            self._pending_steps += 1
+            if self._pending_steps >= self.sync_every:
+                return self.flush()
+            return None
         if getattr(env, "_moments_merged", False):
             self._pending_steps += 1
             if self._pending_steps >= self.sync_every:
@@ -180,7 +282,7 @@ class RunningRewardStats:
             return self.update_from_local(local)
         from . import hip
         w = world()
-        if w > 1:
+        if exchanging():
             if self._gathered is None or self._gathered.shape[0] != w:
                 self._gathered = torch.empty(w, 3, dtype=torch.float64, device=self.device)
             dist.all_gather_into_tensor(self._gathered, self._pending.reshape(1, 3))
@@ -220,9 +322,72 @@ def global_all_ones(local_not_all_ones_flag):
     per-rank "some element != 1" flag; returns a tensor that is 0 iff EVERY rank's action is all
     ones."""
     t = local_not_all_ones_flag.clone()
-    if world() > 1:
+    if exchanging():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
+
+
+def all_reduce_flags(status, slot, group=None):
+    """The two whole-batch action predicates of CARLE.step (env.py:191, 208) made global: ANY_NONZERO(slot) and
+    NOT_ALL_ONES(slot) of the status block are OR-ed over the ranks (all-reduce MAX of two int32) -- the master reset
+    then fires iff EVERY rank's action is all ones, ``steps_since_action`` counts steps without an action on ANY rank.
+    The flags must already be in the block (carle_action_flags_f32 / the pack kernels), the step kernel must read them
+    from there (publish = False)."""
+    flags = status[slot:slot + 3:2]
+    t = flags.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    flags.copy_(t)
+
+
+def batch_scalar_group(wrapper):
+    """-> ``(group,)`` when the batch-global scalars of a hand-coded wrapper (SpeedDetector, PufferDetector) have to be
+    exchanged -- a process group of more than one rank is up and the wrapper was not opted out -- else None.  ``group``
+    None = the default group; ``wrapper._scalar_group`` names another one."""
+    d = wrapper.__dict__
+    if d.get("batch_scalars", "global") == "per_rank":
+        return None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    g = d.get("_scalar_group")
+    return (g,) if exchanging(g) else None
+
+
+def per_rank_scalars(env, on=True):
+    """Opt the hand-coded wrappers of a stack out of (or back into) the exchange of their batch-global scalars: with
+    ``on`` every rank's SpeedDetector / PufferDetector sees its own shard only (speed over the shard's instances, growth
+    of the shard's live cells, the shard's action) -- NOT the unsharded run's rewards; for runs whose ranks are
+    independent experiments rather than shards of one batch."""
+    cur = env
+    while cur is not None:
+        if hasattr(cur, "inner_env") and cur.inner_env is not None:
+            cur.__dict__["batch_scalars"] = "per_rank" if on else "global"
+        cur = getattr(cur, "env", None)
+    return env
+
+
+def collective_info(dev=None):
+    """What a bench / test record needs to prove N ranks: backend, whether the group is up, the RCCL version torch was
+    built against, and every rank's (rank, local_rank, device index) gathered through the group itself."""
+    info = {"collective_backend_initialised": bool(dist.is_available() and dist.is_initialized()),
+            "backend": dist.get_backend() if dist.is_available() and dist.is_initialized() else None,
+            "world_size": world()}
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:                       # torch built without it: say so
+        info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    mine = [rank(), int(os.environ.get("LOCAL_RANK", "0")),
+            dev.index if dev is not None and dev.type == "cuda" and dev.index is not None else -1]
+    if exchanging():
+        on_device = dist.get_backend() == "nccl"
+        t = torch.tensor(mine, dtype=torch.int64, device=dev if on_device else "cpu")
+        rows = torch.empty(world() * 3, dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(rows, t)
+        rows = rows.reshape(-1, 3).tolist()
+    else:
+        rows = [mine]
+    info["rank_device_map"] = [{"rank": r[0], "local_rank": r[1], "device": r[2]} for r in rows]
+    return info
 
 
 def data_parallel(env, group=None, broadcast=True):
@@ -241,8 +406,7 @@ def data_parallel(env, group=None, broadcast=True):
         if isinstance(cur, RND2D):
             wrappers.append(cur)
         cur = getattr(cur, "env", None)
-    w = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    if w == 1 or not wrappers:
+    if not exchanging(group) or not wrappers:
         return wrappers
     inner = wrappers[0].inner_env
     on_device = dist.get_backend(group) == "nccl"

@@ -102,6 +102,11 @@ class CARLE(RLEMixin, nn.Module):
         # reductions per step, still no host synchronisation): actions whose values cancel, or
         # average to exactly 1.0 without all being 1, then behave as in the reference.
         self.exact_action_predicates = bool(kwargs.get("exact_action_predicates", False))
+        # batch sharding (carle_amd.dist): the two predicates are defined on the WHOLE batch's action.  Default: each
+        # rank decides from its shard inside its one-launch step.  True: the flags are evaluated on the action first and
+        # OR-ed over the ranks (all-reduce MAX of two int32 per step) before the step kernel reads them -- the master
+        # reset then fires iff every rank's action is all ones, as in the unsharded run.  No effect without a process group.
+        self.global_action_predicates = bool(kwargs.get("global_action_predicates", False))
         self.storage = kwargs.get("storage", "f32")
         if self.storage not in ("f32", "u8", "b1"):
             raise ValueError("storage must be 'f32' (reference format), 'u8' or 'b1' (bit-packed)")
@@ -190,9 +195,14 @@ class CARLE(RLEMixin, nn.Module):
         stats = self.__dict__.get("_reward_stats")
         if stats is None or self._status is None:
             return
-        ptrs = torch.tensor([stats._batch.data_ptr(), stats._pending.data_ptr()], dtype=torch.int64)
+        trace = stats.__dict__.get("_trace")
+        out = stats._batch if trace is None else trace       # a trace: MOMENTS_OUT is a ring of rows (CARLE_ST_TRACE_*)
+        ptrs = torch.tensor([out.data_ptr(), stats._pending.data_ptr()], dtype=torch.int64)
         self._status[hip.ST_MOMENTS_OUT:hip.ST_MOMENTS_OUT + 4] = \
             ptrs.view(torch.int32).to(self._status.device, non_blocking=True)
+        ring = torch.tensor([0 if trace is None else trace.shape[0],
+                             0 if trace is None else stats._trace_pos % trace.shape[0]], dtype=torch.int32)
+        self._status[hip.ST_TRACE_CAP:hip.ST_TRACE_CAP + 2] = ring.to(self._status.device, non_blocking=True)
 
     def _bits_buffer(self, out, slot):
         """Where the one-launch step of a 256- / 512-column fp32 grid leaves a bit-packed copy of its output (one buffer
@@ -335,6 +345,14 @@ class CARLE(RLEMixin, nn.Module):
         flags = torch.stack([torch.sum(a) != 0, torch.mean(a) != 1.0]).to(torch.int32)
         self._status[slot::2][:2] = flags                # words slot and 2 + slot
 
+    def _share_predicates(self):
+        """``global_action_predicates`` under an exchanging process group: the function that ORs this step's two flags
+        over the ranks (carle_amd.dist.all_reduce_flags), else None."""
+        if not self.global_action_predicates:
+            return None
+        from . import dist as cdist
+        return cdist.all_reduce_flags if cdist.exchanging() else None
+
     def _device_universe(self):
         u = self.universe
         if u is None:
@@ -392,9 +410,10 @@ class CARLE(RLEMixin, nn.Module):
         if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
             if tuple(action.shape) != (self.instances, 1, self.action_width, self.action_height):
                 raise AssertionError(f"action shape {action.shape} does not match the environment")
-            if (self.height == 64 and self.action_width % 8 == 0) or \
+            if self._share_predicates() is None and (
+                    (self.height == 64 and self.action_width % 8 == 0) or
                     (self.height in (256, 512) and self.action_width % 4 == 0 and
-                     (self.width - self.action_width) % 8 == 0):
+                     (self.width - self.action_width) % 8 == 0)):
                 # the toggles are drawn inside the step kernel: no action tensor exists
                 hip.env_step_f32_rand(u_in, out, reward, rule, self._status, slot, self.action_height,
                                       self.action_width, action.p, action.seed, action.offset, None, merge)
@@ -405,13 +424,17 @@ class CARLE(RLEMixin, nn.Module):
             action = action.materialize()
         act, cropped, full = self._device_action(action)
         publish = not cropped
+        share = self._share_predicates()
         if self.exact_action_predicates:
             self._exact_predicates(full, slot)
             publish = False
-        elif cropped:
+        elif cropped or share:
             # the two whole-batch predicates are defined on the action AS PASSED (env.py:191,208);
             # for an oversize action evaluate them on the uncropped tensor (cold path, no sync)
             hip.action_flags_f32(full.contiguous(), self._status, slot)
+            publish = False
+        if share:
+            share(self._status, slot)
         if launch is None:
             bits = self._bits_buffer(out, slot)
             if hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, publish, merge, bits_out=bits):
@@ -644,7 +667,7 @@ class CARLEPacked(CARLE):
         else:
             if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
                 if (tuple(action.shape) == (self.instances, 1, 64, 64) and self.action_width == 64
-                        and not self.exact_action_predicates):
+                        and not self.exact_action_predicates and self._share_predicates() is None):
                     # the toggles are drawn inside the packed step kernel: no action tensor exists
                     out = self._new_out(bits)
                     reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
@@ -666,6 +689,12 @@ class CARLEPacked(CARLE):
             else:
                 act = hip.pack_f32_b1(a32, self._status, slot)   # predicates of the fp32 values
             publish = False
+        share = self._share_predicates()
+        if share:
+            if publish:
+                raise NotImplementedError("global_action_predicates needs fp32 actions (a pre-packed action's predicates are "
+                                          "only known inside the step kernel)")
+            share(self._status, slot)
         out = self._new_out(bits)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
         merge = self.__dict__.get("_final_reward_stats") is not None
@@ -790,6 +819,7 @@ class CARLEBytes(CARLE):
         if getattr(action, "materialize", None) is not None:      # agents.DeviceRandomAction
             aw = self.action_width
             if (tuple(action.shape) == (self.instances, 1, aw, self.action_height) and not self.exact_action_predicates
+                    and self._share_predicates() is None
                     and ((self.height == 64 and aw % 8 == 0) or
                          (self.height in (256, 512) and aw % 4 == 0 and (self.width - aw) % 8 == 0))):
                 # the toggles are drawn inside the step kernel: no action tensor exists
@@ -803,7 +833,8 @@ class CARLEBytes(CARLE):
                 self.universe = out
                 return self._obs(), reward, _done_zeros(self.instances), [{}] * self.instances
             action = action.materialize()
-        if (isinstance(action, torch.Tensor) and action.dtype == torch.uint8 and action.is_cuda
+        share = self._share_predicates()
+        if (isinstance(action, torch.Tensor) and action.dtype == torch.uint8 and action.is_cuda and share is None
                 and tuple(action.shape) == (self.instances, 1, self.action_width, self.action_height)):
             act, cropped = action.contiguous(), False              # hot path: uint8 on the device
             if self.exact_action_predicates:
@@ -814,8 +845,11 @@ class CARLEBytes(CARLE):
             if self.exact_action_predicates:
                 self._exact_predicates(full, slot)
                 cropped = True
-            elif cropped:
+            elif cropped or share:
                 hip.action_flags_f32(full.contiguous(), self._status, slot)
+                cropped = True
+            if share:
+                share(self._status, slot)
         out = self._new_out(u_in)
         reward = torch.empty(self.instances, 1, dtype=torch.float32, device=self.my_device)
         merge = self.__dict__.get("_final_reward_stats") is not None

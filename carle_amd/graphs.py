@@ -93,6 +93,9 @@ class StepGraph:
             raise TypeError("action must be a static tensor on the environment's device")
         if base.logging:
             raise NotImplementedError("RLE logging runs on the host every step; not capturable")
+        if getattr(base, "_share_predicates", None) is not None and base._share_predicates() is not None:
+            raise NotImplementedError("global_action_predicates all-reduces two flags over the process group every step: a "
+                                      "collective is not part of a replayed step")
         w = env
         while w is not base:
             if getattr(w, "train_predictor", False):
@@ -104,6 +107,11 @@ class StepGraph:
             if hasattr(w, "grid_buffer"):
                 raise NotImplementedError(f"{type(w).__name__} rotates its frame buffer on the host every step (other "
                                           "frames, other pointers): its step cannot be replayed")
+            if type(w).__name__ in ("SpeedDetector", "PufferDetector"):
+                from .mcl import _scalar_group
+                if _scalar_group(w) is not None:
+                    raise NotImplementedError(f"{type(w).__name__} exchanges its batch-global scalars over the process group "
+                                              "every step (batch sharding): a collective is not part of a replayed step")
             if backend == "calls" and type(w).__name__ not in _LIBRARY_ONLY_WRAPPERS:
                 raise NotImplementedError(f"{type(w).__name__}.step also launches torch kernels: its step is not made of "
                                           "library calls alone -- use backend='graph'")

@@ -4,9 +4,16 @@
 cycling, state_dict + reward-trace dumps) and ``evaluate`` follows evaluation/eval.py:17-79
 (stack wrappers, optional weights, score = mean summed reward).  Same signatures and return
 values; differences: the per-step ``reward.sum().cpu()`` host round trips of the reference
-(train_mcl.py:68-69, eval.py:69-70) are deferred to the end of each inner loop, wrappers listed in
-``mcl`` are actually used (the reference hard-codes RND2D+AE2D), and environment kwargs can be
-passed through for small test geometries.
+(train_mcl.py:68-69, eval.py:69-70) are gone -- the kernel that finishes a step leaves the step's
+reward moments in a device ring (``dist.RunningRewardStats.start_trace``: no launch, no allocation
+per step where the step epilogue reduces the rewards; one moments launch otherwise) and the ring is
+drained once per inner loop --, wrappers listed in ``mcl`` are actually used (the reference
+hard-codes RND2D+AE2D), and environment kwargs can be passed through for small test geometries.
+
+Batch sharding (one process per GPU, ``carle_amd.dist``; ``instances`` = this rank's shard): with a
+process group up the per-step totals and the score are those of the WHOLE batch (one all-reduce of
+the drained ring per inner loop), the predictors are trained data-parallel, and SpeedDetector /
+PufferDetector exchange their batch-global scalars -- the sharded run reproduces the unsharded one.
 """
 import os
 import time
@@ -18,8 +25,14 @@ from .env import CARLE
 from .mcl import RND2D, AE2D
 
 
-def _drain(sums):
-    return torch.stack(sums).detach().cpu().numpy() if sums else np.zeros(0, np.float32)
+def _reward_trace(env, steps):
+    """Per-step reward totals of one inner loop (train_mcl.py:68-69, eval.py:69-70) without a host round trip or a
+    reduction launch per step, global under batch sharding: see ``RunningRewardStats.start_trace`` / ``drain_trace``."""
+    from . import dist as cdist
+    inner = env.inner_env if env.inner_env is not None else env
+    stats = cdist.RunningRewardStats(inner.my_device, sync_every=1 << 30)      # flushed by the drain, once per loop
+    stats.start_trace(env, max(int(steps), 1))
+    return stats
 
 
 def _data_parallel_or_warn(env):
@@ -52,18 +65,18 @@ def train(agent_fn, instances=16, steps=(64, 2048), rules=(((3,), (2, 3)),), mcl
                      action_width=env.inner_env.action_width, action_height=env.inner_env.action_height)
     exp_id = "mcl" + str(int(time.time()))
     rewards = []
+    stats = _reward_trace(env, steps[1])
     for epoch in range(steps[0]):
         for ruleset in rules:
             env.inner_env.birth = list(ruleset[0])
             env.inner_env.survive = list(ruleset[1])
             obs = env.reset()
             t1 = time.time()
-            sums = []
             for step in range(steps[1]):
                 action = agent(obs)
                 obs, reward, done, info = env.step(action)
-                sums.append(reward.detach().sum())
-            trace = _drain(sums)                       # one host sync per inner loop
+                stats.after_step(env, reward)
+            trace = stats.drain_trace().astype(np.float32)     # one host sync (and one all-reduce) per inner loop
             rewards.extend(list(trace))
             t2 = time.time()
             if verbose:
@@ -96,18 +109,22 @@ def evaluate(Agent, rules, wrappers, params_path=None, steps=1024, verbose=True,
         if wrapper[2] is not None:
             env.load_state_dict(torch.load(wrapper[2], map_location="cpu"))
         env.eval()
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        from . import dist as cdist
+        cdist.data_parallel(env)                     # batch sharding: rank 0's networks everywhere, one global update
     score, total_steps, score_trace = 0.0, 0, []
+    stats = _reward_trace(env, steps)
     for ruleset in rules:
         env.inner_env.birth = list(ruleset[0])
         env.inner_env.survive = list(ruleset[0])     # sic: the reference assigns ruleset[0] twice (eval.py:59)
         obs = env.reset()
-        sums = []
         for step in range(steps):
             action = agent(obs)
             obs, reward, done, info = env.step(action)
-            sums.append(reward.detach().sum())
+            stats.after_step(env, reward)
             total_steps += 1
-        trace = _drain(sums)
+        trace = stats.drain_trace().astype(np.float32)
         score += float(trace.sum())
         score_trace.extend(list(trace))
         if verbose:

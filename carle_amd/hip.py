@@ -12,6 +12,7 @@ from . import _lib
 STATUS_WORDS = 32
 ST_LAST_RESET, ST_STEP_NUMBER, ST_STEPS_SINCE_ACTION, ST_RESETS = 4, 6, 8, 10
 ST_MOMENTS_OUT, ST_MOMENTS_ACC = 12, 14      # two 64-bit device pointers (see carle_hip.h)
+ST_TRACE_CAP, ST_TRACE_IDX = 24, 25          # ring of per-step reward moments behind MOMENTS_OUT (CARLE_ST_TRACE_*)
 
 
 _gpu_ok = False
@@ -726,6 +727,30 @@ def puffer_update_f32(sums4, any_flag_ptr, ring, ring_state, live_total, reward)
         _lib.check(rc, "carle_puffer_update_f32")
 
 
+def wrapper_scalars_local(sums4, live4, com, state, velocity, live_out, any_flag_ptr, exch, what):
+    """Per-shard part of SpeedDetector (what & 1) / PufferDetector (what & 2) under batch sharding: leaves this shard's
+    four terms in ``exch`` (fp64[4]) for the all-reduce (carle_wrapper_scalars_local_f32)."""
+    lib = _lib.load()
+    with _on_device(sums4.device):
+        rc = lib.carle_wrapper_scalars_local_f32(sums4.data_ptr(), _ptr(live4), sums4.shape[0], _ptr(com), _ptr(state),
+                                                 _ptr(velocity), _ptr(live_out), any_flag_ptr, exch.data_ptr(), int(what),
+                                                 _stream(sums4))
+    if rc != 0:
+        _lib.check(rc, "carle_wrapper_scalars_local_f32")
+
+
+def wrapper_scalars_apply(exch, what, speed, ring, ring_state, live_total, reward):
+    """The updates finished with the all-reduced ``exch`` (carle_wrapper_scalars_apply_f32): reward += global speed,
+    PufferDetector's history on the global live-cell total."""
+    lib = _lib.load()
+    with _on_device(exch.device):
+        rc = lib.carle_wrapper_scalars_apply_f32(exch.data_ptr(), int(what), _ptr(speed), _ptr(ring), _ptr(ring_state),
+                                                 ring.numel() if ring is not None else 0, _ptr(live_total),
+                                                 reward.data_ptr(), reward.numel(), _stream(exch))
+    if rc != 0:
+        _lib.check(rc, "carle_wrapper_scalars_apply_f32")
+
+
 def morpho_match_f32(universe, action, patterns, reward=None, reward_scale=1.0, partial=None):
     """MorphoBonus (carle_morpho_match_f32, mcl.py:170-183): (N,2) = [max, min] over all patterns and positions of
     conv2d(|universe - action|, patterns); with ``reward`` (N,1): reward += reward_scale * (max + min).
@@ -801,6 +826,26 @@ def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_fl
                                         stream_env, stream_reward)
     if rc != 0:
         _lib.check(rc, "carle_env_step_f32_rnd")
+
+
+def env_step_f32_rnd_ae(u_in, action, u_out, reward, rule, status, slot, publish_flags, rnd_pred, rnd_rand, rnd_ws,
+                        rnd_bonus, rnd_scale, rnd_valid, ae_params, ae_ws, ae_bonus, ae_scale, ae_valid,
+                        merge_moments=False, partials=None):
+    """AE2D(RND2D(CARLE)).step with both wrappers forward-only at 64x64, more than 16 instances: ONE launch
+    (carle_env_step_f32_rnd_ae).  ``partials``: fp64 scratch of carle_rnd_ae_step_partials_doubles(n) elements when
+    merge_moments."""
+    lib = _lib.load()
+    n, _, h, w = u_in.shape
+    ap, ah, aw = (None, 0, 0) if action is None else (action.data_ptr(), action.shape[2], action.shape[3])
+    with _on_device(u_in.device):
+        rc = lib.carle_env_step_f32_rnd_ae(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h, w, ah, aw, rule,
+                                           status.data_ptr(), slot, _step_flags(publish_flags, merge_moments, True),
+                                           rnd_pred.data_ptr(), rnd_rand.data_ptr(), rnd_ws.data_ptr(), rnd_bonus.data_ptr(),
+                                           float(rnd_scale), 2 if rnd_valid else 0, ae_params.data_ptr(), ae_ws.data_ptr(),
+                                           ae_bonus.data_ptr(), float(ae_scale), 2 if ae_valid else 0, _ptr(partials),
+                                           _stream(u_in))
+    if rc != 0:
+        _lib.check(rc, "carle_env_step_f32_rnd_ae")
 
 
 def ca_step_f32_rnd(u_in, action, u_out, rule, status, slot, pred_params, rand_params, workspace, bonus,

@@ -11,10 +11,11 @@ Underneath, every forward pass that produces a reward (``get_bonus``, ``get_bonu
 The predictor UPDATE (mcl.py:333-341, 354-386): the gradient of the update window is accumulated by
 the training kernels (``carle_rnd2d_train_*`` / ``carle_ae2d_train_*``: fused at 64x64, tiled at
 multiples of 64, staged otherwise) in the same pass that produces the bonus, and ``optimizer.step()``
-is ``carle_adam_update_f32`` (torch.optim.Adam's arithmetic in one launch).  PyTorch autograd is only
-used for geometries the kernels do not cover (H != W or not a multiple of 8): the observations of
-the window are then retained and replayed.  The hand-coded wrappers (Parsimony / Corner / Speed /
-Puffer) keep their per-step state on the device: no host synchronisation per step.
+is ``carle_adam_update_f32`` (torch.optim.Adam's arithmetic in one launch).  There is no autograd path
+behind ``step`` / ``get_bonus_*``: a geometry the gradient kernels do not cover (H = W not a multiple of 8)
+raises ``NotImplementedError`` when an update is asked for (the forward bonus works wherever the staged
+kernels are defined); only a caller's own ``update_predictor(loss)`` differentiates its own loss.  The hand-coded
+wrappers (Parsimony / Corner / Speed / Puffer) keep their per-step state on the device: no host synchronisation per step.
 """
 import weakref
 
@@ -30,7 +31,7 @@ from . import hip
 # nn.Module.__setattr__'s parameter / buffer / sub-module handling (~1 us each)
 _PLAIN_WRAPPER_ATTRS = frozenset((
     "_ws", "_tables_key", "_tables_key_next", "_bonus_buf", "_step_bonus", "buffer_length",
-    "accumulate_loss", "_window", "_grad_used", "live_cells", "speed", "velocity", "center_of_mass",
+    "accumulate_loss", "_grad_used", "live_cells", "speed", "velocity", "center_of_mass",
     "growing_steps"))
 
 
@@ -137,7 +138,6 @@ class RND2D(Motivator):
         self.buffer_length = 0
         self.batch_size = 64
         self.updates = 0
-        self._window = []                    # observations of the current update window
         self._ws = None                      # kernel workspace, reused across steps
         self._tables_key = None              # what the fused-path tables in _ws were built from
         self._tables_key_next = (False, None)
@@ -290,98 +290,27 @@ class RND2D(Motivator):
         prediction = self.predictor(obs)
         return torch.mean(torch.abs((target - prediction) ** 2), dim=[1])
 
-    # -- observation window of the autograd replay (sizes without a fused gradient kernel) --------
-    # retained bytes above which the window is replayed early (gradients keep accumulating in .grad:
-    # parameters are constant inside a window, so the sum is the same)
-    window_bytes_cap = 256 << 20
-
-    def _retain(self, obs, scale=None):
-        """Keeps ``obs`` for the replay.  Binary observations (anything CARLE.step returned) are kept
-        bit-packed (carle_pack_f32_b1: 1/32 of the fp32 bytes) and unpacked per replay chunk; nothing
-        is kept while no predictor parameter requires a gradient (``set_no_grad``).  ``scale``: the loss
-        scale of an EARLY replay when the retained bytes exceed ``window_bytes_cap`` (the window's own scale --
-        1 / batch_size for ``get_bonus_accumulate``); None = never replay early (``get_bonus_update`` replays the
-        one observation itself, with scale 1)."""
-        if not any(p.requires_grad for p in self._pred_blob.params or self.predictor.parameters()):
-            return
-        o, binary = self._obs(obs)
-        if binary and o.dtype == torch.float32 and o.shape[3] % 64 == 0:
-            o = hip.pack_f32_b1(o)
-        self._window.append(o)
-        self.__dict__["_window_bytes"] = self.__dict__.get("_window_bytes", 0) + o.numel() * o.element_size()
-        if scale is not None and self.__dict__["_window_bytes"] > self.window_bytes_cap:
-            self.accumulate_loss = self.accumulate_loss + self._replay_window(scale)
-
-    def _drop_window(self):
-        self._window = []
-        self.__dict__["_window_bytes"] = 0
-
     def update_predictor(self, loss):
         loss.backward()
         # torch's optimizer.step() below consumes the autograd .grad tensors only: the kernel gradient of a window in
         # flight (self._grad) is reduced where it is consumed, in _apply_update
         self._sync_gradients(self._pred_blob.params or list(self.predictor.parameters()), kernel_gradient=False)
         self.optimizer.step()
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=True)
         self.updates += 1
-
-    # cells per autograd pass of the window replay (64 MiB of fp32 input; bounds the activation
-    # memory -- AE2D keeps 4 x (H/2) x (W/2) floats per grid -- and keeps the convolution shapes in
-    # the range MIOpen handles without minutes of first-use tuning)
-    replay_cells = 1 << 24
-
-    def _replay_window(self, scale):
-        """backward of sum_t mean_n(loss_t) * scale over the retained window.  Every step holds
-        the same number of grids, so sum_t mean_n = T * mean_{t,n}: the window is replayed in a few
-        LARGE batches (torch.cat of up to ``replay_cells`` cells) instead of one small pass per step
-        -- at the reference's default geometry (16 instances of 256x256) the per-step passes are pure
-        launch overhead.  Gradients accumulate in .grad exactly as one backward through the summed
-        graph (same sum, different association)."""
-        total = 0.0
-        window, self._window = self._window, []
-        self.__dict__["_window_bytes"] = 0
-        # eval-mode semantics everywhere (Dropout = identity), like the HIP bonus and gradient
-        # kernels: the replay must differentiate the SAME function the reward was computed with,
-        # whatever mode the caller left the wrapper in (the reference's train-mode dropout noise is
-        # a documented deviation, DESIGN.md section 7)
-        was_training = self.predictor.training
-        self.predictor.eval()
-        try:
-            i = 0
-            while i < len(window):
-                cells = max(int(window[i].numel()) * (64 if window[i].dtype == torch.int64 else 1), 1)
-                k = max(1, min(len(window) - i, self.replay_cells // cells))
-                chunk = window[i:i + k]
-                same = all(o.shape == chunk[0].shape and o.dtype == chunk[0].dtype for o in chunk)
-                if not (k > 1 and same):
-                    k, chunk = 1, chunk[:1]
-                batch = torch.cat(chunk, dim=0) if k > 1 else chunk[0]
-                if batch.dtype == torch.int64:
-                    batch = hip.unpack_b1_f32(batch)
-                loss = torch.mean(self._torch_loss(batch)) * (k * scale)
-                loss.backward()
-                total = total + loss.detach()
-                i += k
-        finally:
-            self.predictor.train(was_training)
-        return total
 
     def get_bonus_update(self, obs):
         """Bonus + immediate predictor update on this observation (mcl.py:354-366): the gradient of
         mean_n(loss_n) through the HIP training kernels (fused / tiled / staged, as ``get_bonus_accumulate``),
-        then one Adam step -- no autograd graph.  Geometries the kernels do not cover (H != W or not a multiple
-        of 8) replay the observation through autograd."""
-        self.predictor.zero_grad()                           # drops whatever a window had accumulated, as the reference
+        then one Adam step -- no autograd graph."""
+        self.predictor.zero_grad(set_to_none=True)           # drops whatever a window had accumulated, as the reference
         self._clear_kept_gradient()
         if self._grad is not None and self._grad_used:
             self._grad.zero_()
             self._grad_used = False
-        self._drop_window()
         o = self._obs(obs, allow_packed=True)[0]
         bonus = torch.empty(o.shape[0], dtype=torch.float32, device=o.device)
-        if not self._fused_train(obs, None, bonus, None, batch=1):
-            bonus = self.get_bonus(obs)
-            self._retain(obs)                                # never replayed early: scale 1 below
+        self._fused_train(obs, None, bonus, None, batch=1)
         self._apply_update()
         self._after_update()
         return bonus
@@ -392,20 +321,17 @@ class RND2D(Motivator):
         n = o.shape[0]
         bonus = torch.empty(n, dtype=torch.float32, device=o.device)
         if self.buffer_length == 0:
-            self.predictor.zero_grad()
+            self.predictor.zero_grad(set_to_none=True)
             self._clear_kept_gradient()
             self.accumulate_loss = 0.0
-            self._drop_window()
-        if not self._fused_train(obs, None, bonus, None):
-            self._retain(obs, 1.0 / self.batch_size)
-            bonus = self.get_bonus(obs)
+        self._fused_train(obs, None, bonus, None)
         self.buffer_length += 1
         if self.buffer_length >= self.batch_size:
             self._finish_window()
         return bonus
 
     def _after_update(self):
-        self.optimizer.zero_grad()           # RND2D.update_predictor, mcl.py:339
+        self.optimizer.zero_grad(set_to_none=True)           # RND2D.update_predictor, mcl.py:339
         self.updates += 1
 
     # AE2D.update_predictor steps WITHOUT zeroing the gradients (mcl.py:498-502): the window's gradient stays in .grad
@@ -422,8 +348,7 @@ class RND2D(Motivator):
     # ------------------------------------------------------------------ gym surface
     def _bonus_into(self, obs, reward, stream=None):
         """reward += reward_scale * bonus(obs), fused into the bonus kernel (mcl.py:403-405); in
-        training mode the predictor's gradient is accumulated on the way (fused kernel) or the
-        observation is retained for the autograd replay."""
+        training mode the predictor's gradient is accumulated on the way (the training kernels)."""
         n = reward.shape[0]
         if self._bonus_buf is None or self._bonus_buf.shape[0] != n or self._bonus_buf.device != reward.device:
             self._bonus_buf = torch.empty(n, dtype=torch.float32, device=reward.device)
@@ -431,33 +356,28 @@ class RND2D(Motivator):
             self._hip_forward(obs, False, reward, self._bonus_buf, stream)
             return
         if self.buffer_length == 0:
-            self.predictor.zero_grad()
+            self.predictor.zero_grad(set_to_none=True)
             self._clear_kept_gradient()
             self.accumulate_loss = 0.0
-            self._drop_window()
-        if not self._fused_train(obs, reward, self._bonus_buf, stream):
-            self._retain(obs, 1.0 / self.batch_size)
-            self._hip_forward(obs, False, reward, self._bonus_buf, stream)
+        self._fused_train(obs, reward, self._bonus_buf, stream)
         self.buffer_length += 1
         if self.buffer_length >= self.batch_size:
             self._finish_window()
 
     def _finish_window(self):
         """End of an update window (mcl.py:380-384, 333-341): one Adam step on the window's gradient."""
-        self._apply_update(1.0 / self.batch_size)
+        self._apply_update()
         self._after_update()
         self.buffer_length = 0
 
     # ---- optimizer.step() ------------------------------------------------------------------------------------
-    def _apply_update(self, replay_scale=1.0):
+    def _apply_update(self):
         """optimizer.step() on the gradient of the window: the flat gradient the HIP training kernels accumulated
         goes through ``carle_adam_update_f32`` (torch.optim.Adam's arithmetic in one launch, parameters and the
         kernels' parameter blob updated in place, Adam's moments shared with ``self.optimizer.state`` so that
-        ``optimizer.state_dict()`` keeps working).  Retained observations (geometries without gradient kernels) are
-        replayed through autograd first; whenever autograd gradients or a non-default optimiser are involved the
-        step is torch's own."""
-        if self._window:
-            self.accumulate_loss = self.accumulate_loss + self._replay_window(replay_scale)
+        ``optimizer.state_dict()`` keeps working).  Whenever a caller's own autograd gradients (``.grad`` left by its
+        ``loss.backward()``) or a non-default optimiser are involved, the kernel gradient is added to ``.grad`` and the
+        step is the optimiser's own."""
         params = self._pred_blob.params or list(self.predictor.parameters())
         self._sync_gradients(params)
         if self._grad_used and self._hip_adam_applies(params):
@@ -489,7 +409,7 @@ class RND2D(Motivator):
         if kernel_gradient and self._grad_used:
             self._grad.mul_(weight)
             tdist.all_reduce(self._grad, group=group)
-        grads = [p.grad for p in params if p.grad is not None]       # autograd replay / caller's own backward
+        grads = [p.grad for p in params if p.grad is not None]       # a caller's own backward
         if grads:
             flat = torch.cat([g.reshape(-1) for g in grads]).mul_(weight)
             tdist.all_reduce(flat, group=group)
@@ -564,10 +484,6 @@ class RND2D(Motivator):
     # (tiled forward, nets_tiled.hip)
     _packed_any_size = True
 
-    # False: sizes without a fused gradient kernel retain the window and replay it through PyTorch
-    # autograd (the round-1 path; kept for A/B tests) instead of the staged HIP backward kernels
-    hip_backward_any_size = True
-
     def _tiled_train_buffers(self, o):
         """Workspace, scratch and gradient buffers of the tiled training kernels for the binary observations ``o``
         (as ``_fused_train`` sets them up); returns (predictor blob, random-network blob or None, tables valid,
@@ -601,31 +517,32 @@ class RND2D(Motivator):
 
     def _fused_train(self, obs, reward, bonus_out, stream, batch=None):
         """Bonus + gradient in one library call (carle_rnd2d_train_* / carle_ae2d_train_*): the fused
-        forward+backward kernel for 64x64 binary observations, staged forward + staged backward HIP
-        kernels for every other square size that is a multiple of 8 (the reference's default 256x256).
-        Returns False when neither applies (the caller then retains the observation for the autograd
-        replay)."""
-        # the gradient kernels implement exactly these classes' networks: a subclass of unknown architecture falls
-        # back to the autograd replay of its own ``_torch_loss``
+        forward+backward kernel for 64x64 binary observations, tiled kernels for binary grids of a multiple of 64,
+        staged forward + staged backward HIP kernels for every other square size that is a multiple of 8.  Anything
+        else raises: there is no autograd path behind the bonus calls."""
+        # the gradient kernels implement exactly these classes' networks
         family = _HIP_NET_FAMILY.get(type(self))
         if family is None:
-            return False
+            raise NotImplementedError(f"{type(self).__name__}: the HIP gradient kernels implement the RND2D / AE2D networks of "
+                                      "carle/mcl.py only; a subclass with another architecture must train through its own "
+                                      "update_predictor(loss)")
         is_ae = family == "ae"
         o, binary = self._obs(obs, allow_packed=True)
         packed = o.dtype == torch.int64
         fused64 = binary and o.shape[2] == 64 and (packed or o.shape[3] == 64)
         size_w = o.shape[3] * 64 if packed else o.shape[3]
         # binary grids with H = W a multiple of 64 (the reference's default 256x256): tiled kernels (nets_tiled.hip)
-        tiled = (binary and not fused64 and self.hip_backward_any_size and o.dim() == 4
+        tiled = (binary and not fused64 and o.dim() == 4
                  and o.shape[2] == size_w and o.shape[2] % 64 == 0 and o.shape[2] > 64)
         if not fused64 and not tiled:
-            if not self.hip_backward_any_size:
-                return False
             if packed:
                 o, binary = self._obs(obs)                 # unpacked fp32
                 packed = False
             if o.dim() != 4 or o.shape[2] != o.shape[3] or o.shape[2] % 8 or o.shape[2] < 8:
-                return False
+                raise NotImplementedError(f"{type(self).__name__}: predictor updates need square observations with H = W a "
+                                          f"multiple of 8 (got {tuple(o.shape)}): the HIP gradient kernels cover nothing "
+                                          "else and there is no autograd fallback (set train_predictor=False for the "
+                                          "forward bonus alone)")
         uses_tables = fused64 or tiled
         from . import _lib
         lib = _lib.load()
@@ -818,11 +735,19 @@ class AE2D(RND2D):
         training step (both with predictor updates through the HIP gradient kernels)."""
         rnd, env = self.env, self.inner_env
         if not (type(self) is AE2D and type(rnd) is RND2D and rnd.env is env and not self.async_reward
-                and not rnd.async_reward and env.height == env.width and env.height > 64 and env.height % 64 == 0):
+                and not rnd.async_reward and env.height == env.width and env.height % 64 == 0):
+            return 0
+        if env.height == 64:
+            # 64x64: the WHOLE step -- CA generation, both bonuses, the reward -- is one launch (carle_env_step_f32_rnd_ae)
+            # for forward-only wrappers on an fp32 environment of more than 16 instances with an 8-aligned window
+            if (not self.train_predictor and not rnd.train_predictor and getattr(env, "storage", "f32") == "f32"
+                    and not env.logging and env.instances > 16 and env.action_width % 8 == 0
+                    and os.environ.get("CARLE_FUSED_RND_AE", "1") != "0"):      # (A/B switch)
+                return 3
             return 0
         if not self.train_predictor and not rnd.train_predictor:
             return 1
-        if self.train_predictor and rnd.train_predictor and self.hip_backward_any_size and rnd.hip_backward_any_size:
+        if self.train_predictor and rnd.train_predictor:
             return 2
         return 0
 
@@ -833,11 +758,15 @@ class AE2D(RND2D):
         tile of a grid finishes it) instead of four -- a step there is bound by its dependent dispatches.  Bit-identical to the
         two wrappers stepping one after the other."""
         mode = self._can_pair_step()
+        if mode == 3 and not isinstance(action, torch.Tensor):
+            mode = 0                                         # (array-likes / in-kernel random actions: the wrappers one by one)
         if not mode:
             return super().step(action)
         rnd, env = self.env, self.inner_env
         if isinstance(action, torch.Tensor):
             action = action.to(env.my_device)
+        if mode == 3:
+            return self._fused64_step(action)
         rnd.__dict__["_moments_merged"] = False
         self.__dict__["_moments_merged"] = False
         obs, reward, done, info = env.step(action)
@@ -873,6 +802,48 @@ class AE2D(RND2D):
         self._pair_moments_left(partials)
         return obs, reward, done, info
 
+    def _fused64_step(self, action):
+        """AE2D(RND2D(CARLE)).step at 64x64, forward passes: environment step, RND2D bonus, AE2D bonus and the reward in ONE
+        kernel (carle_env_step_f32_rnd_ae) -- the AE2D forward runs on the bit rows the CA + RND2D workgroup still holds.
+        Bit-identical to RND2D's one-launch step followed by AE2D's bonus kernel on its observation."""
+        from . import _lib
+        lib = _lib.load()
+        rnd, env = self.env, self.inner_env
+        dev, n = env.my_device, env.instances
+        for w, need in ((rnd, lib.carle_rnd2d_workspace_floats(n, 64, 64)), (self, lib.carle_ae2d_workspace_floats(n, 64, 64))):
+            if w._ws is None or w._ws.numel() < need or w._ws.device != dev:
+                w._ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
+                w._tables_key = None
+        if rnd._step_bonus is None or rnd._step_bonus.shape[0] != n + 1 or rnd._step_bonus.device != dev:
+            rnd._step_bonus = torch.empty(n + 1, dtype=torch.float32, device=dev)
+        if self._bonus_buf is None or self._bonus_buf.shape[0] != n or self._bonus_buf.device != dev:
+            self._bonus_buf = torch.empty(n, dtype=torch.float32, device=dev)
+        pb, rb, ab = rnd._pred_blob.get(dev), rnd._rand_blob.get(dev), self._pred_blob.get(dev)
+        rkey = (id(rnd._ws), (rnd._pred_blob.version, rnd._rand_blob.version))          # RND2D._fused_step's key form
+        akey = (id(self._ws), (self._pred_blob.version,), n, 64)                        # _commit_tables' key form
+        rvalid, avalid = rnd._tables_key == rkey, self._tables_key == akey
+        merge = self.__dict__.get("_final_reward_stats") is not None                    # this wrapper is outermost
+        partials = None
+        if merge:
+            pneed = lib.carle_rnd_ae_step_partials_doubles(n)
+            partials = self.__dict__.get("_mom_partials")
+            if partials is None or partials.numel() < pneed or partials.device != dev:
+                env.settled_status()                         # nothing may still point into the old buffer
+                partials = self.__dict__["_mom_partials"] = torch.zeros(pneed, dtype=torch.float64, device=dev)
+
+        def launch(u_in, act, out, reward, rule, status, slot, publish):
+            hip.env_step_f32_rnd_ae(u_in, act, out, reward, rule, status, slot, publish, pb, rb, rnd._ws, rnd._step_bonus,
+                                    rnd.reward_scale, rvalid, ab, self._ws, self._bonus_buf, self.reward_scale, avalid,
+                                    merge, partials)
+            if merge:
+                env.__dict__["_moments_pending"] = True
+        rnd.__dict__["_moments_merged"] = False
+        self.__dict__["_moments_merged"] = False
+        result = env._step(action, launch)
+        self.__dict__["_moments_merged"] = merge
+        rnd._tables_key, self._tables_key = rkey, akey
+        return result
+
     def _pair_moment_buffers(self, need, dev):
         """RunningRewardStats attached to this pair (``attach``): the pair's finish kernel leaves per-workgroup partial sums
         of the step's final rewards and registers them in the environment's status block; the next environment step (or
@@ -898,10 +869,9 @@ class AE2D(RND2D):
         rnd = self.env
         for w in (rnd, self):
             if w.buffer_length == 0:
-                w.predictor.zero_grad()
+                w.predictor.zero_grad(set_to_none=True)
                 w._clear_kept_gradient()
                 w.accumulate_loss = 0.0
-                w._drop_window()
         pb, rb, rvalid, rkey, rgs = rnd._tiled_train_buffers(o)
         ab, _, avalid, akey, ags = self._tiled_train_buffers(o)
         hip.rnd_ae_train(o, pb, rb, rnd._ws, rnd._partial, rnd._grad, rnd._bonus_buf, rnd.reward_scale, rgs, rvalid,
@@ -1021,12 +991,11 @@ class PredictionBonus(AE2D):
 
     def get_bonus_update(self, obs):
         """mcl.py:644-656: zero_grad, the loss of this call, one Adam step on the gradient of its batch mean."""
-        self.predictor.zero_grad()
+        self.predictor.zero_grad(set_to_none=True)
         self._clear_kept_gradient()
         if self._grad is not None and self._grad_used:
             self._grad.zero_()
             self._grad_used = False
-        self._drop_window()
         bonus = self._predict(obs, True, batch=1)
         self._apply_update()
         self._after_update()
@@ -1035,10 +1004,9 @@ class PredictionBonus(AE2D):
     def get_bonus_accumulate(self, obs):
         """mcl.py:658-677: the loss now, an Adam step on the window's mean gradient every ``batch_size`` calls."""
         if self.buffer_length == 0:
-            self.predictor.zero_grad()
+            self.predictor.zero_grad(set_to_none=True)
             self._clear_kept_gradient()
             self.accumulate_loss = 0.0
-            self._drop_window()
         bonus = self._predict(obs, True)
         self.buffer_length += 1
         if self.buffer_length >= self.batch_size:
@@ -1191,13 +1159,17 @@ class MorphoBonus(Motivator):
 
     def reset(self):
         obs = self.env.reset()
-        # imagine a little seed for nucleating patterns (mcl.py:189-190: CPU generator, then moved)
-        seed = (torch.rand(obs.shape) > 0.995).to(self.my_device).float()
-        if obs.dtype == torch.float32 and obs is self.inner_env.universe:
-            obs += seed
+        inner = self.inner_env
+        # imagine a little seed for nucleating patterns (mcl.py:189-190: CPU generator, then moved) -- always of the
+        # UNIVERSE's shape (a packed observation has another one)
+        seed = (torch.rand(inner.instances, 1, inner.height, inner.width) > 0.995).to(self.my_device).float()
+        if getattr(inner, "storage", "f32") == "f32" and obs.dtype == torch.float32 and obs is inner.universe:
+            obs += seed                                      # the reference's in-place add: obs IS the state tensor
         else:
-            self.inner_env.universe = _as_device_f32(obs, self.my_device) + seed
-            obs = self.inner_env.get_observation()
+            # uint8 / bit-packed state (or a wrapper below that returned another tensor): through the setter, so that the
+            # state the step kernels read holds the seed -- not a lazily unpacked fp32 view of it
+            inner.universe = _as_device_f32(inner.universe, self.my_device) + seed
+            obs = inner.get_observation()
         return obs
 
 
@@ -1238,6 +1210,30 @@ def _live_sums(inner, dev):
     sums = hip.instance_sums_f32(_as_device_f32(u, dev))
     inner.__dict__["_live_cache"] = (weakref.ref(u), u._version, sums)
     return sums
+
+
+def _scalar_group(w):
+    """``(group,)`` when this wrapper's batch-global scalars are exchanged over a process group (batch sharding,
+    carle_amd.dist.batch_scalar_group), None for a single process / a per-rank stack."""
+    import torch.distributed as tdist
+    if not (tdist.is_available() and tdist.is_initialized()):
+        return None
+    from . import dist as cdist
+    return cdist.batch_scalar_group(w)
+
+
+def _exchange_buffer(w, dev):
+    """fp64[4] on the device: [sum v^2, had a previous centre of mass, live cells, action had a non-zero] of this shard,
+    all-reduced in place (carle_wrapper_scalars_local_f32 / _apply_f32)."""
+    e = w.__dict__.get("_exch")
+    if e is None or e.device != dev:
+        e = w.__dict__["_exch"] = torch.zeros(4, dtype=torch.float64, device=dev)
+    return e
+
+
+def _all_reduce_sum(t, grp):
+    import torch.distributed as tdist
+    tdist.all_reduce(t, group=grp[0])
 
 
 class SpeedDetector(Motivator):
@@ -1307,7 +1303,16 @@ class SpeedDetector(Motivator):
         com, vel, speed, live, has_prev = self._dev_buffers(sums.shape[0], dev)
         if not reward.is_contiguous():                      # (never for the rewards this package produces)
             raise ValueError("SpeedDetector needs a contiguous reward tensor")
-        hip.speed_update_f32(sums, live4, com, has_prev, vel, speed, live, reward.reshape(-1))
+        grp = _scalar_group(self)
+        if grp is None:
+            hip.speed_update_f32(sums, live4, com, has_prev, vel, speed, live, reward.reshape(-1))
+        else:
+            # batch sharding: the speed couples ALL instances (mcl.py:789) -- this shard's sum of squares, one all-reduce,
+            # the global speed onto this shard's rewards
+            exch = _exchange_buffer(self, dev)
+            hip.wrapper_scalars_local(sums, live4, com, has_prev, vel, live, None, exch, 1)
+            _all_reduce_sum(exch, grp)
+            hip.wrapper_scalars_apply(exch, 1, speed, None, None, None, reward.reshape(-1))
         self._after_update(com, vel, speed, live)
 
     def _after_update(self, com, vel, speed, live):
@@ -1384,7 +1389,55 @@ class PufferDetector(Motivator):
     def live_cells(self, value):
         pass                                    # recomputed every step (mcl.py:832)
 
+    def _any_flag_ptr(self, action, dev):
+        """Device address of "this step's action had a non-zero element" (mcl.py:835), None for no action."""
+        if action is None:
+            return None
+        inner = self.inner_env
+        st = inner.__dict__.get("_status")
+        if st is None:
+            # no status block to ask (foreign inner environment): the reference's predicate as a device flag
+            flag = (torch.sum(_as_device_f32(action, dev)) != 0).to(torch.int32).reshape(1)
+            self.__dict__["_flag_keep"] = flag
+            return flag.data_ptr()
+        # ANY_NONZERO of the slot the step just used (the flags stay until the next step recycles them)
+        return st.data_ptr() + 4 * (inner._slot ^ 1)
+
+    def _sharded_step(self, action, grp):
+        """Batch sharding (carle_amd.dist): the live-cell total and the action's truthiness are the WHOLE batch's
+        (mcl.py:832,835).  Directly on a SpeedDetector that exchanges too, both wrappers share the one all-reduce."""
+        sp, inner = self.env, self.inner_env
+        dev = inner.my_device
+        both = type(sp) is SpeedDetector and _scalar_group(sp) is not None
+        obs, reward, done, info = (sp.env if both else sp).step(action)
+        if not reward.is_contiguous():
+            raise ValueError("PufferDetector needs a contiguous reward tensor")
+        ring, state, total = self._ring_state(dev)
+        exch = _exchange_buffer(self, dev)
+        flag_ptr = self._any_flag_ptr(action, dev)
+        if both:
+            o = _as_device_f32(obs, dev)
+            sums = hip.instance_sums_f32(o, _cached_device(sp, "mass_weight_h", dev), _cached_device(sp, "mass_weight_w", dev))
+            same = inner.__dict__.get("universe") is obs
+            if same:
+                inner.__dict__["_live_cache"] = (weakref.ref(obs), obs._version, sums)
+            live4 = None if same else _live_sums(inner, dev)
+            com, vel, speed, live, has_prev = sp._dev_buffers(sums.shape[0], dev)
+            hip.wrapper_scalars_local(sums, live4, com, has_prev, vel, live, flag_ptr, exch, 3)
+            _all_reduce_sum(exch, grp)
+            hip.wrapper_scalars_apply(exch, 3, speed, ring, state, total, reward.reshape(-1))
+            sp._after_update(com, vel, speed, live)
+        else:
+            sums = _live_sums(inner, dev)
+            hip.wrapper_scalars_local(sums, None, None, None, None, None, flag_ptr, exch, 2)
+            _all_reduce_sum(exch, grp)
+            hip.wrapper_scalars_apply(exch, 2, None, ring, state, total, reward.reshape(-1))
+        return obs, reward, done, info
+
     def step(self, action):
+        grp = _scalar_group(self)
+        if grp is not None:
+            return self._sharded_step(action, grp)
         sp = self.env
         inner = self.inner_env
         dev = inner.my_device
@@ -1409,17 +1462,7 @@ class PufferDetector(Motivator):
         else:
             sums = _live_sums(inner, dev)
         ring, state, total = self._ring_state(dev)
-        flag_ptr = None
-        if action is not None:
-            st = inner.__dict__.get("_status")
-            if st is None:
-                # no status block to ask (foreign inner environment): the reference's predicate as a device flag
-                flag = (torch.sum(_as_device_f32(action, dev)) != 0).to(torch.int32).reshape(1)
-                self.__dict__["_flag_keep"] = flag
-                flag_ptr = flag.data_ptr()
-            else:
-                # ANY_NONZERO of the slot the step just used (the flags stay until the next step recycles them)
-                flag_ptr = st.data_ptr() + 4 * (inner._slot ^ 1)
+        flag_ptr = self._any_flag_ptr(action, dev)
         if pair:
             com, vel, speed, live, has_prev = sp._dev_buffers(obs.shape[0], dev)
             hip.speed_puffer_f32(obs, _cached_device(sp, "mass_weight_h", dev), _cached_device(sp, "mass_weight_w", dev), sums,

@@ -67,7 +67,12 @@ extern "C" {
                                                        moments are still to be merged (carle_env_step_f32_rnd) ...     */
 #define CARLE_ST_MOM_COUNT           22             /* ... number of pairs (0 = nothing pending) ...                   */
 #define CARLE_ST_MOM_N               23             /* ... and number of rewards they cover                            */
-#define CARLE_ST_WORDS               32             /* words 24..31 reserved, zero */
+#define CARLE_ST_TRACE_CAP            24             /* > 1: MOMENTS_OUT points at TRACE_CAP consecutive double[3] rows, and ...  */
+#define CARLE_ST_TRACE_IDX            25             /* ... the step that writes its moments takes row TRACE_IDX % TRACE_CAP and
+                                                       increments TRACE_IDX: the per-step reward totals of the harness loops
+                                                       (train_mcl.py:68-69, eval.py:69-70) without a launch per step.  0 / 1: the one
+                                                       triple at MOMENTS_OUT, as before.  A run of k steps in one launch writes k rows */
+#define CARLE_ST_WORDS               32             /* words 26..31 reserved, zero */
 
 /* `publish_flags` argument of the carle_env_step_* entry points (bit set) */
 #define CARLE_STEP_PUBLISH_FLAGS     1   /* the step kernel writes the action predicates into the status block */
@@ -510,6 +515,23 @@ int carle_env_step_b1_rand(const uint64_t *u_in, uint64_t *u_out, float *reward,
                            int ah, int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset,
                            int32_t *status, int slot, int step_flags, void *stream);
 
+/* AE2D(RND2D(CARLE)).step -- the stack carle/train_mcl.py:36-40 builds -- with both wrappers forward-only, 64x64 fp32
+ * grids, more than 16 instances, action NULL or AW % 8 == 0: carle/env.py:188-242 + carle/mcl.py:398-407 (RND2D.step) +
+ * carle/mcl.py:504-512 with 398-407 again (AE2D's bonus and reward update) in ONE kernel: the AE2D forward runs on the
+ * bit rows the CA + RND2D workgroup still holds (no second read of the observation; the conv1 pattern address of a cell
+ * is formed once for both nets).  reward[i] = (0 + rnd_scale * rnd_bonus[i]) + ae_scale * ae_bonus[i], rounded as torch
+ * rounds the two in-place updates.  step_flags: CARLE_STEP_DEFERRED is required (counters pending, see above),
+ * PUBLISH_FLAGS / MERGE_MOMENTS as for carle_env_step_f32_rnd; moment_partials: carle_rnd_ae_step_partials_doubles(n)
+ * doubles, caller-owned, alive until the next call on the status block.  rnd_bonus: n + 1 floats, ae_bonus: n floats.
+ * Bit-identical to carle_env_step_f32_rnd followed by carle_ae2d_bonus_f32 on its observation. */
+int64_t carle_rnd_ae_step_partials_doubles(int64_t n);
+int carle_env_step_f32_rnd_ae(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h, int w,
+                              int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
+                              const float *rnd_pred_params, const float *rnd_rand_params, float *rnd_workspace,
+                              float *rnd_bonus, float rnd_scale, int rnd_net_flags, const float *ae_params,
+                              float *ae_workspace, float *ae_bonus, float ae_scale, int ae_net_flags,
+                              double *moment_partials, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-instance sums for the hand-coded reward wrappers: for every instance i
  * of x (n x elems floats): out4[4i] = sum x, out4[4i+k+1] = sum x * w_k for the (nullable) weight
@@ -557,6 +579,27 @@ int carle_speed_puffer_f32(const float *obs, int64_t n, int64_t elems, const flo
                            int32_t *counter, float *com, int32_t *state, float *velocity, float *speed, float *live_out,
                            const int32_t *any_flag, float *ring, int32_t *ring_state, int cap, float *live_total,
                            float *reward, void *stream);
+
+/* The same two updates under BATCH SHARDING (one process per GPU, carle_amd/dist.py), where the reference's scalars couple
+ * the whole batch: SpeedDetector's speed = sqrt(sum over ALL instances of velocity^2) (carle/mcl.py:789), PufferDetector's
+ * live-cell total and "the action has a non-zero element" (mcl.py:832, 835).  Split around ONE all-reduce(SUM) of
+ * exch = double[4] = { sum of this shard's velocity^2, 1.0 if a previous centre of mass existed, this shard's live cells,
+ * 1.0 if this shard's action had a non-zero element }:
+ *   carle_wrapper_scalars_local_f32   what & 1: SpeedDetector's per-instance part (com, velocity, live_out, state as in
+ *                                     carle_speed_update_f32; exch[0], exch[1]); what & 2: PufferDetector's (exch[2] from
+ *                                     column 0 of live4, or of sums4 when live4 is NULL; exch[3] from any_flag, NULL = no
+ *                                     action).  Entries of a part not asked for are written as 0.
+ *   -- caller: all-reduce(SUM) of exch over the ranks (RCCL / gloo) --
+ *   carle_wrapper_scalars_apply_f32   what & 1: speed = sqrt(exch[0]) -> speed_out, reward += speed (if exch[1] != 0);
+ *                                     what & 2: the history update of carle_puffer_update_f32 with total = exch[2] and
+ *                                     "action" = exch[3] != 0, reward += 1 when it fires.  Same order as the stacked wrappers
+ *                                     (speed first, mcl.py:795, then the growth bonus, mcl.py:843).
+ * With one rank and no all-reduce the pair is carle_speed_update_f32 / carle_puffer_update_f32 (fp64 sums, same rounding). */
+int carle_wrapper_scalars_local_f32(const float *sums4, const float *live4, int64_t n, float *com, int32_t *state,
+                                    float *velocity, float *live_out, const int32_t *any_flag, double *exch, int what,
+                                    void *stream);
+int carle_wrapper_scalars_apply_f32(const double *exch, int what, float *speed, float *ring, int32_t *ring_state, int cap,
+                                    float *live_total, float *reward, int64_t n, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Reward statistics for batch-sharded runs (build-side feature required by the north star; the

@@ -73,6 +73,88 @@ def test_running_stats_two_ranks_gloo(total):
     assert res[0][3] == res[1][3]              # bit-identical statistics on every rank
 
 
+class _Plain:
+    """Stands in for an environment / a wrapper on the CPU: only the attributes the host logic looks at."""
+    _moments_merged = False
+
+
+def _host_logic_worker(rank, world, port, total, q):
+    """The batch-global exchanges added in round 5, host side on CPU tensors: the trace ring of per-step reward moments
+    drained with ONE all-reduce, the two action flags OR-ed over the ranks, which wrappers exchange their scalars."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from carle_amd import dist as cd
+    assert not cd.exchanging() and cd.batch_scalar_group(_Plain()) is None      # no group yet: nothing to exchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(11)
+        rewards = rng.normal(size=(7, total)).astype(np.float32)
+        start, count = cd.shard(total)
+        stats = cd.RunningRewardStats("cpu", sync_every=1 << 30)
+        env = _Plain()
+        assert stats.start_trace(env, 5) is False                               # nothing to attach to: the moments path
+        drained = []
+        for t in range(7):                                                      # 7 steps through a ring of 5 rows, drained at 3
+            stats.after_step(env, torch.from_numpy(rewards[t, start:start + count]).reshape(-1, 1))
+            if t == 2:
+                drained.append(stats.drain_trace())
+        drained.append(stats.drain_trace())
+        # flags: [ANY_NONZERO(0), ANY_NONZERO(1), NOT_ALL_ONES(0), NOT_ALL_ONES(1)]
+        status = torch.zeros(32, dtype=torch.int32)
+        status[1] = 1 if rank == 1 else 0                                       # slot 1: rank 1 saw a non-zero element
+        status[3] = 1 if rank == 0 else 0                                       # slot 1: rank 0 saw an element != 1
+        status[0] = 0
+        status[2] = 0                                                           # slot 0: nobody saw anything
+        cd.all_reduce_flags(status, 1)
+        cd.all_reduce_flags(status, 0)
+        w = _Plain()
+        grp = cd.batch_scalar_group(w)
+        w.__dict__["batch_scalars"] = "per_rank"
+        q.put((rank, [d.tolist() for d in drained], stats.state.tolist(), status[:4].tolist(), grp,
+               cd.batch_scalar_group(w), cd.exchanging()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trace_flags_and_scalar_groups_two_ranks_gloo():
+    world, total = 2, 9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_host_logic_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rewards = np.random.default_rng(11).normal(size=(7, total)).astype(np.float32).astype(np.float64)
+    sums = rewards.sum(axis=1)
+    flat = rewards.reshape(-1)
+    for r in res:
+        first, second = r[1]
+        np.testing.assert_allclose(first, sums[:3], rtol=1e-10, atol=1e-9)      # the WHOLE batch's totals, on every rank
+        np.testing.assert_allclose(second, sums[3:], rtol=1e-10, atol=1e-9)     # the ring started over after the drain
+        np.testing.assert_allclose(r[2], [flat.size, flat.mean(), ((flat - flat.mean()) ** 2).sum()], rtol=1e-10)
+        assert r[3] == [0, 1, 0, 1]                                             # OR over the ranks, slot by slot
+        assert r[4] == (None,) and r[5] is None and r[6] is True
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]                    # bit-identical on both ranks
+
+
+def test_trace_ring_wraps_to_the_last_rows():
+    from carle_amd import dist as cd
+    stats = cd.RunningRewardStats("cpu", sync_every=1 << 30)
+    env = _Plain()
+    stats.start_trace(env, 4)
+    for t in range(6):
+        stats.after_step(env, torch.full((3, 1), float(t)))
+    assert stats.drain_trace().tolist() == [6.0, 9.0, 12.0, 15.0]               # the last four of six steps, oldest first
+    stats.after_step(env, torch.full((3, 1), 7.0))
+    assert stats.drain_trace().tolist() == [21.0]
+    assert stats.count == 21
+
+
 def test_shard_partition():
     from carle_amd import dist as cd
     for total in (0, 1, 7, 8, 4096, 32768):

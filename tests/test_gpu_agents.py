@@ -211,11 +211,10 @@ def test_fused_random_step_on_u8_and_packed_state(storage, n, size, monkeypatch)
         assert len(calls) == 4 and set(calls) == {"env_step_%s_rand" % storage}     # the fused entry really ran
 
 
-def test_random_network_agent_one_threshold_and_geometry_fallback():
+def test_random_network_agent_one_threshold_and_geometry_domain():
     """The same observation gives the same action with and without the sigmoid values requested (one threshold form in
     every kernel path: split-K, 64- and 128-tile), and a geometry the reference's module accepts but the kernels do not
-    (100x100 -> 625 inputs) is evaluated by the module on the device, announced by a warning."""
-    import warnings
+    (100x100 -> 625 inputs) raises: there is no torch evaluation behind the agent."""
     from carle_amd.agents import RandomNetworkAgent
     for n, hw in ((3, 64), (130, 64), (1029, 64), (2, 256)):
         torch.manual_seed(n)
@@ -231,10 +230,5 @@ def test_random_network_agent_one_threshold_and_geometry_fallback():
     torch.manual_seed(5)
     agent = RandomNetworkAgent(observation_width=100, observation_height=100, action_width=8, action_height=8)
     obs = (torch.rand(2, 1, 100, 100, device="cuda") < 0.3).float()
-    with warnings.catch_warnings(record=True) as rec:
-        warnings.simplefilter("always")
-        action = agent(obs)
-        agent(obs)
-    assert tuple(action.shape) == (2, 1, 8, 8) and len([w for w in rec if "outside the HIP kernels" in str(w.message)]) == 1
-    ref = (agent.network.to("cuda")(obs) <= agent.toggle_rate).float().reshape(2, 1, 8, 8)
-    assert torch.equal(action, ref)
+    with pytest.raises(NotImplementedError, match="outside the HIP kernels' domain"):
+        agent(obs)                                           # no torch evaluation in the kernels' place

@@ -573,3 +573,65 @@ def test_c_consumer_steps_on_the_gpu(tmp_path):
     child_env = {k: v for k, v in os.environ.items() if not k.startswith("CARLE_")}
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, env=child_env)
     assert out.returncode == 0 and "abi gpu ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_abi_from_two_host_threads():
+    """include/carle_hip.h: "asynchronous on the passed stream ... safe from several host threads on different streams".
+    Two host threads, each with its own HIP stream and its own environment (fp32 one-launch step / bit-packed step),
+    step concurrently through the C ABI (ctypes releases the GIL inside every call): both trajectories bit-identical to
+    the oracle, counters right, and the thread-local error text of one thread is never the other's."""
+    import threading
+    from carle_amd import _lib
+    lib = _lib.load()
+    errors, done = [], {}
+    start = threading.Barrier(2)
+
+    def run(tid):
+        try:
+            rng = np.random.default_rng(500 + tid)
+            n, steps = 23 + 18 * tid, 48
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                env = _env(width=64, height=64, instances=n, storage="f32" if tid == 0 else "b1",
+                           **({"obs": "f32"} if tid else {}))
+                env.rules_from_string("B3/S23" if tid == 0 else "B36/S23")
+                env.reset()
+                u = (rng.random((n, 1, 64, 64)) < 0.4).astype(np.float32)
+                env.universe = torch.from_numpy(u).cuda()
+                mask = O.rule_mask(env.birth, env.survive)
+                acts = [(rng.random((n, 1, 64, 64)) < 0.1).astype(np.float32) for _ in range(steps)]
+                dev_acts = [torch.from_numpy(a).cuda() for a in acts]
+                stream.synchronize()
+                start.wait(timeout=120)
+                got = []
+                for t in range(steps):
+                    got.append(env.step(dev_acts[t])[0])
+                    if t % 8 == tid:
+                        # an argument error in between: its text must be THIS thread's (thread-local storage)
+                        if tid == 0:
+                            rc = lib.carle_ca_step_f32(None, None, None, 1, 64, 64, 0, 0, 0, None, 0, None)
+                            assert rc != 0 and b"NULL" in lib.carle_last_error(), lib.carle_last_error()
+                        else:
+                            rc = lib.carle_instance_sums_f32(got[-1].data_ptr(), -1, 1, None, None, None, got[-1].data_ptr(), None)
+                            assert rc != 0 and b"negative" in lib.carle_last_error(), lib.carle_last_error()
+                stream.synchronize()
+                for t in range(steps):
+                    u, reset, _ = O.c_env_step(u, acts[t], mask)
+                    assert not reset
+                    assert np.array_equal(got[t].cpu().numpy(), u), (tid, t)
+                assert env.step_number == steps
+            done[tid] = True
+        except BaseException as e:                           # noqa: BLE001 -- reported by the main thread
+            errors.append((tid, repr(e)))
+            try:
+                start.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(600)
+    assert not errors, errors
+    assert done == {0: True, 1: True}

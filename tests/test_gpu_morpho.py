@@ -89,6 +89,36 @@ def test_other_storages_step_like_fp32(storage):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("storage,obs_format", [("u8", "u8"), ("u8", "f32"), ("b1", "b1"), ("b1", "f32")])
+def test_reset_seeds_the_state_the_kernels_read(storage, obs_format):
+    """MorphoBonus.reset() on uint8 / bit-packed environments, in either observation format: the seed (mcl.py:
+    189-190, the same CPU generator draw as on fp32 storage) must land in the STATE -- universe / universe_bits --, be what
+    reset() returns, and evolve: one zero-action step equals the fp32 environment's."""
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import MorphoBonus
+    runs = []
+    for st in ("f32", storage):
+        kw = {} if st == "f32" else {"storage": st, "obs": obs_format}
+        env = CARLE(width=64, height=64, instances=3, device="cuda:0", **kw)
+        w = MorphoBonus(env)
+        torch.manual_seed(77)
+        obs = w.reset()
+        state = env.universe.float().cpu().numpy().copy()                    # (b1: unpacked from universe_bits)
+        assert state.sum() > 0 and set(np.unique(state)) <= {0.0, 1.0}
+        if st == "b1":
+            from carle_amd import hip
+            assert np.array_equal(hip.unpack_b1_f32(env.universe_bits).cpu().numpy(), state)
+        seen = obs if obs.dtype == torch.float32 else (env.universe if obs.dtype == torch.int64 else obs.float())
+        assert np.array_equal(seen.float().cpu().numpy(), state)             # what reset() returned is that state
+        o1, r1, _, _ = w.step(torch.zeros(3, 1, 64, 64, device="cuda"))
+        runs.append((state, env.universe.float().cpu().numpy().copy(), r1.cpu().numpy().copy()))
+    assert np.array_equal(runs[0][0], runs[1][0])                            # the same seed draw ...
+    assert np.array_equal(runs[0][1], runs[1][1])                            # ... evolved by the CA on every storage
+    assert np.array_equal(runs[0][2], runs[1][2])
+    exp, _, _ = O.c_env_step(runs[0][0], np.zeros((3, 1, 64, 64), np.float32), O.rule_mask(env.birth, env.survive))
+    assert np.array_equal(runs[1][1], exp)
+
+
 def test_shape_and_argument_errors():
     from carle_amd import hip, _lib
     from carle_amd.env import CARLE

@@ -437,33 +437,36 @@ def test_training_mode_flag_does_not_change_the_numbers(size):
         np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=1e-4, atol=1e-5, err_msg=k)
 
 
-def test_replay_window_is_bounded_and_packed():
-    """Sizes without a fused gradient kernel retain the window bit-packed (1/32 of the fp32 bytes)
-    and replay early above window_bytes_cap; the update equals the uncapped one."""
+def test_no_autograd_path_behind_the_bonus_calls(monkeypatch):
+    """There is no torch fallback behind step / get_bonus_*: every supported geometry updates its predictor through the HIP
+    gradient kernels (loss.backward is never called), and a geometry they do not cover (H = W not a multiple of 8) raises
+    as soon as an update is asked for instead of being differentiated by autograd."""
     from carle_amd.env import CARLE
-    from carle_amd.mcl import RND2D
-    sds = []
-    for cap in (256 << 20, 3 * 8 * 128 * 128 // 8):          # second: room for 3 packed steps
+    from carle_amd.mcl import RND2D, AE2D
+    called = []
+    monkeypatch.setattr(torch.Tensor, "backward", lambda self, *a, **k: called.append(1))
+    for size in (128, 40):                                   # tiled kernels / per-layer kernels
         torch.manual_seed(23)
-        env = CARLE(width=128, height=128, instances=8, device="cuda:0")
-        w = RND2D(env)
-        w.window_bytes_cap = cap
-        w.batch_size = 10
+        env = CARLE(width=size, height=size, action_width=min(64, size), action_height=min(64, size), instances=4,
+                    device="cuda:0")
+        w = AE2D(RND2D(env))
+        w.batch_size = w.env.batch_size = 3
         w.eval(); w.reset()
         g = torch.Generator().manual_seed(1)
-        for t in range(10):
-            w.step((torch.rand(8, 1, 64, 64, generator=g) < 0.3).float())
-            if t < 9:
-                assert all(o.dtype == torch.int64 for o in w._window)
-                assert sum(o.numel() * 8 for o in w._window) <= max(cap, 8 * 128 * 128 // 8)
-        assert w.updates == 1 and not w._window
-        sds.append({k: v.detach().cpu().numpy() for k, v in w.state_dict().items()})
-    for k in sds[0]:
-        np.testing.assert_allclose(sds[0][k], sds[1][k], rtol=0, atol=2e-6, err_msg=k)
-    # no gradient wanted -> nothing retained
-    w.set_no_grad()
-    w.step(torch.zeros(8, 1, 64, 64))
-    assert not w._window
+        before = {k: v.detach().clone() for k, v in w.state_dict().items()}
+        for t in range(3):
+            w.step((torch.rand(4, 1, min(64, size), min(64, size), generator=g) < 0.3).float())
+        assert w.env.updates == 1 and not called
+        assert any(not torch.equal(before[k], v) for k, v in w.state_dict().items())
+    env = CARLE(width=20, height=20, action_width=20, action_height=20, instances=2, device="cuda:0")
+    for cls in (RND2D, AE2D):
+        w = cls(env)
+        w.eval(); w.reset()
+        with pytest.raises(NotImplementedError, match="multiple of 8"):
+            w.step(torch.zeros(2, 1, 20, 20))
+        with pytest.raises(NotImplementedError, match="multiple of 8"):
+            w.get_bonus_update(torch.zeros(2, 1, 20, 20, device="cuda"))
+    assert not called
 
 
 def test_cfg3_full_size_against_the_oracle():
@@ -584,27 +587,36 @@ def test_staged_backward_matches_autograd(size, n, binary):
 
 @pytest.mark.parametrize("size", [32, 256])
 def test_staged_backward_window_equals_autograd_replay(size):
-    """A whole update window (rewards + Adam) through the staged HIP backward kernels equals the
-    round-1 path (retained window + PyTorch autograd replay) on the same stack."""
+    """A whole update window (rewards + Adam) through the HIP backward kernels (per-layer at 32, tiled at 256) equals the
+    reference's own sequence restated HERE with PyTorch autograd on the same stack (mcl.py:368-386: zero_grad at the start
+    of a window, loss / batch_size accumulated, backward + Adam at its end)."""
     outs = []
     for hip_bwd in (True, False):
         torch.manual_seed(31)
         env, rnd, ae = _stack(size, 3)
         for w in (rnd, ae):
-            w.hip_backward_any_size = hip_bwd
             w.batch_size = 3
+            w.train_predictor = hip_bwd                             # False: forward bonus only, the window is the test's
             w.eval()
         ae.reset()
         gen = torch.Generator().manual_seed(4)
         env.universe = (torch.rand(3, 1, size, size, generator=gen) < 0.3).float().cuda()
-        rews = []
+        rews, filled, updates = [], 0, 0
         for t in range(7):                                          # two updates + one pending step
             a = (torch.rand(3, 1, min(64, size), min(64, size), generator=gen) < 0.2).float()
             obs, reward, done, info = ae.step(a)
             rews.append(reward.clone())
-            if hip_bwd:
-                assert not rnd._window and not ae._window            # nothing retained, no autograd
-        assert rnd.updates == 2
+            if not hip_bwd:
+                for w in (rnd, ae):
+                    if filled == 0:
+                        w.predictor.zero_grad()
+                    (torch.mean(w._torch_loss(obs)) / w.batch_size).backward()
+                filled += 1
+                if filled == 3:
+                    for w in (rnd, ae):
+                        w.optimizer.step()
+                    filled, updates = 0, updates + 1
+        assert (rnd.updates if hip_bwd else updates) == 2
         outs.append((torch.stack(rews).cpu().numpy(),
                      {k: v.detach().cpu().numpy() for k, v in ae.state_dict().items()}))
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
@@ -632,7 +644,6 @@ def test_reference_training_trajectory_256():
     acts = G.unpack(z["actions"], (6, n, 1, 64, 64))
     for t in range(6):
         obs, reward, done, info = ae.step(torch.from_numpy(acts[t]))
-        assert not rnd._window and not ae._window
         np.testing.assert_allclose(reward.cpu().numpy(), z["rewards"][t], rtol=0, atol=TRAJ_REWARD_TOL)
     assert [rnd.updates, ae.updates] == z["updates"].tolist()
     assert np.array_equal(obs.cpu().numpy(), G.unpack(z["final_obs"], (n, 1, 256, 256)))
@@ -1023,35 +1034,6 @@ def test_get_bonus_update_runs_on_the_hip_path(cls, size, n, monkeypatch):
     for (k, a), (_, b), (_, c) in zip(hipw.state_dict().items(), accw.state_dict().items(), refw.state_dict().items()):
         assert torch.equal(a, b), k
         _assert_updated_weights_close(a, c, k)
-
-
-def test_early_window_replay_keeps_its_scale():
-    """the autograd replay window (geometries without gradient kernels: H != W) replayed early above
-    window_bytes_cap uses the window's own loss scale, get_bonus_update never replays early, and a discarded window
-    leaves no stale byte count behind."""
-    from carle_amd.env import CARLE
-    from carle_amd.mcl import RND2D
-    outs = []
-    for cap in (1 << 40, 1):
-        torch.manual_seed(4)
-        env = CARLE(width=64, height=64, instances=3, device="cuda:0")
-        w = RND2D(env)
-        w.eval(); w.reset()
-        w.hip_backward_any_size = False                     # force retention + autograd replay (the round-1 path)
-        w._fused_train = lambda *a, **k: False
-        w.window_bytes_cap = cap
-        w.batch_size = 3
-        g = torch.Generator(device="cuda").manual_seed(8)
-        obs = [(torch.rand(3, 1, 64, 64, device="cuda", generator=g) < 0.3).float() for _ in range(5)]
-        w.get_bonus_accumulate(obs[0])                      # a window in progress ...
-        w.get_bonus_update(obs[1])                          # ... discarded by zero_grad; one update with scale 1
-        assert w.__dict__.get("_window_bytes", 0) == 0 and not w._window
-        for o in obs[2:]:
-            w.get_bonus_accumulate(o)
-        outs.append({k: v.detach().clone() for k, v in w.state_dict().items()})
-        assert w.updates == 2
-    for k in outs[0]:
-        assert torch.allclose(outs[0][k], outs[1][k], rtol=0, atol=1e-5), (k, (outs[0][k] - outs[1][k]).abs().max())
 
 
 @pytest.mark.parametrize("storage,size,n", [("f32", 256, 16), ("f32", 128, 5), ("b1", 256, 7), ("u8", 192, 3), ("f32", 512, 2)])
