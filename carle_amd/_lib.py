@@ -51,6 +51,10 @@ SIGNATURES = {
     "carle_env_step_f32_rnd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
                                         _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
                                         _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "carle_env_step_f32_rnd_bits": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
+                                             _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
+                                             _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
+                                             ctypes.POINTER(ctypes.c_int)]),
     "carle_rnd_step_partials_doubles": (_c_i64, [_c_i64]),
     "carle_rnd_ae_step_partials_doubles": (_c_i64, [_c_i64]),
     "carle_env_step_f32_rnd_ae": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,

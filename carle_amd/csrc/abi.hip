@@ -27,6 +27,7 @@ static Knobs read_knobs() {
     k.wide_blocks = env_i64("CARLE_WIDE_BLOCKS");
     k.rnd_blocks = env_i64("CARLE_RND_BLOCKS");
     k.rnd_waves = env_i64("CARLE_RND_WAVES");
+    k.rnd_pair = env_i64("CARLE_RND_PAIR");
     k.rnd_cached_load_max_bytes = env_i64("CARLE_RND_CACHED_LOAD_MAX_BYTES");
     k.net_blocks = env_i64("CARLE_NET_BLOCKS");
     k.b1_dbg = env_i64("CARLE_B1_DBG");
@@ -476,6 +477,14 @@ extern "C" int carle_ca_step_f32_rnd(const float *u_in, const float *action, flo
                          bonus, (net_flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream), nullptr);
 }
 
+static int env_step_f32_rnd_impl(const float *u_in, const float *action, float *u_out,
+                                 float *reward, int64_t n, int h, int w, int ah, int aw,
+                                 uint32_t rule, int32_t *status, int slot, int publish_flags,
+                                 const float *pred_params, const float *rand_params,
+                                 float *workspace, float *bonus, float reward_scale,
+                                 int net_flags, double *moment_partials, void *event, void *stream_env,
+                                 void *stream_reward, uint64_t *bits_out, int *bits_written);
+
 extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out,
                                       float *reward, int64_t n, int h, int w, int ah, int aw,
                                       uint32_t rule, int32_t *status, int slot, int publish_flags,
@@ -483,6 +492,34 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
                                       float *workspace, float *bonus, float reward_scale,
                                       int net_flags, double *moment_partials, void *event, void *stream_env,
                                       void *stream_reward) {
+    return env_step_f32_rnd_impl(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot, publish_flags, pred_params,
+                                 rand_params, workspace, bonus, reward_scale, net_flags, moment_partials, event, stream_env,
+                                 stream_reward, nullptr, nullptr);
+}
+
+// The same, and where the step is ONE launch (the fused 64x64 kernel, CARLE_STEP_DEFERRED) the kernel also leaves a
+// bit-packed copy of the observation in bits_out (n x 64 row words, 16-byte aligned): *bits_written says whether it did.
+extern "C" int carle_env_step_f32_rnd_bits(const float *u_in, const float *action, float *u_out,
+                                           float *reward, int64_t n, int h, int w, int ah, int aw,
+                                           uint32_t rule, int32_t *status, int slot, int publish_flags,
+                                           const float *pred_params, const float *rand_params,
+                                           float *workspace, float *bonus, float reward_scale,
+                                           int net_flags, double *moment_partials, void *event, void *stream_env,
+                                           void *stream_reward, uint64_t *bits_out, int *bits_written) {
+    if (bits_written) *bits_written = 0;
+    if (bits_out && !aligned16(bits_out)) return fail_arg(CARLE_E_ALIGN, "carle_env_step_f32_rnd_bits: bits_out must be 16-byte aligned");
+    return env_step_f32_rnd_impl(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot, publish_flags, pred_params,
+                                 rand_params, workspace, bonus, reward_scale, net_flags, moment_partials, event, stream_env,
+                                 stream_reward, bits_out, bits_written);
+}
+
+static int env_step_f32_rnd_impl(const float *u_in, const float *action, float *u_out,
+                                 float *reward, int64_t n, int h, int w, int ah, int aw,
+                                 uint32_t rule, int32_t *status, int slot, int publish_flags,
+                                 const float *pred_params, const float *rand_params,
+                                 float *workspace, float *bonus, float reward_scale,
+                                 int net_flags, double *moment_partials, void *event, void *stream_env,
+                                 void *stream_reward, uint64_t *bits_out, int *bits_written) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: status is NULL");
     if (!pred_params || !rand_params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: NULL reward-net pointer");
@@ -509,6 +546,8 @@ extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, fl
             ea.publish = (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? 1 : 0;
             ea.merge_moments = merge ? 1 : 0;
             ea.partials = merge ? moment_partials + (size_t)slot * 2 * (size_t)rnd64_blocks(n) : nullptr;
+            ea.bits_out = bits_out;
+            if (bits_out && bits_written) *bits_written = 1;
             if (int e = ca_step_rnd64(u_in, action, u_out, n, aw, rule, status, slot, pred_params, rand_params, workspace,
                                       bonus, tables_valid, static_cast<hipStream_t>(stream_env), &ea))
                 return e;

@@ -54,19 +54,6 @@ struct CaRndShared {
     double racc[2];              // ENV: sum / sum of squares of this workgroup's rewards (wave 1, lane 0)
 };
 
-// 1 if the fp32 bit pattern is a non-zero NUMBER (NaN counts, -0.0 does not; the truthiness of
-// torch.logical_xor, env.py:182) in two VALU ops: the add drops the sign, v_min_u32 clamps to 1.
-// (Written as asm: hipcc rewrites umin(x, 1) into compare + select, three ops and a VCC hazard.)
-__device__ __forceinline__ uint32_t nz1(uint32_t bits) {
-    uint32_t r;
-    const uint32_t t = bits + bits;
-    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(t));
-    return r;
-}
-__device__ __forceinline__ uint32_t nibble_fast(const uint4 &v) {
-    return nz1(v.x) | (nz1(v.y) << 1) | (nz1(v.z) << 2) | (nz1(v.w) << 3);
-}
-
 struct Quads { uint4 v[4], a[4]; };     // one grid's loads of a lane: 4 state + 4 action quads
 
 // ENV instantiation (CARLE_STEP_DEFERRED): the whole RND2D.step -- CARLE.step + bonus + reward -- in this ONE launch, no
@@ -83,6 +70,9 @@ struct Quads { uint4 v[4], a[4]; };     // one grid's loads of a lane: 4 state +
 
 #ifndef CARLE_RND_WG_PER_CU
 #define CARLE_RND_WG_PER_CU 4
+#endif
+#ifndef CARLE_RND_REDGEN
+#define CARLE_RND_REDGEN 0           // 1: the generation on every wavefront, two barriers per grid (measured slower: EXPERIMENTS.md 5.2)
 #endif
 
 // NT_ST: streaming stores (state arrays beyond the Infinity Cache); NT_LD: streaming hint on the STATE loads (the action
@@ -188,7 +178,7 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
             w_notone = __ballot(seen_g.not_all_ones<F32Cells>()) != 0ull;
             any_acc |= __ballot(seen_g.any_nonzero<F32Cells>()) != 0ull;
             notone_acc |= w_notone;
-            if (lane == 0 && wv != 0) s.notone[wv] = w_notone ? 1u : 0u;
+            if (lane == 0 && (CARLE_RND_REDGEN || wv != 0)) s.notone[wv] = w_notone ? 1u : 0u;
         }
         RND_STAMP(1);
         // the four rows' DPP chains are independent: interleaved, they fill each other's wait states
@@ -206,9 +196,13 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
         __syncthreads();
         RND_STAMP(3);
 
-        // ---- B: one generation, lane = row (wave 0; rows above / below by DPP wave rotates = y seam)
-        //      E2 (wave 1, at the same time): linear layers + bonus of the PREVIOUS grid of this workgroup
-        if (wv == 0) {
+        // ---- B: one generation, lane = row (rows above / below by DPP wave rotates = y seam)
+        //      E2 (wave 1): linear layers + bonus of the PREVIOUS grid of this workgroup
+        // CARLE_RND_REDGEN (round 5): EVERY wavefront runs the generation (~120 VALU instructions, redundantly) and writes
+        // the 64 new row words -- the same values four times -- so that phases C and D read rows this very wavefront wrote
+        // (LDS keeps a wavefront's order) and the barrier that used to separate B from C / D is gone: two barriers per grid
+        // instead of three, and wavefronts 2 and 3 no longer idle through B.
+        if (CARLE_RND_REDGEN || wv == 0) {
             const uint64_t c = ((uint64_t)s.rows_in[lane][1] << 32) | s.rows_in[lane][0];
             const uint64_t wst = rotl64(c, 1), est = rotr64(c, 1);          // torus seam in x
             uint64_t h0, h1, p0, p1;
@@ -227,13 +221,18 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
                 // wavefront 0 knows its own 16 action rows: not all ones there (always, under an agent) -> no reset, and
                 // no LDS round trip on the generation's critical path; else the other wavefronts' verdicts, then the batch
                 if (ea.publish && __builtin_expect(!w_notone, 0)) {
-                    const bool own_notone = (s.notone[1] | s.notone[2] | s.notone[3]) != 0u;
+                    // (REDGEN: all four wavefronts decide, and decide alike: the four verdicts were stored before the barrier,
+                    // and batch_action_all_ones() gives every caller the batch's answer)
+                    const bool own_notone = CARLE_RND_REDGEN ? (s.notone[0] | s.notone[1] | s.notone[2] | s.notone[3]) != 0u
+                                                             : (s.notone[1] | s.notone[2] | s.notone[3]) != 0u;
                     if (!own_notone) reset = batch_action_all_ones<F32Cells>(act, n, aw, status, slot);
                 }
                 if (reset) nx = 0ull;
             }
             s.net.rows[1 + lane] = nx;
-        } else if (wv == 1 && pending >= 0) {
+            if (ENV && ea.bits_out && wv == 0) ea.bits_out[g * 64 + lane] = nx;     // the observation once more, 1 bit per cell (512 B)
+        }
+        if ((CARLE_RND_REDGEN || wv != 0) && wv == 1 && pending >= 0) {
             const float b = rnd_linear_bonus(s.feat, s.net.lin, lane, pending, nullptr, nullptr);
             if (lane == 0) bonus[pending] = b;
             if (ENV && lane == 0) {
@@ -243,7 +242,7 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
             }
         }
         RND_STAMP(4);
-        __syncthreads();
+        if (!CARLE_RND_REDGEN) __syncthreads();
         RND_STAMP(5);
 
         // ---- C: fp32 store of the new state (the lane's own four quads): the lane's dword of the row
@@ -832,6 +831,10 @@ __global__ __launch_bounds__(512, 4) void ca_step_rnd_ae64_kernel(
 }
 
 void rnd2d_prepare_tables(const float *pp, const float *rp, float *ws, hipStream_t s);
+void rnd2d_prepare_pair_tables(float *ws, hipStream_t s);
+int ca_step_rnd64_pair(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
+                       int32_t *status, int slot, float *ws, float *bonus, hipStream_t s, const RndEnvArgs &ea,
+                       bool nt_st, bool cached_ld);
 void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
 
 // workgroups of the one-launch AE2D(RND2D(CARLE)) step (= its reward-moment partial pairs)
@@ -885,7 +888,10 @@ int64_t rnd64_blocks(int64_t n) {
 int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
                   int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
                   bool tables_valid, hipStream_t s, const RndEnvArgs *env) {
-    if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
+    if (!tables_valid) {
+        rnd2d_prepare_tables(pp, rp, ws, s);
+        rnd2d_prepare_pair_tables(ws, s);             // (the pair-table form of the one-launch step, ca_rnd_pair.hip)
+    }
     // Two grids per workgroup (the second one's loads travel during the first one's network phases); batches up to
     // 1024 grids one workgroup each.  Four per CU are resident, the others start as those retire -- out of phase, so
     // the memory system is not idle while every workgroup computes its last grid.  Kernel alone (tools/kbench_rnd.py,
@@ -902,6 +908,8 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
     const bool nt_st = n * 16384 > lim;
     const int64_t ld_lim = knobs().rnd_cached_load_max_bytes >= 0 ? knobs().rnd_cached_load_max_bytes : 128ll << 20;
     const bool cached_ld = !nt_st && n * 16384 <= ld_lim;
+    if (env && n > 16 && knobs().rnd_pair > 0)       // one workgroup per CU, conv1 through the pair table (ca_rnd_pair.hip)
+        return ca_step_rnd64_pair(u_in, action, u_out, n, aw, rule, status, slot, ws, bonus, s, *env, nt_st, cached_ld);
     // eight wavefronts per grid, two workgroups per CU (CARLE_RND_WAVES=8; the ENV form, which is the whole step): 512
     // resident workgroups walk all grids
     const bool x8 = knobs().rnd_waves == 8;

@@ -818,8 +818,11 @@ __global__ __launch_bounds__(256) void unpack_b1_f32_kernel(const uint64_t *__re
 // first 112 MiB of each array keep the default policy -- 2 x 112 MiB fit with room to spare, their re-read always hits --
 // and the grids behind them stream past the cache with the nt hint instead of fighting for it: every process gets the
 // same time.  Multiple of 8 grids: the XCDs keep equal shares.  CARLE_B1_RESIDENT_BYTES overrides (0 = no limit: until round 4).
+// 512-column grids only: 256-column batches of the same bytes bring 4x the grids and 4x the action records (8 MiB per step at
+// N = 16384) into the cache, 2 x 112 MiB + records no longer fit and the slice thrashes (N=16384: 56.5 us against 45.0 us all
+// streaming; with a 96 MiB slice 44.3: profiles/r05_b1_resident_ab.txt) -- they keep the round-4 policy.
 static int64_t b1_resident_grids(int64_t n, int ww) {
-    int64_t res = 112ll << 20;
+    int64_t res = ww == 8 ? 112ll << 20 : 0;
     if (knobs().b1_resident_bytes >= 0) res = knobs().b1_resident_bytes;
     if (res == 0) return INT64_MAX;
     const int64_t grid_bytes = (int64_t)(64 * ww) * ww * 8;
@@ -835,7 +838,7 @@ static int launch_b1_mode(const uint64_t *u_in, const uint64_t *act, uint64_t *u
     // the one-launch step keeps a resident slice and streams the rest at EVERY size from the LDS threshold on (see
     // b1_resident_grids): beyond the old streaming threshold too, the 112 MiB that do fit are re-read out of the cache
     // (512x512 N=6144 66.6-67.5 -> 63.7-65.6 us, N=8192 89.4-91.0 -> 86.7-88.9; CARLE_B1_HYBRID_ALL=0: all-streaming there)
-    if (env && lds == 2 && knobs().b1_hybrid_all != 0) lds = 1;
+    if (env && lds == 2 && knobs().b1_hybrid_all != 0 && (WW == 8 || knobs().b1_resident_bytes > 0)) lds = 1;
     // 64-row grids (a unit = a whole grid): persistent, just under 32 one-wave workgroups per CU (8 per SIMD).  8 x 1021: a
     // multiple of 8 (a wave stays on "its" XCD's grids) whose per-XCD stride 1021 is prime, so a wave's successive work
     // items rotate through the strips -- with a stride that is a multiple of the strip count every wave

@@ -69,6 +69,7 @@ struct Knobs {
     int64_t b1_blocks, b1_units;         // CARLE_B1_BLOCKS / CARLE_B1_UNITS: launch caps of the packed kernel
     int64_t wide_blocks;                 // CARLE_WIDE_BLOCKS: launch cap of the wavefront-per-strip kernels
     int64_t rnd_blocks;                  // CARLE_RND_BLOCKS: workgroups of the fused CA + RND2D kernel
+    int64_t rnd_pair;                    // CARLE_RND_PAIR: 1 = the one-launch CA + RND2D step through the pair table (ca_rnd_pair.hip)
     int64_t rnd_waves;                   // CARLE_RND_WAVES: 8 = eight wavefronts per grid (ca_step_rnd64x8_kernel), else four
     int64_t rnd_cached_load_max_bytes;   // CARLE_RND_CACHED_LOAD_MAX_BYTES
     int64_t net_blocks;                  // CARLE_NET_BLOCKS: workgroups of the 64x64 reward-net kernels
@@ -114,6 +115,8 @@ struct RndEnvArgs {
     float reward_scale = 1.0f;
     int publish = 1, merge_moments = 0;
     double *partials = nullptr;          // gridDim.x (sum, sum of squares) pairs, this step's buffer
+    uint64_t *bits_out = nullptr;        // N x 64 row words: a bit-packed copy of the new state for a reward net stacked on the
+                                         // RND2D (AE2D reads 512 B instead of 16 KiB per grid); nullable
 };
 
 // Hides a uniform pointer from loop-invariant code motion: the scalar loads behind it stay in the phase

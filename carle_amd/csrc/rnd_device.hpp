@@ -30,6 +30,19 @@ __device__ __forceinline__ uint64_t spread_nibbles(uint32_t x) {
     return t;
 }
 
+// 1 if the fp32 bit pattern is a non-zero NUMBER (NaN counts, -0.0 does not; the truthiness of
+// torch.logical_xor, env.py:182) in two VALU ops: the add drops the sign, v_min_u32 clamps to 1.
+// (Written as asm: hipcc rewrites umin(x, 1) into compare + select, three ops and a VCC hazard.)
+__device__ __forceinline__ uint32_t nz1(uint32_t bits) {
+    uint32_t r;
+    const uint32_t t = bits + bits;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(t));
+    return r;
+}
+__device__ __forceinline__ uint32_t nibble_fast(const uint4 &v) {
+    return nz1(v.x) | (nz1(v.y) << 1) | (nz1(v.z) << 2) | (nz1(v.w) << 3);
+}
+
 // LDS image of one workgroup (4 wavefronts) that owns one 64x64 grid at a time
 struct RndBlockShared {
     float4 lut_p[512];                 // conv1 + relu of the predictor, per 9-bit neighbourhood pattern

@@ -810,22 +810,34 @@ def speed_puffer_f32(obs, w_h, w_w, sums4, counter, com, state, velocity, speed,
 
 def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_flags, pred_params,
                      rand_params, workspace, bonus, reward_scale, tables_valid,
-                     event_handle, stream_env, stream_reward, merge_moments=False, deferred=False, partials=None):
+                     event_handle, stream_env, stream_reward, merge_moments=False, deferred=False, partials=None,
+                     bits_out=None):
     """CARLE.step + RND2D bonus of the fresh observation in one library call (see carle_hip.h).  deferred: ONE
     launch (no epilogue kernel); with merge_moments it needs ``partials`` (fp64 scratch of
     carle_rnd_step_partials_doubles(n) elements that outlives the call until the next one on the status block)."""
     lib = _lib.load()
     n, _, h, w = u_in.shape
     with _on_device(u_in.device):
-        rc = lib.carle_env_step_f32_rnd(u_in.data_ptr(), action.data_ptr(), u_out.data_ptr(),
-                                        reward.data_ptr(), n, h, w, action.shape[2], action.shape[3],
-                                        rule, status.data_ptr(), slot,
-                                        _step_flags(publish_flags, merge_moments, deferred), pred_params.data_ptr(),
-                                        rand_params.data_ptr(), workspace.data_ptr(), bonus.data_ptr(), float(reward_scale),
-                                        2 if tables_valid else 0, _ptr(partials), event_handle,
-                                        stream_env, stream_reward)
+        if bits_out is None:
+            rc = lib.carle_env_step_f32_rnd(u_in.data_ptr(), action.data_ptr(), u_out.data_ptr(),
+                                            reward.data_ptr(), n, h, w, action.shape[2], action.shape[3],
+                                            rule, status.data_ptr(), slot,
+                                            _step_flags(publish_flags, merge_moments, deferred), pred_params.data_ptr(),
+                                            rand_params.data_ptr(), workspace.data_ptr(), bonus.data_ptr(), float(reward_scale),
+                                            2 if tables_valid else 0, _ptr(partials), event_handle,
+                                            stream_env, stream_reward)
+        else:
+            # bits_out (int64 (N,1,64,1)): where the step is one launch it also leaves a bit-packed copy of the observation
+            rc = lib.carle_env_step_f32_rnd_bits(u_in.data_ptr(), action.data_ptr(), u_out.data_ptr(),
+                                                 reward.data_ptr(), n, h, w, action.shape[2], action.shape[3],
+                                                 rule, status.data_ptr(), slot,
+                                                 _step_flags(publish_flags, merge_moments, deferred), pred_params.data_ptr(),
+                                                 rand_params.data_ptr(), workspace.data_ptr(), bonus.data_ptr(),
+                                                 float(reward_scale), 2 if tables_valid else 0, _ptr(partials), event_handle,
+                                                 stream_env, stream_reward, bits_out.data_ptr(), ctypes.byref(_bits_written))
     if rc != 0:
         _lib.check(rc, "carle_env_step_f32_rnd")
+    return bits_out is not None and _bits_written.value != 0
 
 
 def env_step_f32_rnd_ae(u_in, action, u_out, reward, rule, status, slot, publish_flags, rnd_pred, rnd_rand, rnd_ws,

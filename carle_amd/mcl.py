@@ -157,6 +157,10 @@ class RND2D(Motivator):
         # state (CARLE._bits_buffer) -- the tiled kernels of this wrapper read that instead of the fp32 cells
         if getattr(self.inner_env, "storage", None) == "f32" and os.environ.get("CARLE_PACKED_COPY", "1") != "0":
             self.inner_env.__dict__["want_packed_copy"] = True       # (CARLE_PACKED_COPY=0: A/B switch)
+            # ... and a reward net stacked directly on an RND2D (AE2D(RND2D(env)), train_mcl.py:36-40): the RND2D's one-launch
+            # 64x64 step hands the observation over bit-packed as well (512 B per grid for the 64x64 kernels above it)
+            if type(env) is RND2D and env.env is self.inner_env:
+                env.__dict__["_hand_bits"] = True
 
     # ------------------------------------------------------------------ networks
     def initialize_predictor(self):
@@ -637,6 +641,12 @@ class RND2D(Motivator):
                 env.settled_status()                         # nothing may still point into the old buffer
                 partials = self.__dict__["_mom_partials"] = torch.zeros(pneed, dtype=torch.float64, device=dev)
 
+        bits_bufs = None
+        if self.__dict__.get("_hand_bits"):                  # a reward net above reads the observation bit-packed
+            bits_bufs = self.__dict__.get("_bits_bufs")
+            if bits_bufs is None or bits_bufs[0].shape[0] != n or bits_bufs[0].device != dev:
+                bits_bufs = self.__dict__["_bits_bufs"] = [torch.empty(n, 1, 64, 1, dtype=torch.int64, device=dev) for _ in (0, 1)]
+
         def launch(u_in, act, out, reward, rule, status, slot, publish):
             main_raw = hip._stream(u_in)
             if rs is None:
@@ -645,9 +655,11 @@ class RND2D(Motivator):
                 rs_raw = rs.raw
                 ev = rs.event_for_fork(main_raw, out, reward)
             fusable = act.shape[3] % 8 == 0     # (the library fuses -- and can merge the moments -- only with an 8-aligned window)
-            hip.env_step_f32_rnd(u_in, act, out, reward, rule, status, slot, publish, pb, rb, self._ws,
-                                 self._step_bonus, self.reward_scale, valid, ev, main_raw, rs_raw,
-                                 merge and fusable, deferred=True, partials=partials)
+            bits = bits_bufs[slot] if bits_bufs is not None else None
+            if hip.env_step_f32_rnd(u_in, act, out, reward, rule, status, slot, publish, pb, rb, self._ws,
+                                    self._step_bonus, self.reward_scale, valid, ev, main_raw, rs_raw,
+                                    merge and fusable, deferred=True, partials=partials, bits_out=bits):
+                env.__dict__["_obs_bits"] = (weakref.ref(out), out._version, bits)
             self.__dict__["_moments_merged"] = merge and fusable
             if merge and fusable:
                 env.__dict__["_moments_pending"] = True
@@ -742,7 +754,7 @@ class AE2D(RND2D):
             # for forward-only wrappers on an fp32 environment of more than 16 instances with an 8-aligned window
             if (not self.train_predictor and not rnd.train_predictor and getattr(env, "storage", "f32") == "f32"
                     and not env.logging and env.instances > 16 and env.action_width % 8 == 0
-                    and os.environ.get("CARLE_FUSED_RND_AE", "1") != "0"):      # (A/B switch)
+                    and os.environ.get("CARLE_FUSED_RND_AE", "0") != "0"):      # (opt-in: measured slower, EXPERIMENTS.md 5.4)
                 return 3
             return 0
         if not self.train_predictor and not rnd.train_predictor:

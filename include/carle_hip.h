@@ -442,6 +442,16 @@ int carle_rnd_ae_train(const void *obs, int obs_fmt, int64_t n, int h, int w, co
  * aligned, alive until the NEXT call on the status block or carle_env_settle has merged them; NULL without
  * MERGE_MOMENTS).  Counters as described at CARLE_STEP_DEFERRED. */
 int64_t carle_rnd_step_partials_doubles(int64_t n);
+/* carle_env_step_f32_rnd, and where that step is ONE launch (64x64, CARLE_STEP_DEFERRED, more than 16 instances) the kernel
+ * also stores the new state once more as n x 64 row words (bit j of word r = cell (r, j); 512 bytes per grid instead of
+ * 16 KiB) in bits_out (16-byte aligned, nullable) -- the observation as the 64x64 reward-net kernels of a wrapper stacked
+ * on the RND2D read it (carle_ae2d_bonus_b1, carle_ae2d_train_b1: AE2D(RND2D(env)), carle/train_mcl.py:36-40).
+ * *bits_written (nullable) := 1 iff the copy was written. */
+int carle_env_step_f32_rnd_bits(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h, int w,
+                                int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
+                                const float *pred_params, const float *rand_params, float *workspace, float *bonus,
+                                float reward_scale, int net_flags, double *moment_partials, void *event, void *stream_env,
+                                void *stream_reward, uint64_t *bits_out, int *bits_written);
 int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out, float *reward,
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                            int32_t *status, int slot, int publish_flags,

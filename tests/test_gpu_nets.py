@@ -319,26 +319,34 @@ def test_fused_rnd_gradient_matches_autograd(n, packed):
 
 
 def test_fused_training_window_updates_like_autograd():
-    """A whole update window through get_bonus_accumulate: fused-kernel gradients + torch Adam
-    give the same parameters as the retained-window autograd replay."""
+    """A whole update window through get_bonus_accumulate: fused-kernel gradients + the Adam kernel give the same
+    parameters as the reference's own sequence restated HERE with PyTorch autograd on the same network (mcl.py:368-386:
+    zero_grad at the start of a window, loss / batch_size accumulated, backward + Adam at its end)."""
     torch.manual_seed(77)
     env_a, fused, _ = _stack(64, 6)
-    env_b, replay, _ = _stack(64, 6)
-    replay.load_state_dict(fused.state_dict())
+    env_b, ref, _ = _stack(64, 6)
+    ref.load_state_dict(fused.state_dict())
     fused.assume_binary_obs = True                        # fused gradient kernel
-    replay._fused_train = lambda *a, **k: False           # force retention + autograd replay
-    for w in (fused, replay):
+    for w in (fused, ref):
         w.reset()
         w.eval()
         w.batch_size = 3
     g = torch.Generator().manual_seed(3)
+    filled, updates = 0, 0
     for t in range(7):                                     # two updates + one pending step
         obs = (torch.rand(6, 1, 64, 64, generator=g) < 0.3).float().cuda()
         bf = fused.get_bonus_accumulate(obs)
-        br = replay.get_bonus_accumulate(obs)
-        np.testing.assert_allclose(bf.cpu().numpy(), br.cpu().numpy(), rtol=0, atol=2e-5)
-    assert fused.updates == replay.updates == 2
-    for (k, a), (_, b) in zip(fused.state_dict().items(), replay.state_dict().items()):
+        if filled == 0:
+            ref.predictor.zero_grad()
+        loss = ref._torch_loss(obs)
+        (torch.mean(loss) / ref.batch_size).backward()
+        filled += 1
+        if filled == 3:
+            ref.optimizer.step()
+            filled, updates = 0, updates + 1
+        np.testing.assert_allclose(bf.cpu().numpy(), loss.detach().cpu().numpy(), rtol=0, atol=2e-5)
+    assert fused.updates == updates == 2
+    for (k, a), (_, b) in zip(fused.state_dict().items(), ref.state_dict().items()):
         _assert_updated_weights_close(a.cpu(), b.cpu(), k)
 
 

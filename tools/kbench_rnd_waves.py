@@ -14,11 +14,15 @@ from carle_amd.env import CARLE                # noqa: E402
 from carle_amd.mcl import RND2D                # noqa: E402
 
 
+VARIANTS = {4: {}, 8: {"CARLE_RND_WAVES": "8"}, 16: {"CARLE_RND_PAIR": "1"}}
+NAMES = {4: "4 waves per grid, 512-entry tables (shipped) ", 8: "8 waves per grid, 2 workgroups per CU         ",
+         16: "pair table, 1 workgroup of 4 groups per CU     "}
+
+
 def waves(k):
-    if k == 8:
-        os.environ["CARLE_RND_WAVES"] = "8"
-    else:
-        os.environ.pop("CARLE_RND_WAVES", None)
+    for key in ("CARLE_RND_WAVES", "CARLE_RND_PAIR"):
+        os.environ.pop(key, None)
+    os.environ.update(VARIANTS[k])
     hip.reload_knobs()
 
 
@@ -54,7 +58,8 @@ for n in [int(a) for a in sys.argv[1:]] or [4096]:
         return outs
 
     ref = None
-    for k in (4, 8):
+    kinds = [int(x) for x in os.environ.get("KBENCH_KINDS", "4,16").split(",")]
+    for k in kinds:
         waves(k)
         env.reset()
         outs = run(k, 5, keep=True)
@@ -63,9 +68,9 @@ for n in [int(a) for a in sys.argv[1:]] or [4096]:
             ref = outs
         else:
             same = all(torch.equal(a, b) for x, y in zip(ref, outs) for a, b in zip(x, y))
-            print(f"N={n}: eight-wave form bit-identical to the four-wave form over 5 steps: {same}", flush=True)
+            print(f"N={n}: [{NAMES[k].strip()}] bit-identical to the four-wave form over 5 steps: {same}", flush=True)
     for rep in range(3):
-        for k in (4, 8):
+        for k in kinds:
             waves(k)
             run(k, 12)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -75,6 +80,6 @@ for n in [int(a) for a in sys.argv[1:]] or [4096]:
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 300 * 1e3
-            print(f"N={n} {k} waves per grid: {us:6.2f} us per step  {alg / us / 8e6:.3f} of 8 TB/s", flush=True)
+            print(f"N={n} {NAMES[k]}: {us:6.2f} us per step  {alg / us / 8e6:.3f} of 8 TB/s", flush=True)
     del env, w, ring, u0, partials
     torch.cuda.empty_cache()
