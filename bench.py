@@ -224,6 +224,9 @@ def cpu_baseline(n, size, rule, seconds):
 
 def cfg_name(args, n, size):
     if args.format == "f32" and size == 64 and n == 4096:
+        if args.rnd and args.ae:
+            return "BASELINE configs[3] + AE2D: the AE2D(RND2D(CARLE)) stack of train_mcl.py:36-40, " + \
+                ("training step" if args.train else "forward passes")
         return "BASELINE configs[3] (CA + RND2D forward)" if args.rnd else "BASELINE configs[1]"
     if args.format == "f32" and size == 64 and not (args.rnd or args.ae):
         return f"BASELINE configs[1] shape at N={n} (state arrays beyond the Infinity Cache)" \
@@ -314,7 +317,7 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
     cand = []
     if packed:
         alg = n * (size * size * 2 + asize * asize) // 8
-        name = "ca_step_b1_kernel"
+        name = "ca_step_b1_kernel<..., ENV>"
         step_fn = hip.ca_step_b1
     elif bytes_fmt:
         alg = n * (size * size * 2 + asize * asize)
@@ -331,7 +334,9 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
                                                    (size in (256, 512) and state.numel() * state.element_size() <= 32 << 20))
 
     def ca(i):
-        if one_launch:        # the kernel CARLE.step launches: step + master reset + reward + moments, no epilogue kernel
+        if packed:            # the kernel CARLEPacked.step launches (one launch for the 64-column window: resident slice etc.)
+            hip.env_step_b1(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1, True, True)
+        elif one_launch:      # the kernel CARLE.step launches: step + master reset + reward + moments, no epilogue kernel
             (hip.env_step_f32 if args.format == "f32" else hip.env_step_u8)(
                 bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1, True, True)
         else:
@@ -341,22 +346,6 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
         name = name.replace("true, ...>", "true, ..., ENV>")
     nets = args.rnd or args.ae
     fused_rnd = args.rnd and not args.train and args.format == "f32" and size == 64
-    fused_rnd_ae = fused_rnd and args.ae and n > 16 and wenv._can_pair_step() == 3
-    if fused_rnd_ae:
-        # the stack of train_mcl.py:36-40, forward passes: CA step + RND2D + AE2D + reward are ONE kernel
-        rnd = wenv.env
-        dev_ = state.device
-        pb, rb, ab = rnd._pred_blob.get(dev_), rnd._rand_blob.get(dev_), wenv._pred_blob.get(dev_)
-        partials = wenv.__dict__.get("_mom_partials")
-
-        def ca_rnd_ae(i):
-            hip.env_step_f32_rnd_ae(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1, True,
-                                    pb, rb, rnd._ws, rnd._step_bonus, 1.0, True, ab, wenv._ws, wenv._bonus_buf, 1.0, True,
-                                    partials is not None, partials)
-        rnd_flop = 474112
-        ae_flop = 2 * 9 * 4096 * 4 + 2 * 9 * 4 * 2 * 1024 + 2 * 4 * 2 * 1024 + 2 * 4 * 4096
-        cand.append(("ca_step_rnd_ae64_kernel<true, ...>", ca_rnd_ae, alg + 4 * n, n * (rnd_flop + ae_flop)))
-        return cand
     if fused_rnd:
         # BASELINE configs[3]: the CA step and the RND2D forward are ONE kernel -- and, for more than 16 instances, the
         # whole RND2D.step is that one launch (reward and reward-moment partial sums included)

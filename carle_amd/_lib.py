@@ -56,10 +56,6 @@ SIGNATURES = {
                                              _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                              ctypes.POINTER(ctypes.c_int)]),
     "carle_rnd_step_partials_doubles": (_c_i64, [_c_i64]),
-    "carle_rnd_ae_step_partials_doubles": (_c_i64, [_c_i64]),
-    "carle_env_step_f32_rnd_ae": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
-                                           _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int,
-                                           _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp]),
     "carle_ca_step_f32_rnd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
                                        _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
     "carle_rnd2d_train_partial_floats": (_c_i64, [_c_i64]),

@@ -26,8 +26,6 @@ static Knobs read_knobs() {
     k.b1_units = env_i64("CARLE_B1_UNITS");
     k.wide_blocks = env_i64("CARLE_WIDE_BLOCKS");
     k.rnd_blocks = env_i64("CARLE_RND_BLOCKS");
-    k.rnd_waves = env_i64("CARLE_RND_WAVES");
-    k.rnd_pair = env_i64("CARLE_RND_PAIR");
     k.rnd_cached_load_max_bytes = env_i64("CARLE_RND_CACHED_LOAD_MAX_BYTES");
     k.net_blocks = env_i64("CARLE_NET_BLOCKS");
     k.b1_dbg = env_i64("CARLE_B1_DBG");
@@ -435,18 +433,6 @@ int64_t rnd64_blocks(int64_t n);
 // (sum, sum of squares) pair per workgroup
 extern "C" int64_t carle_rnd_step_partials_doubles(int64_t n) { return n > 0 ? 4 * rnd64_blocks(n) : 4; }
 
-namespace carle {
-int ca_step_rnd_ae64(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
-                     int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
-                     bool tables_valid, const float *ap, float *aws, float *ae_bonus, float ae_scale, bool ae_tables_valid,
-                     hipStream_t s, const RndEnvArgs &env);
-int64_t rnd_ae64_blocks(int64_t n);
-}
-
-// doubles of the `moment_partials` scratch of carle_env_step_f32_rnd_ae (two buffers, one per flag slot, of one (sum, sum
-// of squares) pair per workgroup)
-extern "C" int64_t carle_rnd_ae_step_partials_doubles(int64_t n) { return n > 0 ? 4 * rnd_ae64_blocks(n) : 4; }
-
 // argument checks of the fused 64x64 CA + RND2D kernel (shared by the two entry points below)
 static int rnd_step_checks(const char *who, const float *u_in, const float *action, float *u_out, int64_t n,
                            int h, int w, int ah, int aw, uint32_t rule, int slot, const float *workspace) {
@@ -580,37 +566,4 @@ static int env_step_f32_rnd_impl(const float *u_in, const float *action, float *
     }
     return carle_rnd2d_bonus_f32(u_out, n, h, w, pred_params, rand_params, workspace, bonus, nullptr,
                                  nullptr, reward, reward_scale, net_flags | CARLE_NET_OBS_BINARY, rs);
-}
-
-// AE2D(RND2D(CARLE)).step, forward passes, 64x64 fp32 grids: ONE kernel (ca_step_rnd_ae64_kernel, ca_rnd_fused.hip).
-extern "C" int carle_env_step_f32_rnd_ae(const float *u_in, const float *action, float *u_out, float *reward, int64_t n,
-                                         int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
-                                         int step_flags, const float *rnd_pred_params, const float *rnd_rand_params,
-                                         float *rnd_workspace, float *rnd_bonus, float rnd_scale, int rnd_net_flags,
-                                         const float *ae_params, float *ae_workspace, float *ae_bonus, float ae_scale,
-                                         int ae_net_flags, double *moment_partials, void *stream) {
-    if (!status || !reward) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd_ae: status / reward is NULL");
-    if (!rnd_pred_params || !rnd_rand_params || !rnd_workspace || !rnd_bonus || !ae_params || !ae_workspace || !ae_bonus)
-        return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd_ae: NULL reward-net pointer");
-    if (h != 64 || w != 64 || (action && (aw % 8) != 0) || n <= 16)
-        return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_rnd_ae: 64x64 grids, AW % 8 == 0, more than 16 instances (smaller "
-                                      "batches: carle_env_step_f32_rnd, then carle_ae2d_bonus_f32)");
-    if (!(step_flags & CARLE_STEP_DEFERRED))
-        return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_rnd_ae: the step is one launch: CARLE_STEP_DEFERRED must be set");
-    if (int e = rnd_step_checks("carle_env_step_f32_rnd_ae", u_in, action, u_out, n, h, w, ah, aw, rule, slot, rnd_workspace))
-        return e;
-    if (!aligned16(ae_workspace) || !aligned16(status))
-        return fail_arg(CARLE_E_ALIGN, "carle_env_step_f32_rnd_ae: pointers must be 16-byte aligned");
-    const bool merge = (step_flags & CARLE_STEP_MERGE_MOMENTS) != 0;
-    if (merge && (!moment_partials || !aligned16(moment_partials)))
-        return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd_ae: MERGE_MOMENTS needs moment_partials");
-    RndEnvArgs ea;
-    ea.reward = reward;
-    ea.reward_scale = rnd_scale;
-    ea.publish = (step_flags & CARLE_STEP_PUBLISH_FLAGS) ? 1 : 0;
-    ea.merge_moments = merge ? 1 : 0;
-    ea.partials = merge ? moment_partials + (size_t)slot * 2 * (size_t)rnd_ae64_blocks(n) : nullptr;
-    return ca_step_rnd_ae64(u_in, action, u_out, n, aw, rule, status, slot, rnd_pred_params, rnd_rand_params, rnd_workspace,
-                            rnd_bonus, (rnd_net_flags & CARLE_NET_TABLES_VALID) != 0, ae_params, ae_workspace, ae_bonus,
-                            ae_scale, (ae_net_flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream), ea);
 }

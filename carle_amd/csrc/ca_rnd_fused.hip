@@ -25,7 +25,6 @@
 #include <stdlib.h>
 #include "ca_cells.hpp"
 #include "rnd_device.hpp"
-#include "ae_device.hpp"
 
 // Diagnostic build only (tools/kbench/ca_rnd_variants.hip defines CARLE_RND_STAMPS): wave 0 of every
 // workgroup records s_memtime at the phase boundaries of each grid into a debug buffer that nothing
@@ -54,6 +53,19 @@ struct CaRndShared {
     double racc[2];              // ENV: sum / sum of squares of this workgroup's rewards (wave 1, lane 0)
 };
 
+// 1 if the fp32 bit pattern is a non-zero NUMBER (NaN counts, -0.0 does not; the truthiness of
+// torch.logical_xor, env.py:182) in two VALU ops: the add drops the sign, v_min_u32 clamps to 1.
+// (Written as asm: hipcc rewrites umin(x, 1) into compare + select, three ops and a VCC hazard.)
+__device__ __forceinline__ uint32_t nz1(uint32_t bits) {
+    uint32_t r;
+    const uint32_t t = bits + bits;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(t));
+    return r;
+}
+__device__ __forceinline__ uint32_t nibble_fast(const uint4 &v) {
+    return nz1(v.x) | (nz1(v.y) << 1) | (nz1(v.z) << 2) | (nz1(v.w) << 3);
+}
+
 struct Quads { uint4 v[4], a[4]; };     // one grid's loads of a lane: 4 state + 4 action quads
 
 // ENV instantiation (CARLE_STEP_DEFERRED): the whole RND2D.step -- CARLE.step + bonus + reward -- in this ONE launch, no
@@ -70,9 +82,6 @@ struct Quads { uint4 v[4], a[4]; };     // one grid's loads of a lane: 4 state +
 
 #ifndef CARLE_RND_WG_PER_CU
 #define CARLE_RND_WG_PER_CU 4
-#endif
-#ifndef CARLE_RND_REDGEN
-#define CARLE_RND_REDGEN 0           // 1: the generation on every wavefront, two barriers per grid (measured slower: EXPERIMENTS.md 5.2)
 #endif
 
 // NT_ST: streaming stores (state arrays beyond the Infinity Cache); NT_LD: streaming hint on the STATE loads (the action
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
             w_notone = __ballot(seen_g.not_all_ones<F32Cells>()) != 0ull;
             any_acc |= __ballot(seen_g.any_nonzero<F32Cells>()) != 0ull;
             notone_acc |= w_notone;
-            if (lane == 0 && (CARLE_RND_REDGEN || wv != 0)) s.notone[wv] = w_notone ? 1u : 0u;
+            if (lane == 0 && wv != 0) s.notone[wv] = w_notone ? 1u : 0u;
         }
         RND_STAMP(1);
         // the four rows' DPP chains are independent: interleaved, they fill each other's wait states
@@ -196,13 +205,9 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
         __syncthreads();
         RND_STAMP(3);
 
-        // ---- B: one generation, lane = row (rows above / below by DPP wave rotates = y seam)
-        //      E2 (wave 1): linear layers + bonus of the PREVIOUS grid of this workgroup
-        // CARLE_RND_REDGEN (round 5): EVERY wavefront runs the generation (~120 VALU instructions, redundantly) and writes
-        // the 64 new row words -- the same values four times -- so that phases C and D read rows this very wavefront wrote
-        // (LDS keeps a wavefront's order) and the barrier that used to separate B from C / D is gone: two barriers per grid
-        // instead of three, and wavefronts 2 and 3 no longer idle through B.
-        if (CARLE_RND_REDGEN || wv == 0) {
+        // ---- B: one generation, lane = row (wave 0; rows above / below by DPP wave rotates = y seam)
+        //      E2 (wave 1, at the same time): linear layers + bonus of the PREVIOUS grid of this workgroup
+        if (wv == 0) {
             const uint64_t c = ((uint64_t)s.rows_in[lane][1] << 32) | s.rows_in[lane][0];
             const uint64_t wst = rotl64(c, 1), est = rotr64(c, 1);          // torus seam in x
             uint64_t h0, h1, p0, p1;
@@ -221,18 +226,14 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
                 // wavefront 0 knows its own 16 action rows: not all ones there (always, under an agent) -> no reset, and
                 // no LDS round trip on the generation's critical path; else the other wavefronts' verdicts, then the batch
                 if (ea.publish && __builtin_expect(!w_notone, 0)) {
-                    // (REDGEN: all four wavefronts decide, and decide alike: the four verdicts were stored before the barrier,
-                    // and batch_action_all_ones() gives every caller the batch's answer)
-                    const bool own_notone = CARLE_RND_REDGEN ? (s.notone[0] | s.notone[1] | s.notone[2] | s.notone[3]) != 0u
-                                                             : (s.notone[1] | s.notone[2] | s.notone[3]) != 0u;
+                    const bool own_notone = (s.notone[1] | s.notone[2] | s.notone[3]) != 0u;
                     if (!own_notone) reset = batch_action_all_ones<F32Cells>(act, n, aw, status, slot);
                 }
                 if (reset) nx = 0ull;
             }
             s.net.rows[1 + lane] = nx;
-            if (ENV && ea.bits_out && wv == 0) ea.bits_out[g * 64 + lane] = nx;     // the observation once more, 1 bit per cell (512 B)
-        }
-        if ((CARLE_RND_REDGEN || wv != 0) && wv == 1 && pending >= 0) {
+            if (ENV && ea.bits_out) ea.bits_out[g * 64 + lane] = nx;     // the observation once more, 1 bit per cell (512 B)
+        } else if (wv == 1 && pending >= 0) {
             const float b = rnd_linear_bonus(s.feat, s.net.lin, lane, pending, nullptr, nullptr);
             if (lane == 0) bonus[pending] = b;
             if (ENV && lane == 0) {
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
             }
         }
         RND_STAMP(4);
-        if (!CARLE_RND_REDGEN) __syncthreads();
+        __syncthreads();
         RND_STAMP(5);
 
         // ---- C: fp32 store of the new state (the lane's own four quads): the lane's dword of the row
@@ -346,534 +347,7 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The same step with EIGHT wavefronts per grid and TWO workgroups per CU (round 5; DESIGN section 12, idea (b)).  At
-// N = 4096 the four-wave kernel above is the plain step kernel's memory time plus the fill and the drain of its per-grid
-// pipeline: every CU ends the launch with FOUR grids' networks (convert -> generation -> lookups -> conv2 -> linear)
-// behind the last byte, ~3 us.  Here a grid's phases run on twice the lanes (A / C: two quads per lane instead of four, D:
-// eight lookups per thread instead of sixteen, E1: one net per thread instead of two), a CU ends with TWO grids, and the
-// grid loop keeps TWO grids' loads in flight per workgroup (three register sets of 16 VGPRs instead of two of 32), so the
-// bytes in flight per CU stay what they were.  Phase B (the generation: lane = row on ONE wavefront) and E2 (the linear
-// layers on one wavefront) are unchanged.  Bit-identical results: every arithmetic step keeps its order (max is exact).
-// ---------------------------------------------------------------------------------------------------------------
-struct Quads2 { uint4 v[2], a[2]; };    // one grid's loads of a lane: 2 state + 2 action quads
-
-struct CaRndShared8 {
-    RndBlockShared net;
-    uint32_t rows_in[64][2];
-    float feat[2][64];
-    uint32_t notone[8];
-    double racc[2];
-};
-
-template <bool HAS_ACT, bool NT_ST = true, bool NT_LD = true, bool ENV = false>
-__global__ __launch_bounds__(512, 4) void ca_step_rnd64x8_kernel(
-    const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out, int64_t n,
-    int aw, uint32_t rule, int32_t *__restrict__ status, int slot, const float *__restrict__ ws,
-    float *__restrict__ bonus, RndEnvArgs ea = RndEnvArgs()) {
-    __shared__ CaRndShared8 s;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const bool reset_all = ENV && HAS_ACT && !ea.publish && status[CARLE_ST_NOT_ALL_ONES(slot)] == 0;
-    bool any_acc = false, notone_acc = false;
-    if (ENV && tid == 64) { s.racc[0] = 0.0; s.racc[1] = 0.0; }
-    const int q = lane >> 4, k = lane & 15;
-    const int o = (64 - aw) >> 1;
-    const int ax = 4 * k - o;
-    uint32_t rows_in_win = 0;                         // bit i: row 8 wv + 4 i + q is inside the action window
-    if (HAS_ACT && ax >= 0 && ax < aw) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ay = 8 * wv + 4 * i + q - o;
-            if (ay >= 0 && ay < aw) rows_in_win |= 1u << i;
-        }
-    }
-    // byte offset of this lane's quad of row 8 wv + 4 i + q: ((8 wv + 4 i + q) * 16 + k) * 16 = 2048 wv + 1024 i + 16 lane
-    const uint32_t voff = (uint32_t)(128 * wv + lane) * 16u;
-    const uint32_t abase = (HAS_ACT && ax >= 0 && ax < aw) ? (uint32_t)((8 * wv + q - o) * aw + ax) * 4u : 0x40000000u;
-    uint32_t arow[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ay0 = __builtin_amdgcn_readfirstlane(8 * wv) + 4 * i - o;      // row of q = 0; rows ay0..ay0+3 go together
-        arow[i] = (ay0 >= 0 && ay0 < aw) ? (uint32_t)(4 * i * aw) * 4u : 0x40000000u;
-    }
-    const uint32_t act_bytes = (uint32_t)(aw * aw) * 4u;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    auto issue = [&](int64_t g, Quads2 &r, bool valid) __attribute__((always_inline)) {
-        if (!valid) g = 0;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char *>(reinterpret_cast<const char *>(u_in) + g * 16384), 0, valid ? 16384 : 0, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 1024u * i, 0, NT_LD ? 2 : 0);
-            r.v[i] = make_uint4(t.x, t.y, t.z, t.w);
-        }
-        if (HAS_ACT) {
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char *>(reinterpret_cast<const char *>(act) + g * (int64_t)act_bytes), 0,
-                valid ? act_bytes : 0u, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ra, abase + arow[i], 0, 2);
-                r.a[i] = make_uint4(t.x, t.y, t.z, t.w);
-            }
-        }
-    };
-
-    const int64_t first = blockIdx.x, stride = gridDim.x;
-    Quads2 r0, r1, r2;
-    issue(first, r0, first < n);                      // two grids travel while the tables are laid down
-    issue(first + stride, r1, first + stride < n);
-    rnd_block_init<512>(s.net, ws, tid);
-    __syncthreads();
-    ActionSeen seen;
-    int64_t pending = -1;
-
-    // One grid: `cur` holds its loads, `far` receives those of the grid after the next (the next one's are already in flight)
-    auto step = [&](int64_t g, Quads2 &cur, Quads2 &far) __attribute__((always_inline)) {
-        issue(g + 2 * stride, far, g + 2 * stride < n);
-        // ---- A
-        uint32_t x[2];
-        ActionSeen seen_g;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            uint32_t nib = nibble_fast(cur.v[i]);
-            if (HAS_ACT) {
-                if ((rows_in_win >> i) & 1u) { if (ENV) seen_g.add(cur.a[i]); else seen.add(cur.a[i]); }
-                nib ^= nibble_fast(cur.a[i]);         // toggle, env.py:182
-            }
-            x[i] = nib << (4 * (k & 7));
-        }
-        bool w_notone = true;
-        if (ENV && HAS_ACT && ea.publish) {
-            w_notone = __ballot(seen_g.not_all_ones<F32Cells>()) != 0ull;
-            any_acc |= __ballot(seen_g.any_nonzero<F32Cells>()) != 0ull;
-            notone_acc |= w_notone;
-            if (lane == 0 && wv != 0) s.notone[wv] = w_notone ? 1u : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) x[i] |= __builtin_amdgcn_update_dpp(0u, x[i], 0x111, 0xF, 0xF, true);   // row_shr:1
-#pragma unroll
-        for (int i = 0; i < 2; ++i) x[i] |= __builtin_amdgcn_update_dpp(0u, x[i], 0x112, 0xF, 0xF, true);   // row_shr:2
-#pragma unroll
-        for (int i = 0; i < 2; ++i) x[i] |= __builtin_amdgcn_update_dpp(0u, x[i], 0x114, 0xF, 0xF, true);   // row_shr:4
-        if ((k & 7) == 7) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) s.rows_in[8 * wv + 4 * i + q][k >> 3] = x[i];
-        }
-        __syncthreads();
-
-        // ---- B (wave 0) / E2 of the previous grid (wave 1)
-        if (wv == 0) {
-            const uint64_t c = ((uint64_t)s.rows_in[lane][1] << 32) | s.rows_in[lane][0];
-            const uint64_t wst = rotl64(c, 1), est = rotr64(c, 1);
-            uint64_t h0, h1, p0, p1;
-            row_sums(wst, c, est, h0, h1, p0, p1);
-            const uint64_t a0 = dpp64_ror1(h0), a1 = dpp64_ror1(h1);
-            const uint64_t b0 = dpp64_rol1(h0), b1 = dpp64_rol1(h1);
-            uint32_t rule_g = rule;
-            asm volatile("" : "+s"(rule_g));
-            uint64_t nx = apply_rule(neighbour_count(a0, a1, b0, b1, p0, p1), c, rule_g);
-            if (ENV && HAS_ACT) {
-                bool reset = reset_all;
-                if (ea.publish && __builtin_expect(!w_notone, 0)) {
-                    const bool own_notone = (s.notone[1] | s.notone[2] | s.notone[3] | s.notone[4] | s.notone[5] |
-                                             s.notone[6] | s.notone[7]) != 0u;
-                    if (!own_notone) reset = batch_action_all_ones<F32Cells>(act, n, aw, status, slot);
-                }
-                if (reset) nx = 0ull;
-            }
-            s.net.rows[1 + lane] = nx;
-        } else if (wv == 1 && pending >= 0) {
-            const float b = rnd_linear_bonus(s.feat, s.net.lin, lane, pending, nullptr, nullptr);
-            if (lane == 0) bonus[pending] = b;
-            if (ENV && lane == 0) {
-                const float r = ea.reward_scale * b;
-                if (ea.reward) ea.reward[pending] = r;
-                s.racc[0] += (double)r; s.racc[1] = fma((double)r, (double)r, s.racc[1]);
-            }
-        }
-        __syncthreads();
-
-        // ---- C: fp32 store of the new state (two quads per lane)
-        {
-            const uint32_t *rows32 = reinterpret_cast<const uint32_t *>(&s.net.rows[1]);
-            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<char *>(u_out) + g * 16384, 0, 16384, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const uint32_t w = rows32[2 * (8 * wv + 4 * i + q) + (k >> 3)];
-                const uint32_t by = (((w >> (4 * (k & 7))) & 0xFu) * 0x00204081u) & 0x01010101u;
-                u32x4 o4;
-                o4.x = __float_as_uint((float)((by >> 0) & 0xFFu));
-                o4.y = __float_as_uint((float)((by >> 8) & 0xFFu));
-                o4.z = __float_as_uint((float)((by >> 16) & 0xFFu));
-                o4.w = __float_as_uint((float)((by >> 24) & 0xFFu));
-                __builtin_amdgcn_raw_buffer_store_b128(o4, ro, voff + 1024u * i, 0, NT_ST ? 2 : 0);
-            }
-        }
-        // ---- D
-        rnd_block_conv1_x8(s.net, tid);
-        __syncthreads();
-        // ---- E1
-        rnd_block_conv2_x8(s.net, s.feat, tid);
-        pending = g;
-    };
-
-    for (int64_t g = first; g < n;) {                 // unrolled by three: the register sets rotate
-        step(g, r0, r2);
-        g += stride;
-        if (g >= n) break;
-        step(g, r1, r0);
-        g += stride;
-        if (g >= n) break;
-        step(g, r2, r1);
-        g += stride;
-    }
-    if (blockIdx.x == 0 && tid == 0) bonus[n] = ws[kWsDeadBonus];
-    if (pending >= 0) {
-        __syncthreads();
-        if (wv == 1) {
-            const float b = rnd_linear_bonus(s.feat, s.net.lin, lane, pending, nullptr, nullptr);
-            if (lane == 0) bonus[pending] = b;
-            if (ENV && lane == 0) {
-                const float r = ea.reward_scale * b;
-                if (ea.reward) ea.reward[pending] = r;
-                s.racc[0] += (double)r; s.racc[1] = fma((double)r, (double)r, s.racc[1]);
-            }
-        }
-    }
-    if (HAS_ACT && !ENV) publish_flags<F32Cells>(seen, status, slot);
-    if (ENV) {
-        if (HAS_ACT && ea.publish && lane == 0) {
-            if (any_acc) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
-            if (notone_acc) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
-        }
-        if (wv == 1 && lane == 0 && ea.merge_moments && ea.partials)
-            reinterpret_cast<double2 *>(ea.partials)[blockIdx.x] = make_double2(s.racc[0], s.racc[1]);
-        if (blockIdx.x == 0 && wv == 2) {
-            settle_moments_wave(status, lane);
-            if (lane == 0) {
-                uint4 *s4 = reinterpret_cast<uint4 *>(status);
-                uint4 w0 = s4[0], w1 = s4[1], w2 = s4[2];
-                settle_pending(w0, w1, w2);
-                if (!HAS_ACT) {
-                    int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z) + 1;
-                    int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x) + 1;
-                    w1.x = 0u;
-                    w1.z = (uint32_t)step_number; w1.w = (uint32_t)((uint64_t)step_number >> 32);
-                    w2.x = (uint32_t)since; w2.y = (uint32_t)((uint64_t)since >> 32);
-                } else {
-                    w1.y = 1u | 2u | (slot ? 4u : 0u);
-                }
-                s4[1] = w1; s4[2] = w2;
-                const int other = slot ^ 1;
-                status[CARLE_ST_ANY_NONZERO(other)] = 0;
-                status[CARLE_ST_NOT_ALL_ONES(other)] = 0;
-                status[CARLE_ST_SCAN_TICKET(other)] = 0;
-                status[CARLE_ST_SCAN_DONE(other)] = 0;
-                if (ea.merge_moments && ea.partials && ea.reward) {
-                    uint4 w5;
-                    w5.x = (uint32_t)reinterpret_cast<uint64_t>(ea.partials);
-                    w5.y = (uint32_t)(reinterpret_cast<uint64_t>(ea.partials) >> 32);
-                    w5.z = gridDim.x;
-                    w5.w = (uint32_t)n;
-                    s4[5] = w5;
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The whole AE2D(RND2D(CARLE)).step -- the stack of carle/train_mcl.py:36-40, forward passes -- in ONE launch (round 5):
-// ca_step_rnd64x8_kernel<..., ENV> with the AE2D forward (ae_device.hpp) behind the RND2D phases of the same grid, on the
-// bit rows the workgroup still holds.  What the two-launch form paid twice is paid once: the fp32 observation is neither
-// written for the AE2D kernel's sake nor read back (16 KiB per grid), and the 9-bit pattern address of a cell is formed
-// once for the ten conv1 channels of both nets.  Per grid: A | B (+ the previous grid's RND2D linear layers, AE2D error sum
-// and reward on wavefront 1) | C, D (lookups of both nets) | RND2D conv2 + AE2D conv2 | AE2D convT1 | AE2D convT2 + error:
-// five barriers.  66 KB of LDS: two workgroups of eight wavefronts per CU.
-//   reward[g] = (0 + rnd_scale * rnd_bonus) + ae_scale * ae_bonus, products and sums rounded separately (mcl.py:403-405 in
-//   RND2D.step, then in AE2D.step); bonus / ae_bonus receive the two bonuses; moments of the FINAL reward as per-workgroup
-//   partial sums.  Bit-identical to RND2D's one-launch step followed by ae_block64_kernel on its observation.
-// ---------------------------------------------------------------------------------------------------------------
-struct RndAeEnvArgs {
-    RndEnvArgs rnd;
-    const float *ae_ws = nullptr;        // AE2D workspace: conv1 table + parameter block (ae2d_prepare_tables)
-    float *ae_bonus = nullptr;           // N floats
-    float ae_scale = 1.0f;
-};
-
-struct CaRndAeShared {
-    RndBlockShared net;
-    AeBlockSharedX8 ae;
-    uint32_t rows_in[64][2];
-    float feat[2][64];
-    uint32_t notone[8];
-    double racc[2];
-};
-
-template <bool HAS_ACT, bool NT_ST = true, bool NT_LD = true>
-__global__ __launch_bounds__(512, 4) void ca_step_rnd_ae64_kernel(
-    const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out, int64_t n,
-    int aw, uint32_t rule, int32_t *__restrict__ status, int slot, const float *__restrict__ ws,
-    float *__restrict__ bonus, RndAeEnvArgs eaa) {
-    __shared__ CaRndAeShared s;
-    const RndEnvArgs &ea = eaa.rnd;
-    const float *aprm = eaa.ae_ws + kAeX8LutFloats;   // uniform AE2D parameter block
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const bool reset_all = HAS_ACT && !ea.publish && status[CARLE_ST_NOT_ALL_ONES(slot)] == 0;
-    bool any_acc = false, notone_acc = false;
-    if (tid == 64) { s.racc[0] = 0.0; s.racc[1] = 0.0; }
-    const int q = lane >> 4, k = lane & 15;
-    const int o = (64 - aw) >> 1;
-    const int ax = 4 * k - o;
-    uint32_t rows_in_win = 0;
-    if (HAS_ACT && ax >= 0 && ax < aw) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ay = 8 * wv + 4 * i + q - o;
-            if (ay >= 0 && ay < aw) rows_in_win |= 1u << i;
-        }
-    }
-    const uint32_t voff = (uint32_t)(128 * wv + lane) * 16u;
-    const uint32_t abase = (HAS_ACT && ax >= 0 && ax < aw) ? (uint32_t)((8 * wv + q - o) * aw + ax) * 4u : 0x40000000u;
-    uint32_t arow[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ay0 = __builtin_amdgcn_readfirstlane(8 * wv) + 4 * i - o;
-        arow[i] = (ay0 >= 0 && ay0 < aw) ? (uint32_t)(4 * i * aw) * 4u : 0x40000000u;
-    }
-    const uint32_t act_bytes = (uint32_t)(aw * aw) * 4u;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    auto issue = [&](int64_t g, Quads2 &r, bool valid) __attribute__((always_inline)) {
-        if (!valid) g = 0;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char *>(reinterpret_cast<const char *>(u_in) + g * 16384), 0, valid ? 16384 : 0, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 1024u * i, 0, NT_LD ? 2 : 0);
-            r.v[i] = make_uint4(t.x, t.y, t.z, t.w);
-        }
-        if (HAS_ACT) {
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char *>(reinterpret_cast<const char *>(act) + g * (int64_t)act_bytes), 0,
-                valid ? act_bytes : 0u, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ra, abase + arow[i], 0, 2);
-                r.a[i] = make_uint4(t.x, t.y, t.z, t.w);
-            }
-        }
-    };
-
-    const int64_t first = blockIdx.x, stride = gridDim.x;
-    Quads2 r0, r1, r2;
-    issue(first, r0, first < n);
-    issue(first + stride, r1, first + stride < n);
-    rnd_block_init<512>(s.net, ws, tid);
-    ae_x8_init(s.ae, eaa.ae_ws, tid);
-    __syncthreads();
-    int64_t pending = -1;
-
-    // wavefront 1, one phase behind: both bonuses of the grid `pending`, its reward, the workgroup's reward sums
-    auto finish_pending = [&]() __attribute__((always_inline)) {
-        const float b = rnd_linear_bonus(s.feat, s.net.lin, lane, pending, nullptr, nullptr);
-        const float ab = ae_x8_bonus(s.ae, lane);
-        if (lane == 0) {
-            bonus[pending] = b;
-            eaa.ae_bonus[pending] = ab;
-            const float r = reward_accumulate(ea.reward_scale * b, eaa.ae_scale, ab);
-            if (ea.reward) ea.reward[pending] = r;
-            s.racc[0] += (double)r; s.racc[1] = fma((double)r, (double)r, s.racc[1]);
-        }
-    };
-
-    auto step = [&](int64_t g, Quads2 &cur, Quads2 &far) __attribute__((always_inline)) {
-        issue(g + 2 * stride, far, g + 2 * stride < n);
-        // ---- A
-        uint32_t x[2];
-        ActionSeen seen_g;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            uint32_t nib = nibble_fast(cur.v[i]);
-            if (HAS_ACT) {
-                if ((rows_in_win >> i) & 1u) seen_g.add(cur.a[i]);
-                nib ^= nibble_fast(cur.a[i]);         // toggle, env.py:182
-            }
-            x[i] = nib << (4 * (k & 7));
-        }
-        bool w_notone = true;
-        if (HAS_ACT && ea.publish) {
-            w_notone = __ballot(seen_g.not_all_ones<F32Cells>()) != 0ull;
-            any_acc |= __ballot(seen_g.any_nonzero<F32Cells>()) != 0ull;
-            notone_acc |= w_notone;
-            if (lane == 0 && wv != 0) s.notone[wv] = w_notone ? 1u : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) x[i] |= __builtin_amdgcn_update_dpp(0u, x[i], 0x111, 0xF, 0xF, true);   // row_shr:1
-#pragma unroll
-        for (int i = 0; i < 2; ++i) x[i] |= __builtin_amdgcn_update_dpp(0u, x[i], 0x112, 0xF, 0xF, true);   // row_shr:2
-#pragma unroll
-        for (int i = 0; i < 2; ++i) x[i] |= __builtin_amdgcn_update_dpp(0u, x[i], 0x114, 0xF, 0xF, true);   // row_shr:4
-        if ((k & 7) == 7) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) s.rows_in[8 * wv + 4 * i + q][k >> 3] = x[i];
-        }
-        __syncthreads();
-
-        // ---- B (wave 0) / the previous grid's tail (wave 1)
-        if (wv == 0) {
-            const uint64_t c = ((uint64_t)s.rows_in[lane][1] << 32) | s.rows_in[lane][0];
-            const uint64_t wst = rotl64(c, 1), est = rotr64(c, 1);
-            uint64_t h0, h1, p0, p1;
-            row_sums(wst, c, est, h0, h1, p0, p1);
-            const uint64_t a0 = dpp64_ror1(h0), a1 = dpp64_ror1(h1);
-            const uint64_t b0 = dpp64_rol1(h0), b1 = dpp64_rol1(h1);
-            uint32_t rule_g = rule;
-            asm volatile("" : "+s"(rule_g));
-            uint64_t nx = apply_rule(neighbour_count(a0, a1, b0, b1, p0, p1), c, rule_g);
-            if (HAS_ACT) {
-                bool reset = reset_all;
-                if (ea.publish && __builtin_expect(!w_notone, 0)) {
-                    const bool own_notone = (s.notone[1] | s.notone[2] | s.notone[3] | s.notone[4] | s.notone[5] |
-                                             s.notone[6] | s.notone[7]) != 0u;
-                    if (!own_notone) reset = batch_action_all_ones<F32Cells>(act, n, aw, status, slot);
-                }
-                if (reset) nx = 0ull;
-            }
-            s.net.rows[1 + lane] = nx;
-        } else if (wv == 1 && pending >= 0) {
-            finish_pending();
-        }
-        __syncthreads();
-
-        // ---- C: fp32 store of the new state
-        {
-            const uint32_t *rows32 = reinterpret_cast<const uint32_t *>(&s.net.rows[1]);
-            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<char *>(u_out) + g * 16384, 0, 16384, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const uint32_t w = rows32[2 * (8 * wv + 4 * i + q) + (k >> 3)];
-                const uint32_t by = (((w >> (4 * (k & 7))) & 0xFu) * 0x00204081u) & 0x01010101u;
-                u32x4 o4;
-                o4.x = __float_as_uint((float)((by >> 0) & 0xFFu));
-                o4.y = __float_as_uint((float)((by >> 8) & 0xFFu));
-                o4.z = __float_as_uint((float)((by >> 16) & 0xFFu));
-                o4.w = __float_as_uint((float)((by >> 24) & 0xFFu));
-                __builtin_amdgcn_raw_buffer_store_b128(o4, ro, voff + 1024u * i, 0, NT_ST ? 2 : 0);
-            }
-        }
-        // ---- D: conv1 of both nets
-        rnd_ae_conv1_x8(s.net, s.ae, tid);
-        __syncthreads();
-        // ---- E: the two conv2 layers (RND2D: -> feat, read by wave 1 one phase later; AE2D: -> A2)
-        rnd_block_conv2_x8(s.net, s.feat, tid);
-        ae_conv2_x8(s.ae, aprm, tid);
-        __syncthreads();                              // A1 reads done: A3 may overlay plane 0
-        ae_convT1_x8(s.ae, aprm, tid);
-        __syncthreads();
-        ae_convT2_err_x8(s.ae, &s.net.rows[1], aprm, tid);
-        pending = g;
-    };
-
-    for (int64_t g = first; g < n;) {                 // unrolled by three: the register sets rotate
-        step(g, r0, r2);
-        g += stride;
-        if (g >= n) break;
-        step(g, r1, r0);
-        g += stride;
-        if (g >= n) break;
-        step(g, r2, r1);
-        g += stride;
-    }
-    if (pending >= 0) {
-        __syncthreads();
-        if (wv == 1) finish_pending();
-    }
-    if (HAS_ACT && ea.publish && lane == 0) {
-        if (any_acc) status[CARLE_ST_ANY_NONZERO(slot)] = 1;
-        if (notone_acc) status[CARLE_ST_NOT_ALL_ONES(slot)] = 1;
-    }
-    if (wv == 1 && lane == 0 && ea.merge_moments && ea.partials)
-        reinterpret_cast<double2 *>(ea.partials)[blockIdx.x] = make_double2(s.racc[0], s.racc[1]);
-    if (blockIdx.x == 0 && wv == 2) {
-        settle_moments_wave(status, lane);
-        if (lane == 0) {
-            uint4 *s4 = reinterpret_cast<uint4 *>(status);
-            uint4 w0 = s4[0], w1 = s4[1], w2 = s4[2];
-            settle_pending(w0, w1, w2);
-            if (!HAS_ACT) {
-                int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z) + 1;
-                int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x) + 1;
-                w1.x = 0u;
-                w1.z = (uint32_t)step_number; w1.w = (uint32_t)((uint64_t)step_number >> 32);
-                w2.x = (uint32_t)since; w2.y = (uint32_t)((uint64_t)since >> 32);
-            } else {
-                w1.y = 1u | 2u | (slot ? 4u : 0u);
-            }
-            s4[1] = w1; s4[2] = w2;
-            const int other = slot ^ 1;
-            status[CARLE_ST_ANY_NONZERO(other)] = 0;
-            status[CARLE_ST_NOT_ALL_ONES(other)] = 0;
-            status[CARLE_ST_SCAN_TICKET(other)] = 0;
-            status[CARLE_ST_SCAN_DONE(other)] = 0;
-            if (ea.merge_moments && ea.partials && ea.reward) {
-                uint4 w5;
-                w5.x = (uint32_t)reinterpret_cast<uint64_t>(ea.partials);
-                w5.y = (uint32_t)(reinterpret_cast<uint64_t>(ea.partials) >> 32);
-                w5.z = gridDim.x;
-                w5.w = (uint32_t)n;
-                s4[5] = w5;
-            }
-        }
-    }
-}
-
 void rnd2d_prepare_tables(const float *pp, const float *rp, float *ws, hipStream_t s);
-void rnd2d_prepare_pair_tables(float *ws, hipStream_t s);
-int ca_step_rnd64_pair(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
-                       int32_t *status, int slot, float *ws, float *bonus, hipStream_t s, const RndEnvArgs &ea,
-                       bool nt_st, bool cached_ld);
-void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s);
-
-// workgroups of the one-launch AE2D(RND2D(CARLE)) step (= its reward-moment partial pairs)
-int64_t rnd_ae64_blocks(int64_t n) {
-    int64_t blocks = n < 512 ? n : 512;
-    const int64_t v = knobs().rnd_blocks;
-    if (v > 0) blocks = v < n ? v : n;
-    return blocks < 1 ? 1 : blocks;
-}
-
-// validated by the caller (carle_env_step_f32_rnd_ae)
-int ca_step_rnd_ae64(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
-                     int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
-                     bool tables_valid, const float *ap, float *aws, float *ae_bonus, float ae_scale, bool ae_tables_valid,
-                     hipStream_t s, const RndEnvArgs &env) {
-    if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
-    if (!ae_tables_valid) ae2d_prepare_tables(ap, aws, s);
-    const int64_t lim = knobs().stream_store_min_bytes >= 0 ? knobs().stream_store_min_bytes - 1 : 256ll << 20;
-    const bool nt_st = n * 16384 > lim;
-    const int64_t ld_lim = knobs().rnd_cached_load_max_bytes >= 0 ? knobs().rnd_cached_load_max_bytes : 128ll << 20;
-    const bool cached_ld = !nt_st && n * 16384 <= ld_lim;
-    const dim3 grid((unsigned)rnd_ae64_blocks(n)), block(512);
-    RndAeEnvArgs ea;
-    ea.rnd = env;
-    ea.ae_ws = aws;
-    ea.ae_bonus = ae_bonus;
-    ea.ae_scale = ae_scale;
-    const int awk = action ? aw : 64;
-#define CARLE_RA_LAUNCH(ACT, NTS, NTL) \
-    hipLaunchKernelGGL((ca_step_rnd_ae64_kernel<ACT, NTS, NTL>), grid, block, 0, s, u_in, action, u_out, n, awk, rule, status, \
-                       slot, ws, bonus, ea)
-    if (action && cached_ld) CARLE_RA_LAUNCH(true, false, false);
-    else if (action && nt_st) CARLE_RA_LAUNCH(true, true, true);
-    else if (action) CARLE_RA_LAUNCH(true, false, true);
-    else if (nt_st) CARLE_RA_LAUNCH(false, true, true);
-    else CARLE_RA_LAUNCH(false, false, true);
-#undef CARLE_RA_LAUNCH
-    return check_launch("carle_env_step_f32_rnd_ae");
-}
 
 // workgroups of the fused launch (= reward-moment partial pairs of the one-launch step)
 int64_t rnd64_blocks(int64_t n) {
@@ -888,10 +362,7 @@ int64_t rnd64_blocks(int64_t n) {
 int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
                   int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
                   bool tables_valid, hipStream_t s, const RndEnvArgs *env) {
-    if (!tables_valid) {
-        rnd2d_prepare_tables(pp, rp, ws, s);
-        rnd2d_prepare_pair_tables(ws, s);             // (the pair-table form of the one-launch step, ca_rnd_pair.hip)
-    }
+    if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
     // Two grids per workgroup (the second one's loads travel during the first one's network phases); batches up to
     // 1024 grids one workgroup each.  Four per CU are resident, the others start as those retire -- out of phase, so
     // the memory system is not idle while every workgroup computes its last grid.  Kernel alone (tools/kbench_rnd.py,
@@ -908,22 +379,12 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
     const bool nt_st = n * 16384 > lim;
     const int64_t ld_lim = knobs().rnd_cached_load_max_bytes >= 0 ? knobs().rnd_cached_load_max_bytes : 128ll << 20;
     const bool cached_ld = !nt_st && n * 16384 <= ld_lim;
-    if (env && n > 16 && knobs().rnd_pair > 0)       // one workgroup per CU, conv1 through the pair table (ca_rnd_pair.hip)
-        return ca_step_rnd64_pair(u_in, action, u_out, n, aw, rule, status, slot, ws, bonus, s, *env, nt_st, cached_ld);
-    // eight wavefronts per grid, two workgroups per CU (CARLE_RND_WAVES=8; the ENV form, which is the whole step): 512
-    // resident workgroups walk all grids
-    const bool x8 = knobs().rnd_waves == 8;
-    if (x8) blocks = knobs().rnd_blocks > 0 ? blocks : (n < 512 ? n : 512);
-    const dim3 grid((unsigned)blocks), block(x8 ? 512 : 256);
+    const dim3 grid((unsigned)blocks), block(256);
     const RndEnvArgs ea = env ? *env : RndEnvArgs();
     const int awk = action ? aw : 64;
 #define CARLE_RND_LAUNCH(ACT, NTS, NTL, ENVF) \
-    do { \
-        if (x8) hipLaunchKernelGGL((ca_step_rnd64x8_kernel<ACT, NTS, NTL, ENVF>), grid, block, 0, s, u_in, action, u_out, n, awk, \
-                                   rule, status, slot, ws, bonus, ea); \
-        else hipLaunchKernelGGL((ca_step_rnd64_kernel<ACT, NTS, NTL, ENVF>), grid, block, 0, s, u_in, action, u_out, n, awk, rule, \
-                                status, slot, ws, bonus, ea); \
-    } while (0)
+    hipLaunchKernelGGL((ca_step_rnd64_kernel<ACT, NTS, NTL, ENVF>), grid, block, 0, s, u_in, action, u_out, n, awk, rule, \
+                       status, slot, ws, bonus, ea)
 #define CARLE_RND_PICK(ENVF) \
     do { \
         if (action && cached_ld) CARLE_RND_LAUNCH(true, false, false, ENVF); \

@@ -130,8 +130,7 @@ namespace carle {
 
 // workspace: [tables + padded linear layers (kFusedWsFloats)] [conv2 parameters (64)] [all-dead
 // packed grid (128)] [its bonus (4)]
-int64_t rnd2d_pair_workspace_floats();                // ca_rnd_pair.hip: the fused tables + the pair tables of the one-launch step
-int64_t rnd2d_fused_workspace_floats() { return rnd2d_pair_workspace_floats(); }
+int64_t rnd2d_fused_workspace_floats() { return kFusedWsTotal; }
 
 // Tables, and the bonus of the all-dead grid (the observation of every instance after a master
 // reset, env.py:208-216): it depends on the parameters only, so it is evaluated here, once per

@@ -840,26 +840,6 @@ def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_fl
     return bits_out is not None and _bits_written.value != 0
 
 
-def env_step_f32_rnd_ae(u_in, action, u_out, reward, rule, status, slot, publish_flags, rnd_pred, rnd_rand, rnd_ws,
-                        rnd_bonus, rnd_scale, rnd_valid, ae_params, ae_ws, ae_bonus, ae_scale, ae_valid,
-                        merge_moments=False, partials=None):
-    """AE2D(RND2D(CARLE)).step with both wrappers forward-only at 64x64, more than 16 instances: ONE launch
-    (carle_env_step_f32_rnd_ae).  ``partials``: fp64 scratch of carle_rnd_ae_step_partials_doubles(n) elements when
-    merge_moments."""
-    lib = _lib.load()
-    n, _, h, w = u_in.shape
-    ap, ah, aw = (None, 0, 0) if action is None else (action.data_ptr(), action.shape[2], action.shape[3])
-    with _on_device(u_in.device):
-        rc = lib.carle_env_step_f32_rnd_ae(u_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h, w, ah, aw, rule,
-                                           status.data_ptr(), slot, _step_flags(publish_flags, merge_moments, True),
-                                           rnd_pred.data_ptr(), rnd_rand.data_ptr(), rnd_ws.data_ptr(), rnd_bonus.data_ptr(),
-                                           float(rnd_scale), 2 if rnd_valid else 0, ae_params.data_ptr(), ae_ws.data_ptr(),
-                                           ae_bonus.data_ptr(), float(ae_scale), 2 if ae_valid else 0, _ptr(partials),
-                                           _stream(u_in))
-    if rc != 0:
-        _lib.check(rc, "carle_env_step_f32_rnd_ae")
-
-
 def ca_step_f32_rnd(u_in, action, u_out, rule, status, slot, pred_params, rand_params, workspace, bonus,
                     tables_valid):
     """The fused 64x64 CA + RND2D kernel alone (no epilogue); bonus has N + 1 elements."""

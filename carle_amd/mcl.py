@@ -750,12 +750,9 @@ class AE2D(RND2D):
                 and not rnd.async_reward and env.height == env.width and env.height % 64 == 0):
             return 0
         if env.height == 64:
-            # 64x64: the WHOLE step -- CA generation, both bonuses, the reward -- is one launch (carle_env_step_f32_rnd_ae)
-            # for forward-only wrappers on an fp32 environment of more than 16 instances with an 8-aligned window
-            if (not self.train_predictor and not rnd.train_predictor and getattr(env, "storage", "f32") == "f32"
-                    and not env.logging and env.instances > 16 and env.action_width % 8 == 0
-                    and os.environ.get("CARLE_FUSED_RND_AE", "0") != "0"):      # (opt-in: measured slower, EXPERIMENTS.md 5.4)
-                return 3
+            # 64x64: the wrappers step one after the other -- two launches: RND2D's one-launch step (which also hands the
+            # observation over bit-packed) and AE2D's bonus kernel.  (One kernel for the three was built in round 5 and
+            # measured slower: EXPERIMENTS.md 5.4.)
             return 0
         if not self.train_predictor and not rnd.train_predictor:
             return 1
@@ -770,15 +767,11 @@ class AE2D(RND2D):
         tile of a grid finishes it) instead of four -- a step there is bound by its dependent dispatches.  Bit-identical to the
         two wrappers stepping one after the other."""
         mode = self._can_pair_step()
-        if mode == 3 and not isinstance(action, torch.Tensor):
-            mode = 0                                         # (array-likes / in-kernel random actions: the wrappers one by one)
         if not mode:
             return super().step(action)
         rnd, env = self.env, self.inner_env
         if isinstance(action, torch.Tensor):
             action = action.to(env.my_device)
-        if mode == 3:
-            return self._fused64_step(action)
         rnd.__dict__["_moments_merged"] = False
         self.__dict__["_moments_merged"] = False
         obs, reward, done, info = env.step(action)
@@ -813,48 +806,6 @@ class AE2D(RND2D):
         self._commit_tables()
         self._pair_moments_left(partials)
         return obs, reward, done, info
-
-    def _fused64_step(self, action):
-        """AE2D(RND2D(CARLE)).step at 64x64, forward passes: environment step, RND2D bonus, AE2D bonus and the reward in ONE
-        kernel (carle_env_step_f32_rnd_ae) -- the AE2D forward runs on the bit rows the CA + RND2D workgroup still holds.
-        Bit-identical to RND2D's one-launch step followed by AE2D's bonus kernel on its observation."""
-        from . import _lib
-        lib = _lib.load()
-        rnd, env = self.env, self.inner_env
-        dev, n = env.my_device, env.instances
-        for w, need in ((rnd, lib.carle_rnd2d_workspace_floats(n, 64, 64)), (self, lib.carle_ae2d_workspace_floats(n, 64, 64))):
-            if w._ws is None or w._ws.numel() < need or w._ws.device != dev:
-                w._ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
-                w._tables_key = None
-        if rnd._step_bonus is None or rnd._step_bonus.shape[0] != n + 1 or rnd._step_bonus.device != dev:
-            rnd._step_bonus = torch.empty(n + 1, dtype=torch.float32, device=dev)
-        if self._bonus_buf is None or self._bonus_buf.shape[0] != n or self._bonus_buf.device != dev:
-            self._bonus_buf = torch.empty(n, dtype=torch.float32, device=dev)
-        pb, rb, ab = rnd._pred_blob.get(dev), rnd._rand_blob.get(dev), self._pred_blob.get(dev)
-        rkey = (id(rnd._ws), (rnd._pred_blob.version, rnd._rand_blob.version))          # RND2D._fused_step's key form
-        akey = (id(self._ws), (self._pred_blob.version,), n, 64)                        # _commit_tables' key form
-        rvalid, avalid = rnd._tables_key == rkey, self._tables_key == akey
-        merge = self.__dict__.get("_final_reward_stats") is not None                    # this wrapper is outermost
-        partials = None
-        if merge:
-            pneed = lib.carle_rnd_ae_step_partials_doubles(n)
-            partials = self.__dict__.get("_mom_partials")
-            if partials is None or partials.numel() < pneed or partials.device != dev:
-                env.settled_status()                         # nothing may still point into the old buffer
-                partials = self.__dict__["_mom_partials"] = torch.zeros(pneed, dtype=torch.float64, device=dev)
-
-        def launch(u_in, act, out, reward, rule, status, slot, publish):
-            hip.env_step_f32_rnd_ae(u_in, act, out, reward, rule, status, slot, publish, pb, rb, rnd._ws, rnd._step_bonus,
-                                    rnd.reward_scale, rvalid, ab, self._ws, self._bonus_buf, self.reward_scale, avalid,
-                                    merge, partials)
-            if merge:
-                env.__dict__["_moments_pending"] = True
-        rnd.__dict__["_moments_merged"] = False
-        self.__dict__["_moments_merged"] = False
-        result = env._step(action, launch)
-        self.__dict__["_moments_merged"] = merge
-        rnd._tables_key, self._tables_key = rkey, akey
-        return result
 
     def _pair_moment_buffers(self, need, dev):
         """RunningRewardStats attached to this pair (``attach``): the pair's finish kernel leaves per-workgroup partial sums

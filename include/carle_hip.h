@@ -525,23 +525,6 @@ int carle_env_step_b1_rand(const uint64_t *u_in, uint64_t *u_out, float *reward,
                            int ah, int aw, uint32_t rule, float p, uint64_t seed, uint64_t offset,
                            int32_t *status, int slot, int step_flags, void *stream);
 
-/* AE2D(RND2D(CARLE)).step -- the stack carle/train_mcl.py:36-40 builds -- with both wrappers forward-only, 64x64 fp32
- * grids, more than 16 instances, action NULL or AW % 8 == 0: carle/env.py:188-242 + carle/mcl.py:398-407 (RND2D.step) +
- * carle/mcl.py:504-512 with 398-407 again (AE2D's bonus and reward update) in ONE kernel: the AE2D forward runs on the
- * bit rows the CA + RND2D workgroup still holds (no second read of the observation; the conv1 pattern address of a cell
- * is formed once for both nets).  reward[i] = (0 + rnd_scale * rnd_bonus[i]) + ae_scale * ae_bonus[i], rounded as torch
- * rounds the two in-place updates.  step_flags: CARLE_STEP_DEFERRED is required (counters pending, see above),
- * PUBLISH_FLAGS / MERGE_MOMENTS as for carle_env_step_f32_rnd; moment_partials: carle_rnd_ae_step_partials_doubles(n)
- * doubles, caller-owned, alive until the next call on the status block.  rnd_bonus: n + 1 floats, ae_bonus: n floats.
- * Bit-identical to carle_env_step_f32_rnd followed by carle_ae2d_bonus_f32 on its observation. */
-int64_t carle_rnd_ae_step_partials_doubles(int64_t n);
-int carle_env_step_f32_rnd_ae(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h, int w,
-                              int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
-                              const float *rnd_pred_params, const float *rnd_rand_params, float *rnd_workspace,
-                              float *rnd_bonus, float rnd_scale, int rnd_net_flags, const float *ae_params,
-                              float *ae_workspace, float *ae_bonus, float ae_scale, int ae_net_flags,
-                              double *moment_partials, void *stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Per-instance sums for the hand-coded reward wrappers: for every instance i
  * of x (n x elems floats): out4[4i] = sum x, out4[4i+k+1] = sum x * w_k for the (nullable) weight

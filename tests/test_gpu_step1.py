@@ -332,71 +332,6 @@ def test_one_launch_rnd_step_equals_two_launch_path_and_oracle(n, aw, stats, mon
         np.testing.assert_allclose(m1[0], [allr.size, allr.mean(), ((allr - allr.mean()) ** 2).sum()], rtol=1e-10)
 
 
-@pytest.mark.parametrize("n,aw,stats", [(17, 64, True), (100, 64, False), (515, 32, True), (2050, 64, True)])
-def test_one_launch_rnd_ae_step_equals_the_two_kernel_path_and_oracle(n, aw, stats, monkeypatch):
-    """AE2D(RND2D(CARLE)).step at 64x64, forward passes (train_mcl.py:36-40's stack): carle_env_step_f32_rnd_ae -- CA
-    generation, both bonuses and the reward in ONE kernel -- against RND2D's one-launch step followed by AE2D's bonus kernel
-    (CARLE_FUSED_RND_AE=0): observations (also against the C oracle), rewards, both bonus vectors, counters bit-identical;
-    rewards within 1e-5 of oracle/nets.py; the reward statistics (per-workgroup partial sums, merged one call later) equal to
-    fp64 rounding.  Crafted actions: master resets, all ones but one element, all-ones grids."""
-    from carle_amd import dist as cd
-    from carle_amd.env import CARLE
-    from carle_amd.mcl import RND2D, AE2D
-    from oracle import nets as ON
-    rng = np.random.default_rng(n + aw)
-    u0 = (rng.random((n, 1, 64, 64)) < 0.4).astype(np.float32)
-    acts = [a for a in _crafted_actions(rng, n, aw) if a is not None]
-    res = []
-    for fused in (True, False):
-        monkeypatch.setenv("CARLE_FUSED_RND_AE", "1" if fused else "0")
-        torch.manual_seed(4)
-        env = CARLE(width=64, height=64, action_width=aw, action_height=aw, instances=n, device="cuda:0")
-        w = AE2D(RND2D(env, train_predictor=False), train_predictor=False)
-        w.env.reward_scale, w.reward_scale = 0.7, 1.3
-        w.eval(); w.reset()
-        assert w._can_pair_step() == (3 if fused else 0)
-        st = None
-        if stats:
-            st = cd.RunningRewardStats("cuda:0", sync_every=1 << 30)
-            assert st.attach(w) is fused                     # (the two-kernel path: stand-alone moments per step)
-        env.universe = torch.from_numpy(u0).cuda()
-        out = []
-        for t, a in enumerate(acts):
-            obs, reward, done, info = w.step(torch.from_numpy(a).cuda())
-            if st is not None:
-                assert bool(w._moments_merged) is fused
-                st.after_step(w, reward)
-            out.append((obs.clone(), reward.clone(), w.env._step_bonus[:n].clone(), w._bonus_buf.clone()))
-        snap = None
-        if st is not None:
-            st.flush()
-            snap = (st.state.cpu().numpy().copy(), st.last_batch.cpu().numpy().copy())
-        sd = {k: v.detach().cpu().numpy() for k, v in w.state_dict().items()}
-        res.append((out, env.step_number, env.steps_since_action, env.master_resets, snap, sd))
-    monkeypatch.delenv("CARLE_FUSED_RND_AE", raising=False)
-    ref = _oracle_loop(u0, acts, O.rule_mask([3], [2, 3]))
-    (o1, sn1, ssa1, r1, m1, sd), (o2, sn2, ssa2, r2, m2, _) = res
-    rsd = {k[len("env."):]: v for k, v in sd.items() if k.startswith("env.predictor") or k.startswith("env.random_network")}
-    asd = {k: v for k, v in sd.items() if k.startswith("predictor")}
-    saw_reset = False
-    for t, ((oa, ra, ba, ca), (ob, rb, bb, cb)) in enumerate(zip(o1, o2)):
-        assert np.array_equal(oa.cpu().numpy(), ref[t][0]), t
-        assert torch.equal(oa, ob), t
-        assert torch.equal(ba, bb) and torch.equal(ca, cb), (t, (ba - bb).abs().max(), (ca - cb).abs().max())
-        assert torch.equal(ra, rb), (t, (ra - rb).abs().max())
-        exp = np.float32(0.7) * ON.rnd_bonus(ref[t][0], rsd).numpy() + np.float32(1.3) * ON.ae_bonus(ref[t][0], asd).numpy()
-        np.testing.assert_allclose(ra.reshape(-1).cpu().numpy(), exp, rtol=0, atol=1e-5)
-        if int(oa.count_nonzero()) == 0:                         # a master reset: one reward value for every instance
-            assert float(ra.max()) == float(ra.min()) > 0
-            saw_reset = True
-    assert saw_reset
-    assert (sn1, ssa1, r1) == (sn2, ssa2, r2) == ref[-1][1:]
-    if stats:
-        allr = torch.cat([r.reshape(-1) for _, r, _, _ in o1]).double().cpu().numpy()
-        np.testing.assert_allclose(m1[0], m2[0], rtol=1e-12, atol=1e-15)
-        np.testing.assert_allclose(m1[0], [allr.size, allr.mean(), ((allr - allr.mean()) ** 2).sum()], rtol=1e-10)
-
-
 def test_pending_rnd_moments_are_merged_by_whatever_comes_next(monkeypatch):
     """The partial sums a one-launch CA + RND2D step leaves behind are merged by the next launch on the status block:
     another wrapper step, a bare step of the inner environment, run(), multistep(), a stats flush -- same totals."""

@@ -30,6 +30,19 @@ __device__ __forceinline__ uint64_t spread_nibbles(uint32_t x) {
     return t;
 }
 
+// 1 if the fp32 bit pattern is a non-zero NUMBER (NaN counts, -0.0 does not; the truthiness of
+// torch.logical_xor, env.py:182) in two VALU ops: the add drops the sign, v_min_u32 clamps to 1.
+// (Written as asm: hipcc rewrites umin(x, 1) into compare + select, three ops and a VCC hazard.)
+__device__ __forceinline__ uint32_t nz1(uint32_t bits) {
+    uint32_t r;
+    const uint32_t t = bits + bits;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(t));
+    return r;
+}
+__device__ __forceinline__ uint32_t nibble_fast(const uint4 &v) {
+    return nz1(v.x) | (nz1(v.y) << 1) | (nz1(v.z) << 2) | (nz1(v.w) << 3);
+}
+
 // LDS image of one workgroup (4 wavefronts) that owns one 64x64 grid at a time
 struct RndBlockShared {
     float4 lut_p[512];                 // conv1 + relu of the predictor, per 9-bit neighbourhood pattern
@@ -48,20 +61,25 @@ struct RndBlockShared {
 // own s_waitcnt vmcnt(0) -- eight dependent round trips at the head of every workgroup (and the first of them also
 // waited for the first grid's loads, which the fused CA + RND2D kernel requests ahead of this): round 2, seen in the
 // disassembly.
+// NT: threads of the workgroup (256: four wavefronts per grid; 512: eight, ca_step_rnd64x8_kernel)
+template <int NT = 256>
 __device__ __forceinline__ void rnd_block_init(RndBlockShared &s, const float *__restrict__ ws, int tid) {
     static_assert((2 * kLinFloats) % 4 == 0 && (6 * kPlaneFloats) % 4 == 0 && kLutFloats % 4 == 0, "float4 copies");
-    constexpr int kLin4 = 2 * kLinFloats / 4, kLinIt = (kLin4 + 255) / 256;
+    static_assert(NT == 256 || NT == 512, "four or eight wavefronts");
+    constexpr int kLin4 = 2 * kLinFloats / 4, kLinIt = (kLin4 + NT - 1) / NT;
     const float4 *src = reinterpret_cast<const float4 *>(ws);
     const float2 *src2 = reinterpret_cast<const float2 *>(ws + 2048);
     const float4 *lsrc = reinterpret_cast<const float4 *>(ws + kLutFloats);
-    const float4 p0 = src[tid], p1 = src[tid + 256];
-    const float2 r0 = src2[tid], r1 = src2[tid + 256];
+    // (NT == 512: one table entry per thread; the second element is the first again -- a benign duplicate store)
+    const int t1 = NT == 256 ? tid + 256 : tid;
+    const float4 p0 = src[tid], p1 = src[t1];
+    const float2 r0 = src2[tid], r1 = src2[t1];
     // tails without a branch (the compiler would sink the load into it and wait there): a thread beyond the end
     // repeats its previous element, load and store -- a benign duplicate
     float4 l[kLinIt];
     int li[kLinIt];
 #pragma unroll
-    for (int k = 0; k < kLinIt; ++k) { const int i = tid + 256 * k; li[k] = i < kLin4 ? i : i - 256; l[k] = lsrc[li[k]]; }
+    for (int k = 0; k < kLinIt; ++k) { const int i = tid + NT * k; li[k] = i < kLin4 ? i : i - NT; l[k] = lsrc[li[k]]; }
     // conv2 parameters (behind the tables in the workspace: pred w[36] b at +0, rand w[18] b at +40): every thread
     // handles entry tid % 96 of w2 and entry tid % 4 of b2
     const int e = tid % 96, net = e / 48, c = (e % 48) / 12, t = e % 12;
@@ -70,13 +88,13 @@ __device__ __forceinline__ void rnd_block_init(RndBlockShared &s, const float *_
     const int be = tid & 3;
     const float b2v = ws[kFusedWsFloats + (be == 1 ? 58 : 36)];
 
-    s.lut_p[tid] = p0; s.lut_p[tid + 256] = p1;
-    s.lut_r[tid] = r0; s.lut_r[tid + 256] = r1;
+    s.lut_p[tid] = p0; s.lut_p[t1] = p1;
+    s.lut_r[tid] = r0; s.lut_r[t1] = r1;
     float4 *ldst = reinterpret_cast<float4 *>(s.lin);
 #pragma unroll
     for (int k = 0; k < kLinIt; ++k) ldst[li[k]] = l[k];
     float4 *pl = reinterpret_cast<float4 *>(&s.planes[0][0]);
-    for (int i = tid; i < 6 * kPlaneFloats / 4; i += 256) pl[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 6 * kPlaneFloats / 4; i += NT) pl[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 66) s.rows[tid] = 0ull;
     (&s.w2[0][0][0])[e] = w2_in ? w2v : 0.0f;
     s.b2[be] = be < 2 ? b2v : 0.0f;
@@ -101,8 +119,8 @@ __device__ __forceinline__ uint32_t row_nibbles_to_dword(uint32_t nib, int k) {
 #ifndef CARLE_RND_CONV1_BATCH
 #define CARLE_RND_CONV1_BATCH 4
 #endif
-// Timing probe only (tools/ab_libs.sh builds, EXPERIMENTS.md 5.2): fewer than 16 lookups per window give WRONG planes --
-// what halving the lookups (a 12-bit pair table) could save at most, with occupancy and table size as they are
+// Timing probe only (tools/ab_libs.sh builds): fewer than 16 lookups per window give WRONG planes -- what halving the
+// lookups (a 12-bit pair table) could save at most, with occupancy and table size as they are
 #ifndef CARLE_RND_CONV1_LOOKUPS
 #define CARLE_RND_CONV1_LOOKUPS 16
 #endif
@@ -205,6 +223,83 @@ __device__ __forceinline__ void rnd_block_conv2(const RndBlockShared &s, float (
         const float mx = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1])) + (net == 0 ? bias0 : bias1);
         if (c == 0) feat[net][f] = fmaxf(mx, 0.0f);
     }
+}
+
+// ---- eight wavefronts per grid (ca_step_rnd64x8_kernel): the same two stages on 512 threads -------------------------
+// conv1: thread = (pooling window tid / 2, half tid % 2): the half's EIGHT lookups (window rows 2 half, 2 half + 1: four
+// row segments instead of six), one batch, then the two halves' maxima meet through one DPP (lane ^ 1); max is exact in
+// any order, so the planes are bit-identical to rnd_block_conv1's.
+__device__ __forceinline__ void rnd_block_conv1_x8(RndBlockShared &s, int tid) {
+    const int win = tid >> 1, half = tid & 1;
+    const int py = win >> 4, px = win & 15;
+    uint32_t seg[4];                                  // [west | 4 cells | east] of rows 4py-1+2half .. 4py+2+2half
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint64_t row = s.rows[4 * py + 2 * half + r];
+        seg[r] = (uint32_t)(px == 0 ? row << 1 : row >> (4 * px - 1)) & 0x3Fu;
+    }
+    float4 pa[8];
+    float2 pb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int dy = j >> 2, dx = j & 3;
+        const uint32_t p = ((seg[dy] >> dx) & 7u) | (((seg[dy + 1] >> dx) & 7u) << 3) | (((seg[dy + 2] >> dx) & 7u) << 6);
+        pa[j] = s.lut_p[p];
+        pb[j] = s.lut_r[p];
+    }
+    __builtin_amdgcn_sched_barrier(0);                // all eight lookups are issued before the first max
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        m0 = fmaxf(m0, pa[j].x); m1 = fmaxf(m1, pa[j].y); m2 = fmaxf(m2, pa[j].z); m3 = fmaxf(m3, pa[j].w);
+        m4 = fmaxf(m4, pb[j].x); m5 = fmaxf(m5, pb[j].y);
+    }
+    m0 = fmaxf(m0, dpp_quad_xor1(m0)); m1 = fmaxf(m1, dpp_quad_xor1(m1)); m2 = fmaxf(m2, dpp_quad_xor1(m2));
+    m3 = fmaxf(m3, dpp_quad_xor1(m3)); m4 = fmaxf(m4, dpp_quad_xor1(m4)); m5 = fmaxf(m5, dpp_quad_xor1(m5));
+    // both halves hold the window's maxima: half 0 writes the predictor's planes 0..2, half 1 the rest (three stores each)
+    const int off = (py + 1) * kPlaneStride + px + 1;
+    s.planes[3 * half][off] = half ? m3 : m0;
+    s.planes[3 * half + 1][off] = half ? m4 : m1;
+    s.planes[3 * half + 2][off] = half ? m5 : m2;
+}
+
+// conv2: thread = (net tid / 256, pooling window f, input channel c) -- rnd_block_conv2 with one net per thread; same
+// summation order: taps (ky, kx) inside a channel, then (c0 + c1) + (c2 + c3).
+__device__ __forceinline__ void rnd_block_conv2_x8(const RndBlockShared &s, float (*__restrict__ feat)[64], int tid) {
+    const int net = tid >> 8, f = (tid & 255) >> 2, c = tid & 3;
+    const int fy = f >> 3, fx = f & 7;
+    float patch[4][4], w[12];
+    const float *pl = &s.planes[net == 0 ? c : 4 + (c & 1)][(2 * fy) * kPlaneStride + 2 * fx];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride);
+        const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kPlaneStride + 2);
+        patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
+    }
+    const float4 *wp = reinterpret_cast<const float4 *>(&s.w2[net][c][0]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float4 t = wp[i];
+        w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
+    }
+    const float bias = s.b2[net];
+    __builtin_amdgcn_sched_barrier(0);
+    float o[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc = fmaf(w[ky * 3 + kx], patch[dy + ky][dx + kx], acc);
+            acc += dpp_quad_xor1(acc);                // channels (c0 + c1), (c2 + c3)
+            acc += dpp_quad_xor2(acc);                // all four
+            o[dy][dx] = acc;
+        }
+    const float mx = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1])) + bias;
+    if (c == 0) feat[net][f] = fmaxf(mx, 0.0f);
 }
 
 // Stage 5 on ONE wavefront (all 64 lanes): the two 64->16 linear layers + tanh and the bonus
