@@ -77,6 +77,9 @@ SIGNATURES = {
                                       _c_vp, ctypes.c_float, _c_int, _c_vp]),
     "carle_ae2d_bonus_b1": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp,
                                      _c_vp, ctypes.c_float, _c_int, _c_vp]),
+    "carle_ae2d_stats_partials_doubles": (_c_i64, [_c_i64]),
+    "carle_ae2d_bonus_b1_stats": (_c_int, [_c_vp, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_float, _c_int,
+                                           _c_vp, _c_vp, _c_vp]),
     "carle_morpho_partial_floats": (_c_i64, [_c_i64, _c_int]),
     "carle_morpho_match_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_i64, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
                                         ctypes.c_float, _c_vp]),

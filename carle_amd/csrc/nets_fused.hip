@@ -222,12 +222,17 @@ struct AeBlockShared {
 
 // TGT (PredictionBonus, mcl.py:581-605): the squared error is taken against another bit-packed frame `tgt` of the same
 // universes instead of the input itself
-template <bool PACKED_OBS, bool TGT = false>
+// STATS (round 5; an AE2D that is the OUTERMOST wrapper of a stack whose rewards feed a RunningRewardStats): the rewards this
+// kernel finishes are the step's final ones, so every workgroup leaves (sum, sum of squares) of the rewards it wrote in
+// `partials` and workgroup 0 registers them in the environment's status block (CARLE_ST_MOM_*): the next launch on the block
+// merges them -- the stand-alone moments launch (a dependent 5 us dispatch per step) is gone, as for the tiled pair.
+template <bool PACKED_OBS, bool TGT = false, bool STATS = false>
 __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
     const void *__restrict__ obs_v, const float *__restrict__ ws, float *__restrict__ bonus,
     float *__restrict__ recon, float *__restrict__ reward, float reward_scale, int64_t n,
-    const uint64_t *__restrict__ tgt) {
+    const uint64_t *__restrict__ tgt, double *__restrict__ partials = nullptr, int32_t *__restrict__ status = nullptr) {
     __shared__ AeBlockShared s;
+    double rsum = 0.0, rsq = 0.0;                    // STATS: thread 0's sums over this workgroup's grids
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float *prm = ws + kAeLutFloats;            // uniform parameter block
     // (the 124 uniform weights are scalar-loaded inside the phase that uses them: opaque_uniform)
@@ -426,12 +431,32 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
         if (tid == 0) {
             const float b = ((s.red[0] + s.red[1]) + (s.red[2] + s.red[3])) * (1.0f / 4096.0f);
             bonus[g] = b;
-            if (reward) reward[g] = reward_accumulate(reward[g], reward_scale, b);
+            if (reward) {
+                const float r = reward_accumulate(reward[g], reward_scale, b);
+                reward[g] = r;
+                if (STATS) { rsum += (double)r; rsq = fma((double)r, (double)r, rsq); }
+            }
+        }
+    }
+    if (STATS && tid == 0) {
+        reinterpret_cast<double2 *>(partials)[blockIdx.x] = make_double2(rsum, rsq);
+        if (blockIdx.x == 0) {                       // pending reward moments of this step: merged by the next call on the block
+            uint4 w5;
+            w5.x = (uint32_t)reinterpret_cast<uint64_t>(partials);
+            w5.y = (uint32_t)(reinterpret_cast<uint64_t>(partials) >> 32);
+            w5.z = gridDim.x;
+            w5.w = (uint32_t)n;
+            reinterpret_cast<uint4 *>(status)[5] = w5;
         }
     }
 }
 
 int64_t ae2d_fused_workspace_floats() { return kAeWsFloats; }
+int64_t ae2d_fused64_blocks(int64_t n) {
+    int64_t blocks = n < 1280 ? n : 1280;             // persistent: 5 workgroups are resident per CU
+    if (const int64_t v = knobs().net_blocks; v > 0) blocks = v < n ? v : n;   // experiment knob, read once
+    return blocks < 1 ? 1 : blocks;
+}
 
 // conv1 table + the uniform parameter block, ws[0 .. kAeWsFloats): shared with the tiled kernel (nets_tiled.hip)
 void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s) {
@@ -440,12 +465,15 @@ void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s) {
 
 int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s,
-                 const uint64_t *tgt) {
+                 const uint64_t *tgt, double *partials, int32_t *status) {
     if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
-    int64_t blocks = n < 1280 ? n : 1280;             // persistent: 5 workgroups are resident per CU
-    if (const int64_t v = knobs().net_blocks; v > 0) blocks = v < n ? v : n;   // experiment knob, read once
-    if (blocks < 1) blocks = 1;
+    const int64_t blocks = ae2d_fused64_blocks(n);
     const uint64_t *no_tgt = nullptr;
+    if (partials && status && packed && !tgt && reward) {
+        hipLaunchKernelGGL((ae_block64_kernel<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,
+                           recon, reward, reward_scale, n, no_tgt, partials, status);
+        return check_launch("carle_ae2d_bonus(fused 64x64, reward moments)");
+    }
     if (tgt)                                          // (bit-packed frames only)
         hipLaunchKernelGGL((ae_block64_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, obs, ws, bonus,
                            recon, reward, reward_scale, n, tgt);

@@ -474,7 +474,8 @@ int ae2d_train64(const void *obs, bool packed, int64_t n, const float *ap, float
 int64_t ae2d_fused_workspace_floats();
 int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s,
-                 const uint64_t *tgt = nullptr);
+                 const uint64_t *tgt = nullptr, double *partials = nullptr, int32_t *status = nullptr);
+int64_t ae2d_fused64_blocks(int64_t n);
 }
 
 using namespace carle;
@@ -666,6 +667,25 @@ extern "C" int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w,
     if (n == 0) return 0;
     return ae2d_fused64(obs, true, n, params, workspace, bonus, recon_out, reward_accum, reward_scale,
                         (flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream));
+}
+
+// carle_ae2d_bonus_b1 for an AE2D that is the OUTERMOST wrapper of a 64x64 stack whose rewards feed the running reward
+// statistics (CARLE_ST_MOMENTS_*): reward_accum is required, and the kernel that finishes the rewards also leaves their
+// (sum, sum of squares) per workgroup in moment_partials (carle_ae2d_stats_partials_doubles(n) doubles, caller-owned,
+// alive until the next call on the status block) and registers them in `status` -- merged by that next call (or
+// carle_env_settle) exactly as the one-launch RND2D step's are.  No stand-alone moments launch per step.
+extern "C" int64_t carle_ae2d_stats_partials_doubles(int64_t n) { return n > 0 ? 2 * ae2d_fused64_blocks(n) : 2; }
+
+extern "C" int carle_ae2d_bonus_b1_stats(const uint64_t *obs, int64_t n, int h, int w, const float *params, float *workspace,
+                                         float *bonus, float *reward_accum, float reward_scale, int flags,
+                                         double *moment_partials, int32_t *status, void *stream) {
+    if (!obs || !params || !workspace || !bonus || !reward_accum || !moment_partials || !status)
+        return fail_arg(CARLE_E_NULL, "carle_ae2d_bonus_b1_stats: NULL pointer");
+    if (h != 64 || w != 64 || n <= 0) return fail_arg(CARLE_E_DIMS, "carle_ae2d_bonus_b1_stats: 64x64 bit-packed grids, n > 0");
+    if (!aligned16(moment_partials) || !aligned16(status))
+        return fail_arg(CARLE_E_ALIGN, "carle_ae2d_bonus_b1_stats: moment_partials / status must be 16-byte aligned");
+    return ae2d_fused64(obs, true, n, params, workspace, bonus, nullptr, reward_accum, reward_scale,
+                        (flags & CARLE_NET_TABLES_VALID) != 0, static_cast<hipStream_t>(stream), nullptr, moment_partials, status);
 }
 
 extern "C" int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float *params,

@@ -235,7 +235,8 @@ class RunningRewardStats:
         into the pending triple, so ``after_step`` has nothing to launch.  ``env`` must be the
         OUTERMOST environment the caller steps -- a bare ``CARLE`` (any storage), an ``RND2D``
         sitting directly on one (its bonus is part of the fused step), or the pair ``AE2D(RND2D(CARLE))``
-        at tiled sizes (the pair's finish kernel leaves the partial sums) -- because the epilogue only
+        (tiled sizes: the pair's finish kernel leaves the partial sums; 64x64 forward passes: AE2D's bonus
+        kernel does) -- because the epilogue only
         sees the rewards that exist when it runs.  Returns False (and changes nothing) otherwise;
         ``after_step`` then falls back to the stand-alone moments kernel."""
         inner = getattr(env, "inner_env", None) or env
@@ -244,7 +245,8 @@ class RunningRewardStats:
         if env is not inner:
             from .mcl import RND2D, AE2D
             # ... or the pair AE2D(RND2D(CARLE)) at tiled sizes, whose rewards are final in the pair's finish kernel
-            pair = type(env) is AE2D and env._can_pair_step() != 0
+            # (... or its forward-only form at 64x64, whose rewards are final in AE2D's bonus kernel)
+            pair = type(env) is AE2D and (env._can_pair_step() != 0 or env._can_leave_moments())
             if not pair and (type(env) is not RND2D or env.env is not inner or env.train_predictor):
                 return False
         inner._install_reward_stats(self)

@@ -207,6 +207,19 @@ def ae2d_bonus_f32(obs, params, workspace=None, want_recon=False, binary=False,
     return (bonus, recon, workspace) if want_recon else (bonus, workspace)
 
 
+def ae2d_bonus_b1_stats(obs, params, workspace, bonus, reward, reward_scale, tables_valid, partials, status, stream=None):
+    """AE2D bonus of bit-packed 64x64 observations with ``reward += scale * bonus`` AND the reward moments of the step left as
+    per-workgroup partial sums registered in the environment's status block (carle_ae2d_bonus_b1_stats)."""
+    lib = _lib.load()
+    n = obs.shape[0]
+    with _on_device(obs.device):
+        rc = lib.carle_ae2d_bonus_b1_stats(obs.data_ptr(), n, 64, 64, params.data_ptr(), workspace.data_ptr(), bonus.data_ptr(),
+                                           reward.data_ptr(), float(reward_scale), 2 if tables_valid else 0, partials.data_ptr(),
+                                           status.data_ptr(), stream if stream is not None else _stream(obs))
+    if rc != 0:
+        _lib.check(rc, "carle_ae2d_bonus_b1_stats")
+
+
 def ae2d_predict(obs, target, params, workspace=None, scratch=None, grad=None, grad_scale=0.0, want_recon=False,
                  bonus_out=None, stream=None, tables_valid=False):
     """PredictionBonus.get_bonus (carle/mcl.py:581-605): bonus (N,) = mean_hw (target - decoder(obs))^2 for two frames

@@ -731,10 +731,41 @@ class AE2D(RND2D):
         for p in self.predictor.parameters():
             p.requires_grad = False
 
+    def _can_leave_moments(self):
+        """This AE2D is the top of AE2D(RND2D(CARLE)) at 64x64 (train_mcl.py:36-40), forward passes: its bonus kernel finishes
+        the step's rewards and can leave their moments for the running statistics (carle_ae2d_bonus_b1_stats)."""
+        rnd, env = self.env, self.inner_env
+        return (type(self) is AE2D and type(rnd) is RND2D and rnd.env is env and not self.async_reward and not rnd.async_reward
+                and not self.train_predictor and not rnd.train_predictor and env.height == env.width == 64
+                and getattr(env, "storage", "f32") == "f32")
+
     def _hip_forward(self, obs, want_outputs=False, reward=None, bonus_out=None, stream=None):
         obs, binary = self._obs(obs, allow_packed=True)
         pb = self._pred_blob.get(obs.device)
         valid = self._tables_valid(obs, binary, (self._pred_blob.version,))
+        status = self.inner_env.__dict__.get("_status")
+        if (reward is not None and not want_outputs and stream is None and obs.dtype == torch.int64 and obs.shape[2] == 64
+                and obs.shape[3] == 1 and status is not None and self.__dict__.get("_final_reward_stats") is not None):
+            # the rewards this kernel finishes are the step's final ones and a RunningRewardStats is attached to this wrapper:
+            # their moments leave as per-workgroup partial sums, merged by the next launch on the status block
+            from . import _lib
+            lib = _lib.load()
+            n, dev = obs.shape[0], obs.device
+            need = lib.carle_ae2d_workspace_floats(n, 64, 64)
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
+                valid = False
+            pneed = lib.carle_ae2d_stats_partials_doubles(n)
+            partials = self.__dict__.get("_mom_partials64")
+            if partials is None or partials.numel() < pneed or partials.device != dev:
+                self.inner_env.settled_status()              # nothing may still point into the old buffer
+                partials = self.__dict__["_mom_partials64"] = torch.zeros(pneed, dtype=torch.float64, device=dev)
+            bonus = bonus_out if bonus_out is not None else torch.empty(n, dtype=torch.float32, device=dev)
+            hip.ae2d_bonus_b1_stats(obs, pb, self._ws, bonus, reward, self.reward_scale, valid, partials, status)
+            self._commit_tables()
+            self.__dict__["_moments_merged"] = True
+            self.inner_env.__dict__["_moments_pending"] = True
+            return bonus, self._ws
         res = hip.ae2d_bonus_f32(obs, pb, self._ws, want_outputs, binary, reward, self.reward_scale,
                                  bonus_out, stream, valid)
         self._ws = res[-1]

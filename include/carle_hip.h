@@ -368,6 +368,16 @@ int carle_ae2d_bonus_f32(const float *obs, int64_t n, int h, int w, const float 
 int carle_ae2d_bonus_b1(const uint64_t *obs, int64_t n, int h, int w, const float *params,
                         float *workspace, float *bonus, float *recon_out,
                         float *reward_accum, float reward_scale, int flags, void *stream);
+/* carle_ae2d_bonus_b1 for an AE2D that is the OUTERMOST wrapper of a 64x64 stack -- AE2D(RND2D(env)), carle/train_mcl.py:36-40 --
+ * whose rewards feed the running reward statistics (CARLE_ST_MOMENTS_*): reward_accum is required, and the kernel that
+ * finishes the step's rewards also leaves their (sum, sum of squares) per workgroup in moment_partials
+ * (carle_ae2d_stats_partials_doubles(n) doubles, caller-owned, 16-byte aligned, alive until the next call on the status
+ * block) and registers them in `status`: the next call on the block (or carle_env_settle) merges them, as for
+ * carle_env_step_f32_rnd with CARLE_STEP_DEFERRED | MERGE_MOMENTS.  No stand-alone moments launch per step. */
+int64_t carle_ae2d_stats_partials_doubles(int64_t n);
+int carle_ae2d_bonus_b1_stats(const uint64_t *obs, int64_t n, int h, int w, const float *params, float *workspace,
+                              float *bonus, float *reward_accum, float reward_scale, int flags, double *moment_partials,
+                              int32_t *status, void *stream);
 
 /* PredictionBonus.get_bonus (carle/mcl.py:581-605): the AE2D predictor applied to frame t-k (`obs`), squared error against
  * frame t (`target`, same shape): bonus[i] = mean_{h,w} (target_i - decoder(obs_i))^2.  Per-layer kernels: any H = W

@@ -79,22 +79,28 @@ def test_step_epilogue_merges_reward_moments(kind):
                                rtol=1e-9, atol=1e-12)
     if kind.startswith("rnd"):
         assert float(allr.sum()) > 0
-    # a stacked wrapper adds its bonus after the epilogue: attach refuses, after_step falls back
-    stack = AE2D(RND2D(CARLE(**kw), train_predictor=False), train_predictor=False)
-    other = cd.RunningRewardStats("cuda:0")
-    assert not other.attach(stack)
-    stack.eval(); stack.reset()
-    obs, reward, done, info = stack.step(torch.zeros(n, 1, asize, asize))
-    other.after_step(stack, reward)
-    np.testing.assert_allclose(other.mean, float(reward.double().mean()), rtol=1e-9)
+    # a stacked wrapper that adds its bonus after the last kernel that can reduce the rewards: attach refuses, after_step
+    # falls back to the stand-alone moments launch.  (AE2D(RND2D(env)) forward-only IS accepted since round 5: AE2D's
+    # bonus kernel leaves the moments, test_pair_finish_kernel_leaves_the_reward_moments.)
+    from carle_amd.mcl import CornerBonus
+    assert cd.RunningRewardStats("cuda:0").attach(AE2D(RND2D(CARLE(**kw), train_predictor=False), train_predictor=False))
+    for stack in (CornerBonus(RND2D(CARLE(**kw), train_predictor=False)), AE2D(RND2D(CARLE(**kw), train_predictor=False))):
+        other = cd.RunningRewardStats("cuda:0")
+        assert not other.attach(stack)
+        stack.eval(); stack.reset()
+        obs, reward, done, info = stack.step(torch.zeros(n, 1, asize, asize))
+        other.after_step(stack, reward)
+        np.testing.assert_allclose(other.mean, float(reward.double().mean()), rtol=1e-9)
 
 
 @pytest.mark.parametrize("train,storage,size,n", [(False, "f32", 256, 16), (True, "f32", 256, 16), (False, "b1", 128, 37),
-                                                  (True, "f32", 128, 1030)])
+                                                  (True, "f32", 128, 1030), (False, "f32", 64, 40), (False, "f32", 64, 2050)])
 def test_pair_finish_kernel_leaves_the_reward_moments(train, storage, size, n):
-    """AE2D(RND2D(CARLE)) at tiled sizes: the rewards are final in the pair's finish kernel, which leaves their partial
-    sums for the next environment step to merge (carle_rnd_ae_bonus / carle_rnd_ae_train with moment_partials) -- the
-    statistics equal those of explicit update() calls, across reset() and a change of mode."""
+    """AE2D(RND2D(CARLE)): the rewards are final in the pair's finish kernel (tiled sizes: carle_rnd_ae_bonus /
+    carle_rnd_ae_train with moment_partials) or in AE2D's bonus kernel (64x64 forward passes, round 5:
+    carle_ae2d_bonus_b1_stats on the bit-packed observation RND2D's one-launch step hands over), which leaves their
+    partial sums for the next environment step to merge -- the statistics equal those of explicit update() calls, across
+    reset() and a change of mode."""
     from carle_amd import dist as cd
     from carle_amd.env import CARLE
     from carle_amd.mcl import RND2D, AE2D
