@@ -254,17 +254,20 @@ class RunningRewardStats:
         self._inner_env = inner
         return True
 
-    def after_step(self, env, reward, stream=None):
+    def after_step(self, env, reward, stream=None, steps=1):
         """Account for one finished step of ``env``: nothing to launch when its epilogue already
-        merged the rewards (see ``attach``), else ``update(reward, stream)``."""
+        merged the rewards (see ``attach``), else ``update(reward, stream)``.  ``steps``: a ``CARLE.run`` / ``multistep``
+        call of that many steps whose launch merged every step's moments itself (one trace row per step)."""
+        steps = max(1, int(steps)) if getattr(env, "_moments_merged", False) else 1
         if self._trace is not None:
             self._trace_step(env, reward, stream)
-            self._pending_steps += 1
+            self._trace_pos += steps - 1
+            self._pending_steps += steps
             if self._pending_steps >= self.sync_every:
                 return self.flush()
             return None
         if getattr(env, "_moments_merged", False):
-            self._pending_steps += 1
+            self._pending_steps += steps
             if self._pending_steps >= self.sync_every:
                 return self.flush()
             return None

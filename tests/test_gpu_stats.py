@@ -354,3 +354,64 @@ def test_run_merges_reward_moments_like_the_step_loop(n):
     assert a[2] == b[2], (a[2], b[2])
     assert np.array_equal(a[3], b[3]) and a[3][0] == 12 * n
     assert a[4:] == b[4:] == (4, 0, 1) or a[4:] == b[4:]
+
+
+@pytest.mark.parametrize("kind", ["bare", "rnd", "pair256", "rnd_ae64", "stack"])
+def test_trace_ring_keeps_every_steps_reward_total(kind):
+    """RunningRewardStats.start_trace / drain_trace (the harness's per-step reward totals, train_mcl.py:68-69 / eval.py:69-70):
+    the kernel that writes a step's reward moments takes the next row of a device ring (CARLE_ST_TRACE_*) -- bare CARLE, the
+    fused RND2D step (moments settled one launch later), the tiled pair, AE2D's stats kernel at 64x64 -- or, for a stack the
+    epilogues cannot serve, the stand-alone moments kernel writes the row.  Totals equal reward.sum() per step, across
+    reset(), a drain in the middle, run() (one row per step) and a ring shorter than the loop (the last rows survive)."""
+    from carle_amd import dist as cd
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import RND2D, AE2D, CornerBonus
+    torch.manual_seed(6)
+    n = 40
+    size = 256 if kind == "pair256" else 64
+    env = CARLE(width=size, height=size, instances=n, device="cuda:0")
+    if kind == "bare":
+        w = env
+    elif kind == "rnd":
+        w = RND2D(env, train_predictor=False)
+    elif kind in ("pair256", "rnd_ae64"):
+        w = AE2D(RND2D(env, train_predictor=False), train_predictor=False)
+    else:
+        w = CornerBonus(RND2D(env, train_predictor=False))
+    if w is not env:
+        w.eval()
+    w.reset()
+    stats = cd.RunningRewardStats("cuda:0", sync_every=1 << 30)
+    attached = stats.start_trace(w, 5)
+    assert attached is (kind != "stack")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    env.universe = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+    expected, got = [], []
+
+    def step():
+        a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
+        obs, reward, done, info = w.step(a)
+        stats.after_step(w, reward)
+        expected.append(float(reward.double().sum()))
+
+    for t in range(3):
+        step()
+    got += stats.drain_trace().tolist()                      # a drain in the middle: the ring starts over
+    step()
+    w.reset()                                                # ... and a reset between two steps of a loop
+    env.universe = (torch.rand(n, 1, size, size, device="cuda", generator=g) < 0.3).float()
+    for t in range(3):
+        step()
+    got += stats.drain_trace().tolist()
+    np.testing.assert_allclose(got, expected, rtol=1e-6, atol=1e-9)
+    assert len(got) == 7 and (kind == "bare" or min(abs(x) for x in expected) > 0)
+    for t in range(8):                                       # more steps than rows: the last five survive, oldest first
+        step()
+    np.testing.assert_allclose(stats.drain_trace().tolist(), expected[-5:], rtol=1e-6, atol=1e-9)
+    assert stats.count == n * len(expected)
+    if kind == "bare":                                       # k steps in ONE launch: k rows
+        obs, reward, done, info = env.run(steps=3)
+        assert env._moments_merged
+        stats.after_step(env, reward, steps=3)
+        rows = stats.drain_trace().tolist()
+        assert rows == [0.0, 0.0, 0.0] and stats.count == n * (len(expected) + 3)

@@ -42,11 +42,9 @@ for arg in sys.argv[1:] or ["4096"]:
         return e0.elapsed_time(e1) / reps * 1e3
 
     for rep in range(2):
-        for name, env in (("all cacheable      ", {"CARLE_B1_RESIDENT_BYTES": "0"}),
-                          ("resident 112 MiB   ", {}),
-                          ("resident  96 MiB   ", {"CARLE_B1_RESIDENT_BYTES": str(96 << 20)}),
-                          ("resident 120 MiB   ", {"CARLE_B1_RESIDENT_BYTES": str(120 << 20)}),
-                          ("r4 policy          ", {"CARLE_B1_RESIDENT_BYTES": "0", "CARLE_B1_HYBRID_ALL": "0"})):
+        sizes = [int(x) for x in os.environ.get("KBENCH_RESIDENT_MIB", "0,112,96,120").split(",")]
+        for name, env in [("all cacheable      " if m == 0 else f"resident {m:3d} MiB   ", {"CARLE_B1_RESIDENT_BYTES": str(m << 20)})
+                          for m in sizes] + [("r4 policy          ", {"CARLE_B1_RESIDENT_BYTES": "0", "CARLE_B1_HYBRID_ALL": "0"})]:
             for k in ("CARLE_B1_RESIDENT_BYTES", "CARLE_B1_HYBRID_ALL"):
                 os.environ.pop(k, None)
             os.environ.update(env)
