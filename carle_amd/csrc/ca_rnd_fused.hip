@@ -87,7 +87,7 @@ struct Quads { uint4 v[4], a[4]; };     // one grid's loads of a lane: 4 state +
 // NT_ST: streaming stores (state arrays beyond the Infinity Cache); NT_LD: streaming hint on the STATE loads (the action
 // loads always carry it) -- up to 128 MiB per state array the re-read state comes out of the caches faster without it
 // (N=4096: 36.7 -> 36.0 us, N=8192: 65.2 -> 63.7; N=16384: 122 -> 134 us, so larger batches keep the hint)
-template <bool HAS_ACT, bool NT_ST = true, bool NT_LD = true, bool ENV = false>
+template <bool HAS_ACT, bool NT_ST = true, bool NT_LD = true, bool ENV = false, bool BITS = false>
 __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel(
     const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out, int64_t n,
     int aw, uint32_t rule, int32_t *__restrict__ status, int slot, const float *__restrict__ ws,
@@ -232,7 +232,6 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
                 if (reset) nx = 0ull;
             }
             s.net.rows[1 + lane] = nx;
-            if (ENV && ea.bits_out) ea.bits_out[g * 64 + lane] = nx;     // the observation once more, 1 bit per cell (512 B)
         } else if (wv == 1 && pending >= 0) {
             const float b = rnd_linear_bonus(s.feat, s.net.lin, lane, pending, nullptr, nullptr);
             if (lane == 0) bonus[pending] = b;
@@ -262,6 +261,21 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
                 o4.z = __float_as_uint((float)((by >> 16) & 0xFFu));
                 o4.w = __float_as_uint((float)((by >> 24) & 0xFFu));
                 __builtin_amdgcn_raw_buffer_store_b128(o4, ro, voff + 1024u * i, 0, NT_ST ? 2 : 0);      // aux 2 = nt
+            }
+            // BITS: the observation once more, 1 bit per cell (512 B per grid), for a reward net stacked on this RND2D: the
+            // row words as phase B left them, by a wavefront that is not on the generation's critical path, through a
+            // scalar descriptor (no address VGPRs: this kernel sits at its 128-VGPR budget).  Same box, round 5: 37.0 us
+            // (the step without a copy: 36.5; the 2 MiB more are 0.4 of that); stored by wavefront 0 in phase B: 38.5; here
+            // with a 64-bit address per lane: 39.2.  A template parameter, not a test of the pointer: the run-time test
+            // alone cost the instantiation WITHOUT a copy 1.9 us (36.40-36.49 against 38.28-38.37 us)
+            if (BITS && wv == 3) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+                    reinterpret_cast<char *>(ea.bits_out) + g * 512, 0, 512, 0x00020000);
+                u32x2 w2;
+                w2.x = rows32[2 * lane];
+                w2.y = rows32[2 * lane + 1];
+                __builtin_amdgcn_raw_buffer_store_b64(w2, rb, 8u * lane, 0, 0);
             }
         }
 
@@ -382,9 +396,14 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
     const dim3 grid((unsigned)blocks), block(256);
     const RndEnvArgs ea = env ? *env : RndEnvArgs();
     const int awk = action ? aw : 64;
+    const bool bits = env && ea.bits_out != nullptr;
 #define CARLE_RND_LAUNCH(ACT, NTS, NTL, ENVF) \
-    hipLaunchKernelGGL((ca_step_rnd64_kernel<ACT, NTS, NTL, ENVF>), grid, block, 0, s, u_in, action, u_out, n, awk, rule, \
-                       status, slot, ws, bonus, ea)
+    do { \
+        if (ENVF && bits) hipLaunchKernelGGL((ca_step_rnd64_kernel<ACT, NTS, NTL, ENVF, ENVF>), grid, block, 0, s, u_in, action, \
+                                             u_out, n, awk, rule, status, slot, ws, bonus, ea); \
+        else hipLaunchKernelGGL((ca_step_rnd64_kernel<ACT, NTS, NTL, ENVF>), grid, block, 0, s, u_in, action, u_out, n, awk, \
+                                rule, status, slot, ws, bonus, ea); \
+    } while (0)
 #define CARLE_RND_PICK(ENVF) \
     do { \
         if (action && cached_ld) CARLE_RND_LAUNCH(true, false, false, ENVF); \

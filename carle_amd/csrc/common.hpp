@@ -121,6 +121,7 @@ struct RndEnvArgs {
 // that uses them (from the scalar cache) instead of being hoisted out of the grid / tile loop, where 124-140
 // uniform weights overflow the SGPR file and spill into VGPR lanes (v_writelane / v_readlane per use).
 typedef const float __attribute__((address_space(4))) kfloat;   // constant address space: s_load
+typedef float f32x2 __attribute__((ext_vector_type(2)));          // an operand of v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32
 __device__ __forceinline__ kfloat *opaque_uniform(const float *p) {
     asm volatile("" : "+s"(p));
     return (kfloat *)p;

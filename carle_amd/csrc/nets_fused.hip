@@ -174,13 +174,21 @@ namespace carle {
 
 static constexpr int kAeLutFloats = 512 * 4;
 static constexpr int kAeParamFloats = 128;                    // conv2, convT1, convT2 parameters
-static constexpr int kAeWsFloats = kAeLutFloats + kAeParamFloats;
+static constexpr int kAePairFloats = 72;                      // conv2.w interleaved by output channel (64x64 kernels)
+static constexpr int kAeWsFloats = kAeLutFloats + kAeParamFloats + kAePairFloats;
 static constexpr int kA1Stride = 36, kA1Rows = 34, kA1Plane = kA1Rows * kA1Stride;   // also A3
 static constexpr int kA2Stride = 20, kA2Rows = 18, kA2Plane = kA2Rows * kA2Stride;
 
+// PAIRS (the 64x64 kernels' workspace only): conv2.w once more behind the parameter block, the two output channels of
+// every (input channel, tap) side by side -- operand pairs of v_pk_fma_f32 (ae_block64_kernel)
+template <bool PAIRS>
 __global__ __launch_bounds__(512) void ae_prepare_kernel(const float *__restrict__ ap,
                                                          float *__restrict__ ws) {
     const int p = threadIdx.x;
+    if (PAIRS && p >= 256 && p < 256 + 72) {
+        const int i = p - 256;                        // = (cc * 9 + tap) * 2 + oc
+        ws[kAeLutFloats + kAeParamFloats + i] = ap[40 + (i & 1) * 36 + (i >> 1)];
+    }
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
         float acc = 0.0f;
@@ -200,6 +208,15 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
+// sum over each 16-lane DPP row, in every lane of the row: quad_perm xor 1, xor 2, row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum_f32(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
@@ -215,7 +232,7 @@ struct AeBlockShared {
     float a2[2 * kA2Plane];
     uint64_t rows[66];               // the grid, one 64-bit word per row at [1..64]; [0], [65] stay zero
     uint64_t trows[64];              // TGT: the frame the reconstruction is compared with (PredictionBonus)
-    float red[4];
+    float red[16];                   // squared error per 16-lane row of the workgroup
 };
 
 // (kfloat / opaque_uniform: common.hpp)
@@ -314,11 +331,15 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
         __syncthreads();
 
         // ---- conv2 (4->2, 3x3, zero pad) + relu + 2x2 pool -> A2 (py, px)
+        // both output channels of a tap in ONE v_pk_fma_f32 (weights: the interleaved copy, an SGPR pair; the input value
+        // broadcast by op_sel): 144 packed instead of 288 scalar FMAs per thread and grid, the same order of summation
         {
-            kfloat *w2 = opaque_uniform(prm), *b2 = w2 + 72;
-            float acc2[2][2][2];
+            kfloat *b2 = opaque_uniform(prm) + 72;
+            const f32x2 __attribute__((address_space(4))) *w2p =
+                reinterpret_cast<const f32x2 __attribute__((address_space(4))) *>(opaque_uniform(prm + kAeParamFloats));
+            f32x2 acc2[2][2];
 #pragma unroll
-            for (int oc = 0; oc < 2; ++oc) { acc2[oc][0][0] = 0.f; acc2[oc][0][1] = 0.f; acc2[oc][1][0] = 0.f; acc2[oc][1][1] = 0.f; }
+            for (int dy = 0; dy < 2; ++dy) { acc2[dy][0] = f32x2{0.f, 0.f}; acc2[dy][1] = f32x2{0.f, 0.f}; }
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 const float *pl = s.a1 + cc * kA1Plane + (2 * py) * kA1Stride + 2 * px;   // padded rows 2py.., cols 2px..
@@ -330,24 +351,21 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
                     patch[r][0] = lo.x; patch[r][1] = lo.y; patch[r][2] = hi.x; patch[r][3] = hi.y;
                 }
 #pragma unroll
-                for (int oc = 0; oc < 2; ++oc)
+                for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
+                    for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
-                        for (int dx = 0; dx < 2; ++dx)
+                        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                                for (int kx = 0; kx < 3; ++kx)
-                                    acc2[oc][dy][dx] = fmaf(w2[(oc * 4 + cc) * 9 + ky * 3 + kx],
-                                                            patch[dy + ky][dx + kx], acc2[oc][dy][dx]);
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const float pv = patch[dy + ky][dx + kx];
+                                acc2[dy][dx] = __builtin_elementwise_fma(w2p[cc * 9 + ky * 3 + kx], f32x2{pv, pv}, acc2[dy][dx]);
+                            }
             }
-#pragma unroll
-            for (int oc = 0; oc < 2; ++oc) {
-                const float mx = fmaxf(fmaxf(acc2[oc][0][0], acc2[oc][0][1]),
-                                       fmaxf(acc2[oc][1][0], acc2[oc][1][1])) + b2[oc];
-                s.a2[oc * kA2Plane + (py + 1) * kA2Stride + px + 1] = fmaxf(mx, 0.0f);
-            }
+            const float mx0 = fmaxf(fmaxf(acc2[0][0].x, acc2[0][1].x), fmaxf(acc2[1][0].x, acc2[1][1].x)) + b2[0];
+            const float mx1 = fmaxf(fmaxf(acc2[0][0].y, acc2[0][1].y), fmaxf(acc2[1][0].y, acc2[1][1].y)) + b2[1];
+            s.a2[0 * kA2Plane + (py + 1) * kA2Stride + px + 1] = fmaxf(mx0, 0.0f);
+            s.a2[1 * kA2Plane + (py + 1) * kA2Stride + px + 1] = fmaxf(mx1, 0.0f);
         }
         __syncthreads();                              // A1 reads done: A3 may overlay plane 0
 
@@ -387,49 +405,63 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
         __syncthreads();
 
         // ---- convT2 (1->1) + sigmoid + squared error on the thread's own 4x4 cells
+        // columns cx and cx + 2 of the block take the same taps: one v_pk_fma_f32 / v_pk_add_f32 serves both (the A3 values
+        // arrive as horizontal pairs (0,1), (1,2), (2,3) of each row); per cell the order of summation of the scalar form.
+        // The exponent of the sigmoid in one more packed fma: -log2(e) * (acc + bias) = fma(acc, -log2 e, -log2 e * bias)
         float sq = 0.0f;
         {
             kfloat *wt2 = opaque_uniform(prm) + 107;
-            const float bt2 = wt2[16];
-            float t3[4][4];                           // A3 rows 2py-1..2py+2, cols 2px-1..2px+2 (padded)
+            constexpr float kNegLog2e = -1.4426950408889634f;
+            const float bt2s = kNegLog2e * wt2[16];
+            typedef f32x2 __attribute__((aligned(4))) f32x2_a4;
+            f32x2 h01[4], h12[4], h23[4];             // A3 rows 2py-1..2py+2 (padded), column pairs from 2px-1
             const float *pl = s.a1 + (2 * py) * kA1Stride + 2 * px;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float2 lo = *reinterpret_cast<const float2 *>(pl + r * kA1Stride);
-                const float2 hi = *reinterpret_cast<const float2 *>(pl + r * kA1Stride + 2);
-                t3[r][0] = lo.x; t3[r][1] = lo.y; t3[r][2] = hi.x; t3[r][3] = hi.y;
+                h01[r] = *reinterpret_cast<const f32x2 *>(pl + r * kA1Stride);
+                h12[r] = *reinterpret_cast<const f32x2_a4 *>(pl + r * kA1Stride + 1);
+                h23[r] = *reinterpret_cast<const f32x2 *>(pl + r * kA1Stride + 2);
             }
+            f32x2 sq2 = {0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint32_t bits = (uint32_t)((TGT ? s.trows[4 * py + r] : s.rows[1 + 4 * py + r]) >> (4 * px)) & 0xFu;
+                const int my = r >> 1;                                // local A3 index of iy = m is m + 1
+                const int ry0 = my + 1, ky0 = (r & 1) ? 2 : 1;
+                const int ry1 = (r & 1) ? my + 2 : my, ky1 = (r & 1) ? 0 : 3;
                 float out4[4];
 #pragma unroll
-                for (int cx = 0; cx < 4; ++cx) {
-                    const int my = r >> 1, mx = cx >> 1;              // local A3 index of iy=m is m+1
-                    const int ry0 = my + 1, ky0 = (r & 1) ? 2 : 1;
-                    const int ry1 = (r & 1) ? my + 2 : my, ky1 = (r & 1) ? 0 : 3;
-                    const int cx0 = mx + 1, kx0 = (cx & 1) ? 2 : 1;
-                    const int cx1 = (cx & 1) ? mx + 2 : mx, kx1 = (cx & 1) ? 0 : 3;
-                    float acc = 0.0f;
-                    acc = fmaf(t3[ry0][cx0], wt2[ky0 * 4 + kx0], acc);
-                    acc = fmaf(t3[ry0][cx1], wt2[ky0 * 4 + kx1], acc);
-                    acc = fmaf(t3[ry1][cx0], wt2[ky1 * 4 + kx0], acc);
-                    acc = fmaf(t3[ry1][cx1], wt2[ky1 * 4 + kx1], acc);
-                    const float pr = fast_sigmoid(acc + bt2);
-                    out4[cx] = pr;
-                    const float df = (float)((bits >> cx) & 1u) - pr;
-                    sq = fmaf(df, df, sq);
+                for (int cx = 0; cx < 2; ++cx) {      // cells cx and cx + 2: inputs (mx + 1) = (1, 2); (mx) = (0, 1) or (mx + 2) = (2, 3)
+                    const int kx0 = cx ? 2 : 1, kx1 = cx ? 0 : 3;
+                    const f32x2 in0a = h12[ry0], in0b = cx ? h23[ry0] : h01[ry0];
+                    const f32x2 in1a = h12[ry1], in1b = cx ? h23[ry1] : h01[ry1];
+                    f32x2 acc = {0.f, 0.f};
+                    acc = __builtin_elementwise_fma(in0a, f32x2{wt2[ky0 * 4 + kx0], wt2[ky0 * 4 + kx0]}, acc);
+                    acc = __builtin_elementwise_fma(in0b, f32x2{wt2[ky0 * 4 + kx1], wt2[ky0 * 4 + kx1]}, acc);
+                    acc = __builtin_elementwise_fma(in1a, f32x2{wt2[ky1 * 4 + kx0], wt2[ky1 * 4 + kx0]}, acc);
+                    acc = __builtin_elementwise_fma(in1b, f32x2{wt2[ky1 * 4 + kx1], wt2[ky1 * 4 + kx1]}, acc);
+                    const f32x2 t = __builtin_elementwise_fma(acc, f32x2{kNegLog2e, kNegLog2e}, f32x2{bt2s, bt2s});
+                    const f32x2 den = f32x2{1.0f, 1.0f} + f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                    const f32x2 pr = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};   // sigmoid, twice
+                    out4[cx] = pr.x; out4[cx + 2] = pr.y;
+                    const f32x2 df = f32x2{(float)((bits >> cx) & 1u), (float)((bits >> (cx + 2)) & 1u)} - pr;
+                    sq2 = __builtin_elementwise_fma(df, df, sq2);
                 }
                 if (recon)
                     *reinterpret_cast<float4 *>(recon + g * 4096 + (4 * py + r) * 64 + 4 * px) =
                         make_float4(out4[0], out4[1], out4[2], out4[3]);
             }
+            sq = sq2.x + sq2.y;
         }
-        sq = wave_sum_f32(sq);
-        if (lane == 0) s.red[wv] = sq;
+        sq = row16_sum_f32(sq);                       // (four DPP adds; the wave-wide butterfly was six ds_bpermute)
+        if ((lane & 15) == 0) s.red[tid >> 4] = sq;
         __syncthreads();                              // also: rows / A3 reads done before the next grid
         if (tid == 0) {
-            const float b = ((s.red[0] + s.red[1]) + (s.red[2] + s.red[3])) * (1.0f / 4096.0f);
+            const float4 *r4 = reinterpret_cast<const float4 *>(s.red);
+            float b = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b += (r4[i].x + r4[i].y) + (r4[i].z + r4[i].w);
+            b *= 1.0f / 4096.0f;
             bonus[g] = b;
             if (reward) {
                 const float r = reward_accumulate(reward[g], reward_scale, b);
@@ -460,13 +492,13 @@ int64_t ae2d_fused64_blocks(int64_t n) {
 
 // conv1 table + the uniform parameter block, ws[0 .. kAeWsFloats): shared with the tiled kernel (nets_tiled.hip)
 void ae2d_prepare_tables(const float *ap, float *ws, hipStream_t s) {
-    hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
+    hipLaunchKernelGGL(ae_prepare_kernel<false>, dim3(1), dim3(512), 0, s, ap, ws);
 }
 
 int ae2d_fused64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *recon, float *reward, float reward_scale, bool tables_valid, hipStream_t s,
                  const uint64_t *tgt, double *partials, int32_t *status) {
-    if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
+    if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel<true>, dim3(1), dim3(512), 0, s, ap, ws);
     const int64_t blocks = ae2d_fused64_blocks(n);
     const uint64_t *no_tgt = nullptr;
     if (partials && status && packed && !tgt && reward) {
@@ -1410,7 +1442,7 @@ int ae2d_train64_rows(int64_t n) {                 // = workgroups of ae_train_b
 int ae2d_train64(const void *obs, bool packed, int64_t n, const float *ap, float *ws, float *bonus,
                  float *reward, float reward_scale, float grad_scale, float *partial, float *grad,
                  bool tables_valid, hipStream_t s, const uint64_t *tgt) {
-    if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel, dim3(1), dim3(512), 0, s, ap, ws);
+    if (!tables_valid) hipLaunchKernelGGL(ae_prepare_kernel<true>, dim3(1), dim3(512), 0, s, ap, ws);
     const int rows = ae2d_train64_rows(n);
     const uint64_t *no_tgt = nullptr;
     if (tgt)                                          // (bit-packed frames only)
