@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
 
         RND_STAMP(6);
         // ---- D: conv1 (table lookup) + relu + 4x4 max-pool; thread = pooling window
-        rnd_block_conv1(s.net, tid);
+        rnd_block_conv1(s.net, tid, ws);
         RND_STAMP(7);
         __syncthreads();
         RND_STAMP(8);

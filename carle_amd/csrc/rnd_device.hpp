@@ -106,8 +106,10 @@ __device__ __forceinline__ uint32_t row_nibbles_to_dword(uint32_t nib, int k) {
 #ifndef CARLE_RND_CONV1_LOOKUPS
 #define CARLE_RND_CONV1_LOOKUPS 16
 #endif
-template <int BATCH = CARLE_RND_CONV1_BATCH>
-__device__ __forceinline__ void rnd_block_conv1(RndBlockShared &s, int tid) {
+// VMEM_P / VMEM_R: of the window's 16 lookups, the first VMEM_P (predictor table) / VMEM_R (random-net table) read the
+// table's copy in the workspace through the vector L1 instead of LDS (ws: the workspace the tables were copied from)
+template <int BATCH = CARLE_RND_CONV1_BATCH, int VMEM_P = 0, int VMEM_R = 0>
+__device__ __forceinline__ void rnd_block_conv1(RndBlockShared &s, int tid, const float *__restrict__ ws = nullptr) {
     static_assert(16 % BATCH == 0, "whole batches");
     const int py = tid >> 4, px = tid & 15;
     uint32_t seg[6];                                  // [west | 4 cells | east] of rows 4py-1..4py+4
@@ -126,8 +128,8 @@ __device__ __forceinline__ void rnd_block_conv1(RndBlockShared &s, int tid) {
             const int c = b * BATCH + j, dy = c >> 2, dx = c & 3;
             const uint32_t p = ((seg[dy] >> dx) & 7u) | (((seg[dy + 1] >> dx) & 7u) << 3) |
                                (((seg[dy + 2] >> dx) & 7u) << 6);
-            pa[j] = s.lut_p[p];
-            pb[j] = s.lut_r[p];
+            pa[j] = c < VMEM_P ? reinterpret_cast<const float4 *>(ws)[p] : s.lut_p[p];
+            pb[j] = c < VMEM_R ? reinterpret_cast<const float2 *>(ws + 2048)[p] : s.lut_r[p];
         }
         __builtin_amdgcn_sched_barrier(0);            // the whole batch is issued before its first max
 #pragma unroll
