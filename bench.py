@@ -458,10 +458,11 @@ def run_rank(args):
 
 EXTRA_CONFIGS = (
     # (label, argument overrides): BASELINE.json configs[2] (one GPU's shard), [3], [4] and the stacked forward of the north star
-    ("configs[2] shard", dict(size=256, steps=8, warmup=2)),
-    ("configs[3] + RND2D forward", dict(rnd=True, steps=64, warmup=8)),
-    ("configs[4] bit-packed HighLife", dict(format="b1", size=512, rule="B36/S23", steps=32, warmup=4)),
-    ("RND2D + AE2D forward stack (train_mcl.py:36-40)", dict(rnd=True, ae=True, steps=64, warmup=8)),
+    # (blocks as long as the headline's: with 64-step blocks the per-block barrier + flush showed as 1.5-2 us per step)
+    ("configs[2] shard", dict(size=256, steps=32, warmup=4)),
+    ("configs[3] + RND2D forward", dict(rnd=True, steps=256, warmup=16)),
+    ("configs[4] bit-packed HighLife", dict(format="b1", size=512, rule="B36/S23", steps=128, warmup=8)),
+    ("RND2D + AE2D forward stack (train_mcl.py:36-40)", dict(rnd=True, ae=True, steps=256, warmup=16)),
 )
 
 
