@@ -256,14 +256,14 @@ extern "C" int carle_env_step_f32(const float *u_in, const float *action, float 
 }
 
 // carle_env_step_f32 that ALSO leaves a bit-packed copy of the new state where the launch can produce it for free (the
-// one-launch step of 256 / 512-column grids: the tiled reward-net kernels read 512 bytes per tile instead of 22 KB);
+// one-launch step of 64 / 256 / 512-column grids: the reward-net kernels read 512 bytes per grid / tile instead of 16 / 22 KB);
 // *bits_written (host) says whether it did -- 0: bits_out was not touched.
 extern "C" int carle_env_step_f32_bits(const float *u_in, const float *action, float *u_out, float *reward, int64_t n,
                                        int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
                                        int publish_flags, uint64_t *bits_out, int *bits_written, void *stream) {
     if (bits_written) *bits_written = 0;
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_bits: status is NULL");
-    if (bits_out && (publish_flags & CARLE_STEP_DEFERRED) && !(h == 64 && w == 64))
+    if (bits_out && (publish_flags & CARLE_STEP_DEFERRED))
         if (const int e = env_step_one_launch_f32(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
                                                   publish_flags, stream, bits_out, bits_written); e != -1000)
             return e;

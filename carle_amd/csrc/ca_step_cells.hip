@@ -71,13 +71,57 @@ struct EnvArgs {
     float *reward = nullptr;       // N floats, zeroed (nullable)
     int publish = 1;               // 0: the caller stored the action flags of `slot` beforehand
     int merge_moments = 0;
-    uint64_t *bits_out = nullptr;  // wide grids (256 / 512 columns): also a bit-packed copy of the new state (H rows of W/64
-                                   // words per grid, carle_pack_f32_b1's layout) -- what the tiled reward-net kernels
-                                   // read 30x faster than the fp32 cells (nullable)
+    uint64_t *bits_out = nullptr;  // 64 / 256 / 512 columns: also a bit-packed copy of the new state (H rows of W/64 words per
+                                   // grid, carle_pack_f32_b1's layout) -- what the reward-net kernels read 30x faster than
+                                   // the fp32 cells (nullable)
 };
 
+// The 64x64 step kernel holds a grid as 64 lanes x 16 nibbles: lane (q = lane / 16, k = lane % 16) has, in nibble i, columns
+// 4k..4k+3 of row 4i + q.  Transposing the 16 x 16 nibbles of every 16-lane DPP row gives lane (q, i) the whole row 4i + q as
+// one 64-bit word (nibble k = columns 4k..4k+3): carle_pack_f32_b1's layout.  Four butterfly stages, 16 DPP moves + 14
+// permutes / selects: stage s exchanges, between lanes k and k ^ s, the nibbles whose index differs from the lane in bit s.
+__device__ __forceinline__ uint64_t transpose_nibbles16(uint64_t x, int lane) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    {   // s = 8 (a dword): the lane with bit 3 clear keeps its low dword and takes the partner's low dword as its high one
+        const bool b = (lane & 8) != 0;
+        const uint32_t send = b ? lo : hi;
+        const uint32_t got = __builtin_amdgcn_update_dpp(0u, send, 0x128, 0xF, 0xF, false);      // row_ror:8 = lane ^ 8
+        lo = b ? got : lo;
+        hi = b ? hi : got;
+    }
+    {   // s = 4 (16 bits inside every dword): partner by row_shl:4 for banks 0 / 2, row_shr:4 for banks 1 / 3
+        const bool b = (lane & 4) != 0;
+        const uint32_t sel = b ? 0x03020706u : 0x05040100u;     // v_perm_b32(partner, own): selector 4-7 = partner's bytes, 0-3 = own
+        uint32_t plo = __builtin_amdgcn_update_dpp(0u, lo, 0x104, 0xF, 0x5, false);              // row_shl:4 -> banks 0, 2
+        plo = __builtin_amdgcn_update_dpp(plo, lo, 0x114, 0xF, 0xA, false);                        // row_shr:4 -> banks 1, 3
+        uint32_t phi = __builtin_amdgcn_update_dpp(0u, hi, 0x104, 0xF, 0x5, false);
+        phi = __builtin_amdgcn_update_dpp(phi, hi, 0x114, 0xF, 0xA, false);
+        lo = __builtin_amdgcn_perm(plo, lo, sel);
+        hi = __builtin_amdgcn_perm(phi, hi, sel);
+    }
+    {   // s = 2 (bytes inside every 16 bits)
+        const bool b = (lane & 2) != 0;
+        const uint32_t sel = b ? 0x03070105u : 0x06020400u;
+        const uint32_t plo = __builtin_amdgcn_update_dpp(0u, lo, 0x4E, 0xF, 0xF, false);         // quad_perm [2,3,0,1]
+        const uint32_t phi = __builtin_amdgcn_update_dpp(0u, hi, 0x4E, 0xF, 0xF, false);
+        lo = __builtin_amdgcn_perm(plo, lo, sel);
+        hi = __builtin_amdgcn_perm(phi, hi, sel);
+    }
+    {   // s = 1 (nibbles inside every byte): rotate the partner's dword by a nibble towards the slot it fills
+        const bool b = (lane & 1) != 0;
+        const uint32_t keep = b ? 0xF0F0F0F0u : 0x0F0F0F0Fu, rot = b ? 4u : 28u;
+        const uint32_t plo = __builtin_amdgcn_update_dpp(0u, lo, 0xB1, 0xF, 0xF, false);         // quad_perm [1,0,3,2]
+        const uint32_t phi = __builtin_amdgcn_update_dpp(0u, hi, 0xB1, 0xF, 0xF, false);
+        lo = (lo & keep) | (__builtin_amdgcn_alignbit(plo, plo, rot) & ~keep);
+        hi = (hi & keep) | (__builtin_amdgcn_alignbit(phi, phi, rot) & ~keep);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// BITS (ENV, fp32 cells; round 5): the launch also leaves the new state bit-packed (64 row words per grid) for a reward net
+// that sits on this environment -- the 64x64 net kernels then read 512 B instead of 16 KiB per grid
 template <class C, class A, bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256,
-          bool RAND_ACT = false, bool ENV = false>
+          bool RAND_ACT = false, bool ENV = false, bool BITS = false>
 __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
     const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
     typename C::T *__restrict__ u_out, int64_t n, int aw, uint32_t rule, int32_t *__restrict__ status,
@@ -185,6 +229,7 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
     typename C::T *gout = u_out + g * 4096 + 4 * lane;
 #pragma unroll
     for (int i = 0; i < 16; ++i) C::template store<NT_ST>(gout + i * 256, (uint32_t)(nxt >> (4 * i)) & 0xFu);
+    if (ENV && BITS) ea.bits_out[g * 64 + 4 * k + q] = transpose_nibbles16(nxt, lane);      // lane (q, i = k): row 4i + q
 
     if (ENV) {
         if (ea.reward && lane == 0) ea.reward[g] = 0.0f;               // env.py:238
@@ -1078,6 +1123,24 @@ static int env_step_one_launch(const typename C::T *u_in, const typename A::T *a
     const dim3 grid((unsigned)n), block(64);
     const bool nt_st = stream_stores((int64_t)bytes, sizeof(typename C::T));
     const RandAct ra;
+    if (bits_out && sizeof(typename C::T) == 4) {      // fp32 cells under a reward net: + the bit-packed copy (BITS)
+        if ((reinterpret_cast<uintptr_t>(bits_out) & 7u) != 0) return fail(CARLE_E_ALIGN, "bits_out must be 8-byte aligned");
+        ea.bits_out = bits_out;
+        if (bits_written) *bits_written = 1;
+        if (action && nt_st)
+            hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, true, 64, false, true, true>), grid, block, 0, s, u_in,
+                               action, u_out, n, aw, rule, status, slot, ra, ea);
+        else if (action)
+            hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, false, 64, false, true, true>), grid, block, 0, s, u_in,
+                               action, u_out, n, aw, rule, status, slot, ra, ea);
+        else if (nt_st)
+            hipLaunchKernelGGL((ca_step_64_kernel<C, A, false, true, true, 64, false, true, true>), grid, block, 0, s, u_in,
+                               action, u_out, n, 0, rule, status, slot, ra, ea);
+        else
+            hipLaunchKernelGGL((ca_step_64_kernel<C, A, false, true, false, 64, false, true, true>), grid, block, 0, s, u_in,
+                               action, u_out, n, 0, rule, status, slot, ra, ea);
+        return check_launch(who);
+    }
     if (action && nt_st)
         hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, true, 64, false, true>), grid, block, 0, s, u_in, action,
                            u_out, n, aw, rule, status, slot, ra, ea);

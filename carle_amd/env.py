@@ -205,9 +205,9 @@ class CARLE(RLEMixin, nn.Module):
         self._status[hip.ST_TRACE_CAP:hip.ST_TRACE_CAP + 2] = ring.to(self._status.device, non_blocking=True)
 
     def _bits_buffer(self, out, slot):
-        """Where the one-launch step of a 256- / 512-column fp32 grid leaves a bit-packed copy of its output (one buffer
+        """Where the one-launch step of a 64- / 256- / 512-column fp32 grid leaves a bit-packed copy of its output (one buffer
         per step parity) -- only while a reward net that reads it sits on this environment (``want_packed_copy``)."""
-        if not self.__dict__.get("want_packed_copy") or out.dtype != torch.float32 or out.shape[3] not in (256, 512) \
+        if not self.__dict__.get("want_packed_copy") or out.dtype != torch.float32 or out.shape[3] not in (64, 256, 512) \
                 or out.shape[2] != out.shape[3]:
             return None
         bufs = self.__dict__.get("_bits_bufs")

@@ -217,9 +217,9 @@ int carle_env_step_f32(const float *u_in, const float *action, float *u_out, flo
                        int32_t *status, int slot, int publish_flags, void *stream);
 /* carle_env_step_f32 that ALSO leaves a bit-packed copy of the new state (H rows of W/64 words per grid: the layout of
  * carle_pack_f32_b1) in bits_out where the launch produces it for free -- the one-launch step (CARLE_STEP_DEFERRED) of
- * 256- / 512-column grids.  The tiled reward-net kernels (carle_rnd2d_bonus_b1, carle_rnd_ae_bonus with CARLE_FMT_B1, ...)
- * read 512 bytes per tile from it instead of 22 KB of fp32 cells (carle/mcl.py:398-407 on the observation of
- * carle/env.py:229).  *bits_written (host int, nullable) = 1 if the copy was written, 0 if bits_out was not touched. */
+ * 64- / 256- / 512-column grids.  The reward-net kernels (carle_rnd2d_bonus_b1, carle_ae2d_train_b1, carle_rnd_ae_bonus with
+ * CARLE_FMT_B1, ...) read 512 bytes per grid / tile from it instead of 16 / 22 KB of fp32 cells (carle/mcl.py:398-407 on the
+ * observation of carle/env.py:229).  *bits_written (host int, nullable) = 1 if the copy was written, 0 if bits_out was not touched. */
 int carle_env_step_f32_bits(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h, int w,
                             int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags, uint64_t *bits_out,
                             int *bits_written, void *stream);

@@ -463,3 +463,83 @@ def test_packed_master_reset_of_a_batch_larger_than_the_resident_wavefronts(_b1_
         s = hip.env_settle(st).cpu()
         assert s[4].item() == 0 and s[16:20].tolist() == [0, 0, 0, 0]
         st[0:4] = 0
+
+
+@pytest.mark.parametrize("n,asize", [(1, 64), (3, 32), (17, 64), (300, 48), (1025, 64), (33, 0)])
+def test_one_launch_step_also_leaves_the_packed_copy_at_64(n, asize):
+    """carle_env_step_f32_bits at 64x64 (round 5): the one-launch kernel transposes its nibbles into row words and
+    stores them beside the fp32 state -- the same grids as without the copy, the copy equal to carle_pack_f32_b1 of
+    them, also when the master reset fires (all-ones action) and with other rules."""
+    from carle_amd import hip
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cuda").manual_seed(1000 + n)
+    for rule in (hip.rule_mask([3], [2, 3]), hip.rule_mask([3, 6], [2, 3]), hip.rule_mask([1, 3, 5, 7], [0, 2, 4, 6, 8])):
+        u = (torch.rand(n, 1, 64, 64, device=dev, generator=g) < 0.4).float()
+        for t in range(4):
+            if asize:
+                act = (torch.rand(n, 1, asize, asize, device=dev, generator=g) < 0.2).float()
+                if t == 2:
+                    act = torch.ones_like(act)                 # master reset (env.py:208-216)
+            else:
+                act = None
+            outs = []
+            for with_bits in (False, True):
+                st = hip.new_status(dev)
+                out = torch.empty_like(u)
+                reward = torch.full((n, 1), 7.0, device=dev)
+                bits = torch.full((n, 1, 64, 1), -1, dtype=torch.int64, device=dev) if with_bits else None
+                wrote = hip.env_step_f32(u, act, out, reward, rule, st, t & 1, True, False, bits_out=bits)
+                assert wrote == with_bits
+                assert float(reward.abs().max()) == 0.0
+                outs.append((out, bits, hip.env_settle(st).clone()))
+            assert torch.equal(outs[0][0], outs[1][0])
+            assert torch.equal(outs[1][1], hip.pack_f32_b1(outs[1][0]))
+            # last-reset flag and the three counters (the action flags of the slot are transient: N <= 16 without the copy
+            # runs the small-batch kernel, which does not keep them)
+            assert torch.equal(outs[0][2][4:5], outs[1][2][4:5]) and torch.equal(outs[0][2][6:12], outs[1][2][6:12])
+            if asize and t == 2:
+                assert float(outs[1][0].sum()) == 0.0 and int(outs[1][1].abs().sum()) == 0
+            u = outs[1][0]
+
+
+def test_reward_nets_on_a_64_column_environment_read_the_packed_copy():
+    """An AE2D directly on a CARLE(64x64), and an RND2D in training mode: the environment's step hands them the observation
+    bit-packed (CARLE.packed_copy_of), the rewards equal those of the same stacks reading the fp32 cells (CARLE_PACKED_COPY=0
+    at construction) bit for bit."""
+    import os
+    from carle_amd.env import CARLE
+    from carle_amd.mcl import AE2D, RND2D
+
+    def run(kind, packed):
+        old = os.environ.get("CARLE_PACKED_COPY")
+        os.environ["CARLE_PACKED_COPY"] = "1" if packed else "0"
+        try:
+            torch.manual_seed(5)
+            env = CARLE(width=64, height=64, instances=40, device="cuda:0")
+            w = AE2D(env) if kind == "ae" else RND2D(env)
+            if kind == "ae":
+                w.eval()
+            w.batch_size = 3
+        finally:
+            if old is None:
+                del os.environ["CARLE_PACKED_COPY"]
+            else:
+                os.environ["CARLE_PACKED_COPY"] = old
+        g = torch.Generator(device="cuda").manual_seed(9)
+        w.reset()
+        env.universe = (torch.rand(40, 1, 64, 64, device="cuda", generator=g) < 0.3).float()
+        rs, seen = [], 0
+        for t in range(7):
+            a = (torch.rand(40, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
+            obs, r, _, _ = w.step(a)
+            seen += env.packed_copy_of(obs) is not None
+            rs.append(r.clone())
+        return torch.stack(rs), seen, obs.clone()
+
+    for kind in ("ae", "rnd_train"):
+        r1, seen1, o1 = run(kind, True)
+        r0, seen0, o0 = run(kind, False)
+        assert seen1 == 7 and seen0 == 0
+        assert torch.equal(o1, o0)
+        assert torch.equal(r1, r0), (kind, float((r1 - r0).abs().max()))
+        assert float(r1.abs().max()) > 0
