@@ -153,12 +153,16 @@ def test_fused64_batch_sizes(n):
 
 
 def test_fused_path_is_taken_through_the_env():
-    """obs returned by CARLE.step is recognised as binary (identity with env.universe)."""
+    """obs returned by CARLE.step is recognised as binary (identity with env.universe) -- and, since the step of a 64-column
+    environment under a reward net leaves a bit-packed copy (round 5), handed on as that copy."""
     env, rnd, ae = _stack(64, 4)
     ae.reset()
     obs = env.step((torch.rand(4, 1, 64, 64) < 0.3).float())[0]
     o, binary = rnd._obs(obs, allow_packed=True)
-    assert binary and o is obs
+    assert binary and o is env.packed_copy_of(obs) and o.dtype == torch.int64
+    assert torch.equal(o, __import__("carle_amd.hip", fromlist=["hip"]).pack_f32_b1(obs))
+    o1, binary1 = rnd._obs(obs, allow_packed=False)
+    assert binary1 and o1 is obs
     o2, binary2 = rnd._obs(obs.clone(), allow_packed=True)
     assert not binary2
 
