@@ -333,16 +333,34 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
     one_launch = args.format in ("f32", "u8") and ((size == 64 and n > 16) or
                                                    (size in (256, 512) and state.numel() * state.element_size() <= 32 << 20))
 
+    # fp32 64x64 beyond 16 instances (round 5): CARLE.step reads its input state from the bit-packed copy its previous launch
+    # left (512 B per grid) instead of the fp32 cells (16 KiB) -- the kernel below is that launch, and its algorithmic bytes
+    # are what it has to move: the fp32 action in, the fp32 observation out, the packed state in and out
+    from carle_amd import env as cenv
+    packed_state = one_launch and args.format == "f32" and size == 64 and cenv._PACKED_STATE
+    if packed_state:
+        sbits = [hip.pack_f32_b1(bufs[0]), torch.empty(n, 1, 64, 1, dtype=torch.int64, device=state.device)]
+        alg_reference = alg
+        alg = n * (size * size * 4 + asize * asize * 4 + 2 * 512)
+        name = "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true, ..., ENV, BITS, PACKED_IN>"
+        dominant_kernels.notes = {name: {
+            "traffic_model": "fp32 action in (4 B/cell) + fp32 observation out (4 B/cell) + bit-packed state in and out "
+                             "(2 x 1/8 B/cell): the fp32 state is written every step and not read back",
+            "bytes_per_launch_if_the_fp32_state_were_read": alg_reference}}
+
     def ca(i):
         if packed:            # the kernel CARLEPacked.step launches (one launch for the 64-column window: resident slice etc.)
             hip.env_step_b1(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1, True, True)
+        elif packed_state:    # the kernel CARLE.step launches from its second step on
+            hip.env_step_f32_packed(sbits[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1,
+                                    True, True, bits_out=sbits[(i & 1) ^ 1])
         elif one_launch:      # the kernel CARLE.step launches: step + master reset + reward + moments, no epilogue kernel
             (hip.env_step_f32 if args.format == "f32" else hip.env_step_u8)(
                 bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1, True, True)
         else:
             step_fn(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], rule, env._status, 0)
 
-    if one_launch:
+    if one_launch and not packed_state:
         name = name.replace("true, ...>", "true, ..., ENV>")
     nets = args.rnd or args.ae
     fused_rnd = args.rnd and not args.train and args.format == "f32" and size == 64
@@ -356,7 +374,11 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
         raw = hip._stream(state)
 
         def ca_rnd(i):
-            if n > 16:
+            if packed_state:      # what RND2D.step launches from its second step on: state in as row words (see above)
+                hip.env_step_f32_rnd(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1,
+                                     True, pb, rb, ws, bonus, 1.0, True, None, raw, None, partials is not None,
+                                     deferred=True, partials=partials, bits_out=sbits[(i & 1) ^ 1], bits_in=sbits[i & 1])
+            elif n > 16:
                 hip.env_step_f32_rnd(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], reward, rule, env._status, i & 1,
                                      True, pb, rb, ws, bonus, 1.0, True, None, raw, None, partials is not None,
                                      deferred=True, partials=partials)
@@ -364,8 +386,12 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
                 hip.ca_step_f32_rnd(bufs[i & 1], ring[i % len(ring)], bufs[(i & 1) ^ 1], rule, env._status, 0,
                                     pb, rb, ws, bonus, True)
         rnd_flop = 2 * 9 * size * size * 6 + 2 * 9 * (size // 4) ** 2 * 6 + 2 * (size // 8) ** 2 * 16 * 2
-        cand.append(("ca_step_rnd64_kernel<true, ..., ENV>" if n > 16 else "ca_step_rnd64_kernel<true>", ca_rnd,
-                     alg + 4 * n, n * rnd_flop))
+        rname = ("ca_step_rnd64_kernel<true, ..., ENV, BITS, PACKED_IN>" if packed_state else
+                 "ca_step_rnd64_kernel<true, ..., ENV>" if n > 16 else "ca_step_rnd64_kernel<true>")
+        if packed_state:
+            dominant_kernels.notes[rname] = dict(dominant_kernels.notes[name])
+            dominant_kernels.notes[rname]["bytes_per_launch_if_the_fp32_state_were_read"] = alg_reference + 4 * n
+        cand.append((rname, ca_rnd, alg + 4 * n, n * rnd_flop))
     else:
         cand.append((name, ca, alg, None))
     if nets and size == 64 and args.format == "f32":
@@ -687,6 +713,7 @@ def measure(args, rank, world, dev, pinned, light=False):
         if slow:
             warnings.append(f"host stalls inside the timed region (step, ms): {slow[:8]}; median host time per step "
                             f"{med * 1e6:.1f} us")
+    dominant_kernels.notes = {}
     cands = dominant_kernels(args, env, wenv, ring, hip, n, size, asize)
     timed = []
     for name, launch, alg, flop in cands:
@@ -709,7 +736,8 @@ def measure(args, rank, world, dev, pinned, light=False):
                 **pmc_traffic(kname, args.format, size, n),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us": k_ms * 1e3, "launches_timed": reps,
-                "frac_of_measured_copy_ceiling": achieved / 6.29e12}
+                "frac_of_measured_copy_ceiling": achieved / 6.29e12,
+                **dominant_kernels.notes.get(kname, {})}
         state_bytes = int(env.universe_bits.numel() * 8 if packed else env.universe.numel() * env.universe.element_size())
         if state_bytes <= 256 << 20:
             # the library keeps the output of step t cacheable below 256 MiB per state array (write-back stores / cached

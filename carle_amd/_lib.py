@@ -55,6 +55,9 @@ SIGNATURES = {
                                              _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
                                              _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                              ctypes.POINTER(ctypes.c_int)]),
+    "carle_env_step_f32_rnd_packed": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
+                                               _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
+                                               _c_vp, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
     "carle_rnd_step_partials_doubles": (_c_i64, [_c_i64]),
     "carle_ca_step_f32_rnd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
                                        _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp]),
@@ -98,6 +101,8 @@ SIGNATURES = {
                                     _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp]),
     "carle_env_step_f32_bits": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
                                     _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp, ctypes.POINTER(ctypes.c_int), _c_vp]),
+    "carle_env_step_f32_packed": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int,
+                                           _c_int, _c_u32, _c_vp, _c_int, _c_int, _c_vp, _c_vp]),
     "carle_env_run_f32": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_u32,
                                    ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _c_int, _c_vp, _c_int, _c_int,
                                    _c_vp]),

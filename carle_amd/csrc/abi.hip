@@ -212,7 +212,8 @@ int env_run_noaction64(const float *u_in, float *u_out, float *reward, int64_t n
                        int32_t *status, int slot0, int step_flags, void *stream);
 int env_step_one_launch_f32(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h,
                             int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
-                            void *stream, uint64_t *bits_out = nullptr, int *bits_written = nullptr);
+                            void *stream, uint64_t *bits_out = nullptr, int *bits_written = nullptr,
+                            const uint64_t *bits_in = nullptr);
 int env_step_one_launch_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out, float *reward,
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
                            int step_flags, void *stream);
@@ -268,6 +269,23 @@ extern "C" int carle_env_step_f32_bits(const float *u_in, const float *action, f
                                                   publish_flags, stream, bits_out, bits_written); e != -1000)
             return e;
     return carle_env_step_f32(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot, publish_flags, stream);
+}
+
+// The one-launch step of N x 64 x 64 fp32 grids whose INPUT state is taken from the bit-packed copy a previous
+// carle_env_step_f32_bits / carle_env_step_f32_packed / carle_pack_f32_b1 left of it (bits_in, n x 64 row words) instead of the
+// fp32 cells: the launch reads 512 B instead of 16 KiB per grid, writes the fp32 observation u_out (carle/env.py:229) and its
+// packed copy bits_out as before.  The caller vouches that bits_in IS the current state (CARLE.step: the very tensor the last
+// step returned, unmodified since).  CARLE_STEP_DEFERRED semantics (one launch, counters settled lazily).
+extern "C" int carle_env_step_f32_packed(const uint64_t *bits_in, const float *action, float *u_out, float *reward, int64_t n,
+                                         int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
+                                         int step_flags, uint64_t *bits_out, void *stream) {
+    if (!status || !bits_in || !bits_out) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_packed: NULL pointer");
+    if (h != 64 || w != 64 || n < 1) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: n >= 1 grids of 64x64");
+    if (action && (aw % 8) != 0) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: action width must be a multiple of 8");
+    if (knobs().two_launch_step > 0) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: CARLE_TWO_LAUNCH_STEP is set");
+    const int e = env_step_one_launch_f32(nullptr, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
+                                          step_flags | CARLE_STEP_DEFERRED, stream, bits_out, nullptr, bits_in);
+    return e == -1000 ? fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: geometry without a one-launch step") : e;
 }
 
 extern "C" int carle_ca_step_b1(const uint64_t *, const uint64_t *, uint64_t *, int64_t, int, int, int,
@@ -425,7 +443,7 @@ extern "C" int carle_rnd2d_bonus_f32(const float *, int64_t, int, int, const flo
 namespace carle {
 int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
                   int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
-                  bool tables_valid, hipStream_t s, const RndEnvArgs *env);
+                  bool tables_valid, hipStream_t s, const RndEnvArgs *env, bool packed_in = false);
 int64_t rnd64_blocks(int64_t n);
 }
 
@@ -469,7 +487,7 @@ static int env_step_f32_rnd_impl(const float *u_in, const float *action, float *
                                  const float *pred_params, const float *rand_params,
                                  float *workspace, float *bonus, float reward_scale,
                                  int net_flags, double *moment_partials, void *event, void *stream_env,
-                                 void *stream_reward, uint64_t *bits_out, int *bits_written);
+                                 void *stream_reward, uint64_t *bits_out, int *bits_written, const uint64_t *bits_in = nullptr);
 
 extern "C" int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out,
                                       float *reward, int64_t n, int h, int w, int ah, int aw,
@@ -499,13 +517,35 @@ extern "C" int carle_env_step_f32_rnd_bits(const float *u_in, const float *actio
                                  stream_reward, bits_out, bits_written);
 }
 
+// carle_env_step_f32_rnd_bits whose INPUT state is read from the bit-packed copy a previous launch left of it (bits_in, n x 64
+// row words) instead of the fp32 cells -- see carle_env_step_f32_packed.  One launch or an error: n > 16 grids of 64x64, an
+// 8-aligned window, CARLE_STEP_DEFERRED.  bits_in and bits_out must not overlap.
+extern "C" int carle_env_step_f32_rnd_packed(const uint64_t *bits_in, const float *action, float *u_out,
+                                             float *reward, int64_t n, int h, int w, int ah, int aw,
+                                             uint32_t rule, int32_t *status, int slot, int publish_flags,
+                                             const float *pred_params, const float *rand_params,
+                                             float *workspace, float *bonus, float reward_scale,
+                                             int net_flags, double *moment_partials, void *event, void *stream_env,
+                                             void *stream_reward, uint64_t *bits_out) {
+    if (!bits_in || !bits_out || !reward) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd_packed: NULL pointer");
+    if (!aligned16(bits_in) || !aligned16(bits_out))
+        return fail_arg(CARLE_E_ALIGN, "carle_env_step_f32_rnd_packed: bits_in / bits_out must be 16-byte aligned");
+    if (h != 64 || w != 64 || n <= 16 || (action && (aw % 8) != 0))
+        return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_rnd_packed: more than 16 grids of 64x64, action width a multiple of 8");
+    if (overlap(bits_in, (size_t)n * 512, bits_out, (size_t)n * 512))
+        return fail_arg(CARLE_E_ALIAS, "carle_env_step_f32_rnd_packed: bits_in and bits_out overlap");
+    return env_step_f32_rnd_impl(nullptr, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
+                                 publish_flags | CARLE_STEP_DEFERRED, pred_params, rand_params, workspace, bonus, reward_scale,
+                                 net_flags, moment_partials, event, stream_env, stream_reward, bits_out, nullptr, bits_in);
+}
+
 static int env_step_f32_rnd_impl(const float *u_in, const float *action, float *u_out,
                                  float *reward, int64_t n, int h, int w, int ah, int aw,
                                  uint32_t rule, int32_t *status, int slot, int publish_flags,
                                  const float *pred_params, const float *rand_params,
                                  float *workspace, float *bonus, float reward_scale,
                                  int net_flags, double *moment_partials, void *event, void *stream_env,
-                                 void *stream_reward, uint64_t *bits_out, int *bits_written) {
+                                 void *stream_reward, uint64_t *bits_out, int *bits_written, const uint64_t *bits_in) {
     if (!status) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: status is NULL");
     if (!pred_params || !rand_params || !workspace || !bonus)
         return fail_arg(CARLE_E_NULL, "carle_env_step_f32_rnd: NULL reward-net pointer");
@@ -518,8 +558,9 @@ static int env_step_f32_rnd_impl(const float *u_in, const float *action, float *
     // the bonus into the reward.  Everything runs on stream_env; stream_reward (if any) is ordered
     // behind it so that reward consumers enqueued there see the result.
     if (h == 64 && w == 64 && (!action || (aw % 8) == 0) && n > 0 && reward) {
-        if (int e = rnd_step_checks("carle_env_step_f32_rnd", u_in, action, u_out, n, h, w, ah, aw, rule, slot,
-                                    workspace))
+        // (a packed input state: the checks see u_out in u_in's place -- the fp32 input does not exist)
+        if (int e = rnd_step_checks("carle_env_step_f32_rnd", bits_in ? u_out + (size_t)n * 4096 : u_in, action, u_out, n, h, w,
+                                    ah, aw, rule, slot, workspace))
             return e;
         const size_t bytes = (size_t)n * h * w * sizeof(float);
         const bool merge = (publish_flags & CARLE_STEP_MERGE_MOMENTS) != 0;
@@ -534,11 +575,14 @@ static int env_step_f32_rnd_impl(const float *u_in, const float *action, float *
             ea.partials = merge ? moment_partials + (size_t)slot * 2 * (size_t)rnd64_blocks(n) : nullptr;
             ea.bits_out = bits_out;
             if (bits_out && bits_written) *bits_written = 1;
-            if (int e = ca_step_rnd64(u_in, action, u_out, n, aw, rule, status, slot, pred_params, rand_params, workspace,
-                                      bonus, tables_valid, static_cast<hipStream_t>(stream_env), &ea))
+            if (int e = ca_step_rnd64(bits_in ? reinterpret_cast<const float *>(bits_in) : u_in, action, u_out, n, aw, rule, status,
+                                      slot, pred_params, rand_params, workspace, bonus, tables_valid,
+                                      static_cast<hipStream_t>(stream_env), &ea, bits_in != nullptr))
                 return e;
             return fork ? carle_stream_fork(event, stream_env, stream_reward) : 0;
         }
+        if (bits_in) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_rnd_packed: no one-launch step for these arguments "
+                                                   "(n > 16, CARLE_STEP_DEFERRED, aligned status / moment_partials)");
         if (int e = ca_step_rnd64(u_in, action, u_out, n, aw, rule,
                                   (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot,
                                   pred_params, rand_params, workspace, bonus, tables_valid,

@@ -87,7 +87,10 @@ struct Quads { uint4 v[4], a[4]; };     // one grid's loads of a lane: 4 state +
 // NT_ST: streaming stores (state arrays beyond the Infinity Cache); NT_LD: streaming hint on the STATE loads (the action
 // loads always carry it) -- up to 128 MiB per state array the re-read state comes out of the caches faster without it
 // (N=4096: 36.7 -> 36.0 us, N=8192: 65.2 -> 63.7; N=16384: 122 -> 134 us, so larger batches keep the hint)
-template <bool HAS_ACT, bool NT_ST = true, bool NT_LD = true, bool ENV = false, bool BITS = false>
+// PACKED_IN (round 5; with ENV and BITS): `u_in` points at the bit-packed copy the previous launch left of the state (64 row
+// words per grid) instead of the fp32 cells -- a lane then loads the four row dwords its phase-A stores need (4 B each, the
+// same address for the 8 lanes that build a dword) where it loaded four 16-byte quads, and phase A converts the action only.
+template <bool HAS_ACT, bool NT_ST = true, bool NT_LD = true, bool ENV = false, bool BITS = false, bool PACKED_IN = false>
 __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel(
     const float *__restrict__ u_in, const float *__restrict__ act, float *__restrict__ u_out, int64_t n,
     int aw, uint32_t rule, int32_t *__restrict__ status, int slot, const float *__restrict__ ws,
@@ -135,12 +138,23 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
     // phase it is not needed in (a conditional load would keep its old contents alive)
     auto issue = [&](int64_t g, Quads &r, bool valid) __attribute__((always_inline)) {
         if (!valid) g = 0;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char *>(reinterpret_cast<const char *>(u_in) + g * 16384), 0, valid ? 16384 : 0, 0x00020000);
+        if (PACKED_IN) {
+            // row 16w + 4i + q, dword k / 8 of the packed state: r.v[0] holds the four (i = x, y, z, w); r.v[1..3] stay unused
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(reinterpret_cast<const char *>(u_in) + g * 512), 0, valid ? 512 : 0, 0x00020000);
+            const uint32_t soff = (uint32_t)(16 * wv + q) * 8u + (uint32_t)(k >> 3) * 4u;
+            r.v[0].x = __builtin_amdgcn_raw_buffer_load_b32(rs, soff, 0, 0);
+            r.v[0].y = __builtin_amdgcn_raw_buffer_load_b32(rs, soff + 32u, 0, 0);
+            r.v[0].z = __builtin_amdgcn_raw_buffer_load_b32(rs, soff + 64u, 0, 0);
+            r.v[0].w = __builtin_amdgcn_raw_buffer_load_b32(rs, soff + 96u, 0, 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(reinterpret_cast<const char *>(u_in) + g * 16384), 0, valid ? 16384 : 0, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 1024u * i, 0, NT_LD ? 2 : 0);   // aux 2 = nt
-            r.v[i] = make_uint4(t.x, t.y, t.z, t.w);
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 1024u * i, 0, NT_LD ? 2 : 0);   // aux 2 = nt
+                r.v[i] = make_uint4(t.x, t.y, t.z, t.w);
+            }
         }
         if (HAS_ACT) {
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
         ActionSeen seen_g;                            // ENV: the predicates of THIS grid (folded into two scalars below,
 #pragma unroll                                        //      no per-lane accumulator lives across the grid loop)
         for (int i = 0; i < 4; ++i) {
-            uint32_t nib = nibble_fast(cur.v[i]);
+            uint32_t nib = PACKED_IN ? 0u : nibble_fast(cur.v[i]);
             if (HAS_ACT) {
                 if ((rows_in_win >> i) & 1u) { if (ENV) seen_g.add(cur.a[i]); else seen.add(cur.a[i]); }
                 nib ^= nibble_fast(cur.a[i]);         // toggle, env.py:182
@@ -198,8 +212,15 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] |= __builtin_amdgcn_update_dpp(0u, x[i], 0x114, 0xF, 0xF, true);   // row_shr:4
         if ((k & 7) == 7) {
+            if (PACKED_IN) {                          // the toggles' row dwords on the state's
+                s.rows_in[16 * wv + 0 + q][k >> 3] = x[0] ^ cur.v[0].x;
+                s.rows_in[16 * wv + 4 + q][k >> 3] = x[1] ^ cur.v[0].y;
+                s.rows_in[16 * wv + 8 + q][k >> 3] = x[2] ^ cur.v[0].z;
+                s.rows_in[16 * wv + 12 + q][k >> 3] = x[3] ^ cur.v[0].w;
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s.rows_in[16 * wv + 4 * i + q][k >> 3] = x[i];
+                for (int i = 0; i < 4; ++i) s.rows_in[16 * wv + 4 * i + q][k >> 3] = x[i];
+            }
         }
         RND_STAMP(2);
         __syncthreads();
@@ -373,9 +394,10 @@ int64_t rnd64_blocks(int64_t n) {
 }
 
 // validated by the caller (carle_env_step_f32_rnd); bonus has n + 1 elements.  env != nullptr: the one-launch step.
+// packed_in (with env and env->bits_out): u_in points at the bit-packed copy of the state (n x 64 row words), not at fp32 cells
 int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t n, int aw, uint32_t rule,
                   int32_t *status, int slot, const float *pp, const float *rp, float *ws, float *bonus,
-                  bool tables_valid, hipStream_t s, const RndEnvArgs *env) {
+                  bool tables_valid, hipStream_t s, const RndEnvArgs *env, bool packed_in) {
     if (!tables_valid) rnd2d_prepare_tables(pp, rp, ws, s);
     // Two grids per workgroup (the second one's loads travel during the first one's network phases); batches up to
     // 1024 grids one workgroup each.  Four per CU are resident, the others start as those retire -- out of phase, so
@@ -397,6 +419,22 @@ int ca_step_rnd64(const float *u_in, const float *action, float *u_out, int64_t 
     const RndEnvArgs ea = env ? *env : RndEnvArgs();
     const int awk = action ? aw : 64;
     const bool bits = env && ea.bits_out != nullptr;
+    if (packed_in) {
+        if (!bits) return fail_arg(CARLE_E_NULL, "fused CA + RND2D step: a packed input state needs the one-launch step with bits_out");
+        if (action && nt_st)
+            hipLaunchKernelGGL((ca_step_rnd64_kernel<true, true, true, true, true, true>), grid, block, 0, s, u_in, action, u_out, n,
+                               awk, rule, status, slot, ws, bonus, ea);
+        else if (action)
+            hipLaunchKernelGGL((ca_step_rnd64_kernel<true, false, true, true, true, true>), grid, block, 0, s, u_in, action, u_out, n,
+                               awk, rule, status, slot, ws, bonus, ea);
+        else if (nt_st)
+            hipLaunchKernelGGL((ca_step_rnd64_kernel<false, true, true, true, true, true>), grid, block, 0, s, u_in, action, u_out, n,
+                               awk, rule, status, slot, ws, bonus, ea);
+        else
+            hipLaunchKernelGGL((ca_step_rnd64_kernel<false, false, true, true, true, true>), grid, block, 0, s, u_in, action, u_out, n,
+                               awk, rule, status, slot, ws, bonus, ea);
+        return check_launch("carle_env_step_f32_rnd_packed(fused CA + RND2D)");
+    }
 #define CARLE_RND_LAUNCH(ACT, NTS, NTL, ENVF) \
     do { \
         if (ENVF && bits) hipLaunchKernelGGL((ca_step_rnd64_kernel<ACT, NTS, NTL, ENVF, ENVF>), grid, block, 0, s, u_in, action, \

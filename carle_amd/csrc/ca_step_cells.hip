@@ -71,6 +71,7 @@ struct EnvArgs {
     float *reward = nullptr;       // N floats, zeroed (nullable)
     int publish = 1;               // 0: the caller stored the action flags of `slot` beforehand
     int merge_moments = 0;
+    const uint64_t *bits_in = nullptr;   // PACKED_IN (64x64): the bit-packed copy a previous launch left of u_in -- read INSTEAD of it
     uint64_t *bits_out = nullptr;  // 64 / 256 / 512 columns: also a bit-packed copy of the new state (H rows of W/64 words per
                                    // grid, carle_pack_f32_b1's layout) -- what the reward-net kernels read 30x faster than
                                    // the fp32 cells (nullable)
@@ -120,8 +121,11 @@ __device__ __forceinline__ uint64_t transpose_nibbles16(uint64_t x, int lane) {
 
 // BITS (ENV, fp32 cells; round 5): the launch also leaves the new state bit-packed (64 row words per grid) for a reward net
 // that sits on this environment -- the 64x64 net kernels then read 512 B instead of 16 KiB per grid
+// PACKED_IN (with BITS): the state comes in as the 64 row words the previous launch left (512 B per grid instead of 16 KiB of
+// fp32 cells that carry the same 4 096 bits): the inverse of the transpose above.  The fp32 state is still written every
+// step -- it is the observation the caller gets -- but never read back by the next one.
 template <class C, class A, bool HAS_ACT, bool NT_LD = false, bool NT_ST = false, int BLOCK = 256,
-          bool RAND_ACT = false, bool ENV = false, bool BITS = false>
+          bool RAND_ACT = false, bool ENV = false, bool BITS = false, bool PACKED_IN = false>
 __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
     const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
     typename C::T *__restrict__ u_out, int64_t n, int aw, uint32_t rule, int32_t *__restrict__ status,
@@ -130,16 +134,21 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
     const int64_t g = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (g >= n) return;                              // wave-uniform
     static_assert(!(ENV && RAND_ACT), "the in-kernel random agent keeps the two-launch step");
+    static_assert(!PACKED_IN || (ENV && BITS), "the packed input is the previous launch's packed output");
     const int q = lane >> 4, k = lane & 15;
     const typename C::T *gin = u_in + g * 4096 + 4 * lane;   // 1024 quads per grid, 64 per load
 
     typename C::Quad v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = C::template load<NT_LD>(gin + i * 256);
     uint64_t c = 0;
-    if (!(HAS_ACT && !RAND_ACT)) {
+    if (PACKED_IN) {
+        c = transpose_nibbles16(__builtin_nontemporal_load(ea.bits_in + g * 64 + 4 * k + q), lane);
+    } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) c |= (uint64_t)C::nibble(v[i]) << (4 * i);
+        for (int i = 0; i < 16; ++i) v[i] = C::template load<NT_LD>(gin + i * 256);
+        if (!(HAS_ACT && !RAND_ACT)) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c |= (uint64_t)C::nibble(v[i]) << (4 * i);
+        }
     }
 
     bool own_notone = true;                          // ENV: some action element of this grid differs from one
@@ -176,24 +185,33 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
             // drop it): a load inside a per-row `if` is followed by its own s_waitcnt vmcnt(0) -- sixteen
             // dependent memory round trips per wave instead of one (round 2, seen in the disassembly).
             typename A::Quad a[16];
+            if (PACKED_IN) {                          // no state quads: the sixteen action loads are the launch's only wide loads
 #pragma unroll
-            for (int i = 0; i < kActEarly; ++i) {
-                const int ay = 4 * i + q - o;
-                const bool in = col_in && ay >= 0 && ay < aw;
-                a[i] = A::template load<NT_LD>(in ? abase + (int64_t)ay * aw : abase0);
-            }
+                for (int i = 0; i < 16; ++i) {
+                    const int ay = 4 * i + q - o;
+                    const bool in = col_in && ay >= 0 && ay < aw;
+                    a[i] = A::template load<NT_LD>(in ? abase + (int64_t)ay * aw : abase0);
+                }
+            } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) c |= (uint64_t)C::nibble(v[i]) << (4 * i);
-            // the remaining loads reuse the state's registers: their addresses are made to depend on the packed
-            // state (an opaque zero), or the compiler requests all 32 quads at once (137 VGPRs, 3 waves per SIMD)
-            uint32_t z = 0;
-            if (kActEarly < 16)
-                asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"((uint32_t)c), "v"((uint32_t)(c >> 32)));
+                for (int i = 0; i < kActEarly; ++i) {
+                    const int ay = 4 * i + q - o;
+                    const bool in = col_in && ay >= 0 && ay < aw;
+                    a[i] = A::template load<NT_LD>(in ? abase + (int64_t)ay * aw : abase0);
+                }
 #pragma unroll
-            for (int i = kActEarly; i < 16; ++i) {
-                const int ay = 4 * i + q - o;
-                const bool in = col_in && ay >= 0 && ay < aw;
-                a[i] = A::template load<NT_LD>((in ? abase + (int64_t)ay * aw : abase0) + z);
+                for (int i = 0; i < 16; ++i) c |= (uint64_t)C::nibble(v[i]) << (4 * i);
+                // the remaining loads reuse the state's registers: their addresses are made to depend on the packed
+                // state (an opaque zero), or the compiler requests all 32 quads at once (137 VGPRs, 3 waves per SIMD)
+                uint32_t z = 0;
+                if (kActEarly < 16)
+                    asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"((uint32_t)c), "v"((uint32_t)(c >> 32)));
+#pragma unroll
+                for (int i = kActEarly; i < 16; ++i) {
+                    const int ay = 4 * i + q - o;
+                    const bool in = col_in && ay >= 0 && ay < aw;
+                    a[i] = A::template load<NT_LD>((in ? abase + (int64_t)ay * aw : abase0) + z);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -1082,7 +1100,7 @@ template <class C, class A>
 static int env_step_one_launch(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
                                float *reward, int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status,
                                int slot, int step_flags, void *stream, const char *who, uint64_t *bits_out = nullptr,
-                               int *bits_written = nullptr) {
+                               int *bits_written = nullptr, const uint64_t *bits_in = nullptr) {
     if (bits_written) *bits_written = 0;
     const bool fast64 = h == 64 && w == 64 && (!action || (aw % 8) == 0);
     const bool wide = h == w && (w == 256 || w == 512) && (!action || ((aw % 4) == 0 && ((w - aw) % 8) == 0));
@@ -1098,14 +1116,18 @@ static int env_step_one_launch(const typename C::T *u_in, const typename A::T *a
         snprintf(buf, sizeof buf, "%s: %s", who, what);
         return fail_arg(code, buf);
     };
-    if (!u_in || !u_out) return fail(CARLE_E_NULL, "u_in/u_out is NULL");
+    if (bits_in && !(fast64 && bits_out && sizeof(typename C::T) == 4))
+        return fail(CARLE_E_DIMS, "a packed input state: 64x64 fp32 grids, with bits_out");
+    if ((!u_in && !bits_in) || !u_out) return fail(CARLE_E_NULL, "u_in/u_out is NULL");
     if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
     if (rule >> 18) return fail(CARLE_E_RULE, "rule mask exceeds 18 bits");
     if (slot != 0 && slot != 1) return fail(CARLE_E_DIMS, "slot must be 0 or 1");
-    if (!aligned16(u_in) || !aligned16(u_out) || (action && !aligned16(action)) || !aligned16(status))
+    if ((u_in && !aligned16(u_in)) || !aligned16(u_out) || (action && !aligned16(action)) || !aligned16(status))
         return fail(CARLE_E_ALIGN, "pointers must be 16-byte aligned");
     const size_t bytes = (size_t)n * h * w * sizeof(typename C::T);
-    if (overlap(u_in, bytes, u_out, bytes)) return fail(CARLE_E_ALIAS, "u_in and u_out overlap");
+    if (u_in && !bits_in && overlap(u_in, bytes, u_out, bytes)) return fail(CARLE_E_ALIAS, "u_in and u_out overlap");
+    if (bits_in && ((reinterpret_cast<uintptr_t>(bits_in) & 7u) != 0 || overlap(bits_in, (size_t)n * 512, bits_out, (size_t)n * 512)))
+        return fail(CARLE_E_ALIAS, "bits_in must be 8-byte aligned and must not overlap bits_out");
     EnvArgs ea;
     ea.reward = reward;
     ea.publish = (step_flags & CARLE_STEP_PUBLISH_FLAGS) ? 1 : 0;
@@ -1127,6 +1149,22 @@ static int env_step_one_launch(const typename C::T *u_in, const typename A::T *a
         if ((reinterpret_cast<uintptr_t>(bits_out) & 7u) != 0) return fail(CARLE_E_ALIGN, "bits_out must be 8-byte aligned");
         ea.bits_out = bits_out;
         if (bits_written) *bits_written = 1;
+        if (bits_in) {                                 // the state comes in packed: u_in is not read
+            ea.bits_in = bits_in;
+            if (action && nt_st)
+                hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, true, 64, false, true, true, true>), grid, block, 0, s,
+                                   u_in, action, u_out, n, aw, rule, status, slot, ra, ea);
+            else if (action)
+                hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, false, 64, false, true, true, true>), grid, block, 0, s,
+                                   u_in, action, u_out, n, aw, rule, status, slot, ra, ea);
+            else if (nt_st)
+                hipLaunchKernelGGL((ca_step_64_kernel<C, A, false, true, true, 64, false, true, true, true>), grid, block, 0, s,
+                                   u_in, action, u_out, n, 0, rule, status, slot, ra, ea);
+            else
+                hipLaunchKernelGGL((ca_step_64_kernel<C, A, false, true, false, 64, false, true, true, true>), grid, block, 0, s,
+                                   u_in, action, u_out, n, 0, rule, status, slot, ra, ea);
+            return check_launch(who);
+        }
         if (action && nt_st)
             hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, true, 64, false, true, true>), grid, block, 0, s, u_in,
                                action, u_out, n, aw, rule, status, slot, ra, ea);
@@ -1266,9 +1304,9 @@ int env_step_small64_rand(const float *u_in, float *u_out, float *reward, int64_
 namespace carle {
 int env_step_one_launch_f32(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h,
                             int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
-                            void *stream, uint64_t *bits_out, int *bits_written) {
+                            void *stream, uint64_t *bits_out, int *bits_written, const uint64_t *bits_in) {
     return env_step_one_launch<F32Cells, F32Cells>(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
-                                                   step_flags, stream, "carle_env_step_f32", bits_out, bits_written);
+                                                   step_flags, stream, "carle_env_step_f32", bits_out, bits_written, bits_in);
 }
 int env_step_one_launch_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out, float *reward,
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,

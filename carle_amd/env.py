@@ -15,6 +15,7 @@ What is different underneath:
     ``steps_since_action`` in device memory; reading those attributes synchronises lazily;
   * this build is GPU-only: without a HIP device ``reset``/``step`` raise (no CPU fallback).
 """
+import os
 import time
 import weakref
 
@@ -26,6 +27,10 @@ from . import hip
 from .rle import RLEMixin
 
 _MOORE = ((1.0, 1.0, 1.0), (1.0, 0.0, 1.0), (1.0, 1.0, 1.0))
+# CARLE_PACKED_STATE=0: the 64x64 step always reads the fp32 state, as up to round 4 (A/B switch; read once at import).
+# Default: a step reads the bit-packed copy the previous step left of its own output -- valid only for the very tensor that
+# step returned, untouched by torch since (``CARLE._packed_state_of``); anything else reads the fp32 cells.
+_PACKED_STATE = os.environ.get("CARLE_PACKED_STATE", "1") != "0"
 
 
 def _resolve_device(kwargs):
@@ -207,14 +212,28 @@ class CARLE(RLEMixin, nn.Module):
     def _bits_buffer(self, out, slot):
         """Where the one-launch step of a 64- / 256- / 512-column fp32 grid leaves a bit-packed copy of its output (one buffer
         per step parity) -- only while a reward net that reads it sits on this environment (``want_packed_copy``)."""
-        if not self.__dict__.get("want_packed_copy") or out.dtype != torch.float32 or out.shape[3] not in (64, 256, 512) \
-                or out.shape[2] != out.shape[3]:
+        if out.dtype != torch.float32 or out.shape[3] not in (64, 256, 512) or out.shape[2] != out.shape[3]:
+            return None
+        # ... or, for batches of 64x64 grids beyond the single-workgroup kernel, always: the next step then reads its input
+        # state from the copy (512 B per grid) instead of the fp32 cells (16 KiB) -- ``_packed_state_of``
+        if not self.__dict__.get("want_packed_copy") and not (out.shape[3] == 64 and out.shape[0] > 16 and _PACKED_STATE):
             return None
         bufs = self.__dict__.get("_bits_bufs")
         shape = (out.shape[0], 1, out.shape[2], out.shape[3] // 64)
         if bufs is None or tuple(bufs[0].shape) != shape or bufs[0].device != out.device:
             bufs = self.__dict__["_bits_bufs"] = [torch.empty(shape, dtype=torch.int64, device=out.device) for _ in (0, 1)]
         return bufs[slot]
+
+    def _packed_state_of(self, u_in, bits_out):
+        """The bit-packed copy of the CURRENT state ``u_in`` if the last step left one (``u_in`` is the very tensor that step
+        returned and no torch operation has written to it since: identity + version counter), for the one-launch step that
+        reads it instead of the fp32 cells (``carle_env_step_f32_packed``: 64x64 grids).  None: read the fp32 state."""
+        if bits_out is None or not _PACKED_STATE or u_in.shape[3] != 64 or u_in.shape[2] != 64:
+            return None
+        bits = self.packed_copy_of(u_in)
+        if bits is None or bits is bits_out or bits.data_ptr() == bits_out.data_ptr() or bits.shape != bits_out.shape:
+            return None
+        return bits
 
     def packed_copy_of(self, obs):
         """The bit-packed copy (int64 (N,1,H,W/64)) the last step left of ``obs``, or None: only for the very tensor the
@@ -437,8 +456,13 @@ class CARLE(RLEMixin, nn.Module):
             share(self._status, slot)
         if launch is None:
             bits = self._bits_buffer(out, slot)
-            if hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, publish, merge, bits_out=bits):
-                # the launch left a bit-packed copy of the new state: the tiled reward nets read that
+            state_bits = self._packed_state_of(u_in, bits)
+            if state_bits is not None:
+                # the last step left the state bit-packed as well: this one reads 512 B instead of 16 KiB per grid
+                hip.env_step_f32_packed(state_bits, act, out, reward, rule, self._status, slot, publish, merge, bits_out=bits)
+                self.__dict__["_obs_bits"] = (weakref.ref(out), out._version, bits)
+            elif hip.env_step_f32(u_in, act, out, reward, rule, self._status, slot, publish, merge, bits_out=bits):
+                # the launch left a bit-packed copy of the new state: the reward nets (and the next step) read that
                 self.__dict__["_obs_bits"] = (weakref.ref(out), out._version, bits)
             self._moments_merged = merge
         else:

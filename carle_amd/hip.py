@@ -384,6 +384,24 @@ def env_step_f32(u_in, action, u_out, reward, rule, status, slot, publish_flags=
     return bits_out is not None and _bits_written.value != 0
 
 
+def env_step_f32_packed(bits_in, action, u_out, reward, rule, status, slot, publish_flags=True, merge_moments=False,
+                        bits_out=None):
+    """The one-launch step of 64x64 fp32 grids reading its input state from the bit-packed copy ``bits_in`` (int64 (N,1,64,1))
+    the previous step left, instead of the fp32 cells (carle_env_step_f32_packed); writes ``u_out`` and ``bits_out``."""
+    lib = _lib.load()
+    n, _, h, w = u_out.shape
+    if action is None:
+        ap, ah, aw = None, 0, 0
+    else:
+        ap, ah, aw = action.data_ptr(), action.shape[2], action.shape[3]
+    with _on_device(u_out.device):
+        rc = lib.carle_env_step_f32_packed(bits_in.data_ptr(), ap, u_out.data_ptr(), reward.data_ptr(), n, h, w, ah, aw, rule,
+                                           status.data_ptr(), slot, _step_flags(publish_flags, merge_moments, True),
+                                           bits_out.data_ptr(), _stream(u_out))
+    if rc != 0:
+        _lib.check(rc, "carle_env_step_f32_packed")
+
+
 def env_run_f32(u_in, buf_a, buf_b, actions, reward, rule, status, slot0, k, ah=0, aw=0, p=-1.0, seed=0, offset=0,
                 merge_moments=False, deferred=True):
     """k CARLE.step calls in one library call (carle_env_run_f32): the state is READ from u_in and the steps
@@ -824,13 +842,26 @@ def speed_puffer_f32(obs, w_h, w_w, sums4, counter, com, state, velocity, speed,
 def env_step_f32_rnd(u_in, action, u_out, reward, rule, status, slot, publish_flags, pred_params,
                      rand_params, workspace, bonus, reward_scale, tables_valid,
                      event_handle, stream_env, stream_reward, merge_moments=False, deferred=False, partials=None,
-                     bits_out=None):
+                     bits_out=None, bits_in=None):
     """CARLE.step + RND2D bonus of the fresh observation in one library call (see carle_hip.h).  deferred: ONE
     launch (no epilogue kernel); with merge_moments it needs ``partials`` (fp64 scratch of
-    carle_rnd_step_partials_doubles(n) elements that outlives the call until the next one on the status block)."""
+    carle_rnd_step_partials_doubles(n) elements that outlives the call until the next one on the status block).
+    bits_in (int64 (N,1,64,1), with bits_out): the input state is read from this bit-packed copy, ``u_in`` is not touched
+    (carle_env_step_f32_rnd_packed)."""
     lib = _lib.load()
-    n, _, h, w = u_in.shape
-    with _on_device(u_in.device):
+    n, _, h, w = u_out.shape
+    with _on_device(u_out.device):
+        if bits_in is not None:
+            rc = lib.carle_env_step_f32_rnd_packed(bits_in.data_ptr(), action.data_ptr(), u_out.data_ptr(),
+                                                   reward.data_ptr(), n, h, w, action.shape[2], action.shape[3],
+                                                   rule, status.data_ptr(), slot,
+                                                   _step_flags(publish_flags, merge_moments, True), pred_params.data_ptr(),
+                                                   rand_params.data_ptr(), workspace.data_ptr(), bonus.data_ptr(),
+                                                   float(reward_scale), 2 if tables_valid else 0, _ptr(partials), event_handle,
+                                                   stream_env, stream_reward, bits_out.data_ptr())
+            if rc != 0:
+                _lib.check(rc, "carle_env_step_f32_rnd_packed")
+            return True
         if bits_out is None:
             rc = lib.carle_env_step_f32_rnd(u_in.data_ptr(), action.data_ptr(), u_out.data_ptr(),
                                             reward.data_ptr(), n, h, w, action.shape[2], action.shape[3],

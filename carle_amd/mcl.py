@@ -642,7 +642,9 @@ class RND2D(Motivator):
                 partials = self.__dict__["_mom_partials"] = torch.zeros(pneed, dtype=torch.float64, device=dev)
 
         bits_bufs = None
-        if self.__dict__.get("_hand_bits"):                  # a reward net above reads the observation bit-packed
+        # a reward net above reads the observation bit-packed -- and so does this step itself, next time (CARLE._packed_state_of)
+        from .env import _PACKED_STATE
+        if self.__dict__.get("_hand_bits") or (_PACKED_STATE and n > 16):
             bits_bufs = self.__dict__.get("_bits_bufs")
             if bits_bufs is None or bits_bufs[0].shape[0] != n or bits_bufs[0].device != dev:
                 bits_bufs = self.__dict__["_bits_bufs"] = [torch.empty(n, 1, 64, 1, dtype=torch.int64, device=dev) for _ in (0, 1)]
@@ -656,9 +658,12 @@ class RND2D(Motivator):
                 ev = rs.event_for_fork(main_raw, out, reward)
             fusable = act.shape[3] % 8 == 0     # (the library fuses -- and can merge the moments -- only with an 8-aligned window)
             bits = bits_bufs[slot] if bits_bufs is not None else None
+            # the state as the previous step left it bit-packed (only if ``u_in`` is that very tensor, untouched): 512 B
+            # instead of 16 KiB per grid
+            state_bits = env._packed_state_of(u_in, bits) if fusable and n > 16 else None
             if hip.env_step_f32_rnd(u_in, act, out, reward, rule, status, slot, publish, pb, rb, self._ws,
                                     self._step_bonus, self.reward_scale, valid, ev, main_raw, rs_raw,
-                                    merge and fusable, deferred=True, partials=partials, bits_out=bits):
+                                    merge and fusable, deferred=True, partials=partials, bits_out=bits, bits_in=state_bits):
                 env.__dict__["_obs_bits"] = (weakref.ref(out), out._version, bits)
             self.__dict__["_moments_merged"] = merge and fusable
             if merge and fusable:

@@ -223,6 +223,16 @@ int carle_env_step_f32(const float *u_in, const float *action, float *u_out, flo
 int carle_env_step_f32_bits(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h, int w,
                             int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags, uint64_t *bits_out,
                             int *bits_written, void *stream);
+/* The one-launch step (CARLE_STEP_DEFERRED semantics) of n >= 1 grids of 64x64 fp32 cells whose INPUT state is read from its
+ * bit-packed copy bits_in (n x 64 row words, as a previous carle_env_step_f32_bits / carle_env_step_f32_packed /
+ * carle_pack_f32_b1 left it) instead of the fp32 cells -- the same 4 096 bits per grid in 512 B instead of 16 KiB.  The fp32
+ * observation u_out (carle/env.py:229) and its packed copy bits_out are written as by carle_env_step_f32_bits; grids, counters,
+ * reward and flags are those of carle_env_step_f32 on the fp32 state.  The caller vouches that bits_in IS the current state
+ * (carle_amd.env.CARLE.step: the very tensor the last step returned, not modified since); bits_in and bits_out must not
+ * overlap.  action: fp32 (n,1,ah,aw) window with aw a multiple of 8, or NULL. */
+int carle_env_step_f32_packed(const uint64_t *bits_in, const float *action, float *u_out, float *reward, int64_t n, int h,
+                              int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
+                              uint64_t *bits_out, void *stream);
 
 /* Applies a pending CARLE_STEP_DEFERRED step to the counters of the status block (one tiny kernel; a no-op on the
  * device when nothing is pending).  Call before copying the counters to the host (env.py:142-145,199-200,230). */
@@ -462,6 +472,16 @@ int carle_env_step_f32_rnd_bits(const float *u_in, const float *action, float *u
                                 const float *pred_params, const float *rand_params, float *workspace, float *bonus,
                                 float reward_scale, int net_flags, double *moment_partials, void *event, void *stream_env,
                                 void *stream_reward, uint64_t *bits_out, int *bits_written);
+/* carle_env_step_f32_rnd_bits whose INPUT state is read from its bit-packed copy bits_in (n x 64 row words, as a previous
+ * carle_env_step_f32_rnd_bits / _rnd_packed / carle_env_step_f32_bits / carle_pack_f32_b1 left it) instead of the fp32 cells: see
+ * carle_env_step_f32_packed.  Always ONE launch (more than 16 grids of 64x64, action width a multiple of 8; CARLE_STEP_DEFERRED
+ * semantics) or an error; bits_in / bits_out 16-byte aligned, not overlapping.  The caller vouches that bits_in IS the
+ * current state. */
+int carle_env_step_f32_rnd_packed(const uint64_t *bits_in, const float *action, float *u_out, float *reward, int64_t n, int h,
+                                  int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
+                                  const float *pred_params, const float *rand_params, float *workspace, float *bonus,
+                                  float reward_scale, int net_flags, double *moment_partials, void *event, void *stream_env,
+                                  void *stream_reward, uint64_t *bits_out);
 int carle_env_step_f32_rnd(const float *u_in, const float *action, float *u_out, float *reward,
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule,
                            int32_t *status, int slot, int publish_flags,

@@ -502,7 +502,7 @@ def test_one_launch_step_also_leaves_the_packed_copy_at_64(n, asize):
             u = outs[1][0]
 
 
-def test_reward_nets_on_a_64_column_environment_read_the_packed_copy():
+def test_reward_nets_on_a_64_column_environment_read_the_packed_copy(monkeypatch):
     """An AE2D directly on a CARLE(64x64), and an RND2D in training mode: the environment's step hands them the observation
     bit-packed (CARLE.packed_copy_of), the rewards equal those of the same stacks reading the fp32 cells (CARLE_PACKED_COPY=0
     at construction) bit for bit."""
@@ -510,7 +510,10 @@ def test_reward_nets_on_a_64_column_environment_read_the_packed_copy():
     from carle_amd.env import CARLE
     from carle_amd.mcl import AE2D, RND2D
 
+    import carle_amd.env as E
+
     def run(kind, packed):
+        monkeypatch.setattr(E, "_PACKED_STATE", packed)      # (else the step leaves the copy for its own next step anyway)
         old = os.environ.get("CARLE_PACKED_COPY")
         os.environ["CARLE_PACKED_COPY"] = "1" if packed else "0"
         try:
@@ -543,3 +546,125 @@ def test_reward_nets_on_a_64_column_environment_read_the_packed_copy():
         assert torch.equal(o1, o0)
         assert torch.equal(r1, r0), (kind, float((r1 - r0).abs().max()))
         assert float(r1.abs().max()) > 0
+
+
+def test_step_reads_the_packed_copy_of_its_own_last_output_and_nothing_else(monkeypatch):
+    """Round 5: at 64x64 (N > 16) CARLE.step reads its input state from the bit-packed copy the previous step left
+    (carle_env_step_f32_packed) -- only while ``universe`` is the very tensor that step returned, untouched since.  An
+    in-place edit, an assignment, a non-binary state, reset(): each falls back to the fp32 cells, and the trajectory equals
+    that of an environment that never takes the packed path, bit for bit (master reset included)."""
+    import carle_amd.env as E
+    from carle_amd import hip
+    calls = {"packed": 0}
+    real = hip.env_step_f32_packed
+
+    def spy(*a, **k):
+        calls["packed"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(hip, "env_step_f32_packed", spy)
+
+    def trajectory(packed_state):
+        monkeypatch.setattr(E, "_PACKED_STATE", packed_state)
+        g = torch.Generator(device="cuda").manual_seed(77)
+        env = E.CARLE(width=64, height=64, instances=40, device="cuda:0")
+        env.reset()
+        env.universe = (torch.rand(40, 1, 64, 64, device="cuda", generator=g) < 0.35).float()
+        out, taken = [], []
+        for t in range(14):
+            a = (torch.rand(40, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
+            if t == 5:
+                a = torch.ones_like(a)                                   # master reset
+            if t == 3:
+                env.universe[7, 0, 10:20, 10:20] = 1.0 - env.universe[7, 0, 10:20, 10:20]     # in-place edit: version bump
+            if t == 7:
+                env.universe = env.universe.clone()                      # another tensor with the same cells
+            if t == 9:
+                env.universe = torch.rand(40, 1, 64, 64, device="cuda", generator=g)          # non-binary state
+            if t == 11:
+                env.reset()
+            before = calls["packed"]
+            obs = env.step(a)[0]
+            taken.append(calls["packed"] - before)
+            out.append(obs.clone())
+        return out, taken, (env.step_number, env.steps_since_action)
+
+    ref, taken_ref, counters_ref = trajectory(False)
+    got, taken, counters = trajectory(True)
+    assert taken_ref == [0] * 14
+    #        t = 0 (assigned state)  1  2  3 (edited)  4  5  6  7 (clone)  8  9 (new state)  10  11 (reset)  12  13
+    assert taken == [0, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1, 0, 1, 1], taken
+    for t, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), t
+    assert counters == counters_ref
+    assert float(got[5].sum()) == 0.0 and float(got[4].sum()) > 0 and float(got[6].sum()) > 0     # the master reset at t = 5
+
+
+@pytest.mark.parametrize("n,asize", [(17, 64), (300, 32), (4099, 64), (65, 0)])
+def test_packed_input_step_against_the_oracle(n, asize):
+    """carle_env_step_f32_packed itself: state in as row words, fp32 state + row words out; twelve steps against the C oracle
+    on the fp32 cells, three rules."""
+    from carle_amd import hip
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    for birth, survive in (([3], [2, 3]), ([3, 6], [2, 3]), ([2], [])):
+        rule = hip.rule_mask(birth, survive)
+        u = (torch.rand(n, 1, 64, 64, device=dev, generator=g) < 0.4).float()
+        bits = [hip.pack_f32_b1(u), torch.empty(n, 1, 64, 1, dtype=torch.int64, device=dev)]
+        st = hip.new_status(dev)
+        cpu = u.cpu().numpy()
+        for t in range(12):
+            act = (torch.rand(n, 1, asize, asize, device=dev, generator=g) < 0.15).float() if asize else None
+            out = torch.empty(n, 1, 64, 64, device=dev)
+            reward = torch.empty(n, 1, device=dev)
+            hip.env_step_f32_packed(bits[t & 1], act, out, reward, rule, st, t & 1, True, False, bits_out=bits[(t & 1) ^ 1])
+            cpu = O.c_env_step(cpu, None if act is None else act.cpu().numpy(), rule)[0]
+            assert np.array_equal(out.cpu().numpy(), cpu), (birth, t)
+            assert torch.equal(bits[(t & 1) ^ 1], hip.pack_f32_b1(out))
+
+
+def test_fused_rnd_step_reads_the_packed_state_too(monkeypatch):
+    """RND2D.step (forward only, 64x64, N > 16): from its second step on the fused kernel takes the state as the row words its
+    previous launch left (carle_env_step_f32_rnd_packed); observations, rewards and counters equal those of the stack that
+    always reads the fp32 cells, bit for bit -- through an in-place edit, an assigned state and a master reset."""
+    import carle_amd.env as E
+    from carle_amd import hip
+    from carle_amd.mcl import RND2D
+    calls = {"packed": 0}
+    lib_call = hip.env_step_f32_rnd
+
+    def spy(*a, **k):
+        calls["packed"] += k.get("bits_in") is not None
+        return lib_call(*a, **k)
+    monkeypatch.setattr(hip, "env_step_f32_rnd", spy)
+
+    def trajectory(packed_state):
+        monkeypatch.setattr(E, "_PACKED_STATE", packed_state)
+        torch.manual_seed(11)
+        g = torch.Generator(device="cuda").manual_seed(78)
+        env = E.CARLE(width=64, height=64, instances=33, device="cuda:0")
+        w = RND2D(env, train_predictor=False)
+        w.eval()
+        w.reset()
+        env.universe = (torch.rand(33, 1, 64, 64, device="cuda", generator=g) < 0.35).float()
+        obs_l, rew_l, taken = [], [], []
+        for t in range(10):
+            a = (torch.rand(33, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
+            if t == 4:
+                a = torch.ones_like(a)
+            if t == 2:
+                env.universe[3, 0, :8, :8] = 1.0
+            if t == 6:
+                env.universe = (torch.rand(33, 1, 64, 64, device="cuda", generator=g) < 0.5).float()
+            before = calls["packed"]
+            obs, r, _, _ = w.step(a)
+            taken.append(calls["packed"] - before)
+            obs_l.append(obs.clone())
+            rew_l.append(r.clone())
+        return obs_l, rew_l, taken, (env.step_number, env.steps_since_action)
+
+    o0, r0, t0, c0 = trajectory(False)
+    o1, r1, t1, c1 = trajectory(True)
+    assert t0 == [0] * 10 and t1 == [0, 1, 0, 1, 1, 1, 0, 1, 1, 1], (t0, t1)
+    for t in range(10):
+        assert torch.equal(o0[t], o1[t]) and torch.equal(r0[t], r1[t]), t
+    assert c0 == c1 and float(o1[4].sum()) == 0.0
