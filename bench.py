@@ -336,8 +336,7 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
     # fp32 64x64 beyond 16 instances (round 5): CARLE.step reads its input state from the bit-packed copy its previous launch
     # left (512 B per grid) instead of the fp32 cells (16 KiB) -- the kernel below is that launch, and its algorithmic bytes
     # are what it has to move: the fp32 action in, the fp32 observation out, the packed state in and out
-    from carle_amd import env as cenv
-    packed_state = one_launch and args.format == "f32" and size == 64 and cenv._PACKED_STATE
+    packed_state = one_launch and args.format == "f32" and size == 64 and getattr(env, "packed_state", False)
     if packed_state:
         sbits = [hip.pack_f32_b1(bufs[0]), torch.empty(n, 1, 64, 1, dtype=torch.int64, device=state.device)]
         alg_reference = alg

@@ -112,6 +112,13 @@ class CARLE(RLEMixin, nn.Module):
         # OR-ed over the ranks (all-reduce MAX of two int32 per step) before the step kernel reads them -- the master
         # reset then fires iff every rank's action is all ones, as in the unsharded run.  No effect without a process group.
         self.global_action_predicates = bool(kwargs.get("global_action_predicates", False))
+        # 64x64 fp32 batches of more than 16 instances: every step also leaves its output as 64 row words per grid, and the
+        # next step reads THOSE (512 B) instead of the fp32 cells (16 KiB) -- as long as ``universe`` is the very tensor
+        # the last step returned and no torch operation has written to it since (identity + version counter; anything else
+        # reads the fp32 cells: ``_packed_state_of``).  Same trajectories bit for bit.  What the check cannot see is a write
+        # through ``universe.data`` or through the raw device pointer (DLPack, a foreign kernel): code that edits the state
+        # that way passes packed_state=False (or sets CARLE_PACKED_STATE=0 for the process).
+        self.packed_state = bool(kwargs.get("packed_state", _PACKED_STATE))
         self.storage = kwargs.get("storage", "f32")
         if self.storage not in ("f32", "u8", "b1"):
             raise ValueError("storage must be 'f32' (reference format), 'u8' or 'b1' (bit-packed)")
@@ -216,7 +223,7 @@ class CARLE(RLEMixin, nn.Module):
             return None
         # ... or, for batches of 64x64 grids beyond the single-workgroup kernel, always: the next step then reads its input
         # state from the copy (512 B per grid) instead of the fp32 cells (16 KiB) -- ``_packed_state_of``
-        if not self.__dict__.get("want_packed_copy") and not (out.shape[3] == 64 and out.shape[0] > 16 and _PACKED_STATE):
+        if not self.__dict__.get("want_packed_copy") and not (out.shape[3] == 64 and out.shape[0] > 16 and self.packed_state):
             return None
         bufs = self.__dict__.get("_bits_bufs")
         shape = (out.shape[0], 1, out.shape[2], out.shape[3] // 64)
@@ -228,7 +235,7 @@ class CARLE(RLEMixin, nn.Module):
         """The bit-packed copy of the CURRENT state ``u_in`` if the last step left one (``u_in`` is the very tensor that step
         returned and no torch operation has written to it since: identity + version counter), for the one-launch step that
         reads it instead of the fp32 cells (``carle_env_step_f32_packed``: 64x64 grids).  None: read the fp32 state."""
-        if bits_out is None or not _PACKED_STATE or u_in.shape[3] != 64 or u_in.shape[2] != 64:
+        if bits_out is None or not self.packed_state or u_in.shape[3] != 64 or u_in.shape[2] != 64:
             return None
         bits = self.packed_copy_of(u_in)
         if bits is None or bits is bits_out or bits.data_ptr() == bits_out.data_ptr() or bits.shape != bits_out.shape:

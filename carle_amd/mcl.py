@@ -643,8 +643,7 @@ class RND2D(Motivator):
 
         bits_bufs = None
         # a reward net above reads the observation bit-packed -- and so does this step itself, next time (CARLE._packed_state_of)
-        from .env import _PACKED_STATE
-        if self.__dict__.get("_hand_bits") or (_PACKED_STATE and n > 16):
+        if self.__dict__.get("_hand_bits") or (getattr(env, "packed_state", False) and n > 16):
             bits_bufs = self.__dict__.get("_bits_bufs")
             if bits_bufs is None or bits_bufs[0].shape[0] != n or bits_bufs[0].device != dev:
                 bits_bufs = self.__dict__["_bits_bufs"] = [torch.empty(n, 1, 64, 1, dtype=torch.int64, device=dev) for _ in (0, 1)]
