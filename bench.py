@@ -336,14 +336,17 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
     # fp32 64x64 beyond 16 instances (round 5): CARLE.step reads its input state from the bit-packed copy its previous launch
     # left (512 B per grid) instead of the fp32 cells (16 KiB) -- the kernel below is that launch, and its algorithmic bytes
     # are what it has to move: the fp32 action in, the fp32 observation out, the packed state in and out
-    packed_state = one_launch and args.format == "f32" and size == 64 and getattr(env, "packed_state", False)
+    packed_state = (args.format == "f32" and getattr(env, "packed_state", False) and
+                    ((size == 64 and one_launch) or size in (256, 512)))
     if packed_state:
-        sbits = [hip.pack_f32_b1(bufs[0]), torch.empty(n, 1, 64, 1, dtype=torch.int64, device=state.device)]
+        sbits = [hip.pack_f32_b1(bufs[0]), torch.empty(n, 1, size, size // 64, dtype=torch.int64, device=state.device)]
         alg_reference = alg
-        alg = n * (size * size * 4 + asize * asize * 4 + 2 * 512)
-        name = "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true, ..., ENV, BITS, PACKED_IN>"
+        alg = n * (size * size * 4 + asize * asize * 4 + 2 * size * size // 8)
+        name = ("ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true, ..., ENV, BITS, PACKED_IN>" if size == 64 else
+                "ca_step_wide_kernel<carle::F32Cells, carle::F32Cells, true, ..., ENV, PK=2>" if one_launch else
+                "ca_step_wide_kernel<carle::F32Cells, carle::F32Cells, true, ..., PK=2> (timed with its 5 us epilogue launch)")"
         dominant_kernels.notes = {name: {
-            "traffic_model": "fp32 action in (4 B/cell) + fp32 observation out (4 B/cell) + bit-packed state in and out "
+            "traffic_model": "fp32 action window in + fp32 observation out (4 B/cell) + bit-packed state in and out "
                              "(2 x 1/8 B/cell): the fp32 state is written every step and not read back",
             "bytes_per_launch_if_the_fp32_state_were_read": alg_reference}}
 

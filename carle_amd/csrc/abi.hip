@@ -217,6 +217,8 @@ int env_step_one_launch_f32(const float *u_in, const float *action, float *u_out
 int env_step_one_launch_u8(const uint8_t *u_in, const void *action, int action_fmt, uint8_t *u_out, float *reward,
                            int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
                            int step_flags, void *stream);
+int ca_step_wide_packed_f32(const float *u_in, const uint64_t *bits_in, const float *action, float *u_out, uint64_t *bits_out,
+                            int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, void *stream);
 int env_step_one_launch_b1(const uint64_t *u_in, const uint64_t *action, uint64_t *u_out, float *reward, int64_t n, int h,
                            int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags, void *stream);
 
@@ -268,6 +270,17 @@ extern "C" int carle_env_step_f32_bits(const float *u_in, const float *action, f
         if (const int e = env_step_one_launch_f32(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
                                                   publish_flags, stream, bits_out, bits_written); e != -1000)
             return e;
+    // 256 / 512 columns beyond the one-launch step (or with it switched off): step kernel with the copy + epilogue, which
+    // clears the copy together with the state on a master reset
+    if (bits_out && aligned16(bits_out))
+        if (const int e = ca_step_wide_packed_f32(u_in, nullptr, action, u_out, bits_out, n, h, w, ah, aw, rule,
+                                                  (publish_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream);
+            e != -1000) {
+            if (e) return e;
+            if (bits_written) *bits_written = 1;
+            return ca_finish_impl(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot, action != nullptr,
+                                  bits_out, (int64_t)n * h * (w / 8), nullptr, 0.0f, publish_flags & CARLE_STEP_MERGE_MOMENTS, stream);
+        }
     return carle_env_step_f32(u_in, action, u_out, reward, n, h, w, ah, aw, rule, status, slot, publish_flags, stream);
 }
 
@@ -280,12 +293,24 @@ extern "C" int carle_env_step_f32_packed(const uint64_t *bits_in, const float *a
                                          int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot,
                                          int step_flags, uint64_t *bits_out, void *stream) {
     if (!status || !bits_in || !bits_out) return fail_arg(CARLE_E_NULL, "carle_env_step_f32_packed: NULL pointer");
-    if (h != 64 || w != 64 || n < 1) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: n >= 1 grids of 64x64");
-    if (action && (aw % 8) != 0) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: action width must be a multiple of 8");
-    if (knobs().two_launch_step > 0) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: CARLE_TWO_LAUNCH_STEP is set");
+    if (n < 1 || h != w || (w != 64 && w != 256 && w != 512))
+        return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: n >= 1 grids of 64x64, 256x256 or 512x512");
+    if (w == 64) {
+        if (action && (aw % 8) != 0) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: action width must be a multiple of 8");
+        if (knobs().two_launch_step > 0) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: CARLE_TWO_LAUNCH_STEP is set");
+    }
     const int e = env_step_one_launch_f32(nullptr, action, u_out, reward, n, h, w, ah, aw, rule, status, slot,
                                           step_flags | CARLE_STEP_DEFERRED, stream, bits_out, nullptr, bits_in);
-    return e == -1000 ? fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: geometry without a one-launch step") : e;
+    if (e != -1000) return e;
+    // 256 / 512 columns beyond the one-launch step: step kernel + epilogue (which clears state AND copy on a master reset)
+    if (!aligned16(bits_in) || !aligned16(bits_out))
+        return fail_arg(CARLE_E_ALIGN, "carle_env_step_f32_packed: bits_in / bits_out must be 16-byte aligned");
+    const int e2 = ca_step_wide_packed_f32(nullptr, bits_in, action, u_out, bits_out, n, h, w, ah, aw, rule,
+                                           (step_flags & CARLE_STEP_PUBLISH_FLAGS) ? status : nullptr, slot, stream);
+    if (e2 == -1000) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32_packed: geometry without a packed-input step kernel");
+    if (e2) return e2;
+    return ca_finish_impl(u_out, (int64_t)n * h * w * (int64_t)sizeof(float), reward, n, status, slot, action != nullptr,
+                          bits_out, (int64_t)n * h * (w / 8), nullptr, 0.0f, step_flags & CARLE_STEP_MERGE_MOMENTS, stream);
 }
 
 extern "C" int carle_ca_step_b1(const uint64_t *, const uint64_t *, uint64_t *, int64_t, int, int, int,

@@ -620,7 +620,11 @@ static constexpr int kWideWaves = CARLE_WIDE_WAVES;
 // loads (256 bytes, a cache hit for all but the first workgroup of the grid); an element there that is not one rules the
 // reset out (always, under an agent), otherwise batch_action_all_ones() verifies the batch.  The verdict reaches the
 // other wavefronts through the LDS exchange (and barrier) the edge rows use anyway.
-template <class C, class A, bool HAS_ACT, int NS, int RW, bool RAND_ACT = false, bool NT_ST = true, bool ENV = false>
+// PK (round 5, fp32 cells): 1 = the launch also leaves the new state bit-packed in ea.bits_out (H rows of W/64 words per grid),
+// by the nibble transpose of ca_step_64_kernel -- the 16 lanes of a DPP row hold 16 rows x 16 column quads of one word column;
+// 2 = and it reads its INPUT state from ea.bits_in, the copy the previous launch left (one 8-byte load per lane and 16-row
+// block instead of sixteen quads; the two outer halo rows: one dword each).  With or without ENV.
+template <class C, class A, bool HAS_ACT, int NS, int RW, bool RAND_ACT = false, bool NT_ST = true, bool ENV = false, int PK = 0>
 __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
     const typename C::T *__restrict__ u_in, const typename A::T *__restrict__ act,
     typename C::T *__restrict__ u_out, int64_t n, int ah, int aw, uint32_t rule,
@@ -699,6 +703,34 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
     // memory round trip for the edge waves (seen in the disassembly, round 2).
     uint32_t oz;
     asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+    uint64_t c[NS][RW];
+    uint32_t halo[NS];                               // bits 0-3: row above, bits 4-7: row below
+    if (PK == 2) {
+        // the state as row words: lane (j = k / 16, i = k % 16) loads word 4s + j of row r0 + 16m + i; the transpose leaves lane k
+        // with the nibbles of column quad k (of segment s) for the sixteen rows.  Halo rows: the dword that holds this lane's quad.
+        const uint64_t *bin = ea.bits_in + g * (int64_t)H * (W / 64);
+        const uint32_t *bin32 = reinterpret_cast<const uint32_t *>(bin);
+        uint32_t ht[NS], hb[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            ht[s] = oz; hb[s] = oz;
+            if (top_global) ht[s] = bin32[(int64_t)rt * (W / 32) + 8 * s + (k >> 3)];
+            if (bot_global) hb[s] = bin32[(int64_t)rb * (W / 32) + 8 * s + (k >> 3)];
+        }
+        uint64_t wd[NS][RW];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int m = 0; m < RW; ++m)
+                wd[s][m] = __builtin_nontemporal_load(bin + (int64_t)(r0 + 16 * m + (k & 15)) * (W / 64) + 4 * s + (k >> 4));
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int m = 0; m < RW; ++m) c[s][m] = transpose_nibbles16(wd[s][m], k);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            halo[s] = ((ht[s] >> (4 * (k & 7))) & 0xFu) | (((hb[s] >> (4 * (k & 7))) & 0xFu) << 4);
+    } else {
     typename C::Quad vt[NS], vb[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -709,8 +741,6 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
         if (bot_global) vb[s] = C::template load<false>(gin + (int64_t)rb * W + 256 * s + 4 * k);
     }
 
-    uint64_t c[NS][RW];
-    uint32_t halo[NS];                               // bits 0-3: row above, bits 4-7: row below
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
@@ -727,6 +757,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) halo[s] = C::nibble(vt[s]) | (C::nibble(vb[s]) << 4);
+    }
 
     if (HAS_ACT) {
         if (compact) {
@@ -899,7 +930,10 @@ __global__ __launch_bounds__(64 * kWideWaves) void ca_step_wide_kernel(
             for (int i = 0; i < 16; ++i)
                 C::template store<NT_ST>(gout + (int64_t)(r0 + 16 * m + i) * W + 256 * s + 4 * k,
                                         (uint32_t)(nx >> (4 * i)) & 0xFu);
-            if (ENV && ea.bits_out) {                // kernel argument: the same for every wavefront
+            if (PK != 0) {                           // lane (j, i): word 4s + j of row r0 + 16m + i
+                ea.bits_out[g * (int64_t)H * (W / 64) + (int64_t)(r0 + 16 * m + (k & 15)) * (W / 64) + 4 * s + (k >> 4)] =
+                    transpose_nibbles16(nx, k);
+            } else if (ENV && ea.bits_out) {         // kernel argument: the same for every wavefront
                 // the 16 lanes of a DPP row hold the nibbles of 64 columns of one grid row: OR them into the row's two
                 // dwords (lanes 7 and 15 of the row end up with them) -- 5 operations per row
                 uint32_t *b32 = reinterpret_cast<uint32_t *>(ea.bits_out) + g * (int64_t)H * (W / 32);
@@ -931,12 +965,36 @@ static unsigned persistent_blocks(int64_t work_items) {
 template <class C, class A, int NS, int RW>
 static int launch_wide(const typename C::T *u_in, const typename A::T *action, typename C::T *u_out,
                        int64_t n, int ah, int aw, uint32_t rule, int32_t *status, int slot,
-                       hipStream_t s, const EnvArgs *env = nullptr) {
+                       hipStream_t s, const EnvArgs *env = nullptr, const EnvArgs *packed = nullptr) {
     const int64_t wgs = n * (WideGeom<NS, RW>::kW / WideGeom<NS, RW>::kR / kWideWaves);
     if (wgs > 0x7FFFFFFFll) return fail_arg(CARLE_E_DIMS, "carle_ca_step: batch too large");
     constexpr int64_t kGridBytes = (int64_t)WideGeom<NS, RW>::kW * WideGeom<NS, RW>::kW * (int64_t)sizeof(typename C::T);
     const bool nt_st = stream_stores(n * kGridBytes, sizeof(typename C::T));
     const dim3 grid(persistent_blocks(wgs)), block(64 * kWideWaves);
+    if (packed) {
+        // fp32 cells with the packed copy (PK): packed->bits_out always, packed->bits_in selects PK = 2; `env`: one launch
+        if (sizeof(typename C::T) != 4) return fail_arg(CARLE_E_DIMS, "carle_env_step: the packed copy goes with fp32 cells");
+        const EnvArgs ea = *packed;
+        const RandAct ra;
+        const int aah = action ? ah : 0, aaw = action ? aw : 0;
+#define CARLE_WIDE_PK(ACT, NTS, ENVF, PKV) \
+        hipLaunchKernelGGL((ca_step_wide_kernel<C, A, ACT, NS, RW, false, NTS, ENVF, PKV>), grid, block, 0, s, u_in, action, u_out, n, \
+                           aah, aaw, rule, status, slot, ra, ea)
+#define CARLE_WIDE_PK2(ENVF, PKV) \
+        do { \
+            if (action && nt_st) CARLE_WIDE_PK(true, true, ENVF, PKV); \
+            else if (action) CARLE_WIDE_PK(true, false, ENVF, PKV); \
+            else if (nt_st) CARLE_WIDE_PK(false, true, ENVF, PKV); \
+            else CARLE_WIDE_PK(false, false, ENVF, PKV); \
+        } while (0)
+        if (env && ea.bits_in) CARLE_WIDE_PK2(true, 2);
+        else if (env) CARLE_WIDE_PK2(true, 1);
+        else if (ea.bits_in) CARLE_WIDE_PK2(false, 2);
+        else CARLE_WIDE_PK2(false, 1);
+#undef CARLE_WIDE_PK2
+#undef CARLE_WIDE_PK
+        return check_launch("carle_env_step(wide, packed copy)");
+    }
     if (env) {                                       // the one-launch step (CARLE_STEP_DEFERRED)
         const EnvArgs ea = *env;
         const RandAct ra;
@@ -1116,8 +1174,8 @@ static int env_step_one_launch(const typename C::T *u_in, const typename A::T *a
         snprintf(buf, sizeof buf, "%s: %s", who, what);
         return fail_arg(code, buf);
     };
-    if (bits_in && !(fast64 && bits_out && sizeof(typename C::T) == 4))
-        return fail(CARLE_E_DIMS, "a packed input state: 64x64 fp32 grids, with bits_out");
+    if (bits_in && !((fast64 || wide) && bits_out && sizeof(typename C::T) == 4))
+        return fail(CARLE_E_DIMS, "a packed input state: 64 / 256 / 512-column fp32 grids, with bits_out");
     if ((!u_in && !bits_in) || !u_out) return fail(CARLE_E_NULL, "u_in/u_out is NULL");
     if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
     if (rule >> 18) return fail(CARLE_E_RULE, "rule mask exceeds 18 bits");
@@ -1126,7 +1184,8 @@ static int env_step_one_launch(const typename C::T *u_in, const typename A::T *a
         return fail(CARLE_E_ALIGN, "pointers must be 16-byte aligned");
     const size_t bytes = (size_t)n * h * w * sizeof(typename C::T);
     if (u_in && !bits_in && overlap(u_in, bytes, u_out, bytes)) return fail(CARLE_E_ALIAS, "u_in and u_out overlap");
-    if (bits_in && ((reinterpret_cast<uintptr_t>(bits_in) & 7u) != 0 || overlap(bits_in, (size_t)n * 512, bits_out, (size_t)n * 512)))
+    if (bits_in && ((reinterpret_cast<uintptr_t>(bits_in) & 7u) != 0 ||
+                    overlap(bits_in, (size_t)n * h * (w / 8), bits_out, (size_t)n * h * (w / 8))))
         return fail(CARLE_E_ALIAS, "bits_in must be 8-byte aligned and must not overlap bits_out");
     EnvArgs ea;
     ea.reward = reward;
@@ -1137,10 +1196,12 @@ static int env_step_one_launch(const typename C::T *u_in, const typename A::T *a
         if (bits_out) {
             if ((reinterpret_cast<uintptr_t>(bits_out) & 7u) != 0) return fail(CARLE_E_ALIGN, "bits_out must be 8-byte aligned");
             ea.bits_out = bits_out;
+            ea.bits_in = bits_in;
             if (bits_written) *bits_written = 1;
         }
-        if (w == 256) return launch_wide<C, A, 1, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, &ea);
-        return launch_wide<C, A, 2, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, &ea);
+        const EnvArgs *pk = bits_in ? &ea : nullptr;      // (fp32 in + copy out keeps the round-3 store of the ENV instantiation)
+        if (w == 256) return launch_wide<C, A, 1, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, &ea, pk);
+        return launch_wide<C, A, 2, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, &ea, pk);
     }
     const dim3 grid((unsigned)n), block(64);
     const bool nt_st = stream_stores((int64_t)bytes, sizeof(typename C::T));
@@ -1302,6 +1363,32 @@ int env_step_small64_rand(const float *u_in, float *u_out, float *reward, int64_
 }  // namespace carle
 
 namespace carle {
+// The wide step kernel (no epilogue) of N x 256x256 / 512x512 fp32 grids with the packed copy: bits_out always, the input state
+// from bits_in when given (u_in is then not read).  -1000: geometry without the wide kernel.
+int ca_step_wide_packed_f32(const float *u_in, const uint64_t *bits_in, const float *action, float *u_out, uint64_t *bits_out,
+                            int64_t n, int h, int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, void *stream) {
+    const bool wide = h == w && (w == 256 || w == 512) && (!action || ((aw % 4) == 0 && ((w - aw) % 8) == 0));
+    if (!wide || n < 1 || !bits_out) return -1000;
+    if ((!u_in && !bits_in) || !u_out) return fail_arg(CARLE_E_NULL, "carle_env_step_f32 (packed copy): u_in/u_out is NULL");
+    if (int e = check_dims(n, h, w, action != nullptr, ah, aw)) return e;
+    if (rule >> 18) return fail_arg(CARLE_E_RULE, "carle_env_step_f32 (packed copy): rule mask exceeds 18 bits");
+    if (slot != 0 && slot != 1) return fail_arg(CARLE_E_DIMS, "carle_env_step_f32 (packed copy): slot must be 0 or 1");
+    if ((u_in && !aligned16(u_in)) || !aligned16(u_out) || (action && !aligned16(action)) || !aligned16(bits_out) ||
+        (bits_in && !aligned16(bits_in)))
+        return fail_arg(CARLE_E_ALIGN, "carle_env_step_f32 (packed copy): pointers must be 16-byte aligned");
+    const size_t bytes = (size_t)n * h * w * sizeof(float), pbytes = (size_t)n * h * (w / 8);
+    if (u_in && !bits_in && overlap(u_in, bytes, u_out, bytes))
+        return fail_arg(CARLE_E_ALIAS, "carle_env_step_f32 (packed copy): u_in and u_out overlap");
+    if (bits_in && overlap(bits_in, pbytes, bits_out, pbytes))
+        return fail_arg(CARLE_E_ALIAS, "carle_env_step_f32 (packed copy): bits_in and bits_out overlap");
+    EnvArgs ea;
+    ea.bits_in = bits_in;
+    ea.bits_out = bits_out;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (w == 256) return launch_wide<F32Cells, F32Cells, 1, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, nullptr, &ea);
+    return launch_wide<F32Cells, F32Cells, 2, kWideRW>(u_in, action, u_out, n, ah, aw, rule, status, slot, s, nullptr, &ea);
+}
+
 int env_step_one_launch_f32(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h,
                             int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
                             void *stream, uint64_t *bits_out, int *bits_written, const uint64_t *bits_in) {

@@ -223,7 +223,7 @@ class CARLE(RLEMixin, nn.Module):
             return None
         # ... or, for batches of 64x64 grids beyond the single-workgroup kernel, always: the next step then reads its input
         # state from the copy (512 B per grid) instead of the fp32 cells (16 KiB) -- ``_packed_state_of``
-        if not self.__dict__.get("want_packed_copy") and not (out.shape[3] == 64 and out.shape[0] > 16 and self.packed_state):
+        if not self.__dict__.get("want_packed_copy") and not (self.packed_state and (out.shape[3] != 64 or out.shape[0] > 16)):
             return None
         bufs = self.__dict__.get("_bits_bufs")
         shape = (out.shape[0], 1, out.shape[2], out.shape[3] // 64)
@@ -235,7 +235,7 @@ class CARLE(RLEMixin, nn.Module):
         """The bit-packed copy of the CURRENT state ``u_in`` if the last step left one (``u_in`` is the very tensor that step
         returned and no torch operation has written to it since: identity + version counter), for the one-launch step that
         reads it instead of the fp32 cells (``carle_env_step_f32_packed``: 64x64 grids).  None: read the fp32 state."""
-        if bits_out is None or not self.packed_state or u_in.shape[3] != 64 or u_in.shape[2] != 64:
+        if bits_out is None or not self.packed_state or u_in.shape[3] not in (64, 256, 512) or u_in.shape[2] != u_in.shape[3]:
             return None
         bits = self.packed_copy_of(u_in)
         if bits is None or bits is bits_out or bits.data_ptr() == bits_out.data_ptr() or bits.shape != bits_out.shape:

@@ -223,13 +223,15 @@ int carle_env_step_f32(const float *u_in, const float *action, float *u_out, flo
 int carle_env_step_f32_bits(const float *u_in, const float *action, float *u_out, float *reward, int64_t n, int h, int w,
                             int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags, uint64_t *bits_out,
                             int *bits_written, void *stream);
-/* The one-launch step (CARLE_STEP_DEFERRED semantics) of n >= 1 grids of 64x64 fp32 cells whose INPUT state is read from its
- * bit-packed copy bits_in (n x 64 row words, as a previous carle_env_step_f32_bits / carle_env_step_f32_packed /
- * carle_pack_f32_b1 left it) instead of the fp32 cells -- the same 4 096 bits per grid in 512 B instead of 16 KiB.  The fp32
+/* CARLE.step (CARLE_STEP_DEFERRED semantics where the geometry has a one-launch step, step kernel + epilogue otherwise) of
+ * n >= 1 grids of 64x64, 256x256 or 512x512 fp32 cells whose INPUT state is read from its bit-packed copy bits_in (H rows of
+ * W/64 words per grid, as a previous carle_env_step_f32_bits / carle_env_step_f32_packed / carle_pack_f32_b1 left it) instead
+ * of the fp32 cells -- the same bits in 1/32 of the bytes (64x64: 512 B instead of 16 KiB per grid).  The fp32
  * observation u_out (carle/env.py:229) and its packed copy bits_out are written as by carle_env_step_f32_bits; grids, counters,
  * reward and flags are those of carle_env_step_f32 on the fp32 state.  The caller vouches that bits_in IS the current state
  * (carle_amd.env.CARLE.step: the very tensor the last step returned, not modified since); bits_in and bits_out must not
- * overlap.  action: fp32 (n,1,ah,aw) window with aw a multiple of 8, or NULL. */
+ * overlap; 16-byte aligned for 256 / 512 columns.  action: fp32 (n,1,ah,aw) window (64x64 grids: aw a multiple of 8; wider
+ * grids: aw a multiple of 4 with (w - aw) a multiple of 8), or NULL. */
 int carle_env_step_f32_packed(const uint64_t *bits_in, const float *action, float *u_out, float *reward, int64_t n, int h,
                               int w, int ah, int aw, uint32_t rule, int32_t *status, int slot, int step_flags,
                               uint64_t *bits_out, void *stream);

@@ -668,3 +668,76 @@ def test_fused_rnd_step_reads_the_packed_state_too(monkeypatch):
     for t in range(10):
         assert torch.equal(o0[t], o1[t]) and torch.equal(r0[t], r1[t]), t
     assert c0 == c1 and float(o1[4].sum()) == 0.0
+
+
+@pytest.mark.parametrize("n,size,asize", [(3, 256, 64), (17, 256, 32), (129, 256, 64), (2, 512, 64), (18, 512, 0), (33, 512, 128)])
+def test_wide_steps_with_the_packed_copy_against_the_oracle(n, size, asize):
+    """256 / 512-column fp32 grids (round 5): carle_env_step_f32_bits leaves the packed copy in the one-launch form AND in the
+    two-launch form (129 x 256x256 = 33.8 MiB per array: beyond the one-launch step), carle_env_step_f32_packed reads it back.
+    Eight steps against the C oracle, the copy equal to carle_pack_f32_b1 of every output, a master reset in the middle."""
+    from carle_amd import hip
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cuda").manual_seed(n * size)
+    birth, survive = [3, 6], [2, 3]
+    rule = hip.rule_mask(birth, survive)
+    u = (torch.rand(n, 1, size, size, device=dev, generator=g) < 0.4).float()
+    bits = [torch.empty(n, 1, size, size // 64, dtype=torch.int64, device=dev) for _ in (0, 1)]
+    st = hip.new_status(dev)
+    cpu = u.cpu().numpy()
+    for t in range(8):
+        act = None
+        if asize:
+            act = (torch.rand(n, 1, asize, asize, device=dev, generator=g) < 0.15).float()
+            if t == 4:
+                act = torch.ones_like(act)
+        out = torch.empty_like(u)
+        reward = torch.full((n, 1), 3.0, device=dev)
+        if t == 0:
+            assert hip.env_step_f32(u, act, out, reward, rule, st, t & 1, True, False, bits_out=bits[1])
+        else:
+            hip.env_step_f32_packed(bits[t & 1], act, out, reward, rule, st, t & 1, True, False, bits_out=bits[(t & 1) ^ 1])
+        cpu = O.c_env_step(cpu, None if act is None else act.cpu().numpy(), rule)[0]
+        assert np.array_equal(out.cpu().numpy(), cpu), t
+        assert torch.equal(bits[(t & 1) ^ 1], hip.pack_f32_b1(out)), t
+        assert float(reward.abs().max()) == 0.0
+        u = out
+    hip.env_settle(st)
+    assert int(st[6]) == (3 if asize else 8)          # CARLE_ST_STEP_NUMBER: the master reset at t = 4 restarts the count
+
+
+def test_wide_environment_reads_its_packed_state(monkeypatch):
+    """CARLE(256x256), N = 5 (one launch) and N = 130 (two launches): the packed path from the second step on, the
+    trajectory of the environment that never takes it, an in-place edit and an assignment in between."""
+    import carle_amd.env as E
+    from carle_amd import hip
+    calls = {"packed": 0}
+    real = hip.env_step_f32_packed
+
+    def spy(*a, **k):
+        calls["packed"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(hip, "env_step_f32_packed", spy)
+    for n in (5, 130):
+        def trajectory(packed_state):
+            monkeypatch.setattr(E, "_PACKED_STATE", packed_state)
+            g = torch.Generator(device="cuda").manual_seed(n)
+            env = E.CARLE(width=256, height=256, instances=n, device="cuda:0")
+            env.reset()
+            env.universe = (torch.rand(n, 1, 256, 256, device="cuda", generator=g) < 0.3).float()
+            outs, taken = [], []
+            for t in range(7):
+                a = (torch.rand(n, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
+                if t == 3:
+                    env.universe[0, 0, 100:110, 100:110] = 1.0
+                if t == 5:
+                    env.universe = env.universe.clone()
+                before = calls["packed"]
+                outs.append(env.step(a)[0].clone())
+                taken.append(calls["packed"] - before)
+            return outs, taken, (env.step_number, env.steps_since_action)
+        ref, t0, c0 = trajectory(False)
+        got, t1, c1 = trajectory(True)
+        assert t0 == [0] * 7 and t1 == [0, 1, 1, 0, 1, 0, 1], (n, t1)
+        assert c0 == c1
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
