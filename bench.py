@@ -344,7 +344,7 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
         alg = n * (size * size * 4 + asize * asize * 4 + 2 * size * size // 8)
         name = ("ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true, ..., ENV, BITS, PACKED_IN>" if size == 64 else
                 "ca_step_wide_kernel<carle::F32Cells, carle::F32Cells, true, ..., ENV, PK=2>" if one_launch else
-                "ca_step_wide_kernel<carle::F32Cells, carle::F32Cells, true, ..., PK=2> (timed with its 5 us epilogue launch)")"
+                "ca_step_wide_kernel<carle::F32Cells, carle::F32Cells, true, ..., PK=2> (timed with its 5 us epilogue launch)")
         dominant_kernels.notes = {name: {
             "traffic_model": "fp32 action window in + fp32 observation out (4 B/cell) + bit-packed state in and out "
                              "(2 x 1/8 B/cell): the fp32 state is written every step and not read back",
