@@ -342,7 +342,9 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
         sbits = [hip.pack_f32_b1(bufs[0]), torch.empty(n, 1, size, size // 64, dtype=torch.int64, device=state.device)]
         alg_reference = alg
         alg = n * (size * size * 4 + asize * asize * 4 + 2 * size * size // 8)
-        name = ("ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true, ..., ENV, BITS, PACKED_IN>" if size == 64 else
+        name = ("ca_step_64_packed2_kernel<carle::F32Cells, ...> (= ca_step_64_kernel<..., ENV, BITS, PACKED_IN>, two grids per "
+                "wavefront)" if size == 64 and 3072 < n <= 4096 and os.environ.get("CARLE_PACKED_GRIDS", "") != "1" else
+                "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true, ..., ENV, BITS, PACKED_IN>" if size == 64 else
                 "ca_step_wide_kernel<carle::F32Cells, carle::F32Cells, true, ..., ENV, PK=2>" if one_launch else
                 "ca_step_wide_kernel<carle::F32Cells, carle::F32Cells, true, ..., PK=2> (timed with its 5 us epilogue launch)")
         dominant_kernels.notes = {name: {

@@ -26,6 +26,7 @@ static Knobs read_knobs() {
     k.b1_units = env_i64("CARLE_B1_UNITS");
     k.wide_blocks = env_i64("CARLE_WIDE_BLOCKS");
     k.rnd_blocks = env_i64("CARLE_RND_BLOCKS");
+    k.packed_grids = env_i64("CARLE_PACKED_GRIDS");
     k.rnd_cached_load_max_bytes = env_i64("CARLE_RND_CACHED_LOAD_MAX_BYTES");
     k.net_blocks = env_i64("CARLE_NET_BLOCKS");
     k.b1_dbg = env_i64("CARLE_B1_DBG");

@@ -140,8 +140,10 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
 
     typename C::Quad v[16];
     uint64_t c = 0;
-    if (PACKED_IN) {
-        c = transpose_nibbles16(__builtin_nontemporal_load(ea.bits_in + g * 64 + 4 * k + q), lane);
+    uint64_t w_in = 0;                               // PACKED_IN: row 4k + q of the state (transposed into `c` once the
+    if (PACKED_IN) {                                 // action loads are out: ONE memory round trip, not two)
+        w_in = __builtin_nontemporal_load(ea.bits_in + g * 64 + 4 * k + q);
+        if (!(HAS_ACT && !RAND_ACT)) c = transpose_nibbles16(w_in, lane);
     } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = C::template load<NT_LD>(gin + i * 256);
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
                     const bool in = col_in && ay >= 0 && ay < aw;
                     a[i] = A::template load<NT_LD>(in ? abase + (int64_t)ay * aw : abase0);
                 }
+                c = transpose_nibbles16(w_in, lane);
             } else {
 #pragma unroll
                 for (int i = 0; i < kActEarly; ++i) {
@@ -253,6 +256,84 @@ __global__ __launch_bounds__(BLOCK) void ca_step_64_kernel(
         if (ea.reward && lane == 0) ea.reward[g] = 0.0f;               // env.py:238
         if (g == 0) env_step_bookkeeping(status, slot, n, HAS_ACT, ea.merge_moments && ea.reward != nullptr);
     }
+}
+
+// ca_step_64_kernel<..., ENV, BITS, PACKED_IN> with an action, TWO grids per wavefront (g and g + ceil(n / 2)).  With one grid
+// per wavefront and every wavefront of a 4 096-grid batch resident at once, the launch is ONE generation of waves in lockstep:
+// everybody loads, then everybody computes, then everybody stores -- the memory system sees reads and writes one after the
+// other.  Here the second grid's action is requested as soon as the first one's is packed into its toggle word, so its 16 KiB
+// travel while the first grid's generation is computed and its 16 KiB are stored.  Pays exactly where the halved wavefront
+// count still fills the chip evenly, two per SIMD (same box, N = 3328 / 3584 / 3840 / 4096: 20.1 / 19.9 / 22.7 / 22.0 us against
+// 20.6 / 21.9 / 22.9 / 23.8); below (N = 3072: 19.5 against 17.3) and above (4352: 26.7 / 25.9, 8192: 44.5 / 43.0) the longer
+// waves cost more in imbalance than the overlap gives.  A persistent loop of this shape (2 048 wavefronts, any N) gained 4 % at
+// N = 4096 and lost 10 % at N = 65536: larger batches desynchronise by themselves.
+template <class A, bool NT_ST>
+__global__ __launch_bounds__(64) void ca_step_64_packed2_kernel(
+    const typename A::T *__restrict__ act, float *__restrict__ u_out, int64_t n, int aw, uint32_t rule,
+    int32_t *__restrict__ status, int slot, EnvArgs ea) {
+    const int lane = threadIdx.x;
+    const int64_t half = (n + 1) >> 1;
+    const int64_t g0 = blockIdx.x, g1 = g0 + half;
+    const bool two = g1 < n;                         // (wave-uniform)
+    const int q = lane >> 4, k = lane & 15;
+    const int o = (64 - aw) >> 1;
+    const int ax = 4 * k - o;
+    const bool col_in = ax >= 0 && ax < aw;
+
+    auto issue = [&](int64_t g, typename A::Quad (&a)[16], uint64_t &w) __attribute__((always_inline)) {
+        w = __builtin_nontemporal_load(ea.bits_in + g * 64 + 4 * k + q);
+        const typename A::T *abase0 = act + g * (int64_t)aw * aw, *abase = abase0 + ax;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {               // unconditional loads (see ca_step_64_kernel)
+            const int ay = 4 * i + q - o;
+            const bool in = col_in && ay >= 0 && ay < aw;
+            a[i] = A::template load<true>(in ? abase + (int64_t)ay * aw : abase0);
+        }
+    };
+    auto toggled = [&](typename A::Quad (&a)[16], uint64_t w, bool &own_notone) __attribute__((always_inline)) -> uint64_t {
+        uint64_t c = transpose_nibbles16(w, lane), tog = 0;
+        ActionSeen seen;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ay = 4 * i + q - o;
+            if (col_in && ay >= 0 && ay < aw) {
+                see(seen, a[i]);
+                tog |= (uint64_t)A::nibble(a[i]) << (4 * i);
+            }
+        }
+        own_notone = true;
+        if (ea.publish) own_notone = publish_flags<A>(seen, status, slot);
+        return c ^ tog;                              // toggle, env.py:182
+    };
+    auto finish = [&](int64_t g, uint64_t c, bool own_notone) __attribute__((always_inline)) {
+        uint64_t nxt = patch_generation64(c, lane, rule);
+        bool reset;                                  // master reset (env.py:208-216)
+        if (!ea.publish) {
+            reset = __builtin_nontemporal_load(status + CARLE_ST_NOT_ALL_ONES(slot)) == 0;
+        } else {
+            reset = false;
+            if (__builtin_expect(!own_notone, 0)) reset = batch_action_all_ones<A>(act, n, aw, status, slot);
+        }
+        if (reset) nxt = 0ull;
+        float *gout = u_out + g * 4096 + 4 * lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) F32Cells::template store<NT_ST>(gout + i * 256, (uint32_t)(nxt >> (4 * i)) & 0xFu);
+        ea.bits_out[g * 64 + 4 * k + q] = transpose_nibbles16(nxt, lane);
+        if (ea.reward && lane == 0) ea.reward[g] = 0.0f;               // env.py:238
+    };
+
+    typename A::Quad a[16];
+    uint64_t w;
+    bool nn0, nn1;
+    issue(g0, a, w);
+    const uint64_t c0 = toggled(a, w, nn0);
+    if (two) issue(g1, a, w);                        // in flight during the first grid's generation and stores
+    finish(g0, c0, nn0);
+    if (two) {
+        const uint64_t c1 = toggled(a, w, nn1);
+        finish(g1, c1, nn1);
+    }
+    if (g0 == 0) env_step_bookkeeping(status, slot, n, 1, ea.merge_moments && ea.reward != nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1212,6 +1293,20 @@ static int env_step_one_launch(const typename C::T *u_in, const typename A::T *a
         if (bits_written) *bits_written = 1;
         if (bits_in) {                                 // the state comes in packed: u_in is not read
             ea.bits_in = bits_in;
+            // with an action, 3072 < n <= 4096: two grids per wavefront (CARLE_PACKED_GRIDS = 1 / 2 forces one / two)
+            const int64_t kg = knobs().packed_grids;
+            if (action && n >= 2 && (kg == 2 || (kg != 1 && n > 3072 && n <= 4096))) {
+                if constexpr (sizeof(typename C::T) == 4 && sizeof(typename A::T) == 4) {
+                    const dim3 grid2((unsigned)((n + 1) / 2));
+                    if (nt_st)
+                        hipLaunchKernelGGL((ca_step_64_packed2_kernel<A, true>), grid2, block, 0, s, action, u_out, n, aw, rule,
+                                           status, slot, ea);
+                    else
+                        hipLaunchKernelGGL((ca_step_64_packed2_kernel<A, false>), grid2, block, 0, s, action, u_out, n, aw, rule,
+                                           status, slot, ea);
+                    return check_launch(who);
+                }
+            }
             if (action && nt_st)
                 hipLaunchKernelGGL((ca_step_64_kernel<C, A, true, true, true, 64, false, true, true, true>), grid, block, 0, s,
                                    u_in, action, u_out, n, aw, rule, status, slot, ra, ea);

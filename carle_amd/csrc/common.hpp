@@ -69,6 +69,7 @@ struct Knobs {
     int64_t b1_blocks, b1_units;         // CARLE_B1_BLOCKS / CARLE_B1_UNITS: launch caps of the packed kernel
     int64_t wide_blocks;                 // CARLE_WIDE_BLOCKS: launch cap of the wavefront-per-strip kernels
     int64_t rnd_blocks;                  // CARLE_RND_BLOCKS: workgroups of the fused CA + RND2D kernel
+    int64_t packed_grids;                // CARLE_PACKED_GRIDS: grids per wavefront of the packed-input 64x64 step (1 / 2; unset: by n)
     int64_t rnd_cached_load_max_bytes;   // CARLE_RND_CACHED_LOAD_MAX_BYTES
     int64_t net_blocks;                  // CARLE_NET_BLOCKS: workgroups of the 64x64 reward-net kernels
     int64_t b1_dbg;                      // CARLE_B1_DBG

@@ -599,11 +599,18 @@ def test_step_reads_the_packed_copy_of_its_own_last_output_and_nothing_else(monk
     assert float(got[5].sum()) == 0.0 and float(got[4].sum()) > 0 and float(got[6].sum()) > 0     # the master reset at t = 5
 
 
-@pytest.mark.parametrize("n,asize", [(17, 64), (300, 32), (4099, 64), (65, 0)])
-def test_packed_input_step_against_the_oracle(n, asize):
+@pytest.mark.parametrize("n,asize,grids", [(17, 64, None), (300, 32, None), (4099, 64, None), (65, 0, None), (3500, 64, None),
+                                           (17, 64, "2"), (301, 32, "2"), (2, 8, "2"), (3500, 48, "1")])
+def test_packed_input_step_against_the_oracle(n, asize, grids, monkeypatch):
     """carle_env_step_f32_packed itself: state in as row words, fp32 state + row words out; twelve steps against the C oracle
-    on the fp32 cells, three rules."""
+    on the fp32 cells, three rules.  ``grids``: CARLE_PACKED_GRIDS forced (two grids per wavefront is the library's choice for
+    3072 < n <= 4096 only: ca_step_64_packed2_kernel; odd batches leave the last wavefront with one grid)."""
     from carle_amd import hip
+    if grids is not None:
+        monkeypatch.setenv("CARLE_PACKED_GRIDS", grids)
+    else:
+        monkeypatch.delenv("CARLE_PACKED_GRIDS", raising=False)
+    hip.reload_knobs()
     dev = torch.device("cuda", 0)
     g = torch.Generator(device="cuda").manual_seed(n)
     for birth, survive in (([3], [2, 3]), ([3, 6], [2, 3]), ([2], [])):
@@ -620,6 +627,8 @@ def test_packed_input_step_against_the_oracle(n, asize):
             cpu = O.c_env_step(cpu, None if act is None else act.cpu().numpy(), rule)[0]
             assert np.array_equal(out.cpu().numpy(), cpu), (birth, t)
             assert torch.equal(bits[(t & 1) ^ 1], hip.pack_f32_b1(out))
+    monkeypatch.delenv("CARLE_PACKED_GRIDS", raising=False)
+    hip.reload_knobs()
 
 
 def test_fused_rnd_step_reads_the_packed_state_too(monkeypatch):

@@ -33,7 +33,7 @@ pmc() {     # name, kernel substring, instances, size, format, bench flags...
 # kernel sources of the library it runs, so the bench lines collected below carry this run's traffic figures)
 : > $O/${TAG}_pmc.txt
 # (round 5: the step reads its state bit-packed -- the PACKED_IN instantiation, write-back stores at N=4096, streaming at 65536)
-pmc cfg2 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true, true, false, 64, false, true, true, true>" 4096 64 f32
+pmc cfg2 "ca_step_64_packed2_kernel" 4096 64 f32
 pmc cfg2_n65536 "ca_step_64_kernel<carle::F32Cells, carle::F32Cells, true, true, true, 64, false, true, true, true>" 65536 64 f32 --instances 65536
 pmc cfg4 "ca_step_rnd64_kernel<true, false, true, true, true, true>" 4096 64 f32 --rnd
 pmc cfg5 "ca_step_b1_kernel" 4096 512 b1 --format b1 --size 512 --instances 4096 --rule B36/S23
