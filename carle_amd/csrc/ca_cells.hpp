@@ -144,8 +144,11 @@ __device__ __forceinline__ bool settle_pending(uint4 &w0, uint4 &w1, uint4 &w2) 
     const uint32_t pend = w1.y;                                           // CARLE_ST_PENDING (index 5)
     if (!(pend & 1u)) return false;
     const bool ps = (pend & 4u) != 0u, has_action = (pend & 2u) != 0u;
-    const bool any = has_action && (ps ? w0.y : w0.x) != 0u;
-    const bool reset = has_action && (ps ? w0.w : w0.z) == 0u;
+    // (masks, not `ps ? w0.y : w0.x`: the compiler turns that select into a dynamically indexed copy of w0 in scratch -- or,
+    // promoted, into 16 bytes of LDS per thread of every kernel that settles: 4 KB of the fused CA + RND2D kernel's 37.5)
+    const uint32_t pm = 0u - (uint32_t)ps;
+    const bool any = has_action && ((w0.y & pm) | (w0.x & ~pm)) != 0u;
+    const bool reset = has_action && ((w0.w & pm) | (w0.z & ~pm)) == 0u;
     int64_t step_number = (int64_t)(((uint64_t)w1.w << 32) | w1.z);
     int64_t since = (int64_t)(((uint64_t)w2.y << 32) | w2.x);
     int64_t resets = (int64_t)(((uint64_t)w2.w << 32) | w2.z);
