@@ -746,9 +746,14 @@ def measure(args, rank, world, dev, pinned, light=False):
         if state_bytes <= 256 << 20:
             # the library keeps the output of step t cacheable below 256 MiB per state array (write-back stores / cached
             # packed strips): part of what step t+1 reads comes out of the 256 MiB Infinity Cache, not HBM
-            roof["cache_note"] = ("state array of %d MiB <= 256 MiB Infinity Cache: `achieved` counts algorithmic bytes, part of "
-                                  "the re-read state is served by the cache; run --instances %d for the cache-free figure"
-                                  % (state_bytes >> 20, max(n * 16, 65536) if size == 64 else n * 8))
+            if "traffic_model" in roof:
+                roof["cache_note"] = ("state array of %d MiB <= 256 MiB Infinity Cache: the fp32 observation is written with "
+                                      "write-back stores and not read back by the next step; run --instances %d for the "
+                                      "cache-free figure" % (state_bytes >> 20, max(n * 16, 65536) if size == 64 else n * 8))
+            else:
+                roof["cache_note"] = ("state array of %d MiB <= 256 MiB Infinity Cache: `achieved` counts algorithmic bytes, part "
+                                      "of the re-read state is served by the cache; run --instances %d for the cache-free figure"
+                                      % (state_bytes >> 20, max(n * 16, 65536) if size == 64 else n * 8))
         if flop:
             roof["flop_per_launch"] = flop
             roof["flop_frac_fp32_valu"] = flop / (k_ms * 1e-3) / FP32_PEAK
@@ -794,6 +799,11 @@ def measure(args, rank, world, dev, pinned, light=False):
                                      f" ({args.backend if world > 1 else 'single rank'})" +
                                      ("; all-reduce of the flat predictor gradients before every Adam step"
                                       if args.train and world > 1 and not args.per_rank_predictors else ""),
+                       "state_input": ("the bit-packed copy of the state that the previous step's launch left beside its fp32 "
+                                       "observation (1/32 of the bytes), read while env.universe is the untouched tensor that step "
+                                       "returned; the fp32 observation is written every step, the fp32 action read every step"
+                                       if (args.format == "f32" and size in (64, 256, 512) and getattr(env, "packed_state", False)
+                                           and (size != 64 or n > 16)) else "the state array"),
                        "state_bytes_per_array": int(env.universe_bits.numel() * 8 if packed else
                                                     env.universe.numel() * env.universe.element_size())},
             "cell_updates_per_s": world * n * args.steps * size * size / dt,
