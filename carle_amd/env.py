@@ -240,6 +240,9 @@ class CARLE(RLEMixin, nn.Module):
         bits = self.packed_copy_of(u_in)
         if bits is None or bits is bits_out or bits.data_ptr() == bits_out.data_ptr() or bits.shape != bits_out.shape:
             return None
+        # a step recorded into a HIP graph is replayed on whatever its input buffer holds by then: record the fp32 reader
+        if torch.cuda.is_current_stream_capturing():
+            return None
         return bits
 
     def packed_copy_of(self, obs):

@@ -750,3 +750,33 @@ def test_wide_environment_reads_its_packed_state(monkeypatch):
         assert c0 == c1
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
+
+
+def test_a_step_captured_into_a_hip_graph_reads_the_fp32_state():
+    """A caller's own torch.cuda.graph around env.step: the replay runs on whatever the captured input buffer holds by then,
+    so the capture must record the kernel that READS that buffer -- not the packed copy of what it held at capture time."""
+    import carle_amd.env as E
+    g = torch.Generator(device="cuda").manual_seed(5)
+    env = E.CARLE(width=64, height=64, instances=40, device="cuda:0")
+    env.reset()
+    env.universe = (torch.rand(40, 1, 64, 64, device="cuda", generator=g) < 0.3).float()
+    act = (torch.rand(40, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
+    for _ in range(3):
+        env.step(act)                                  # the packed path is live now
+    static_in = env.universe
+    assert env.packed_copy_of(static_in) is not None
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            obs = env.step(act)[0]
+    torch.cuda.current_stream().wait_stream(side)
+    rule = env.rule_mask()
+    for _ in range(3):
+        new_state = (torch.rand(40, 1, 64, 64, device="cuda", generator=g) < 0.4).float()
+        static_in.copy_(new_state)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = O.c_env_step(new_state.cpu().numpy(), act.cpu().numpy(), rule)[0]
+        assert np.array_equal(obs.cpu().numpy(), want)
