@@ -266,6 +266,14 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
         __syncthreads();
         RND_STAMP(5);
 
+        // ---- D: conv1 (table lookup) + relu + 4x4 max-pool; thread = pooling window.  BEFORE the stores of C since the step
+        // reads its state packed (round 5): with the memory time gone the launch is bound by LDS + VALU work per CU (three
+        // workgroups per CU run as fast as four), and the LDS round trips of the lookups overlap better with the stores
+        // issued behind them than the other way round: 30.8 -> 30.1 us, same box.  (The random net's table through the
+        // vector L1 here: 31.7 / 33.7 us for 8 / 16 of the lookups -- `profiles/r05_rnd_d_first_ab.txt`.)
+        RND_STAMP(6);
+        rnd_block_conv1(s.net, tid, ws);
+        RND_STAMP(7);
         // ---- C: fp32 store of the new state (the lane's own four quads): the lane's dword of the row
         // word, its nibble, bits -> bytes (one multiply), bytes -> 0.0f / 1.0f (hipcc selects v_cvt_f32_ubyteN)
         {
@@ -300,10 +308,6 @@ __global__ __launch_bounds__(256, CARLE_RND_WG_PER_CU) void ca_step_rnd64_kernel
             }
         }
 
-        RND_STAMP(6);
-        // ---- D: conv1 (table lookup) + relu + 4x4 max-pool; thread = pooling window
-        rnd_block_conv1(s.net, tid, ws);
-        RND_STAMP(7);
         __syncthreads();
         RND_STAMP(8);
 
