@@ -757,7 +757,7 @@ def test_a_step_captured_into_a_hip_graph_reads_the_fp32_state():
     so the capture must record the kernel that READS that buffer -- not the packed copy of what it held at capture time."""
     import carle_amd.env as E
     g = torch.Generator(device="cuda").manual_seed(5)
-    env = E.CARLE(width=64, height=64, instances=40, device="cuda:0")
+    env = E.CARLE(width=64, height=64, instances=40, device="cuda:0", packed_state=True)     # (whatever CARLE_PACKED_STATE says)
     env.reset()
     env.universe = (torch.rand(40, 1, 64, 64, device="cuda", generator=g) < 0.3).float()
     act = (torch.rand(40, 1, 64, 64, device="cuda", generator=g) < 0.1).float()
