@@ -336,8 +336,9 @@ def dominant_kernels(args, env, wenv, ring, hip, n, size, asize):
     # fp32 64x64 beyond 16 instances (round 5): CARLE.step reads its input state from the bit-packed copy its previous launch
     # left (512 B per grid) instead of the fp32 cells (16 KiB) -- the kernel below is that launch, and its algorithmic bytes
     # are what it has to move: the fp32 action in, the fp32 observation out, the packed state in and out
+    two_launch_knob = os.environ.get("CARLE_TWO_LAUNCH_STEP", "0") not in ("", "0")     # (A/B knob: no one-launch step, so no copy at 64x64)
     packed_state = (args.format == "f32" and getattr(env, "packed_state", False) and
-                    ((size == 64 and one_launch) or size in (256, 512)))
+                    ((size == 64 and one_launch and not two_launch_knob) or size in (256, 512)))
     if packed_state:
         sbits = [hip.pack_f32_b1(bufs[0]), torch.empty(n, 1, size, size // 64, dtype=torch.int64, device=state.device)]
         alg_reference = alg

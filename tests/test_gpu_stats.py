@@ -101,9 +101,12 @@ def test_pair_finish_kernel_leaves_the_reward_moments(train, storage, size, n):
     carle_ae2d_bonus_b1_stats on the bit-packed observation RND2D's one-launch step hands over), which leaves their
     partial sums for the next environment step to merge -- the statistics equal those of explicit update() calls, across
     reset() and a change of mode."""
+    import os
     from carle_amd import dist as cd
     from carle_amd.env import CARLE
     from carle_amd.mcl import RND2D, AE2D
+    if size == 64 and os.environ.get("CARLE_TWO_LAUNCH_STEP", "0") not in ("", "0"):
+        pytest.skip("the 64x64 hand-off comes from RND2D's ONE-launch step (tools/test_all_paths.sh forces two launches)")
     torch.manual_seed(5)
     env = CARLE(width=size, height=size, instances=n, device="cuda:0", storage=storage)
     w = AE2D(RND2D(env, train_predictor=train), train_predictor=train)
