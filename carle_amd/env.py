@@ -238,7 +238,7 @@ class CARLE(RLEMixin, nn.Module):
         if bits_out is None or not self.packed_state or u_in.shape[3] not in (64, 256, 512) or u_in.shape[2] != u_in.shape[3]:
             return None
         bits = self.packed_copy_of(u_in)
-        if bits is None or bits is bits_out or bits.data_ptr() == bits_out.data_ptr() or bits.shape != bits_out.shape:
+        if bits is None or bits is bits_out or bits.shape != bits_out.shape:      # (the two parity buffers never alias)
             return None
         # a step recorded into a HIP graph is replayed on whatever its input buffer holds by then: record the fp32 reader
         if torch.cuda.is_current_stream_capturing():
