@@ -465,11 +465,18 @@ __global__ __launch_bounds__(256, 4) void ae_block64_kernel(
             typedef f32x2 __attribute__((aligned(4))) f32x2_a4;
             f32x2 h01[4], h12[4], h23[4];             // A3 rows 2py-1..2py+2 (padded), column pairs from 2px-1
             const float *pl = s.a1 + (2 * py) * kA1Stride + 2 * px;
+            // (the aligned pairs as single ds_read_b64, as the conv2 patches above; the unaligned ones are ds_read2_b32 anyway)
+            {
+                const uint32_t a3 = (uint32_t)reinterpret_cast<uintptr_t>(pl);
+                h01[0] = lds_read_b64_issue<(0 * kA1Stride) * 4>(a3); h23[0] = lds_read_b64_issue<(0 * kA1Stride + 2) * 4>(a3);
+                h01[1] = lds_read_b64_issue<(1 * kA1Stride) * 4>(a3); h23[1] = lds_read_b64_issue<(1 * kA1Stride + 2) * 4>(a3);
+                h01[2] = lds_read_b64_issue<(2 * kA1Stride) * 4>(a3); h23[2] = lds_read_b64_issue<(2 * kA1Stride + 2) * 4>(a3);
+                h01[3] = lds_read_b64_issue<(3 * kA1Stride) * 4>(a3); h23[3] = lds_read_b64_issue<(3 * kA1Stride + 2) * 4>(a3);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                h01[r] = *reinterpret_cast<const f32x2 *>(pl + r * kA1Stride);
-                h12[r] = *reinterpret_cast<const f32x2_a4 *>(pl + r * kA1Stride + 1);
-                h23[r] = *reinterpret_cast<const f32x2 *>(pl + r * kA1Stride + 2);
+                for (int r = 0; r < 4; ++r) h12[r] = *reinterpret_cast<const f32x2_a4 *>(pl + r * kA1Stride + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(h01[0]), "+v"(h01[1]), "+v"(h01[2]), "+v"(h01[3]), "+v"(h23[0]), "+v"(h23[1]), "+v"(h23[2]), "+v"(h23[3])
+                             : : "memory");
             }
             f32x2 sq2 = {0.f, 0.f};
 #pragma unroll
